@@ -1,0 +1,154 @@
+/*
+ * modes_hip.h -- C-ABI of the MI355X Mode S / Mode A/C receive path (libmodes_hip.so).
+ *
+ * This is the drop-in boundary for readsb's 2.4 MSPS hot path.  Every entry point names the
+ * reference interface (file:line under the readsb-protobuf tree) it replaces.  Plain C types
+ * only; one context per receiver / GPU / host thread; no shared mutable globals (the reference
+ * keeps this state in file statics: readsb.c:60 `Modes`, convert.c:33, icao_filter.c:38-40,
+ * crc.c:84-88).  All functions return 0 or a negative errno-style code, never throw, and never
+ * print; the last error text of a context is available from msd_last_error().
+ *
+ * The library needs an AMD GPU (gfx950) at run time.  There is no CPU fallback: msd_create()
+ * fails with -ENODEV when no device is present.
+ */
+#ifndef MODES_HIP_H
+#define MODES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSD_CHUNK_SAMPLES 131072u /* MODES_MAG_BUF_SAMPLES, readsb.h:98-99 */
+#define MSD_OVERLAP 326u          /* Modes.trailing_samples, readsb.c:198 */
+
+/* input_format_t, convert.h:29-31 (same numbering); MSD_FMT_MAG16 = already-converted u16
+ * magnitudes, i.e. the contents of struct mag_buf.data (fifo.h:57-73). */
+enum { MSD_FMT_UC8 = 0, MSD_FMT_SC16 = 1, MSD_FMT_SC16Q11 = 2, MSD_FMT_MAG16 = 3 };
+
+/* The receiver options that reach the hot path ("Config / flags"). */
+typedef struct msd_config {
+    int32_t device;             /* HIP device ordinal */
+    int32_t format;             /* --iformat, sdr_ifile.c:88-101 */
+    int32_t preamble_threshold; /* --preamble-threshold, readsb.c:503-505 (default 58) */
+    int32_t nfix_crc;           /* --no-fix = 0, --fix = 1 (readsb.c:491-496); 2 unsupported */
+    int32_t mode_ac;            /* --modeac, readsb.c:509-512 */
+    int32_t reserved0;
+    uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk */
+    void *stream;               /* hipStream_t to launch on; NULL = the context creates one */
+} msd_config;
+
+/* The part of struct modesMessage (readsb.h:340-547) the demodulator determines; this is what
+ * the reference hands to useModesMessage() (demod_2400.c:419,703; mode_s.c:2146). */
+typedef struct msd_message {
+    uint64_t timestampMsg;    /* 12 MHz, demod_2400.c:358 / :695 */
+    uint64_t sysTimestampMsg; /* ms, demod_2400.c:361 / :698 (startup_time taken as 0) */
+    double signalLevel;       /* demod_2400.c:398; 0 for Mode A/C */
+    uint32_t addr;
+    uint32_t crc;
+    int32_t score;
+    uint8_t msgtype; /* DF; 32 = Mode A/C (mode_ac.c:171) */
+    uint8_t msgbits; /* 56 / 112 / 16 */
+    uint8_t correctedbits;
+    uint8_t bestphase; /* 4..8 (demod_2400.c:384); 0 for Mode A/C */
+    uint8_t msg[14];
+    uint8_t iid;
+    uint8_t pad;
+} msd_message;
+
+/* struct stats demodulator counters, stats.h:61-80 */
+typedef struct msd_stats {
+    uint64_t demod_preambles;
+    uint64_t demod_rejected_bad;
+    uint64_t demod_rejected_unknown_icao;
+    uint64_t demod_accepted[3];
+    uint64_t demod_preamblePhase[5];
+    uint64_t demod_bestPhase[5];
+    uint64_t demod_modeac;
+    uint64_t strong_signal_count;
+    uint64_t samples_processed;
+    uint64_t noise_power_count;
+    uint64_t signal_power_count;
+    double noise_power_sum;
+    double signal_power_sum;
+    double peak_signal_power;
+    uint64_t buffers;
+} msd_stats;
+
+/* Timing of the most recent batch, measured with HIP events on the context's stream. */
+typedef struct msd_timing {
+    float scan_kernel_ms;   /* the fused convert+scan+slice+CRC kernel */
+    float other_kernels_ms; /* compaction (+ Mode A/C, + float means) */
+    float d2h_ms;
+    float resolve_ms; /* host, ordered resolve */
+    uint64_t hits;    /* preamble positions reported by the GPU */
+    uint64_t tries;   /* state-dependent candidate records reported by the GPU */
+    uint64_t reruns;  /* batches re-run in halves because a candidate arena overflowed */
+} msd_timing;
+
+typedef struct msd_ctx msd_ctx;
+/* useModesMessage-shaped sink (mode_s.h:37): called synchronously, in order, on the calling
+ * thread; the message is only valid during the call. */
+typedef void (*msd_message_fn)(const msd_message *mm, void *user);
+
+/* A ready-made sink that appends to a caller-owned array (count keeps counting past cap). */
+typedef struct msd_array_sink_state {
+    msd_message *out;
+    size_t cap;
+    size_t count;
+} msd_array_sink_state;
+void msd_array_sink(const msd_message *mm, void *state /* msd_array_sink_state* */);
+
+/* ---- life cycle: replaces modesInit's modesChecksumInit/icaoFilterInit (readsb.c:241-243) and
+ *      init_converter (convert.h:40-43) ---- */
+int msd_create(const msd_config *cfg, msd_ctx **out);
+void msd_destroy(msd_ctx *ctx);
+const char *msd_last_error(const msd_ctx *ctx);
+
+/* ---- streaming form of ifileRun + the consumer loop (sdr_ifile.c:164-237, readsb.c:820-855).
+ * A capture is fed in order, in batches that are whole multiples of MSD_CHUNK_SAMPLES except the
+ * last one (`last` != 0), which also produces the reference's end-of-file behaviour (a final
+ * short or empty buffer).  The IQ bytes live in device memory
+ * (msd_submit_device) or host memory (msd_submit_host copies them over PCIe first).
+ * Messages are delivered to `sink` in the reference's order before the call returns. ---- */
+int msd_submit_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last,
+                      msd_message_fn sink, void *user);
+int msd_submit_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last,
+                    msd_message_fn sink, void *user);
+/* Forget the stream position, ICAO filter, clock and counters (a new capture). */
+int msd_reset(msd_ctx *ctx);
+
+/* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the
+ * oldest outstanding batch, runs the ordered resolve and delivers its messages.  At most
+ * MSD_PIPELINE_DEPTH batches may be outstanding. ---- */
+#define MSD_PIPELINE_DEPTH 2
+int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
+int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
+
+int msd_get_stats(const msd_ctx *ctx, msd_stats *st);
+int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
+/* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
+ * fifo.h:70-71): 2 doubles per buffer, up to cap buffers; returns the number of buffers. */
+int msd_get_buffer_means(const msd_ctx *ctx, double *means, size_t cap);
+
+/* ---- iq_convert_fn-shaped converter (convert.h:33-38): host buffers in, host buffers out,
+ * bit-identical u16 magnitudes and means for UC8 / SC16 / SC16Q11 without DC filter.
+ * `format` is taken from the context.  Either out pointer may be NULL (convert.c:104-110). ---- */
+int msd_convert(msd_ctx *ctx, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
+                double *out_mean_level, double *out_mean_power);
+
+/* ---- demodulate2400 / demodulate2400AC-shaped entry (demod_2400.h:37-38) on one magnitude
+ * buffer laid out like struct mag_buf (fifo.h:57-73): data[0..overlap) is the previous buffer's
+ * tail, data[overlap..validLength) the new samples.  Runs the Mode S demodulator, then (if
+ * mode_ac) the Mode A/C one, then icaoFilterExpire (readsb.c:331), like one turn of the
+ * reference's consumer loop.  Uses the context's filter/clock/counters. ---- */
+int msd_demodulate_magbuf(msd_ctx *ctx, const uint16_t *data, unsigned validLength, unsigned overlap,
+                          uint64_t sampleTimestamp, uint64_t sysTimestamp, double mean_level,
+                          double mean_power, msd_message_fn sink, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,836 @@
+/*
+ * modes_oracle.c -- CPU restatement of the readsb 2.4 MSPS receive path (see modes_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY; "parity unpinned" for the demodulator (see the header for what is
+ * and is not pinned).  Written from the behaviour of the reference, not from its text: the bit
+ * slicer is table-driven, the ICAO filter / CRC tables live in a context instead of file statics,
+ * and the replay loop restates sdr_ifile.c + fifo.c + the readsb.c consumer loop synchronously
+ * (queue depth 1, which is the lossless feed the parity definition of SURVEY.md 8(b) asks for).
+ *
+ * Build with: gcc -std=c11 -O2 -ffp-contract=off (the reference is -std=c11 -O2 on x86-64:
+ * FLT_EVAL_METHOD == 0, no FMA contraction, correctly rounded sqrtf; Makefile:12-13).
+ */
+#include "modes_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+#define FILTER_SLOTS 8192u          /* icao_filter.c:27 */
+#define FILTER_VACANT 0xFFFFFFFFu   /* icao_filter.c:42 */
+#define FILTER_TTL_MS 60000u        /* icao_filter.c:30 */
+#define CRC_POLY 0xfff409u          /* crc.c:31 */
+
+struct syndrome_entry { /* crc.h:32-37, restricted to what nfix<=1 needs */
+    uint32_t syndrome;
+    int bit;
+};
+
+struct orc_ctx {
+    int format, threshold, nfix, mode_ac;
+    /* icao_filter.c:38-40 */
+    uint32_t filt[2][FILTER_SLOTS];
+    int active;
+    uint64_t next_flip; /* icao_filter.c:151 (function static there) */
+    /* crc.c:84-88 */
+    struct syndrome_entry tab56[51], tab112[107];
+    int ntab56, ntab112;
+    /* readsb.h:288-289: startup_time is fixed to 0 here */
+    uint64_t ifile_now;
+    orc_stats st;
+    /* fifo.c:43-44 */
+    uint16_t carry[ORC_OVERLAP];
+    uint16_t *buf; /* one mag_buf's data, ORC_CHUNK_SAMPLES + ORC_OVERLAP samples */
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* IQ -> magnitude (convert.c)                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+static uint16_t g_uc8[65536];
+static int g_uc8_ready;
+
+/* convert.c:35-61.  Table slot i*256+q holds the magnitude for "i" and "q" as that loop names
+ * them; a sample's slot is the little-endian u16 of its (I byte, Q byte) pair, i.e. I + 256*Q,
+ * so the loop's "i" is the sample's Q byte (the table is symmetric, but keep the exact form). */
+static void build_uc8_table(void)
+{
+    if (g_uc8_ready)
+        return;
+    for (int i = 0; i < 256; ++i) {
+        for (int q = 0; q < 256; ++q) {
+            float fi = (i - 127.5) / 127.5; /* double expression rounded to float, convert.c:49 */
+            float fq = (q - 127.5) / 127.5;
+            float magsq = fi * fi + fq * fq;
+            if (magsq > 1)
+                magsq = 1;
+            float mag = sqrtf(magsq);
+            g_uc8[i * 256 + q] = (uint16_t)(mag * 65535.0f + 0.5f);
+        }
+    }
+    g_uc8_ready = 1;
+}
+
+const uint16_t *orc_uc8_table(void)
+{
+    build_uc8_table();
+    return g_uc8;
+}
+
+/* convert.c:63-111 */
+static void convert_uc8(const uint8_t *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
+{
+    uint64_t sum_level = 0, sum_power = 0;
+    for (unsigned k = 0; k < n; ++k) {
+        unsigned slot = (unsigned)iq[2 * k] | ((unsigned)iq[2 * k + 1] << 8);
+        uint16_t v = g_uc8[slot];
+        mag[k] = v;
+        sum_level += v;
+        sum_power += (uint32_t)v * (uint32_t)v;
+    }
+    if (ml)
+        *ml = sum_level / 65536.0 / n; /* convert.c:105 -- 65536, not 65535 */
+    if (mp)
+        *mp = sum_power / 65535.0 / 65535.0 / n; /* convert.c:109 */
+}
+
+/* convert.c:215-253 (scale 32768) and :332-370 (scale 2048): float path, no DC filter.
+ * The level/power sums are sequential float accumulations and the means are float divisions. */
+static void convert_s16(const uint8_t *iq, uint16_t *mag, unsigned n, float scale, double *ml,
+                        double *mp)
+{
+    float sum_level = 0, sum_power = 0;
+    for (unsigned k = 0; k < n; ++k) {
+        int16_t I = (int16_t)((unsigned)iq[4 * k] | ((unsigned)iq[4 * k + 1] << 8));
+        int16_t Q = (int16_t)((unsigned)iq[4 * k + 2] | ((unsigned)iq[4 * k + 3] << 8));
+        float fi = I / scale;
+        float fq = Q / scale;
+        float magsq = fi * fi + fq * fq;
+        if (magsq > 1)
+            magsq = 1;
+        float m = sqrtf(magsq);
+        sum_power += magsq;
+        sum_level += m;
+        mag[k] = (uint16_t)(m * 65535.0f + 0.5f);
+    }
+    if (ml)
+        *ml = sum_level / n;
+    if (mp)
+        *mp = sum_power / n;
+}
+
+void orc_convert(orc_ctx *ctx, const void *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
+{
+    switch (ctx->format) { /* convert.c:425-444 selection, filter_dc == 0 */
+    case ORC_FMT_UC8:
+        convert_uc8(iq, mag, n, ml, mp);
+        break;
+    case ORC_FMT_SC16:
+        convert_s16(iq, mag, n, 32768.0f, ml, mp);
+        break;
+    default:
+        convert_s16(iq, mag, n, 2048.0f, ml, mp);
+        break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CRC-24 and single-bit syndrome tables (crc.c)                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static uint32_t g_crc_byte[256];
+static uint32_t g_bit_syndrome[112];
+static int g_crc_ready;
+
+/* crc.c:67-82 */
+uint32_t orc_checksum(const uint8_t *msg, int bits)
+{
+    int n = bits / 8;
+    uint32_t rem = 0;
+    for (int i = 0; i < n - 3; ++i)
+        rem = ((rem << 8) ^ g_crc_byte[msg[i] ^ ((rem >> 16) & 0xff)]) & 0xffffffu;
+    return rem ^ ((uint32_t)msg[n - 3] << 16) ^ ((uint32_t)msg[n - 2] << 8) ^ msg[n - 1];
+}
+
+/* crc.c:42-65 */
+static void build_crc_tables(void)
+{
+    if (g_crc_ready)
+        return;
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t c = b << 16;
+        for (int k = 0; k < 8; ++k)
+            c = (c & 0x800000u) ? ((c << 1) ^ CRC_POLY) : (c << 1);
+        g_crc_byte[b] = c & 0xffffffu;
+    }
+    g_crc_ready = 1; /* orc_checksum is usable from here */
+    uint8_t probe[14];
+    memset(probe, 0, sizeof probe);
+    for (int i = 0; i < 112; ++i) {
+        probe[i >> 3] ^= (uint8_t)(0x80u >> (i & 7));
+        g_bit_syndrome[i] = orc_checksum(probe, 112);
+        probe[i >> 3] ^= (uint8_t)(0x80u >> (i & 7));
+    }
+}
+
+static int by_syndrome(const void *a, const void *b)
+{
+    const struct syndrome_entry *x = a, *y = b;
+    return (int)x->syndrome - (int)y->syndrome; /* crc.c:94-98 */
+}
+
+/* crc.c:184-354 for max_correct == max_detect == 1: one entry per single-bit error in bits
+ * 5..bits-1 (the DF field is never "corrected"), syndromes taken at offset 112-bits, sorted.
+ * Single-bit syndromes are pairwise distinct, so the collision passes remove nothing. */
+static int build_syndrome_table(struct syndrome_entry *t, int bits)
+{
+    int n = 0;
+    for (int i = 5; i < bits; ++i) {
+        t[n].syndrome = g_bit_syndrome[i + 112 - bits];
+        t[n].bit = i;
+        ++n;
+    }
+    qsort(t, (size_t)n, sizeof t[0], by_syndrome);
+    return n;
+}
+
+/* crc.c:389-412 */
+int orc_diagnose(const orc_ctx *ctx, uint32_t syndrome, int bitlen, int bit[2])
+{
+    bit[0] = bit[1] = -1;
+    if (syndrome == 0)
+        return 0;
+    const struct syndrome_entry *t = (bitlen == 56) ? ctx->tab56 : ctx->tab112;
+    int n = (bitlen == 56) ? ctx->ntab56 : ctx->ntab112;
+    if (n == 0)
+        return -1; /* nfix_crc == 0: no table (crc.c:362-365,408-409) */
+    struct syndrome_entry key = {syndrome, 0};
+    const struct syndrome_entry *hit = bsearch(&key, t, (size_t)n, sizeof t[0], by_syndrome);
+    if (!hit)
+        return -1;
+    bit[0] = hit->bit;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ICAO address filter (icao_filter.c)                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* icao_filter.c:44-65, Jenkins one-at-a-time over the three address bytes */
+static uint32_t addr_hash(uint32_t a)
+{
+    uint32_t h = 0;
+    for (int k = 0; k < 3; ++k) {
+        h += (a >> (8 * k)) & 0xff;
+        h += h << 10;
+        h ^= h >> 6;
+    }
+    h += h << 3;
+    h ^= h >> 11;
+    h += h << 15;
+    return h & (FILTER_SLOTS - 1);
+}
+
+/* icao_filter.c:76-97 */
+void orc_filter_add(orc_ctx *ctx, uint32_t addr)
+{
+    uint32_t *t = ctx->filt[ctx->active];
+    uint32_t h0 = addr_hash(addr), h = h0;
+    int full = 0;
+    while (t[h] != FILTER_VACANT && t[h] != addr) {
+        h = (h + 1) & (FILTER_SLOTS - 1);
+        if (h == h0) {
+            full = 1;
+            break;
+        }
+    }
+    if (full)
+        return; /* icao_filter.c:82-85 returns before the second insert */
+    if (t[h] == FILTER_VACANT)
+        t[h] = addr;
+
+    /* second copy keyed by the low 16 bits (icao_filter.c:89-97) */
+    uint32_t low = addr & 0xffffu;
+    h0 = h = addr_hash(low);
+    while (t[h] != FILTER_VACANT && (t[h] & 0xffffu) != low) {
+        h = (h + 1) & (FILTER_SLOTS - 1);
+        if (h == h0)
+            return;
+    }
+    if (t[h] == FILTER_VACANT)
+        t[h] = addr;
+}
+
+/* icao_filter.c:99-119: table a first, then table b, exact match */
+int orc_filter_test(const orc_ctx *ctx, uint32_t addr)
+{
+    for (int which = 0; which < 2; ++which) {
+        const uint32_t *t = ctx->filt[which];
+        uint32_t h0 = addr_hash(addr), h = h0;
+        while (t[h] != FILTER_VACANT && t[h] != addr) {
+            h = (h + 1) & (FILTER_SLOTS - 1);
+            if (h == h0)
+                break;
+        }
+        if (t[h] == addr)
+            return 1;
+    }
+    return 0;
+}
+
+/* icao_filter.c:150-164 with mstime() == Modes.ifile_now (util.c:61-64) */
+static void filter_expire(orc_ctx *ctx)
+{
+    uint64_t now = ctx->ifile_now;
+    if (now >= ctx->next_flip) {
+        int other = ctx->active ^ 1;
+        memset(ctx->filt[other], 0xFF, sizeof ctx->filt[other]);
+        ctx->active = other;
+        ctx->next_flip = now + FILTER_TTL_MS;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* message scoring and the acceptance part of decode (mode_s.c)                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* mode_s.h:57-102 for the one call shape the path uses: bits 9..32 (the AA field) */
+static uint32_t field_aa(const uint8_t *msg)
+{
+    return ((uint32_t)msg[1] << 16) | ((uint32_t)msg[2] << 8) | msg[3];
+}
+
+/* mode_s.c:81-83 */
+static int bits_for_df(int df)
+{
+    return (df & 0x10) ? 112 : 56;
+}
+
+/* mode_s.c:266-281 for at most one error bit */
+static uint32_t aa_after_fix(uint32_t addr, int nerr, const int bit[2])
+{
+    for (int i = 0; i < nerr; ++i)
+        if (bit[i] >= 8 && bit[i] <= 31)
+            addr ^= 1u << (31 - bit[i]);
+    return addr;
+}
+
+static int all_zero(const uint8_t *p, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (p[i])
+            return 0;
+    return 1;
+}
+
+/* mode_s.c:311-409 */
+int orc_score(orc_ctx *ctx, const uint8_t *msg, int validbits)
+{
+    if (validbits < 56)
+        return -2;
+    int df = msg[0] >> 3;
+    int nbits = bits_for_df(df);
+    if (validbits < nbits)
+        return -2;
+    if (all_zero(msg, nbits / 8))
+        return -2;
+
+    uint32_t crc = orc_checksum(msg, nbits);
+    int bit[2], nerr;
+
+    switch (df) {
+    case 0: case 4: case 5: case 16:
+    case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+        return orc_filter_test(ctx, crc) ? 1000 : -1;
+
+    case 11: {
+        int iid = (int)(crc & 0x7f);
+        nerr = orc_diagnose(ctx, crc & 0xffff80u, nbits, bit);
+        if (nerr < 0 || nerr > 1)
+            return -2;
+        uint32_t addr = aa_after_fix(field_aa(msg), nerr, bit);
+        int known = orc_filter_test(ctx, addr);
+        if (iid == 0)
+            return (known ? 1600 : 750) / (nerr + 1);
+        return known ? 1000 / (nerr + 1) : -1;
+    }
+
+    case 17: case 18: {
+        nerr = orc_diagnose(ctx, crc, nbits, bit);
+        if (nerr < 0)
+            return -2;
+        uint32_t addr = aa_after_fix(field_aa(msg), nerr, bit);
+        return (orc_filter_test(ctx, addr) ? 1800 : 1400) / (nerr + 1);
+    }
+
+    case 20: case 21:
+        return orc_filter_test(ctx, crc) ? 1000 : -2;
+
+    default:
+        return -2;
+    }
+}
+
+/* mode_s.c:424-555 (CRC / address acceptance) and :717-726 (the only icaoFilterAdd call site).
+ * Field decoding in between never rejects.  Returns 0, -1 or -2 like decodeModesMessage. */
+static int decode_accept(orc_ctx *ctx, orc_message *mm, const uint8_t *raw)
+{
+    memcpy(mm->msg, raw, 14);
+    uint8_t *msg = mm->msg;
+    if (all_zero(msg, 7))
+        return -2;
+
+    int df = msg[0] >> 3;
+    mm->msgtype = (uint8_t)df;
+    mm->msgbits = (uint8_t)bits_for_df(df);
+    mm->crc = orc_checksum(msg, mm->msgbits);
+    mm->correctedbits = 0;
+    mm->addr = 0;
+    mm->iid = 0;
+    int bit[2], nerr;
+
+    switch (df) {
+    case 0: case 4: case 5: case 16:
+    case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+        if (!orc_filter_test(ctx, mm->crc))
+            return -1;
+        mm->addr = mm->crc;
+        break;
+
+    case 11:
+        mm->iid = (uint8_t)(mm->crc & 0x7f);
+        if (mm->crc & 0xffff80u) {
+            nerr = orc_diagnose(ctx, mm->crc & 0xffff80u, mm->msgbits, bit);
+            if (nerr < 0 || nerr > 1)
+                return -2;
+            mm->correctedbits = (uint8_t)nerr;
+            for (int i = 0; i < nerr; ++i) /* crc.c:417-425 */
+                msg[bit[i] >> 3] ^= (uint8_t)(0x80u >> (bit[i] & 7));
+            if (!orc_filter_test(ctx, field_aa(msg)))
+                return -1; /* corrected DF11 must match a known aircraft, mode_s.c:492-498 */
+        }
+        break;
+
+    case 17: case 18:
+        if (mm->crc != 0) {
+            nerr = orc_diagnose(ctx, mm->crc, mm->msgbits, bit);
+            if (nerr < 0)
+                return -2;
+            uint32_t before = field_aa(msg);
+            mm->correctedbits = (uint8_t)nerr;
+            for (int i = 0; i < nerr; ++i)
+                msg[bit[i] >> 3] ^= (uint8_t)(0x80u >> (bit[i] & 7));
+            uint32_t after = field_aa(msg);
+            if (before != after && !orc_filter_test(ctx, after))
+                return -1; /* mode_s.c:522-526 */
+        }
+        break;
+
+    case 20: case 21:
+        if (!orc_filter_test(ctx, mm->crc))
+            return -1;
+        mm->addr = mm->crc;
+        break;
+
+    default:
+        return -2;
+    }
+
+    if (df == 11 || df == 17 || df == 18)
+        mm->addr = field_aa(msg); /* mode_s.c:559-562 */
+
+    if (!mm->correctedbits && (df == 17 || (df == 11 && mm->iid == 0)))
+        orc_filter_add(ctx, mm->addr); /* mode_s.c:717-726 */
+    /* the reference leaves stale bytes of an earlier trial behind a short message
+     * (demod_2400.c:207-209 only writes bytelen bytes); report zeros there instead */
+    memset(msg + mm->msgbits / 8, 0, (size_t)(14 - mm->msgbits / 8));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Mode S demodulator (demod_2400.c:73-428)                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* demod_2400.c:73-93 */
+static int correlate(const uint16_t *m, int which)
+{
+    switch (which) {
+    case 0: return 18 * m[0] - 15 * m[1] - 3 * m[2];
+    case 1: return 14 * m[0] - 5 * m[1] - 9 * m[2];
+    case 2: return 16 * m[0] + 5 * m[1] - 20 * m[2];
+    case 3: return 7 * m[0] + 11 * m[1] - 18 * m[2];
+    default: return 4 * m[0] + 15 * m[1] - 20 * m[2] + 1 * m[3];
+    }
+}
+
+/* demod_2400.c:98-177 as data: for each starting phase, the (sample offset, correlator) of the
+ * eight bits of one byte, and how far the read pointer advances afterwards. */
+static const struct { uint8_t off[8], cor[8], advance; } byte_plan[5] = {
+    {{0, 2, 4, 7, 9, 12, 14, 16}, {0, 2, 4, 1, 3, 0, 2, 4}, 19},
+    {{0, 2, 5, 7, 9, 12, 14, 17}, {1, 3, 0, 2, 4, 1, 3, 0}, 19},
+    {{0, 2, 5, 7, 10, 12, 14, 17}, {2, 4, 1, 3, 0, 2, 4, 1}, 19},
+    {{0, 3, 5, 7, 10, 12, 15, 17}, {3, 0, 2, 4, 1, 3, 0, 2}, 19},
+    {{0, 3, 5, 8, 10, 12, 15, 17}, {4, 1, 3, 0, 2, 4, 1, 3}, 20},
+};
+
+void orc_slice(const uint16_t *m, uint32_t j, int try_phase, int nbytes, uint8_t *out)
+{
+    const uint16_t *p = &m[j + 19] + try_phase / 5; /* demod_2400.c:188 */
+    int phase = try_phase % 5;                      /* demod_2400.c:189 */
+    for (int b = 0; b < nbytes; ++b) {
+        unsigned v = 0;
+        for (int k = 0; k < 8; ++k)
+            v = (v << 1) | (correlate(p + byte_plan[phase].off[k], byte_plan[phase].cor[k]) > 0);
+        out[b] = (uint8_t)v;
+        p += byte_plan[phase].advance;
+        phase = (phase + 1) % 5;
+    }
+}
+
+struct trial_state {
+    uint8_t store[2][14];
+    int cur; /* which store the next trial writes into (demod_2400.c:227 ping-pong) */
+    const uint8_t *best;
+    int bestscore, bestphase;
+};
+
+/* demod_2400.c:183-229 */
+static void try_phase(orc_ctx *ctx, const uint16_t *m, uint32_t j, int tp, struct trial_state *ts)
+{
+    ctx->st.demod_preamblePhase[tp - 4]++;
+    uint8_t *msg = ts->store[ts->cur];
+    orc_slice(m, j, tp, 1, msg);
+    int nbytes;
+    switch (msg[0] >> 3) {
+    case 0: case 4: case 5: case 11:
+        nbytes = 7;
+        break;
+    case 16: case 17: case 18: case 20: case 21: case 24:
+        nbytes = 14;
+        break;
+    default:
+        nbytes = 1;
+        break;
+    }
+    int score = -2;
+    if (nbytes > 1) {
+        orc_slice(m, j, tp, nbytes, msg);
+        score = orc_score(ctx, msg, nbytes * 8);
+    }
+    if (score > ts->bestscore) { /* strict: the first-tried phase wins ties */
+        ts->best = msg;
+        ts->bestscore = score;
+        ts->bestphase = tp;
+        ts->cur ^= 1;
+    }
+}
+
+static void emit(orc_message *out, size_t cap, size_t *nout, const orc_message *mm)
+{
+    if (*nout < cap)
+        out[*nout] = *mm;
+    ++*nout;
+}
+
+/* demod_2400.c:236-428 */
+static void demod_mode_s(orc_ctx *ctx, const uint16_t *m, unsigned valid_length,
+                         uint64_t sample_ts, uint64_t sys_ts, double mean_power, orc_message *out,
+                         size_t cap, size_t *nout)
+{
+    uint32_t mlen = valid_length - ORC_OVERLAP;
+    uint64_t sum_scaled_signal_power = 0;
+    struct trial_state ts;
+    memset(&ts, 0, sizeof ts);
+
+    ctx->ifile_now = sys_ts; /* demod_2400.c:252-255 */
+
+    for (uint32_t j = 0; j < mlen; j++) {
+        const uint16_t *pa = &m[j];
+
+        if (!(pa[1] > pa[7] && pa[12] > pa[14] && pa[12] > pa[15]))
+            continue; /* demod_2400.c:276 */
+
+        int32_t base_noise = pa[5] + pa[8] + pa[16] + pa[17] + pa[18];
+        /* samples_dropped is always 0 for ifile input, so demod_2400.c:286-288 is inert */
+        int32_t ref_level = (int32_t)((uint32_t)base_noise * (uint32_t)ctx->threshold);
+        ref_level >>= 5;
+
+        ts.best = NULL;
+        ts.bestscore = -42;
+        ts.bestphase = -1;
+
+        int32_t diff_2_3 = pa[2] - pa[3];
+        int32_t sum_1_4 = pa[1] + pa[4];
+        int32_t diff_10_11 = pa[10] - pa[11];
+        int32_t common3456 = sum_1_4 - diff_2_3 + pa[9] + pa[12];
+
+        if (common3456 - diff_10_11 >= ref_level) {
+            try_phase(ctx, m, j, 4, &ts);
+            try_phase(ctx, m, j, 5, &ts);
+        }
+        if (common3456 + diff_10_11 >= ref_level) {
+            try_phase(ctx, m, j, 6, &ts);
+            try_phase(ctx, m, j, 7, &ts);
+        }
+        if (sum_1_4 + 2 * diff_2_3 + diff_10_11 + pa[12] >= ref_level)
+            try_phase(ctx, m, j, 8, &ts);
+
+        if (ts.bestscore == -42)
+            continue;
+
+        ctx->st.demod_preambles++;
+
+        if (ts.bestscore < 0) {
+            if (ts.bestscore == -1)
+                ctx->st.demod_rejected_unknown_icao++;
+            else
+                ctx->st.demod_rejected_bad++;
+            continue;
+        }
+
+        int msglen = bits_for_df(ts.best[0] >> 3);
+
+        orc_message mm;
+        memset(&mm, 0, sizeof mm);
+        mm.timestampMsg = sample_ts + j * 5 + (8 + 56) * 12 + (unsigned)ts.bestphase;
+        mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u; /* util.c:79-81 */
+        ctx->ifile_now = mm.sysTimestampMsg; /* demod_2400.c:363-366 */
+        mm.score = ts.bestscore;
+        mm.bestphase = (uint8_t)ts.bestphase;
+
+        int result = decode_accept(ctx, &mm, ts.best);
+        if (result < 0) {
+            if (result == -1)
+                ctx->st.demod_rejected_unknown_icao++;
+            else
+                ctx->st.demod_rejected_bad++;
+            continue;
+        }
+        ctx->st.demod_accepted[mm.correctedbits]++;
+        ctx->st.demod_bestPhase[ts.bestphase - 4]++;
+
+        { /* demod_2400.c:386-408 */
+            uint64_t scaled = 0;
+            int signal_len = msglen * 12 / 5;
+            for (int k = 0; k < signal_len; ++k) {
+                uint32_t v = m[j + 19 + k];
+                scaled += v * v;
+            }
+            double signal_power = scaled / 65535.0 / 65535.0;
+            mm.signalLevel = signal_power / signal_len;
+            ctx->st.signal_power_sum += signal_power;
+            ctx->st.signal_power_count += (uint64_t)signal_len;
+            sum_scaled_signal_power += scaled;
+            if (mm.signalLevel > ctx->st.peak_signal_power)
+                ctx->st.peak_signal_power = mm.signalLevel;
+            if (mm.signalLevel > 0.50119)
+                ctx->st.strong_signal_count++;
+        }
+
+        j += (uint32_t)(msglen * 12 / 5); /* demod_2400.c:416 */
+        emit(out, cap, nout, &mm);         /* useModesMessage, demod_2400.c:419 */
+    }
+
+    { /* demod_2400.c:422-427 */
+        double sum_signal_power = sum_scaled_signal_power / 65535.0 / 65535.0;
+        ctx->st.noise_power_sum += (mean_power * mlen - sum_signal_power);
+        ctx->st.noise_power_count += mlen;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Mode A/C demodulator (demod_2400.c:522-708)                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+static void demod_mode_ac(orc_ctx *ctx, const uint16_t *m, unsigned valid_length,
+                          uint64_t sample_ts, uint64_t sys_ts, double mean_level,
+                          double mean_power, orc_message *out, size_t cap, size_t *nout)
+{
+    uint32_t mlen = valid_length - ORC_OVERLAP;
+    double noise_stddev = sqrt(mean_power - mean_level * mean_level);
+    unsigned noise_level = (unsigned)((mean_power + noise_stddev) * 65535 + 0.5);
+
+    for (unsigned f1_sample = 1; f1_sample < mlen; ++f1_sample) {
+        if (!(m[f1_sample - 1] < m[f1_sample + 0]))
+            continue;
+        if (m[f1_sample + 2] > m[f1_sample + 0] || m[f1_sample + 2] > m[f1_sample + 1])
+            continue;
+        unsigned f1_level = (m[f1_sample + 0] + m[f1_sample + 1]) / 2;
+        if (noise_level * 2 > f1_level)
+            continue;
+
+        float f1a_power = (float)m[f1_sample] * m[f1_sample];
+        float f1b_power = (float)m[f1_sample + 1] * m[f1_sample + 1];
+        float fraction = f1b_power / (f1a_power + f1b_power);
+        unsigned f1_clock = (unsigned)(25 * (f1_sample + fraction * fraction) + 0.5);
+
+        unsigned f2_clock = f1_clock + (87 * 14);
+        unsigned f2_sample = f2_clock / 25;
+
+        if (!(m[f2_sample - 1] < m[f2_sample + 0]))
+            continue;
+        if (m[f2_sample + 2] > m[f2_sample + 0] || m[f2_sample + 2] > m[f2_sample + 1])
+            continue;
+        unsigned f2_level = (m[f2_sample + 0] + m[f2_sample + 1]) / 2;
+        if (noise_level * 2 > f2_level)
+            continue;
+
+        unsigned f1f2_level = (f1_level > f2_level ? f1_level : f2_level);
+        float midpoint = sqrtf(noise_level * f1f2_level); /* u32 product, may wrap */
+        unsigned signal_threshold = (unsigned)(midpoint * M_SQRT2 + 0.5);
+        unsigned noise_threshold = (unsigned)(midpoint / M_SQRT2 + 0.5);
+
+        unsigned uncertain_bits = 0, noisy_bits = 0, bits = 0;
+        unsigned clock = f1_clock;
+        for (unsigned bit = 0; bit < 20; ++bit, clock += 87) {
+            unsigned sample = clock / 25;
+            bits <<= 1;
+            noisy_bits <<= 1;
+            uncertain_bits <<= 1;
+            if (m[sample + 2] >= signal_threshold)
+                noisy_bits |= 1;
+            if (m[sample + 0] >= signal_threshold || m[sample + 1] >= signal_threshold)
+                bits |= 1;
+            else if (m[sample + 0] > noise_threshold && m[sample + 1] > noise_threshold)
+                uncertain_bits |= 1;
+        }
+
+        if ((bits & 0x80020) != 0x80020)
+            continue;
+        if ((bits & 0x0101B) != 0)
+            continue;
+        if (noisy_bits || uncertain_bits)
+            continue;
+
+        /* demod_2400.c:672-685: 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 */
+        static const struct { unsigned from, to; } perm[13] = {
+            {0x40000, 0x0010}, {0x20000, 0x1000}, {0x10000, 0x0020}, {0x08000, 0x2000},
+            {0x04000, 0x0040}, {0x02000, 0x4000}, {0x00800, 0x0100}, {0x00400, 0x0001},
+            {0x00200, 0x0200}, {0x00100, 0x0002}, {0x00080, 0x0400}, {0x00040, 0x0004},
+            {0x00004, 0x0080},
+        };
+        unsigned modeac = 0;
+        for (int k = 0; k < 13; ++k)
+            if (bits & perm[k].from)
+                modeac |= perm[k].to;
+
+        orc_message mm;
+        memset(&mm, 0, sizeof mm);
+        mm.timestampMsg = sample_ts + f2_clock / 5;
+        mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+        /* mode_ac.c:168-202, identity part */
+        mm.msgtype = 32;
+        mm.msgbits = 16;
+        mm.msg[0] = (uint8_t)(modeac >> 8);
+        mm.msg[1] = (uint8_t)modeac;
+        mm.addr = (modeac & 0x0000FF7Fu) | 0x01000000u; /* MODES_NON_ICAO_ADDRESS, readsb.h */
+        emit(out, cap, nout, &mm);
+
+        f1_sample += (20 * 87 / 25);
+        ctx->st.demod_modeac++;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* buffer and capture level (readsb.c:820-855, sdr_ifile.c:164-237, fifo.c:166-201)           */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_demod_buffer(orc_ctx *ctx, const uint16_t *data, unsigned valid_length,
+                      uint64_t sample_ts, uint64_t sys_ts, double mean_level, double mean_power,
+                      orc_message *out, size_t cap, size_t *nout)
+{
+    demod_mode_s(ctx, data, valid_length, sample_ts, sys_ts, mean_power, out, cap, nout);
+    if (ctx->mode_ac)
+        demod_mode_ac(ctx, data, valid_length, sample_ts, sys_ts, mean_level, mean_power, out, cap,
+                      nout);
+    ctx->st.samples_processed += valid_length; /* readsb.c:835 */
+    ctx->st.buffers++;
+    filter_expire(ctx); /* backgroundTasks, readsb.c:331; order fixed as "demod, then expire" */
+}
+
+uint64_t orc_replay(orc_ctx *ctx, const void *iq, uint64_t nsamples, orc_message *out, size_t cap,
+                    size_t *nout, double *chunk_means, size_t means_cap)
+{
+    const unsigned bps = (ctx->format == ORC_FMT_UC8) ? 2u : 4u; /* sdr_ifile.c:130-141 */
+    const uint8_t *src = iq;
+    uint64_t sample_counter = 0, nbuf = 0;
+    int eof = 0;
+    *nout = 0;
+
+    while (!eof) {
+        uint64_t sample_ts = (uint64_t)(sample_counter * 12e6 / 2400000.0); /* sdr_ifile.c:187 */
+        uint64_t sys_ts = sample_ts / 12000u;                               /* startup_time = 0 */
+
+        uint64_t left = nsamples - sample_counter;
+        unsigned got = (left >= ORC_CHUNK_SAMPLES) ? ORC_CHUNK_SAMPLES : (unsigned)left;
+        if (got < ORC_CHUNK_SAMPLES)
+            eof = 1; /* short read => EOF (sdr_ifile.c:197-209); an exact multiple therefore
+                        yields one more, empty, buffer */
+
+        double mean_level, mean_power;
+        orc_convert(ctx, src + sample_counter * bps, &ctx->buf[ORC_OVERLAP], got, &mean_level,
+                    &mean_power);
+        unsigned valid_length = ORC_OVERLAP + got;
+
+        /* fifo.c:179-188 */
+        memcpy(ctx->buf, ctx->carry, sizeof ctx->carry);
+        memcpy(ctx->carry, &ctx->buf[valid_length - ORC_OVERLAP], sizeof ctx->carry);
+
+        if (chunk_means && nbuf < means_cap) {
+            chunk_means[2 * nbuf] = mean_level;
+            chunk_means[2 * nbuf + 1] = mean_power;
+        }
+        orc_demod_buffer(ctx, ctx->buf, valid_length, sample_ts, sys_ts, mean_level, mean_power,
+                         out, cap, nout);
+        sample_counter += got;
+        ++nbuf;
+    }
+    return nbuf;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+
+orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_ac)
+{
+    if (format < ORC_FMT_UC8 || format > ORC_FMT_SC16Q11 || nfix_crc < 0 || nfix_crc > 1)
+        return NULL; /* nfix_crc == 2 (--aggressive) is outside the configs, SURVEY.md 8(f) */
+    orc_ctx *ctx = calloc(1, sizeof *ctx);
+    if (!ctx)
+        return NULL;
+    ctx->buf = calloc(ORC_CHUNK_SAMPLES + ORC_OVERLAP, sizeof ctx->buf[0]);
+    if (!ctx->buf) {
+        free(ctx);
+        return NULL;
+    }
+    ctx->format = format;
+    ctx->threshold = preamble_threshold;
+    ctx->nfix = nfix_crc;
+    ctx->mode_ac = mode_ac;
+    build_uc8_table();
+    build_crc_tables();
+    if (nfix_crc == 1) { /* crc.c:367-372 */
+        ctx->ntab56 = build_syndrome_table(ctx->tab56, 56);
+        ctx->ntab112 = build_syndrome_table(ctx->tab112, 112);
+    }
+    memset(ctx->filt, 0xFF, sizeof ctx->filt); /* icao_filter.c:67-71 */
+    ctx->active = 0;
+    ctx->next_flip = 0;
+    return ctx;
+}
+
+void orc_destroy(orc_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    free(ctx->buf);
+    free(ctx);
+}
+
+void orc_get_stats(const orc_ctx *ctx, orc_stats *st)
+{
+    *st = ctx->st;
+}

@@ -1,0 +1,203 @@
+"""ctypes binding of oracle/libmodes_oracle.so -- the CPU restatement used as the parity checker.
+
+TEST INFRASTRUCTURE ONLY ("parity unpinned" for the demodulator, see modes_oracle.h).  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmodes_oracle.so")
+
+FMT_UC8, FMT_SC16, FMT_SC16Q11 = 0, 1, 2
+CHUNK = 131072
+OVERLAP = 326
+
+# numpy mirror of orc_message (modes_oracle.h)
+MESSAGE_DTYPE = np.dtype(
+    [
+        ("timestampMsg", "<u8"),
+        ("sysTimestampMsg", "<u8"),
+        ("signalLevel", "<f8"),
+        ("addr", "<u4"),
+        ("crc", "<u4"),
+        ("score", "<i4"),
+        ("msgtype", "u1"),
+        ("msgbits", "u1"),
+        ("correctedbits", "u1"),
+        ("bestphase", "u1"),
+        ("msg", "u1", (14,)),
+        ("iid", "u1"),
+        ("pad", "u1"),
+    ],
+    align=True,
+)
+assert MESSAGE_DTYPE.itemsize == 56
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("demod_preambles", C.c_uint64),
+        ("demod_rejected_bad", C.c_uint64),
+        ("demod_rejected_unknown_icao", C.c_uint64),
+        ("demod_accepted", C.c_uint64 * 3),
+        ("demod_preamblePhase", C.c_uint64 * 5),
+        ("demod_bestPhase", C.c_uint64 * 5),
+        ("demod_modeac", C.c_uint64),
+        ("strong_signal_count", C.c_uint64),
+        ("samples_processed", C.c_uint64),
+        ("noise_power_count", C.c_uint64),
+        ("signal_power_count", C.c_uint64),
+        ("noise_power_sum", C.c_double),
+        ("signal_power_sum", C.c_double),
+        ("peak_signal_power", C.c_double),
+        ("buffers", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+def build(force=False):
+    """Compile the restatement with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "modes_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "modes_oracle.h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmodes_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int] * 4
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_replay.restype = C.c_uint64
+        L.orc_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
+                                 C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+        L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.orc_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]
+        L.orc_uc8_table.restype = C.POINTER(C.c_uint16)
+        L.orc_checksum.restype = C.c_uint32
+        L.orc_checksum.argtypes = [C.c_char_p, C.c_int]
+        L.orc_diagnose.restype = C.c_int
+        L.orc_diagnose.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_int * 2)]
+        L.orc_score.restype = C.c_int
+        L.orc_score.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_filter_add.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_filter_test.restype = C.c_int
+        L.orc_filter_test.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_slice.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.orc_demod_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64,
+                                       C.c_double, C.c_double, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """One receiver context (its own ICAO filter, clock and counters)."""
+
+    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0):
+        self._h = lib().orc_create(fmt, preamble_threshold, nfix_crc, mode_ac)
+        if not self._h:
+            raise ValueError("orc_create rejected the configuration")
+        self.fmt = fmt
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def bytes_per_sample(self):
+        return 2 if self.fmt == FMT_UC8 else 4
+
+    def replay(self, iq, cap=None, want_means=False):
+        """Run a whole capture (bytes-like / uint8 array).  Returns (messages, stats[, means])."""
+        iq = np.ascontiguousarray(np.frombuffer(iq, dtype=np.uint8) if not isinstance(iq, np.ndarray)
+                                  else iq.view(np.uint8).reshape(-1))
+        nsamples = iq.size // self.bytes_per_sample
+        if cap is None:
+            cap = max(1024, nsamples // 100)
+        nbuf_max = nsamples // CHUNK + 1
+        means = np.zeros((nbuf_max, 2), dtype=np.float64) if want_means else None
+        while True:
+            out = np.zeros(cap, dtype=MESSAGE_DTYPE)
+            n = C.c_size_t(0)
+            lib().orc_replay(self._h, iq.ctypes.data, nsamples, out.ctypes.data, cap, C.byref(n),
+                             means.ctypes.data if want_means else None, nbuf_max)
+            if n.value <= cap:
+                break
+            raise RuntimeError(f"oracle produced {n.value} messages, cap {cap}: use a fresh Oracle "
+                               "with a larger cap (contexts are stateful)")
+        msgs = out[: n.value]
+        return (msgs, self.stats(), means) if want_means else (msgs, self.stats())
+
+    def stats(self):
+        st = Stats()
+        lib().orc_get_stats(self._h, C.byref(st))
+        return st.as_dict()
+
+    def convert(self, iq, nsamples):
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        mag = np.zeros(nsamples, dtype=np.uint16)
+        ml, mp = C.c_double(), C.c_double()
+        lib().orc_convert(self._h, iq.ctypes.data, mag.ctypes.data, nsamples, C.byref(ml), C.byref(mp))
+        return mag, ml.value, mp.value
+
+    def score(self, msg: bytes, validbits=None):
+        return lib().orc_score(self._h, bytes(msg), validbits if validbits is not None else len(msg) * 8)
+
+    def diagnose(self, syndrome, bitlen):
+        bits = (C.c_int * 2)()
+        n = lib().orc_diagnose(self._h, syndrome, bitlen, C.byref(bits))
+        return n, list(bits)
+
+    def filter_add(self, addr):
+        lib().orc_filter_add(self._h, addr)
+
+    def filter_test(self, addr):
+        return bool(lib().orc_filter_test(self._h, addr))
+
+    def demod_buffer(self, data, sample_ts=0, sys_ts=0, mean_level=0.0, mean_power=0.0, cap=4096):
+        data = np.ascontiguousarray(data, dtype=np.uint16)
+        out = np.zeros(cap, dtype=MESSAGE_DTYPE)
+        n = C.c_size_t(0)
+        lib().orc_demod_buffer(self._h, data.ctypes.data, data.size, sample_ts, sys_ts, mean_level,
+                               mean_power, out.ctypes.data, cap, C.byref(n))
+        return out[: n.value]
+
+
+def checksum(msg: bytes) -> int:
+    lib().orc_create(0, 58, 0, 0)  # makes sure the static tables exist (leaks one tiny ctx once)
+    return lib().orc_checksum(bytes(msg), len(msg) * 8)
+
+
+def uc8_table():
+    return np.ctypeslib.as_array(lib().orc_uc8_table(), shape=(65536,)).copy()
+
+
+def slice_bytes(mag, j, try_phase, nbytes):
+    mag = np.ascontiguousarray(mag, dtype=np.uint16)
+    out = np.zeros(nbytes, dtype=np.uint8)
+    lib().orc_slice(mag.ctypes.data, j, try_phase, nbytes, out.ctypes.data)
+    return out

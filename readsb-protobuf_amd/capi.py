@@ -1,0 +1,282 @@
+"""ctypes binding of include/modes_hip.h (libmodes_hip.so) -- the Python face of the C-ABI.
+
+The binding mirrors the reference's interfaces for this path:
+  Demodulator.convert(...)            <-> iq_convert_fn            convert.h:33-38
+  Demodulator.demodulate_magbuf(...)  <-> demodulate2400[AC] + icaoFilterExpire   demod_2400.h:37-38
+  Demodulator.submit_*/launch/collect <-> ifileRun + the consumer loop   sdr_ifile.c:164-237
+There is no CPU fallback: loading or creating a context without the HIP library / a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmodes_hip.so")
+
+FMT_UC8, FMT_SC16, FMT_SC16Q11, FMT_MAG16 = 0, 1, 2, 3
+CHUNK = 131072
+OVERLAP = 326
+PIPELINE_DEPTH = 2
+
+MESSAGE_DTYPE = np.dtype(
+    [
+        ("timestampMsg", "<u8"),
+        ("sysTimestampMsg", "<u8"),
+        ("signalLevel", "<f8"),
+        ("addr", "<u4"),
+        ("crc", "<u4"),
+        ("score", "<i4"),
+        ("msgtype", "u1"),
+        ("msgbits", "u1"),
+        ("correctedbits", "u1"),
+        ("bestphase", "u1"),
+        ("msg", "u1", (14,)),
+        ("iid", "u1"),
+        ("pad", "u1"),
+    ],
+    align=True,
+)
+assert MESSAGE_DTYPE.itemsize == 56
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("format", C.c_int32),
+        ("preamble_threshold", C.c_int32),
+        ("nfix_crc", C.c_int32),
+        ("mode_ac", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("max_batch_samples", C.c_uint64),
+        ("stream", C.c_void_p),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("demod_preambles", C.c_uint64),
+        ("demod_rejected_bad", C.c_uint64),
+        ("demod_rejected_unknown_icao", C.c_uint64),
+        ("demod_accepted", C.c_uint64 * 3),
+        ("demod_preamblePhase", C.c_uint64 * 5),
+        ("demod_bestPhase", C.c_uint64 * 5),
+        ("demod_modeac", C.c_uint64),
+        ("strong_signal_count", C.c_uint64),
+        ("samples_processed", C.c_uint64),
+        ("noise_power_count", C.c_uint64),
+        ("signal_power_count", C.c_uint64),
+        ("noise_power_sum", C.c_double),
+        ("signal_power_sum", C.c_double),
+        ("peak_signal_power", C.c_double),
+        ("buffers", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("scan_kernel_ms", C.c_float),
+        ("other_kernels_ms", C.c_float),
+        ("d2h_ms", C.c_float),
+        ("resolve_ms", C.c_float),
+        ("hits", C.c_uint64),
+        ("tries", C.c_uint64),
+        ("reruns", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class _SinkState(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("cap", C.c_size_t), ("count", C.c_size_t)]
+
+
+EXPORTS = [
+    "msd_create", "msd_destroy", "msd_last_error", "msd_submit_device", "msd_submit_host", "msd_reset",
+    "msd_launch_device", "msd_collect", "msd_get_stats", "msd_get_timing", "msd_get_buffer_means",
+    "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmodes_hip.so (built in-tree by __graft_entry__.build()); fail loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                               "there is no CPU fallback for the demodulator")
+        L = C.CDLL(LIB_PATH)
+        L.msd_create.restype = C.c_int
+        L.msd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.msd_destroy.argtypes = [C.c_void_p]
+        L.msd_last_error.restype = C.c_char_p
+        L.msd_last_error.argtypes = [C.c_void_p]
+        for name in ("msd_submit_device", "msd_submit_host"):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.msd_reset.restype = C.c_int
+        L.msd_reset.argtypes = [C.c_void_p]
+        L.msd_launch_device.restype = C.c_int
+        L.msd_launch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        L.msd_collect.restype = C.c_int
+        L.msd_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.msd_get_stats.restype = C.c_int
+        L.msd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.msd_get_timing.restype = C.c_int
+        L.msd_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.msd_get_buffer_means.restype = C.c_int
+        L.msd_get_buffer_means.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.msd_convert.restype = C.c_int
+        L.msd_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double)]
+        L.msd_demodulate_magbuf.restype = C.c_int
+        L.msd_demodulate_magbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64,
+                                            C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class MsdError(RuntimeError):
+    pass
+
+
+class Demodulator:
+    """One receiver context on one GPU (its own ICAO filter, clock, counters and HIP streams)."""
+
+    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, device=0,
+                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16):
+        self._h = C.c_void_p()
+        self.fmt = fmt
+        cfg = Config(device=device, format=fmt, preamble_threshold=preamble_threshold, nfix_crc=nfix_crc,
+                     mode_ac=mode_ac, reserved0=0, max_batch_samples=max_batch_samples,
+                     stream=C.c_void_p(stream) if stream else None)
+        rc = lib().msd_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MsdError(f"msd_create failed: {os.strerror(-rc)} ({rc})")
+        self._sink_fn = C.cast(lib().msd_array_sink, C.c_void_p)
+        self._buf = np.zeros(message_capacity, dtype=MESSAGE_DTYPE)
+        self._chunks = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().msd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bytes_per_sample(self):
+        return 2 if self.fmt in (FMT_UC8, FMT_MAG16) else 4
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MsdError(f"{lib().msd_last_error(self._h).decode()} ({os.strerror(-rc)}, {rc})")
+
+    def _run(self, call):
+        """Run one C call that delivers messages; returns them as a structured array."""
+        while True:
+            st = _SinkState(self._buf.ctypes.data, self._buf.size, 0)
+            rc = call(self._sink_fn, C.byref(st))
+            self._check(rc)
+            if st.count <= self._buf.size:
+                return self._buf[: st.count].copy()
+            # a context is stateful, so a too-small array cannot simply be retried: grow ahead of time
+            raise MsdError(f"message array too small ({st.count} > {self._buf.size}); "
+                           "construct the Demodulator with a larger message_capacity")
+
+    def reserve_messages(self, n):
+        if n > self._buf.size:
+            self._buf = np.zeros(n, dtype=MESSAGE_DTYPE)
+
+    # --- streaming interface -------------------------------------------------------------------
+    def submit_device(self, dptr, nsamples, last=True):
+        return self._run(lambda fn, st: lib().msd_submit_device(self._h, C.c_void_p(dptr), nsamples, int(last), fn, st))
+
+    def submit_host(self, iq, nsamples=None, last=True):
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        if nsamples is None:
+            nsamples = iq.size // self.bytes_per_sample
+        return self._run(lambda fn, st: lib().msd_submit_host(self._h, iq.ctypes.data, nsamples, int(last), fn, st))
+
+    def launch_device(self, dptr, nsamples, last=False):
+        self._check(lib().msd_launch_device(self._h, C.c_void_p(dptr), nsamples, int(last)))
+
+    def collect(self):
+        return self._run(lambda fn, st: lib().msd_collect(self._h, fn, st))
+
+    def reset(self):
+        self._check(lib().msd_reset(self._h))
+
+    def stats(self):
+        st = Stats()
+        self._check(lib().msd_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def timing(self):
+        t = Timing()
+        self._check(lib().msd_get_timing(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def buffer_means(self, cap=1 << 16):
+        out = np.zeros((cap, 2), dtype=np.float64)
+        n = lib().msd_get_buffer_means(self._h, out.ctypes.data, cap)
+        if n < 0:
+            self._check(n)
+        return out[: min(n, cap)].copy()
+
+    # --- iq_convert_fn ---------------------------------------------------------------------------
+    def convert(self, iq, nsamples):
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        mag = np.zeros(nsamples, dtype=np.uint16)
+        ml, mp = C.c_double(), C.c_double()
+        self._check(lib().msd_convert(self._h, iq.ctypes.data, mag.ctypes.data, nsamples, C.byref(ml), C.byref(mp)))
+        return mag, ml.value, mp.value
+
+    # --- demodulate2400(struct mag_buf *) ----------------------------------------------------------
+    def demodulate_magbuf(self, data, valid_length=None, overlap=OVERLAP, sample_timestamp=0, sys_timestamp=0,
+                          mean_level=0.0, mean_power=0.0):
+        data = np.ascontiguousarray(data, dtype=np.uint16)
+        if valid_length is None:
+            valid_length = data.size
+        return self._run(lambda fn, st: lib().msd_demodulate_magbuf(
+            self._h, data.ctypes.data, valid_length, overlap, sample_timestamp, sys_timestamp, mean_level,
+            mean_power, fn, st))
+
+
+def replay_device(demod, dptr, nsamples, batch_samples):
+    """Replay a device-resident capture through the two-deep pipeline; returns all messages."""
+    bps = demod.bytes_per_sample
+    out = []
+    off = 0
+    inflight = 0
+    while True:
+        n = min(batch_samples, nsamples - off)
+        last = off + n >= nsamples
+        if inflight == PIPELINE_DEPTH:
+            out.append(demod.collect())
+            inflight -= 1
+        demod.launch_device(dptr + off * bps, n, last)
+        inflight += 1
+        off += n
+        if last:
+            break
+    while inflight:
+        out.append(demod.collect())
+        inflight -= 1
+    return np.concatenate(out) if out else np.zeros(0, dtype=MESSAGE_DTYPE)

@@ -1,0 +1,705 @@
+/*
+ * msd_capi.cpp -- the C-ABI of include/modes_hip.h: context, device memory, launch order, the
+ * two-deep batch pipeline, and the hand-off to the ordered resolve stage (msd_resolve.c).
+ *
+ * Stream layout per context:
+ *   compute stream : memset sums -> scan kernel -> offsets+gather [-> float means] (per batch)
+ *   copy stream    : waits on the batch's "kernels done" event, then D2H totals / lists / sums,
+ *                    so a batch's download overlaps the next batch's kernels.
+ * The host resolve of batch k runs while the GPU works on batch k+1 (msd_launch_device /
+ * msd_collect); msd_submit_* is the depth-1 synchronous form.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "modes_hip.h"
+#include "msd_internal.h"
+#include "msd_kernels.h"
+
+extern "C" int msd_tables_selftest(const msd_tables *t);
+
+namespace {
+
+constexpr uint64_t MIN_HIT_ARENA = 131072;      /* every position of one buffer */
+constexpr uint64_t MIN_TRY_ARENA = 131072 * 5;  /* every phase of every position of one buffer */
+constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
+
+struct Slot {
+    bool busy = false;
+    /* batch description */
+    const uint8_t *d_iq = nullptr;
+    const uint8_t *d_prev = nullptr;
+    int have_prev = 0;
+    uint64_t batch_first = 0; /* absolute sample index */
+    uint64_t nsamples = 0;
+    uint32_t nbuffers = 0;
+    int last = 0;
+    /* device */
+    msd_hit *d_hits = nullptr;
+    msd_try *d_tries = nullptr;
+    uint64_t *d_totals = nullptr;
+    uint64_t *d_sums = nullptr;
+    float *d_fmeans = nullptr;
+    /* pinned host */
+    uint64_t *h_totals = nullptr;
+    uint64_t *h_sums = nullptr;
+    float *h_fmeans = nullptr;
+    msd_hit *h_hits = nullptr;
+    size_t h_hits_cap = 0;
+    msd_try *h_tries = nullptr;
+    size_t h_tries_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_kernels = nullptr, ev_totals = nullptr,
+               ev_copy0 = nullptr, ev_copy1 = nullptr;
+};
+
+} /* namespace */
+
+struct msd_ctx {
+    msd_config cfg{};
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    bool own_stream = false;
+    int bps = 2;
+    msd_tables *tables = nullptr;
+    uint16_t *d_lut = nullptr;
+    uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr;
+    /* per-workgroup candidate regions (shared by all batches: stream order serialises them) */
+    msd_hit *d_region_hits = nullptr;
+    msd_try *d_region_tries = nullptr;
+    uint64_t hit_arena = 0, try_arena = 0;
+    msd_wg_counts *d_counts = nullptr;
+    uint64_t *d_offsets = nullptr;
+    uint32_t max_wg = 0, max_buffers = 0;
+    /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
+    uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
+    int tail_cur = 0;
+    bool have_prev = false;
+    uint8_t *d_stage = nullptr; /* msd_submit_host / msd_convert / msd_demodulate_magbuf staging */
+    uint16_t *d_mag = nullptr;
+    Slot slots[MSD_PIPELINE_DEPTH];
+    int head = 0, outstanding = 0;
+    uint64_t next_sample = 0;
+    bool finished = false;
+    msd_resolver resolver{};
+    msd_stats stats{};
+    msd_timing timing{};
+    std::vector<double> means;
+    std::vector<uint32_t> valid;
+    int cu_count = 256;
+    char err[256] = {0};
+};
+
+namespace {
+
+int fail(msd_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), -EIO, "%s failed: %s", #call, hipGetErrorString(e_));              \
+    } while (0)
+
+struct SinkCtx {
+    msd_message_fn fn;
+    void *user;
+};
+void emit_thunk(const msd_message *mm, void *user)
+{
+    SinkCtx *s = static_cast<SinkCtx *>(user);
+    if (s->fn)
+        s->fn(mm, s->user);
+}
+
+int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
+{
+    if (nh > s.h_hits_cap) {
+        size_t cap = s.h_hits_cap ? s.h_hits_cap : (size_t)1 << 16;
+        while (cap < nh)
+            cap *= 2;
+        if (s.h_hits)
+            (void)hipHostFree(s.h_hits);
+        s.h_hits = nullptr;
+        s.h_hits_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_hits), cap * sizeof(msd_hit)));
+        s.h_hits_cap = cap;
+    }
+    if (nt > s.h_tries_cap) {
+        size_t cap = s.h_tries_cap ? s.h_tries_cap : (size_t)1 << 15;
+        while (cap < nt)
+            cap *= 2;
+        if (s.h_tries)
+            (void)hipHostFree(s.h_tries);
+        s.h_tries = nullptr;
+        s.h_tries_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_tries), cap * sizeof(msd_try)));
+        s.h_tries_cap = cap;
+    }
+    return 0;
+}
+
+/* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
+int enqueue(msd_ctx *c, Slot &s, int format)
+{
+    const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    uint32_t target_wg = (uint32_t)c->cu_count * 2u;
+    if (target_wg > c->max_wg)
+        target_wg = c->max_wg;
+    uint32_t tpw = ntiles ? (ntiles + target_wg - 1) / target_wg : 1;
+    if (tpw == 0)
+        tpw = 1;
+    uint32_t nwg = ntiles ? (ntiles + tpw - 1) / tpw : 0;
+
+    HIPCHK(c, hipMemsetAsync(s.d_sums, 0, sizeof(uint64_t) * 2 * (s.nbuffers ? s.nbuffers : 1), c->stream));
+    HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
+    HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
+    if (nwg) {
+        MsdScanParams p{};
+        p.iq = s.d_iq;
+        p.prev_tail = s.d_prev;
+        p.have_prev = s.have_prev;
+        p.threshold = c->cfg.preamble_threshold;
+        p.batch_first = s.batch_first;
+        p.nsamples = s.nsamples;
+        p.ntiles = ntiles;
+        p.tiles_per_wg = tpw;
+        p.lut = c->d_lut;
+        p.crc_tab = c->d_crc;
+        p.syn56 = c->d_syn56;
+        p.syn112 = c->d_syn112;
+        p.nsyn56 = c->tables->nsyn56;
+        p.nsyn112 = c->tables->nsyn112;
+        p.hits = c->d_region_hits;
+        p.tries = c->d_region_tries;
+        /* a tile can never produce more than one hit per position and five tries per hit */
+        uint64_t hcap = c->hit_arena / nwg, tcap = c->try_arena / nwg;
+        if (hcap > (uint64_t)tpw * MSD_TILE)
+            hcap = (uint64_t)tpw * MSD_TILE;
+        if (tcap > (uint64_t)tpw * MSD_TILE * 5)
+            tcap = (uint64_t)tpw * MSD_TILE * 5;
+        p.hcap = (uint32_t)hcap;
+        p.tcap = (uint32_t)tcap;
+        p.counts = c->d_counts;
+        p.chunk_sums = s.d_sums;
+        int rc = msd_launch_scan(&p, format, nwg, c->stream);
+        if (rc)
+            return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
+        rc = msd_launch_gather(c->d_counts, nwg, c->d_offsets, s.d_totals, c->d_region_hits,
+                               c->d_region_tries, p.hcap, p.tcap, s.d_hits, c->hit_arena, s.d_tries,
+                               c->try_arena, c->stream);
+        if (rc)
+            return fail(c, rc, "gather kernel launch failed");
+    } else {
+        HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
+    }
+    if ((format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11) && s.nbuffers) {
+        int rc = msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers,
+                                        s.d_fmeans, c->stream);
+        if (rc)
+            return fail(c, rc, "float means kernel launch failed");
+    }
+    HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
+
+    /* download of the totals on the copy stream, behind this batch's kernels only */
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.ev_kernels, 0));
+    HIPCHK(c, hipMemcpyAsync(s.h_totals, s.d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost,
+                             c->copy_stream));
+    HIPCHK(c, hipEventRecord(s.ev_totals, c->copy_stream));
+    return 0;
+}
+
+/* Wait for a batch, download its candidate lists, resolve in order, deliver messages. */
+int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
+           const uint64_t *ts_override, const double *means_override, uint64_t resolver_first_chunk)
+{
+    HIPCHK(c, hipEventSynchronize(s.ev_totals));
+    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1], ovf = s.h_totals[2];
+    if (ovf)
+        return fail(c, -EOVERFLOW, "candidate arena overflow (%llu hits, %llu tries)",
+                    (unsigned long long)H, (unsigned long long)Tn);
+    int rc = ensure_host(c, s, H, Tn);
+    if (rc)
+        return rc;
+    HIPCHK(c, hipEventRecord(s.ev_copy0, c->copy_stream));
+    if (H)
+        HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->copy_stream));
+    if (Tn)
+        HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->copy_stream));
+    if (s.nbuffers) {
+        HIPCHK(c, hipMemcpyAsync(s.h_sums, s.d_sums, sizeof(uint64_t) * 2 * s.nbuffers, hipMemcpyDeviceToHost,
+                                 c->copy_stream));
+        if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11)
+            HIPCHK(c, hipMemcpyAsync(s.h_fmeans, s.d_fmeans, sizeof(float) * 2 * s.nbuffers,
+                                     hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
+    HIPCHK(c, hipEventSynchronize(s.ev_copy1));
+
+    /* per-buffer sample counts and means (mag_buf.validLength-overlap, .mean_level, .mean_power) */
+    c->valid.assign(s.nbuffers, 0);
+    c->means.assign(2 * (size_t)s.nbuffers, 0.0);
+    for (uint32_t b = 0; b < s.nbuffers; ++b) {
+        const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
+        uint64_t n = s.nsamples > first ? s.nsamples - first : 0;
+        if (n > MSD_CHUNK_SAMPLES)
+            n = MSD_CHUNK_SAMPLES;
+        c->valid[b] = (uint32_t)n;
+        if (means_override) {
+            c->means[2 * b] = means_override[2 * b];
+            c->means[2 * b + 1] = means_override[2 * b + 1];
+        } else if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11) {
+            /* convert.c:245-251: float sum / unsigned -> float division, widened to double */
+            c->means[2 * b] = (double)(s.h_fmeans[2 * b] / (float)(unsigned)n);
+            c->means[2 * b + 1] = (double)(s.h_fmeans[2 * b + 1] / (float)(unsigned)n);
+        } else {
+            /* convert.c:104-110 (note 65536 for the level, 65535^2 for the power) */
+            c->means[2 * b] = (double)s.h_sums[2 * b] / 65536.0 / (double)(unsigned)n;
+            c->means[2 * b + 1] = (double)s.h_sums[2 * b + 1] / 65535.0 / 65535.0 / (double)(unsigned)n;
+        }
+    }
+
+    auto t0 = std::chrono::steady_clock::now();
+    SinkCtx sc{sink, user};
+    msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), c->means.data(),
+                      s.h_hits, H, s.h_tries, Tn, nullptr, 0, ts_override, emit_thunk, &sc);
+    auto t1 = std::chrono::steady_clock::now();
+
+    float ms = 0;
+    c->timing.hits = H;
+    c->timing.tries = Tn;
+    if (hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
+        c->timing.scan_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
+        c->timing.other_kernels_ms = ms;
+    if (hipEventElapsedTime(&ms, s.ev_copy0, s.ev_copy1) == hipSuccess)
+        c->timing.d2h_ms = ms;
+    c->timing.resolve_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    s.busy = false;
+    return 0;
+}
+
+int check_batch(msd_ctx *c, const void *p, uint64_t nsamples, int last)
+{
+    if (!c)
+        return -EINVAL;
+    if (c->finished)
+        return fail(c, -EINVAL, "capture already finished; call msd_reset()");
+    if (nsamples > c->cfg.max_batch_samples)
+        return fail(c, -E2BIG, "batch of %llu samples exceeds max_batch_samples %llu",
+                    (unsigned long long)nsamples, (unsigned long long)c->cfg.max_batch_samples);
+    if (!last && (nsamples == 0 || nsamples % MSD_CHUNK_SAMPLES != 0))
+        return fail(c, -EINVAL, "only the last batch may be a partial buffer");
+    if (nsamples && (!p || (reinterpret_cast<uintptr_t>(p) & 15u)))
+        return fail(c, -EINVAL, "IQ pointer must be non-null and 16-byte aligned");
+    return 0;
+}
+
+int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
+{
+    int rc = check_batch(c, d_iq, nsamples, last);
+    if (rc)
+        return rc;
+    if (c->outstanding >= MSD_PIPELINE_DEPTH)
+        return fail(c, -EBUSY, "pipeline full: call msd_collect() first");
+    Slot &s = c->slots[(c->head + c->outstanding) % MSD_PIPELINE_DEPTH];
+    s.busy = true;
+    s.d_iq = static_cast<const uint8_t *>(d_iq);
+    s.d_prev = c->d_tail[c->tail_cur];
+    s.have_prev = c->have_prev ? 1 : 0;
+    s.batch_first = c->next_sample;
+    s.nsamples = nsamples;
+    s.last = last;
+    /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
+     * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
+    s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
+    rc = enqueue(c, s, c->cfg.format);
+    if (rc) {
+        s.busy = false;
+        return rc;
+    }
+    if (nsamples >= (uint64_t)TAIL_SAMPLES) {
+        const int nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
+        HIPCHK(c, hipMemcpyAsync(c->d_tail[nxt], s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
+                                 (size_t)TAIL_SAMPLES * c->bps, hipMemcpyDeviceToDevice, c->stream));
+        c->tail_cur = nxt;
+        c->have_prev = true;
+    }
+    c->next_sample += nsamples;
+    c->outstanding++;
+    if (last)
+        c->finished = true;
+    return 0;
+}
+
+int collect(msd_ctx *c, msd_message_fn sink, void *user)
+{
+    if (!c)
+        return -EINVAL;
+    if (c->outstanding == 0)
+        return fail(c, -ENODATA, "no batch outstanding");
+    Slot &s = c->slots[c->head];
+    int rc = finish(c, s, c->cfg.format, sink, user, nullptr, nullptr, s.batch_first / MSD_CHUNK_SAMPLES);
+    c->head = (c->head + 1) % MSD_PIPELINE_DEPTH;
+    c->outstanding--;
+    return rc;
+}
+
+void destroy(msd_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream)
+        (void)hipStreamSynchronize(c->copy_stream);
+    for (Slot &s : c->slots) {
+        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
+        if (s.h_totals) (void)hipHostFree(s.h_totals);
+        if (s.h_sums) (void)hipHostFree(s.h_sums);
+        if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
+        if (s.h_hits) (void)hipHostFree(s.h_hits);
+        if (s.h_tries) (void)hipHostFree(s.h_tries);
+        hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
+        for (hipEvent_t *e : evs)
+            if (*e)
+                (void)hipEventDestroy(*e);
+    }
+    (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
+    (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_offsets);
+    for (uint8_t *t : c->d_tail)
+        (void)hipFree(t);
+    (void)hipFree(c->d_stage);
+    (void)hipFree(c->d_mag);
+    if (c->copy_stream)
+        (void)hipStreamDestroy(c->copy_stream);
+    if (c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    free(c->tables);
+    delete c;
+}
+
+} /* namespace */
+
+extern "C" {
+
+void msd_array_sink(const msd_message *mm, void *state)
+{
+    msd_array_sink_state *st = static_cast<msd_array_sink_state *>(state);
+    if (st->count < st->cap)
+        st->out[st->count] = *mm;
+    st->count++;
+}
+
+int msd_create(const msd_config *cfg, msd_ctx **out)
+{
+    if (!cfg || !out)
+        return -EINVAL;
+    *out = nullptr;
+    if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 1 ||
+        cfg->preamble_threshold <= 0)
+        return -EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return -ENODEV; /* no GPU: there is deliberately no CPU fallback */
+    msd_ctx *c = new (std::nothrow) msd_ctx;
+    if (!c)
+        return -ENOMEM;
+    c->cfg = *cfg;
+    if (c->cfg.max_batch_samples == 0)
+        c->cfg.max_batch_samples = MSD_CHUNK_SAMPLES;
+    c->bps = (cfg->format == MSD_FMT_UC8 || cfg->format == MSD_FMT_MAG16) ? 2 : 4;
+
+#define CK(call)                                                              \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            fprintf(stderr, "msd_create: %s: %s\n", #call, hipGetErrorString(e_)); \
+            destroy(c);                                                       \
+            return -EIO;                                                      \
+        }                                                                     \
+    } while (0)
+
+    CK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, cfg->device));
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cfg->stream) {
+        c->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+        CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+
+    c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
+    if (!c->tables) {
+        destroy(c);
+        return -ENOMEM;
+    }
+    msd_tables_build(c->tables, cfg->nfix_crc);
+    if (msd_tables_selftest(c->tables) != 0) {
+        destroy(c);
+        return -EDOM; /* the folded UC8 table would not reproduce the reference's */
+    }
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_lut), sizeof c->tables->uc8_folded));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_crc), sizeof c->tables->crc_byte));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_syn56), sizeof c->tables->syn56 + 16));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_syn112), sizeof c->tables->syn112 + 16));
+    CK(hipMemcpy(c->d_lut, c->tables->uc8_folded, sizeof c->tables->uc8_folded, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_crc, c->tables->crc_byte, sizeof c->tables->crc_byte, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_syn56, c->tables->syn56, sizeof c->tables->syn56, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_syn112, c->tables->syn112, sizeof c->tables->syn112, hipMemcpyHostToDevice));
+
+    const uint64_t B = c->cfg.max_batch_samples;
+    c->hit_arena = B / 8 > MIN_HIT_ARENA ? B / 8 : MIN_HIT_ARENA;
+    c->try_arena = B / 16 > MIN_TRY_ARENA ? B / 16 : MIN_TRY_ARENA;
+    c->max_wg = (uint32_t)c->cu_count * 2u;
+    c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_wg_counts)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_offsets), c->max_wg * 2 * sizeof(uint64_t)));
+    for (uint8_t *&t : c->d_tail) {
+        CK(hipMalloc(reinterpret_cast<void **>(&t), (size_t)TAIL_SAMPLES * 4));
+        CK(hipMemset(t, 0, (size_t)TAIL_SAMPLES * 4));
+    }
+    for (Slot &s : c->slots) {
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_fmeans), 2 * sizeof(float) * c->max_buffers));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_sums), 2 * sizeof(uint64_t) * c->max_buffers));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_fmeans), 2 * sizeof(float) * c->max_buffers));
+        hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
+        for (hipEvent_t *e : evs)
+            CK(hipEventCreate(e));
+    }
+#undef CK
+    c->resolver.stats = &c->stats;
+    c->resolver.mode_ac = cfg->mode_ac;
+    msd_resolver_reset(&c->resolver);
+    *out = c;
+    return 0;
+}
+
+void msd_destroy(msd_ctx *ctx)
+{
+    destroy(ctx);
+}
+
+const char *msd_last_error(const msd_ctx *ctx)
+{
+    return ctx ? ctx->err : "null context";
+}
+
+int msd_reset(msd_ctx *c)
+{
+    if (!c)
+        return -EINVAL;
+    if (c->outstanding)
+        return fail(c, -EBUSY, "batches outstanding");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->next_sample = 0;
+    c->have_prev = false;
+    c->finished = false;
+    msd_resolver_reset(&c->resolver);
+    memset(&c->timing, 0, sizeof c->timing);
+    return 0;
+}
+
+int msd_launch_device(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return launch(c, d_iq, nsamples, last);
+}
+
+int msd_collect(msd_ctx *c, msd_message_fn sink, void *user)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return collect(c, sink, user);
+}
+
+int msd_submit_device(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last, msd_message_fn sink,
+                      void *user)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    while (c->outstanding) {
+        int rc = collect(c, sink, user);
+        if (rc)
+            return rc;
+    }
+    int rc = launch(c, d_iq, nsamples, last);
+    if (rc)
+        return rc;
+    return collect(c, sink, user);
+}
+
+int msd_submit_host(msd_ctx *c, const void *h_iq, uint64_t nsamples, int last, msd_message_fn sink,
+                    void *user)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (nsamples > c->cfg.max_batch_samples)
+        return fail(c, -E2BIG, "batch exceeds max_batch_samples");
+    if (!c->d_stage)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), c->cfg.max_batch_samples * 4 + 64));
+    while (c->outstanding) {
+        int rc = collect(c, sink, user);
+        if (rc)
+            return rc;
+    }
+    if (nsamples)
+        HIPCHK(c, hipMemcpyAsync(c->d_stage, h_iq, nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
+    return msd_submit_device(c, c->d_stage, nsamples, last, sink, user);
+}
+
+int msd_get_stats(const msd_ctx *c, msd_stats *st)
+{
+    if (!c || !st)
+        return -EINVAL;
+    *st = c->stats;
+    return 0;
+}
+
+int msd_get_timing(const msd_ctx *c, msd_timing *t)
+{
+    if (!c || !t)
+        return -EINVAL;
+    *t = c->timing;
+    return 0;
+}
+
+int msd_get_buffer_means(const msd_ctx *c, double *means, size_t cap)
+{
+    if (!c || !means)
+        return -EINVAL;
+    size_t n = c->means.size() / 2;
+    for (size_t i = 0; i < n && i < cap; ++i) {
+        means[2 * i] = c->means[2 * i];
+        means[2 * i + 1] = c->means[2 * i + 1];
+    }
+    return (int)n;
+}
+
+int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
+                double *out_mean_level, double *out_mean_power)
+{
+    if (!c || c->cfg.format == MSD_FMT_MAG16)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (nsamples > c->cfg.max_batch_samples)
+        return fail(c, -E2BIG, "nsamples exceeds max_batch_samples");
+    if (!c->d_stage)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), c->cfg.max_batch_samples * 4 + 64));
+    if (!c->d_mag)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_mag), c->cfg.max_batch_samples * 2 + 64));
+    Slot &s = c->slots[0];
+    if (c->outstanding)
+        return fail(c, -EBUSY, "batches outstanding");
+    HIPCHK(c, hipMemsetAsync(s.d_sums, 0, 2 * sizeof(uint64_t), c->stream));
+    if (nsamples) {
+        HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
+        int rc = msd_launch_convert(c->cfg.format, c->d_stage, nsamples, c->d_lut, c->d_mag,
+                                    reinterpret_cast<unsigned long long *>(s.d_sums), c->stream);
+        if (rc)
+            return fail(c, rc, "convert kernel launch failed");
+        if (c->cfg.format != MSD_FMT_UC8) {
+            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, c->stream);
+            if (rc)
+                return fail(c, rc, "float means kernel launch failed");
+        }
+        HIPCHK(c, hipMemcpyAsync(mag_data, c->d_mag, (size_t)nsamples * 2, hipMemcpyDeviceToHost, c->stream));
+    }
+    uint64_t sums[2] = {0, 0};
+    float fm[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(sums, s.d_sums, sizeof sums, hipMemcpyDeviceToHost, c->stream));
+    if (c->cfg.format != MSD_FMT_UC8 && nsamples)
+        HIPCHK(c, hipMemcpyAsync(fm, s.d_fmeans, sizeof fm, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->cfg.format == MSD_FMT_UC8) {
+        if (out_mean_level)
+            *out_mean_level = (double)sums[0] / 65536.0 / (double)nsamples;
+        if (out_mean_power)
+            *out_mean_power = (double)sums[1] / 65535.0 / 65535.0 / (double)nsamples;
+    } else {
+        if (out_mean_level)
+            *out_mean_level = (double)(fm[0] / (float)nsamples);
+        if (out_mean_power)
+            *out_mean_power = (double)(fm[1] / (float)nsamples);
+    }
+    return 0;
+}
+
+int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength, unsigned overlap,
+                          uint64_t sampleTimestamp, uint64_t sysTimestamp, double mean_level,
+                          double mean_power, msd_message_fn sink, void *user)
+{
+    if (!c || !data)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (overlap != MSD_OVERLAP || validLength < overlap || validLength - overlap > MSD_CHUNK_SAMPLES)
+        return fail(c, -EINVAL, "mag_buf geometry must be overlap=326, at most 131072 new samples");
+    if (c->outstanding)
+        return fail(c, -EBUSY, "batches outstanding");
+    if (!c->d_stage)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), c->cfg.max_batch_samples * 4 + 64));
+    const unsigned mlen = validLength - overlap;
+    Slot &s = c->slots[0];
+    /* data[0..326) -> the two-sample-padded "previous tail"; data[326..) -> the batch */
+    uint8_t *tail = c->d_tail[0];
+    HIPCHK(c, hipMemsetAsync(tail, 0, (size_t)(TAIL_SAMPLES - MSD_OVERLAP) * 2, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tail + (size_t)(TAIL_SAMPLES - MSD_OVERLAP) * 2, data, (size_t)MSD_OVERLAP * 2,
+                             hipMemcpyHostToDevice, c->stream));
+    if (mlen)
+        HIPCHK(c, hipMemcpyAsync(c->d_stage, data + overlap, (size_t)mlen * 2, hipMemcpyHostToDevice, c->stream));
+    s.busy = true;
+    s.d_iq = c->d_stage;
+    s.d_prev = tail;
+    s.have_prev = 1;
+    s.batch_first = 0;
+    s.nsamples = mlen;
+    s.nbuffers = 1;
+    s.last = 1;
+    int rc = enqueue(c, s, MSD_FMT_MAG16);
+    if (rc) {
+        s.busy = false;
+        return rc;
+    }
+    const uint64_t ts[2] = {sampleTimestamp, sysTimestamp};
+    const double means[2] = {mean_level, mean_power};
+    rc = finish(c, s, MSD_FMT_MAG16, sink, user, ts, means, 0);
+    /* the stream interface's tail ring was borrowed: a following msd_submit_* starts afresh */
+    c->have_prev = false;
+    c->tail_cur = 0;
+    return rc;
+}
+
+} /* extern "C" */

@@ -1,0 +1,111 @@
+/*
+ * msd_internal.h -- records exchanged between the GPU candidate stage and the ordered host
+ * resolve stage, and the host-side tables.  C and HIP both include this.
+ *
+ * Why two stages: which messages demodulate2400 accepts depends on two pieces
+ * of sequential state -- the skip-ahead after an accepted message (demod_2400.c:416) and the ICAO
+ * address filter that accepted DF11/DF17 messages write and every score reads
+ * (mode_s.c:343-393,717-726; icao_filter.c).  Everything else is a pure function of the samples.
+ * The GPU therefore evaluates, for every scan position, everything that does not depend on that
+ * state, and emits two ordered lists:
+ *   hits  -- one per scan position where at least one preamble test fired (demod_2400.c:298-330)
+ *   tries -- one per (position, trial phase) whose score can exceed -2, i.e. is either >= 0 or
+ *            depends on the address filter; tries whose score is -2 regardless of the filter
+ *            (unknown DF, all-zero, uncorrectable syndrome) are only counted in the hit's mask.
+ * The resolve stage replays the reference's state machine over those lists.
+ */
+#ifndef MSD_INTERNAL_H
+#define MSD_INTERNAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSD_TILE 4096u          /* scan positions per tile */
+#define MSD_TILE_LOG2 12
+#define MSD_HALO_FRONT 328u     /* samples loaded ahead of a tile: overlap 326 rounded up to 8 */
+#define MSD_TILE_LOAD (MSD_TILE + 296u) /* samples staged per tile (multiple of 8) */
+
+/* hit record: bits 0..39 absolute scan position a (= chunk*131072 + j), bits 40..42 which of the
+ * three preamble tests fired (1: phases 4,5  2: phases 6,7  4: phase 8), bits 43..45 number of
+ * try records that follow for this position. */
+typedef uint64_t msd_hit;
+#define MSD_HIT_POS(h) ((h) & 0xFFFFFFFFFFull)
+#define MSD_HIT_MASK(h) ((unsigned)((h) >> 40) & 7u)
+#define MSD_HIT_NLIVE(h) ((unsigned)((h) >> 43) & 7u)
+
+/* try record, 32 bytes */
+typedef struct msd_try {
+    uint8_t msg[14]; /* sliced bytes, uncorrected (demod_2400.c:191-209) */
+    uint8_t tp;      /* trial phase 4..8 */
+    uint8_t errbit;  /* single-bit error position from the syndrome table, 0xff = none */
+    uint32_t addr;   /* address the score tests: CRC for AP formats, (corrected) AA otherwise */
+    uint32_t crc;    /* modesChecksum of the uncorrected message */
+    uint64_t power;  /* sum of m[j+19+k]^2 over this message's length*12/5 samples */
+} msd_try;
+
+/* Mode A/C candidate: every f1_sample that passes all tests of demod_2400.c:581-668; only the
+ * 69-sample skip-ahead (:705) is left to the resolve stage. */
+typedef struct msd_ac_hit {
+    uint64_t pos;      /* chunk*131072 + f1_sample */
+    uint32_t f2_clock; /* 60 MHz, relative to the buffer start (demod_2400.c:604) */
+    uint32_t modeac;   /* demod_2400.c:672-685 */
+} msd_ac_hit;
+
+/* per persistent workgroup bookkeeping written by the scan kernel */
+typedef struct msd_wg_counts {
+    uint32_t nhits;
+    uint32_t ntries;
+    uint32_t overflow;
+    uint32_t pad;
+} msd_wg_counts;
+
+/* ---- host tables (msd_tables.c) ---- */
+#define MSD_LUT_STRIDE 136u /* folded UC8 table row pitch in u16 (bank spread) */
+typedef struct msd_tables {
+    uint16_t uc8_folded[128 * MSD_LUT_STRIDE]; /* [fold(Q)][fold(I)] of convert.c:35-61 */
+    uint16_t uc8_full[65536];                  /* the reference's table, for msd_tables_selftest */
+    uint32_t crc_byte[256];                    /* crc.c:42-55 */
+    uint32_t syn56[51], syn112[107];           /* sorted: syndrome | bit << 24 (crc.c:184-354) */
+    uint32_t nsyn56, nsyn112;
+} msd_tables;
+void msd_tables_build(msd_tables *t, int nfix_crc);
+uint32_t msd_crc24(const msd_tables *t, const uint8_t *msg, int nbits);
+
+/* ---- ICAO filter (msd_resolve.c), icao_filter.c semantics ---- */
+typedef struct msd_filter {
+    uint32_t slot[2][8192];
+    int active;
+    uint64_t next_flip;
+} msd_filter;
+
+/* ---- resolve stage (msd_resolve.c) ---- */
+struct msd_message;
+struct msd_stats;
+typedef struct msd_resolver {
+    msd_filter filter;
+    uint64_t ifile_now;      /* Modes.ifile_now, readsb.h:289 */
+    uint64_t sample_counter; /* samples consumed so far (sdr_ifile.c:172) */
+    int mode_ac;
+    struct msd_stats *stats;
+} msd_resolver;
+
+typedef void (*msd_emit_fn)(const struct msd_message *mm, void *user);
+
+void msd_resolver_reset(msd_resolver *r);
+/* Replays the buffers [first_chunk, first_chunk + nbuffers) of a batch.  hits/tries (Mode S) and
+ * ac (Mode A/C) are the batch's ordered candidate lists; valid[i] is the i-th buffer's number of
+ * new samples; means holds (mean_level, mean_power) per buffer; ts_override, if not NULL, holds
+ * (sampleTimestamp, sysTimestamp) per buffer instead of the ifile clock of sdr_ifile.c:187-190. */
+void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
+                       const uint32_t *valid, const double *means, const msd_hit *hits,
+                       uint64_t nhits, const msd_try *tries, uint64_t ntries,
+                       const msd_ac_hit *ac, uint64_t nac, const uint64_t *ts_override,
+                       msd_emit_fn emit, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,50 @@
+/* msd_kernels.h -- launch interface between msd_capi.cpp and msd_kernels.hip */
+#ifndef MSD_KERNELS_H
+#define MSD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "modes_hip.h"
+#include "msd_internal.h"
+
+#define MSD_SCAN_THREADS 256
+
+typedef struct MsdScanParams {
+    const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */
+    const uint8_t *prev_tail; /* the MSD_HALO_FRONT samples before it */
+    int have_prev;            /* 0: start of stream or discontinuity -> zero magnitudes (fifo.c:180) */
+    int threshold;            /* Modes.preambleThreshold */
+    uint64_t batch_first;     /* absolute index of iq[0]; multiple of MSD_CHUNK_SAMPLES */
+    uint64_t nsamples;
+    uint32_t ntiles;
+    uint32_t tiles_per_wg;
+    const uint16_t *lut;
+    const uint32_t *crc_tab;
+    const uint32_t *syn56;
+    const uint32_t *syn112;
+    uint32_t nsyn56, nsyn112;
+    msd_hit *hits;
+    msd_try *tries;
+    uint32_t hcap, tcap; /* per-workgroup region capacities */
+    msd_wg_counts *counts;
+    uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
+} MsdScanParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+size_t msd_scan_lds_bytes(int format);
+int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
+int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets, uint64_t *totals,
+                      const msd_hit *hits, const msd_try *tries, uint32_t hcap, uint32_t tcap,
+                      msd_hit *dense_hits, uint64_t dense_hcap, msd_try *dense_tries,
+                      uint64_t dense_tcap, hipStream_t stream);
+int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
+                       uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
+int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
+                           uint32_t nbuffers, float *d_out, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

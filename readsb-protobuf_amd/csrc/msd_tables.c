@@ -1,0 +1,96 @@
+/*
+ * msd_tables.c -- the small constant tables the kernels keep in LDS, computed once on the host.
+ * Compile with -ffp-contract=off: the UC8 table must round exactly like the reference's x86-64
+ * build (float products and sum rounded separately, correctly rounded sqrtf).
+ */
+#include "msd_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* The reference's UC8 magnitude for an (I, Q) byte pair (convert.c:35-61).  Its table slot is the
+ * little-endian u16 of the pair, I + 256*Q, filled by a loop whose outer variable is that slot's
+ * high byte -- so the loop's "i" is Q.  fI is evaluated in double and rounded to float once. */
+static uint16_t uc8_magnitude(int ibyte, int qbyte)
+{
+    float a = (qbyte - 127.5) / 127.5;
+    float b = (ibyte - 127.5) / 127.5;
+    float magsq = a * a + b * b;
+    if (magsq > 1)
+        magsq = 1;
+    float mag = sqrtf(magsq);
+    return (uint16_t)(mag * 65535.0f + 0.5f);
+}
+
+static int fold(int byte)
+{
+    /* (b - 127.5) is +-(k + 0.5) with k = b-128 for b >= 128 and 127-b below; squaring drops
+     * the sign, so the magnitude only depends on k. */
+    return byte >= 128 ? byte - 128 : 127 - byte;
+}
+
+uint32_t msd_crc24(const msd_tables *t, const uint8_t *msg, int nbits)
+{
+    /* crc.c:67-82: table-driven remainder over all but the last three bytes, which are xored in */
+    int n = nbits / 8;
+    uint32_t rem = 0;
+    for (int i = 0; i < n - 3; ++i)
+        rem = ((rem << 8) ^ t->crc_byte[msg[i] ^ (rem >> 16)]) & 0xffffffu;
+    return rem ^ ((uint32_t)msg[n - 3] << 16) ^ ((uint32_t)msg[n - 2] << 8) ^ msg[n - 1];
+}
+
+static int cmp_u24(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a & 0xffffffu, y = *(const uint32_t *)b & 0xffffffu;
+    return (x > y) - (x < y);
+}
+
+void msd_tables_build(msd_tables *t, int nfix_crc)
+{
+    memset(t, 0, sizeof *t);
+    for (int q = 0; q < 256; ++q)
+        for (int i = 0; i < 256; ++i)
+            t->uc8_full[i + 256 * q] = uc8_magnitude(i, q);
+    for (int kq = 0; kq < 128; ++kq)
+        for (int ki = 0; ki < 128; ++ki)
+            t->uc8_folded[kq * MSD_LUT_STRIDE + ki] = uc8_magnitude(128 + ki, 128 + kq);
+
+    for (uint32_t b = 0; b < 256; ++b) { /* crc.c:46-57, generator 0xfff409 (crc.c:31) */
+        uint32_t c = b << 16;
+        for (int k = 0; k < 8; ++k)
+            c = (c & 0x800000u) ? ((c << 1) ^ 0xfff409u) : (c << 1);
+        t->crc_byte[b] = c & 0xffffffu;
+    }
+
+    if (nfix_crc >= 1) {
+        /* crc.c:367-372 with max_correct = max_detect = 1: one entry per bit 5..bits-1 holding the
+         * syndrome of that single-bit error, sorted by syndrome.  Packed as syndrome | bit << 24. */
+        uint8_t probe[14];
+        for (int bits = 56; bits <= 112; bits += 56) {
+            uint32_t *tab = (bits == 56) ? t->syn56 : t->syn112;
+            uint32_t n = 0;
+            for (int i = 5; i < bits; ++i) {
+                memset(probe, 0, sizeof probe);
+                probe[i >> 3] = (uint8_t)(0x80u >> (i & 7));
+                tab[n++] = msd_crc24(t, probe, bits) | ((uint32_t)i << 24);
+            }
+            qsort(tab, n, sizeof tab[0], cmp_u24);
+            if (bits == 56)
+                t->nsyn56 = n;
+            else
+                t->nsyn112 = n;
+        }
+    }
+}
+
+/* Checks the folding identity the kernels rely on; returns the number of mismatching slots. */
+int msd_tables_selftest(const msd_tables *t)
+{
+    int bad = 0;
+    for (int q = 0; q < 256; ++q)
+        for (int i = 0; i < 256; ++i)
+            if (t->uc8_full[i + 256 * q] != t->uc8_folded[fold(q) * MSD_LUT_STRIDE + fold(i)])
+                ++bad;
+    return bad;
+}

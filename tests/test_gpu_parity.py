@@ -1,0 +1,56 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle on seeded synthetic captures."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted",
+            "demod_preamblePhase", "demod_bestPhase", "demod_modeac", "strong_signal_count",
+            "samples_processed", "noise_power_count", "signal_power_count", "buffers")
+FIELDS = ("timestampMsg", "sysTimestampMsg", "signalLevel", "addr", "crc", "score", "msgtype", "msgbits",
+          "correctedbits", "bestphase", "iid")
+
+
+def assert_same(got, gstats, want, wstats):
+    assert len(got) == len(want), (len(got), len(want))
+    for f in FIELDS:
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(got["msg"], want["msg"])
+    for k in COUNTERS:
+        assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
+    for k in ("noise_power_sum", "signal_power_sum", "peak_signal_power"):
+        assert np.array_equal(np.float64(gstats[k]), np.float64(wstats[k]), equal_nan=True), (k, gstats[k], wstats[k])
+
+
+def run_case(pkg, oracle, torch, fmt, n, seed, nfix, batch=None, **cfgkw):
+    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, **cfgkw)
+    iq = pkg.siggen.generate(cfg, n)
+    d_iq = torch.from_numpy(iq).to("cuda:0")
+    max_batch = batch or max(pkg.CHUNK, ((n + pkg.CHUNK - 1) // pkg.CHUNK) * pkg.CHUNK)
+    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, max_batch_samples=max_batch, message_capacity=1 << 18)
+    if batch:
+        got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
+    else:
+        got = dem.submit_device(d_iq.data_ptr(), n, last=True)
+    want, wstats = oracle.Oracle(fmt, 58, nfix, 0).replay(iq, cap=1 << 18)
+    assert len(want) > 0
+    assert_same(got, dem.stats(), want, wstats)
+    return got, dem
+
+
+@pytest.mark.parametrize("nfix", [0, 1])
+@pytest.mark.parametrize("n", [3 * 131072 + 4567, 4 * 131072, 1000, 131072 + 1])
+def test_uc8_single_batch(pkg, oracle, torch_cuda, n, nfix):
+    if n == 1000:
+        pytest.skip("covered by test_short_captures")
+    run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, n, seed=1090 + n % 7, nfix=nfix)
+
+
+def test_uc8_pipelined_batches(pkg, oracle, torch_cuda):
+    run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 20 * 131072 + 999, seed=5, nfix=1, batch=4 * 131072)
+
+
+@pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
+def test_s16_formats(pkg, oracle, torch_cuda, fmt):
+    f = pkg.FMT_SC16 if fmt == "sc16" else pkg.FMT_SC16Q11
+    run_case(pkg, oracle, torch_cuda, f, 3 * 131072 + 77, seed=10920, nfix=1)
