@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s of the MI355X Mode S receive path (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (IQ->magnitude, preamble scan, bit slicing, CRC, scoring,
+ordered resolve) over one synthetic 2.4 MSPS capture that is already resident in HBM when the timed
+region starts.  At N=1 the workload is BASELINE.json configs[1]: a 1 GiB UC8 capture, Mode S only,
+--no-fix.  At N>1 every rank replays its own 1 GiB capture (seed 10901+rank) on its own GPU: the
+path shards by independent capture, so there is no data-path collective ("scaling": "weak").
+
+One JSON line is printed by rank 0; see the contract in the task description for the keys.
+`roofline` is for the dominant kernel (msd_scan_kernel): algorithmic bytes = 2 B per UC8 sample
+ x the samples one launch scans, divided by that kernel's average launch duration
+measured with HIP events on the stream it runs on (msd_timing.scan_kernel_ms).
+`cpu_baseline` is the oracle (our CPU restatement, kind "port") on one host core over a bounded
+sample of the same capture; it is a reported baseline, never the thing shipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=1 << 29, help="samples per capture (1 GiB UC8 = 2^29)")
+    ap.add_argument("--batch", type=int, default=1 << 26, help="samples per GPU batch")
+    ap.add_argument("--format", default="uc8", choices=["uc8", "sc16", "sc16q11"])
+    ap.add_argument("--fix", type=int, default=0, help="nfix_crc (0 = --no-fix, the configs[1] setting)")
+    ap.add_argument("--msgs-per-sec", type=int, default=2000)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 29, help="samples the CPU baseline replays")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also diff the GPU message list against the oracle")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the demodulator has no CPU fallback")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = graft.load_package()
+    fmt = {"uc8": pkg.FMT_UC8, "sc16": pkg.FMT_SC16, "sc16q11": pkg.FMT_SC16Q11}[args.format]
+    bps = 2 if fmt == pkg.FMT_UC8 else 4
+    n = args.samples
+    batch = min(args.batch, ((n + pkg.CHUNK - 1) // pkg.CHUNK) * pkg.CHUNK)
+    batch = max(pkg.CHUNK, (batch // pkg.CHUNK) * pkg.CHUNK)
+
+    # ---- synthetic capture, generated on the host from a seed, then made resident in HBM ----
+    seed = 10901 + rank
+    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec)
+    t0 = time.time()
+    iq = pkg.siggen.generate(cfg, n)
+    gen_s = time.time() - t0
+    d_iq = torch.from_numpy(iq).to(dev)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream(dev)
+    dem = pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=0, device=local_rank,
+                          max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21)
+
+    def one_step(collect_timing=None):
+        dem.reset()
+        nmsg = 0
+        off = 0
+        inflight = 0
+        first = None
+        while True:
+            m = min(batch, n - off)
+            last = off + m >= n
+            if inflight == pkg.capi.PIPELINE_DEPTH:
+                msgs = dem.collect()
+                nmsg += len(msgs)
+                first = msgs if first is None else first
+                if collect_timing is not None:
+                    collect_timing.append(dem.timing())
+                inflight -= 1
+            dem.launch_device(d_iq.data_ptr() + off * bps, m, last)
+            inflight += 1
+            off += m
+            if last:
+                break
+        while inflight:
+            msgs = dem.collect()
+            nmsg += len(msgs)
+            if collect_timing is not None:
+                collect_timing.append(dem.timing())
+            inflight -= 1
+        return nmsg
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    timings = []
+    barrier()
+    t0 = time.perf_counter()
+    nmsg = 0
+    for _ in range(args.steps):
+        nmsg = one_step(timings)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([nmsg], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        nmsg_total = int(c.item())
+    else:
+        nmsg_total = nmsg
+
+    ms_per_step = elapsed * 1e3 / max(1, args.steps)
+    total_samples = n * world
+    value = total_samples / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
+
+    # ---- roofline of the dominant kernel, from HIP events around every launch in the timed region ----
+    scan_ms = [t["scan_kernel_ms"] for t in timings if t["scan_kernel_ms"] > 0]
+    nb = (n + batch - 1) // batch
+    full_launch_ms = [t for i, t in enumerate(scan_ms) if (i % nb) != nb - 1 or n % batch == 0] or scan_ms
+    avg_ms = float(np.mean(full_launch_ms)) if full_launch_ms else float("nan")
+    launch_samples = batch if n >= batch else n
+    achieved_gbs = launch_samples * bps / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "msd_scan_kernel",
+                "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
+                "algorithmic_bytes_per_sample": bps}
+
+    out = {
+        "metric": "IQ Msamples/s, 2.4 MSPS %s, Mode S demodulation (CRC-valid msgs/s alongside)" % args.format.upper(),
+        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32 (u8 IQ -> u16 magnitude -> int32 correlators, 24-bit CRC)", "data": "synthetic",
+        "config": {"workload": "%.3f GiB synthetic 2.4 MSPS %s capture per GPU, Mode S only, %s, preamble threshold 58, "
+                               "%d frames/s, seeds 10901+rank" % (n * bps / 2**30, args.format.upper(),
+                                                                  "--no-fix" if args.fix == 0 else "--fix", args.msgs_per_sec),
+                   "samples_per_gpu": n, "batch_samples": batch, "parallelism": "independent capture per GPU, no collective"},
+        "msgs_per_s": round(nmsg_total / (ms_per_step * 1e-3), 1), "messages_per_step": nmsg_total,
+        "signal_seconds_per_wall_second": round(value * 1e6 / 2.4e6, 1),
+        "roofline": roofline,
+        "pipeline_ms": {k: round(float(np.mean([t[k] for t in timings])), 4) for k in
+                        ("scan_kernel_ms", "other_kernels_ms", "d2h_ms", "resolve_ms")} if timings else None,
+        "capture_generation_s": round(gen_s, 2),
+    }
+
+    # ---- CPU baseline: the oracle on this host, one core, bounded sample (rank 0, N=1 only) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        O = graft.load_oracle()
+        ns = min(n, args.cpu_sample)
+        ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
+        orc = O.Oracle(ofmt, 58, args.fix, 0)
+        t0 = time.perf_counter()
+        want, _ = orc.replay(iq[: ns * bps], cap=1 << 21)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(ns / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                               "sample": "first %d samples (%.2f GiB) of the same capture, oracle replay incl. IQ->magnitude, "
+                                         "%.1f s" % (ns, ns * bps / 2**30, cpu_s),
+                               "msgs_per_s": round(len(want) / cpu_s, 1),
+                               "host": "%d logical CPUs" % (os.cpu_count() or 0)}
+        if args.check:
+            dem.reset()
+            got = pkg.replay_device(dem, d_iq.data_ptr(), ns if ns == n else n, batch)
+            if ns == n:
+                same = len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in
+                                                     ("timestampMsg", "addr", "msgtype", "correctedbits", "score", "crc", "msg"))
+                out["message_set_diff_vs_oracle"] = 0 if same else "DIFFERENT"
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ extern "C" {
 #define MSD_TILE 4096u          /* scan positions per tile */
 #define MSD_TILE_LOG2 12
 #define MSD_HALO_FRONT 328u     /* samples loaded ahead of a tile: overlap 326 rounded up to 8 */
-#define MSD_TILE_LOAD (MSD_TILE + 296u) /* samples staged per tile (multiple of 8) */
+#define MSD_TILE_LOAD (MSD_TILE + MSD_HALO_FRONT) /* samples staged per tile: [a0-328, a0+4096) */
 
 /* hit record: bits 0..39 absolute scan position a (= chunk*131072 + j), bits 40..42 which of the
  * three preamble tests fired (1: phases 4,5  2: phases 6,7  4: phase 8), bits 43..45 number of
