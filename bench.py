@@ -167,7 +167,7 @@ def main():
         "signal_seconds_per_wall_second": round(value * 1e6 / 2.4e6, 1),
         "roofline": roofline,
         "pipeline_ms": {k: round(float(np.mean([t[k] for t in timings])), 4) for k in
-                        ("scan_kernel_ms", "other_kernels_ms", "d2h_ms", "resolve_ms")} if timings else None,
+                        ("scan_kernel_ms", "other_kernels_ms", "d2h_ms", "resolve_ms", "hits", "tries")} if timings else None,
         "capture_generation_s": round(gen_s, 2),
     }
 

@@ -198,6 +198,10 @@ int enqueue(msd_ctx *c, Slot &s, int format)
         p.tcap = (uint32_t)tcap;
         p.counts = c->d_counts;
         p.chunk_sums = s.d_sums;
+        {
+            const char *dbg = getenv("MSD_DEBUG_FLAGS");
+            p.debug_flags = dbg ? atoi(dbg) : 0;
+        }
         int rc = msd_launch_scan(&p, format, nwg, c->stream);
         if (rc)
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -29,6 +29,8 @@ typedef struct MsdScanParams {
     uint32_t hcap, tcap; /* per-workgroup region capacities */
     msd_wg_counts *counts;
     uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
+    int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
+                             2 = stop after the conversion (results are then incomplete) */
 } MsdScanParams;
 
 #ifdef __cplusplus

@@ -308,6 +308,8 @@ __global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
             }
         }
         __syncthreads();
+        if (P.debug_flags & 2)
+            continue;
 
         /* ---- stage 2: preamble tests for every scan position (demod_2400.c:257-335) ---- */
         uint32_t nz = 0; /* positions of mine with a test that fired */
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
         }
         /* most tiles of a quiet band have no hit at all: skip the bookkeeping then */
         const int any = __syncthreads_or(nz != 0);
-        if (!any)
+        if (!any || (P.debug_flags & 1))
             continue;
 
         /* ---- stage 3: ordered hit list ---- */
