@@ -56,6 +56,9 @@ struct Slot {
     size_t h_hits_cap = 0;
     msd_try *h_tries = nullptr;
     size_t h_tries_cap = 0;
+    /* deferred signal power of the accepted messages */
+    uint64_t *d_req = nullptr, *d_pow = nullptr, *h_req = nullptr, *h_pow = nullptr;
+    size_t req_cap = 0;
     hipEvent_t ev_start = nullptr, ev_scan = nullptr, ev_kernels = nullptr, ev_totals = nullptr,
                ev_copy0 = nullptr, ev_copy1 = nullptr;
 };
@@ -92,6 +95,9 @@ struct msd_ctx {
     msd_timing timing{};
     std::vector<double> means;
     std::vector<uint32_t> valid;
+    std::vector<msd_message> out_msgs;
+    std::vector<uint64_t> out_req;
+    std::vector<uint32_t> out_buf;
     int cu_count = 256;
     char err[256] = {0};
 };
@@ -116,15 +122,48 @@ int fail(msd_ctx *c, int code, const char *fmt, ...)
             return fail((c), -EIO, "%s failed: %s", #call, hipGetErrorString(e_));              \
     } while (0)
 
-struct SinkCtx {
-    msd_message_fn fn;
-    void *user;
-};
-void emit_thunk(const msd_message *mm, void *user)
+void emit_thunk(const msd_message *mm, uint64_t power_req, uint32_t buffer, void *user)
 {
-    SinkCtx *s = static_cast<SinkCtx *>(user);
-    if (s->fn)
-        s->fn(mm, s->user);
+    msd_ctx *c = static_cast<msd_ctx *>(user);
+    c->out_msgs.push_back(*mm);
+    c->out_req.push_back(power_req);
+    c->out_buf.push_back(buffer);
+}
+
+int ensure_req(msd_ctx *c, Slot &s, size_t n)
+{
+    if (n <= s.req_cap)
+        return 0;
+    size_t cap = s.req_cap ? s.req_cap : (size_t)1 << 14;
+    while (cap < n)
+        cap *= 2;
+    (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
+    if (s.h_req) (void)hipHostFree(s.h_req);
+    if (s.h_pow) (void)hipHostFree(s.h_pow);
+    s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
+    s.req_cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_pow), cap * sizeof(uint64_t)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_req), cap * sizeof(uint64_t)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_pow), cap * sizeof(uint64_t)));
+    s.req_cap = cap;
+    return 0;
+}
+
+void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
+{
+    p.iq = s.d_iq;
+    p.prev_tail = s.d_prev;
+    p.have_prev = s.have_prev;
+    p.threshold = c->cfg.preamble_threshold;
+    p.batch_first = s.batch_first;
+    p.nsamples = s.nsamples;
+    p.lut = c->d_lut;
+    p.crc_tab = c->d_crc;
+    p.syn56 = c->d_syn56;
+    p.syn112 = c->d_syn112;
+    p.nsyn56 = c->tables->nsyn56;
+    p.nsyn112 = c->tables->nsyn112;
 }
 
 int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
@@ -172,20 +211,9 @@ int enqueue(msd_ctx *c, Slot &s, int format)
     HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
     if (nwg) {
         MsdScanParams p{};
-        p.iq = s.d_iq;
-        p.prev_tail = s.d_prev;
-        p.have_prev = s.have_prev;
-        p.threshold = c->cfg.preamble_threshold;
-        p.batch_first = s.batch_first;
-        p.nsamples = s.nsamples;
+        fill_params(c, s, p);
         p.ntiles = ntiles;
         p.tiles_per_wg = tpw;
-        p.lut = c->d_lut;
-        p.crc_tab = c->d_crc;
-        p.syn56 = c->d_syn56;
-        p.syn112 = c->d_syn112;
-        p.nsyn56 = c->tables->nsyn56;
-        p.nsyn112 = c->tables->nsyn112;
         p.hits = c->d_region_hits;
         p.tries = c->d_region_tries;
         /* a tile can never produce more than one hit per position and five tries per hit */
@@ -281,10 +309,37 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     }
 
     auto t0 = std::chrono::steady_clock::now();
-    SinkCtx sc{sink, user};
-    msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), c->means.data(),
-                      s.h_hits, H, s.h_tries, Tn, nullptr, 0, ts_override, emit_thunk, &sc);
+    c->out_msgs.clear();
+    c->out_req.clear();
+    c->out_buf.clear();
+    msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
+                      nullptr, 0, ts_override, emit_thunk, c);
     auto t1 = std::chrono::steady_clock::now();
+
+    /* signal power of the accepted messages: a small follow-up kernel on the copy stream */
+    const size_t nm = c->out_msgs.size();
+    if (nm) {
+        rc = ensure_req(c, s, nm);
+        if (rc)
+            return rc;
+        memcpy(s.h_req, c->out_req.data(), nm * sizeof(uint64_t));
+        HIPCHK(c, hipMemcpyAsync(s.d_req, s.h_req, nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+        MsdScanParams p{};
+        fill_params(c, s, p);
+        rc = msd_launch_power(&p, format, s.d_req, (uint32_t)nm, reinterpret_cast<unsigned long long *>(s.d_pow),
+                              c->copy_stream);
+        if (rc)
+            return fail(c, rc, "power kernel launch failed");
+        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, nm * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    }
+    msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(),
+                      c->out_req.data(), c->out_buf.data(), s.h_pow, nm);
+    auto t2 = std::chrono::steady_clock::now();
+    if (sink)
+        for (size_t i = 0; i < nm; ++i)
+            sink(&c->out_msgs[i], user);
+    (void)t2;
 
     float ms = 0;
     c->timing.hits = H;
@@ -306,7 +361,7 @@ int check_batch(msd_ctx *c, const void *p, uint64_t nsamples, int last)
         return -EINVAL;
     if (c->finished)
         return fail(c, -EINVAL, "capture already finished; call msd_reset()");
-    if (nsamples > c->cfg.max_batch_samples)
+    if (nsamples > c->cfg.max_batch_samples || nsamples > MSD_MAX_BATCH_SAMPLES)
         return fail(c, -E2BIG, "batch of %llu samples exceeds max_batch_samples %llu",
                     (unsigned long long)nsamples, (unsigned long long)c->cfg.max_batch_samples);
     if (!last && (nsamples == 0 || nsamples % MSD_CHUNK_SAMPLES != 0))
@@ -382,6 +437,9 @@ void destroy(msd_ctx *c)
         if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
         if (s.h_hits) (void)hipHostFree(s.h_hits);
         if (s.h_tries) (void)hipHostFree(s.h_tries);
+        (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
+        if (s.h_req) (void)hipHostFree(s.h_req);
+        if (s.h_pow) (void)hipHostFree(s.h_pow);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
         for (hipEvent_t *e : evs)
             if (*e)
@@ -430,6 +488,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     c->cfg = *cfg;
     if (c->cfg.max_batch_samples == 0)
         c->cfg.max_batch_samples = MSD_CHUNK_SAMPLES;
+    if (c->cfg.max_batch_samples > MSD_MAX_BATCH_SAMPLES)
+        c->cfg.max_batch_samples = MSD_MAX_BATCH_SAMPLES;
     c->bps = (cfg->format == MSD_FMT_UC8 || cfg->format == MSD_FMT_MAG16) ? 2 : 4;
 
 #define CK(call)                                                              \

@@ -23,18 +23,19 @@
 extern "C" {
 #endif
 
-#define MSD_TILE 4096u          /* scan positions per tile */
-#define MSD_TILE_LOG2 12
-#define MSD_HALO_FRONT 328u     /* samples loaded ahead of a tile: overlap 326 rounded up to 8 */
-#define MSD_TILE_LOAD (MSD_TILE + MSD_HALO_FRONT) /* samples staged per tile: [a0-328, a0+4096) */
+#define MSD_TILE 8192u          /* scan positions per tile */
+#define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */
+#define MSD_MAX_BATCH_SAMPLES (1ull << 28) /* hit positions are 28-bit, batch-relative */
 
-/* hit record: bits 0..39 absolute scan position a (= chunk*131072 + j), bits 40..42 which of the
- * three preamble tests fired (1: phases 4,5  2: phases 6,7  4: phase 8), bits 43..45 number of
- * try records that follow for this position. */
+/* hit record: bits 0..27 scan position relative to the batch (absolute a = batch_first + pos,
+ * a = chunk*131072 + j); bits 28..30 which of the three preamble tests fired (1: phases 4,5
+ * 2: phases 6,7  4: phase 8); bits 31..33 number of try records of this position; bits 34..63
+ * index of the first of them in the batch's try list (they are consecutive, in phase order). */
 typedef uint64_t msd_hit;
-#define MSD_HIT_POS(h) ((h) & 0xFFFFFFFFFFull)
-#define MSD_HIT_MASK(h) ((unsigned)((h) >> 40) & 7u)
-#define MSD_HIT_NLIVE(h) ((unsigned)((h) >> 43) & 7u)
+#define MSD_HIT_POS(h) ((h) & 0xFFFFFFFull)
+#define MSD_HIT_MASK(h) ((unsigned)((h) >> 28) & 7u)
+#define MSD_HIT_NLIVE(h) ((unsigned)((h) >> 31) & 7u)
+#define MSD_HIT_TRY(h) ((uint64_t)((h) >> 34))
 
 /* try record, 32 bytes */
 typedef struct msd_try {
@@ -43,7 +44,8 @@ typedef struct msd_try {
     uint8_t errbit;  /* single-bit error position from the syndrome table, 0xff = none */
     uint32_t addr;   /* address the score tests: CRC for AP formats, (corrected) AA otherwise */
     uint32_t crc;    /* modesChecksum of the uncorrected message */
-    uint64_t power;  /* sum of m[j+19+k]^2 over this message's length*12/5 samples */
+    uint32_t pos;    /* batch-relative scan position (same as the owning hit's) */
+    uint32_t pad;
 } msd_try;
 
 /* Mode A/C candidate: every f1_sample that passes all tests of demod_2400.c:581-668; only the
@@ -92,18 +94,26 @@ typedef struct msd_resolver {
     struct msd_stats *stats;
 } msd_resolver;
 
-typedef void (*msd_emit_fn)(const struct msd_message *mm, void *user);
+/* Receives every accepted message in order.  Mode S messages still lack their signal level:
+ * power_req = (batch-relative position << 16) | number of samples to sum, 0 for Mode A/C;
+ * buffer = index of the buffer within the batch. */
+typedef void (*msd_emit_fn)(const struct msd_message *mm, uint64_t power_req, uint32_t buffer, void *user);
 
 void msd_resolver_reset(msd_resolver *r);
 /* Replays the buffers [first_chunk, first_chunk + nbuffers) of a batch.  hits/tries (Mode S) and
  * ac (Mode A/C) are the batch's ordered candidate lists; valid[i] is the i-th buffer's number of
- * new samples; means holds (mean_level, mean_power) per buffer; ts_override, if not NULL, holds
+ * new samples; ts_override, if not NULL, holds
  * (sampleTimestamp, sysTimestamp) per buffer instead of the ifile clock of sdr_ifile.c:187-190. */
 void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
-                       const uint32_t *valid, const double *means, const msd_hit *hits,
+                       const uint32_t *valid, const msd_hit *hits,
                        uint64_t nhits, const msd_try *tries, uint64_t ntries,
                        const msd_ac_hit *ac, uint64_t nac, const uint64_t *ts_override,
                        msd_emit_fn emit, void *user);
+/* Second half of demodulate2400's bookkeeping, once the signal power sums are known
+ * (demod_2400.c:386-408,422-427): fills signalLevel and the power statistics, in order. */
+void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
+                       struct msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
+                       const uint64_t *power, uint64_t nmsgs);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@
 #include "modes_hip.h"
 #include "msd_internal.h"
 
-#define MSD_SCAN_THREADS 256
+#define MSD_SCAN_THREADS 512
 
 typedef struct MsdScanParams {
     const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */
@@ -42,6 +42,8 @@ int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offse
                       const msd_hit *hits, const msd_try *tries, uint32_t hcap, uint32_t tcap,
                       msd_hit *dense_hits, uint64_t dense_hcap, msd_try *dense_tries,
                       uint64_t dense_tcap, hipStream_t stream);
+int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
+                     unsigned long long *d_out, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,

@@ -1,20 +1,29 @@
 /*
  * msd_kernels.hip -- CDNA4 (gfx950) kernels of the Mode S / Mode A/C candidate stage.
  *
- * msd_scan_kernel fuses, per tile of 4096 scan positions:
+ * msd_scan_kernel fuses, per tile of 8192 scan positions:
  *   IQ -> u16 magnitude            convert.c:63-111 (UC8 table), :215-253 / :332-370 (float)
  *   preamble pre-check + 3 tests   demod_2400.c:276-330
  *   5-phase PPM bit slicing        demod_2400.c:73-229 (closed form t = 95 + tp + 12k)
  *   CRC-24 + syndrome lookup       crc.c:67-82, :389-412
  *   state-free part of scoring     mode_s.c:311-409
- *   signal power                   demod_2400.c:386-399
- * Magnitudes live only in LDS: HBM sees the IQ bytes once (+7 % halo) and a few bytes of
- * candidate records per thousand samples.  No MFMA: there is no dense contraction on this path.
+ * Magnitudes live only in LDS: HBM sees each IQ byte once and a few bytes of candidate records
+ * per thousand samples.  No MFMA: there is no dense contraction anywhere on this path.
  *
- * Work decomposition: persistent workgroups, each owning a contiguous run of tiles, so its
- * candidate records come out already ordered and a workgroup-private cursor replaces global
- * atomics; a prefix + gather pass (msd_offsets_kernel / msd_gather_kernel) then concatenates the
- * per-workgroup regions into the dense, position-ordered lists the resolve stage walks.
+ * Work decomposition
+ *   - persistent 512-thread workgroups (8 wavefronts), each owning a contiguous run of tiles; the
+ *     328-sample look-behind of a tile is carried over inside LDS from the previous tile, and the
+ *     next tile's IQ is prefetched into registers while the current one is processed;
+ *   - the scan gives every lane 16 consecutive positions (register-tiled sliding window: 5 LDS
+ *     reads of 16 B feed 16 positions x 19 taps);
+ *   - everything after the scan is wave-autonomous: each wavefront compacts its own 1024
+ *     positions' hits (lane prefix sums over ballots / shuffles), slices, CRCs and classifies them
+ *     in its private LDS scratch with no workgroup barrier; slicing loops are arranged so that the
+ *     PPM phase is uniform across the wavefront (trial phase in the DF step, (tp + byte) mod 5 in
+ *     the payload step), which makes every correlator tap a compile-time LDS offset;
+ *   - hits are appended in position order to a workgroup-private region, tries through a
+ *     workgroup cursor in LDS -- no global atomics; msd_offsets_kernel / msd_gather_kernel then
+ *     concatenate the regions into the dense, ordered lists the resolve stage walks.
  */
 #include <hip/hip_runtime.h>
 
@@ -30,67 +39,36 @@
 
 namespace {
 
-constexpr int NT = MSD_SCAN_THREADS;       /* threads per workgroup */
-constexpr int T = MSD_TILE;                /* scan positions per tile */
-constexpr int LOADN = MSD_TILE_LOAD;       /* samples staged per tile */
-constexpr int NGROUP = LOADN / 8;          /* 8-sample load groups per tile */
-constexpr int FRONT = MSD_HALO_FRONT;      /* 328 */
-constexpr int HPASS = 64;                  /* hits handled per slicing pass */
-constexpr int TSLOTS = HPASS * 5;          /* try slots per pass: 5 phases per hit */
-constexpr int SPT = (TSLOTS + NT - 1) / NT; /* try slots per thread in blocked order */
+constexpr int NT = MSD_SCAN_THREADS;  /* 512 threads = 8 wavefronts */
+constexpr int NW = NT / 64;
+constexpr int T = MSD_TILE;           /* 8192 scan positions per tile */
+constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
+constexpr int GPT = T / 8 / NT;       /* 8-sample load groups per thread per tile (2) */
+constexpr int HROUND = 16;            /* hits per candidate round (one per lane 0..15) */
+constexpr int SURV_CAP = HROUND * 5;
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
-static_assert(T == NT * 16, "each thread owns 16 scan positions of a tile");
-static_assert(LOADN % 8 == 0 && FRONT % 8 == 0, "load groups are 8 samples");
+static_assert(T == NT * 16, "each thread scans 16 consecutive positions");
+static_assert(T % (8 * NT) == 0 && FRONT % 8 == 0, "whole load groups");
+static_assert(MSD_CHUNK_SAMPLES % T == 0, "a tile never straddles two buffers");
 
 /* ---- dynamic LDS carve-up (all offsets multiples of 16) ---- */
-constexpr int OFF_MAGS = 0;                                  /* u16[LOADN + 8] */
-constexpr int OFF_MASK = OFF_MAGS + (LOADN + 8) * 2;         /* u8[T] */
-constexpr int OFF_CRC = OFF_MASK + T;                        /* u32[256] */
-constexpr int OFF_SYN = OFF_CRC + 1024;                      /* u32[51 + 107 (+2 pad)] */
-constexpr int OFF_HITS = OFF_SYN + 640;                      /* u32[HPASS] */
-constexpr int OFF_NLIVE = OFF_HITS + HPASS * 4;              /* u32[HPASS] */
-constexpr int OFF_TMSG = OFF_NLIVE + HPASS * 4;              /* u8[TSLOTS][16] */
-constexpr int OFF_TADDR = OFF_TMSG + TSLOTS * 16;            /* u32[TSLOTS] */
-constexpr int OFF_TCRC = OFF_TADDR + TSLOTS * 4;             /* u32[TSLOTS] */
-constexpr int OFF_TNB = OFF_TCRC + TSLOTS * 4;               /* u8[TSLOTS]: nbytes | 0x80 live */
-constexpr int OFF_TERR = OFF_TNB + TSLOTS;                   /* u8[TSLOTS] */
-constexpr int OFF_SURV = OFF_TERR + TSLOTS;                  /* u16[TSLOTS] */
-constexpr int OFF_LIVE = OFF_SURV + TSLOTS * 2;              /* u16[TSLOTS] */
-constexpr int OFF_POWER = OFF_LIVE + TSLOTS * 2;             /* u64[TSLOTS] */
-constexpr int OFF_SCR = OFF_POWER + TSLOTS * 8;              /* u32[16] scan scratch */
-constexpr int OFF_LUT = OFF_SCR + 64;                        /* u16[128 * LUT_STRIDE], UC8 only */
+constexpr int OFF_MAGS = 0;                               /* u16[FRONT + T + 8] */
+constexpr int OFF_CRC = OFF_MAGS + (FRONT + T + 8) * 2;   /* u32[256] */
+constexpr int OFF_SYN = OFF_CRC + 1024;                   /* u32[160] */
+constexpr int OFF_MISC = OFF_SYN + 640;                   /* u32[64]: wave hit counts, try cursor */
+constexpr int OFF_WAVE = OFF_MISC + 256;                  /* per-wave scratch */
+constexpr int WAVE_HITBUF = 0;                            /* u32[16] */
+constexpr int WAVE_NLIVE = 64;                            /* u32[16] */
+constexpr int WAVE_FIRST = 128;                           /* u32[16] */
+constexpr int WAVE_SMETA = 192;                           /* u32[SURV_CAP] */
+constexpr int WAVE_SMSG = WAVE_SMETA + SURV_CAP * 4;      /* u8[SURV_CAP][16] */
+constexpr int WAVE_BYTES = WAVE_SMSG + SURV_CAP * 16;     /* 1792 */
+constexpr int OFF_LUT = OFF_WAVE + NW * WAVE_BYTES;       /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
 constexpr int LDS_UC8 = OFF_LUT + 128 * LUT_STRIDE * 2;
-static_assert(OFF_MASK % 16 == 0 && OFF_CRC % 16 == 0 && OFF_TMSG % 16 == 0 && OFF_POWER % 16 == 0 &&
+static_assert(OFF_CRC % 16 == 0 && OFF_WAVE % 16 == 0 && WAVE_BYTES % 16 == 0 && WAVE_SMSG % 16 == 0 &&
               OFF_LUT % 16 == 0, "LDS carve offsets must stay 16-byte aligned");
-
-/* exclusive prefix sum of one value per thread over the workgroup; *total = sum */
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *scratch)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if (lane >= o)
-            x += y;
-    }
-    if (lane == 63)
-        scratch[w] = x;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) {
-        uint32_t s = scratch[i];
-        if (i < w)
-            base += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + x - v;
-}
 
 /* (b - 127.5)^2 only depends on k = b-128 (b >= 128) or 127-b (b < 128) */
 __device__ __forceinline__ uint32_t fold8(uint32_t b)
@@ -112,35 +90,130 @@ __device__ __forceinline__ uint32_t mag_from_s16(int I, int Q, float inv_scale)
     return (uint32_t)(uint16_t)(scaled + 0.5f);
 }
 
-/* demod_2400.c:73-93 */
-__device__ __forceinline__ int correlate(const uint16_t *p, int c)
+template <int FMT>
+struct RawGroup { /* the raw bytes of 8 consecutive samples */
+    static constexpr int WORDS = (FMT == MSD_FMT_SC16 || FMT == MSD_FMT_SC16Q11) ? 8 : 4;
+    uint32_t w[WORDS];
+};
+
+/* Fetch the raw bytes of samples [n, n+8); n is a multiple of 8.  Returns a bit per sample that
+ * exists; samples outside the stream (before its start / after a discontinuity / past the end)
+ * have magnitude zero (fifo.c:179-182). */
+template <int FMT>
+__device__ __forceinline__ uint32_t fetch_group(const MsdScanParams &P, int64_t n, RawGroup<FMT> &r)
 {
-    const int m0 = p[0], m1 = p[1], m2 = p[2];
-    switch (c) {
-    case 0: return 18 * m0 - 15 * m1 - 3 * m2;
-    case 1: return 14 * m0 - 5 * m1 - 9 * m2;
-    case 2: return 16 * m0 + 5 * m1 - 20 * m2;
-    case 3: return 7 * m0 + 11 * m1 - 18 * m2;
-    default: return 4 * m0 + 15 * m1 - 20 * m2 + (int)p[3];
+    constexpr int BPS = RawGroup<FMT>::WORDS / 2;
+    const int64_t rel = n - (int64_t)P.batch_first;
+#pragma unroll
+    for (int k = 0; k < RawGroup<FMT>::WORDS; ++k)
+        r.w[k] = 0;
+    const uint8_t *src;
+    int avail = 8;
+    if (rel < 0) {
+        if (!P.have_prev || rel < -(int64_t)FRONT)
+            return 0;
+        src = P.prev_tail + (rel + FRONT) * BPS;
+    } else {
+        const int64_t left = (int64_t)P.nsamples - rel;
+        if (left <= 0)
+            return 0;
+        if (left < 8)
+            avail = (int)left;
+        src = P.iq + rel * BPS;
+    }
+    if (avail == 8) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(src);
+        r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+        if (BPS == 4) {
+            const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
+            r.w[4 % RawGroup<FMT>::WORDS] = b.x; r.w[5 % RawGroup<FMT>::WORDS] = b.y;
+            r.w[6 % RawGroup<FMT>::WORDS] = b.z; r.w[7 % RawGroup<FMT>::WORDS] = b.w;
+        }
+        return 0xffu;
+    }
+    for (int k = 0; k < avail * BPS / 2; ++k) { /* ragged end of the capture */
+        const uint32_t h = *reinterpret_cast<const uint16_t *>(src + 2 * k);
+        r.w[(k >> 1) % RawGroup<FMT>::WORDS] |= h << (16 * (k & 1));
+    }
+    return (1u << avail) - 1u;
+}
+
+template <int FMT>
+__device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t valid, const uint16_t *lut,
+                                              uint32_t (&mg)[8])
+{
+    if (FMT == MSD_FMT_UC8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t pair = (r.w[k >> 1] >> (16 * (k & 1))) & 0xffffu; /* I | Q << 8 */
+            mg[k] = lut[fold8(pair >> 8) * LUT_STRIDE + fold8(pair & 0xffu)];
+        }
+    } else if (FMT == MSD_FMT_MAG16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            mg[k] = (r.w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+    } else {
+        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t w = r.w[k % RawGroup<FMT>::WORDS];
+            mg[k] = mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
+        }
+    }
+    if (valid != 0xffu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (!((valid >> k) & 1u))
+                mg[k] = 0;
     }
 }
 
-/* byte b of the message tried at phase tp for the preamble whose pa = &m[j]: bit k of the message
- * is correlator (95+tp+12k) % 5 at sample j + (95+tp+12k) / 5 (demod_2400.c:98-177,188-189) */
-__device__ __forceinline__ uint32_t slice_byte(const uint16_t *pa, int tp, int b)
+__device__ __forceinline__ uint4 pack8(const uint32_t (&mg)[8])
 {
-    uint32_t v = 0;
-    int t = 95 + tp + 96 * b;
+    uint4 p;
+    p.x = mg[0] | (mg[1] << 16);
+    p.y = mg[2] | (mg[3] << 16);
+    p.z = mg[4] | (mg[5] << 16);
+    p.w = mg[6] | (mg[7] << 16);
+    return p;
+}
+
+/* demod_2400.c:73-93 with a compile-time correlator index */
+template <int C>
+__device__ __forceinline__ int correlate(int m0, int m1, int m2, int m3)
+{
+    if (C == 0) return 18 * m0 - 15 * m1 - 3 * m2;
+    if (C == 1) return 14 * m0 - 5 * m1 - 9 * m2;
+    if (C == 2) return 16 * m0 + 5 * m1 - 20 * m2;
+    if (C == 3) return 7 * m0 + 11 * m1 - 18 * m2;
+    return 4 * m0 + 15 * m1 - 20 * m2 + m3;
+}
+
+/* One message byte whose first bit sits at PPM phase PH (0..4) of sample p[0]: bit k is
+ * correlator (PH + 12k) % 5 at p[(PH + 12k) / 5]  (demod_2400.c:98-177 in closed form).  With PH
+ * uniform across the wavefront every tap is a constant LDS offset and the 21 samples the eight
+ * correlators share are read once. */
+template <int PH>
+__device__ __forceinline__ uint32_t slice_byte_phase(const uint16_t *p)
+{
+    int s[21];
 #pragma unroll
-    for (int k = 0; k < 8; ++k, t += 12) {
-        const int idx = t / 5, c = t - 5 * idx;
-        v = (v << 1) | (correlate(pa + idx, c) > 0 ? 1u : 0u);
+    for (int k = 0; k < 21; ++k)
+        s[k] = p[k];
+    uint32_t v = 0;
+#define MSD_BIT(K)                                                                                   \
+    {                                                                                                \
+        constexpr int t = PH + 12 * (K);                                                             \
+        constexpr int i = t / 5, c = t % 5;                                                          \
+        v = (v << 1) | (correlate<c>(s[i], s[i + 1], s[i + 2], s[(i + 3 > 20) ? 20 : i + 3]) > 0 ? 1u : 0u); \
     }
+    MSD_BIT(0) MSD_BIT(1) MSD_BIT(2) MSD_BIT(3) MSD_BIT(4) MSD_BIT(5) MSD_BIT(6) MSD_BIT(7)
+#undef MSD_BIT
     return v;
 }
 
 /* demod_2400.c:193-205 */
-__device__ __forceinline__ int bytes_for_df(uint32_t df)
+__device__ __forceinline__ uint32_t bytes_for_df(uint32_t df)
 {
     /* short: 0,4,5,11  long: 16,17,18,20,21,24  else give up after one byte */
     const uint32_t short_set = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
@@ -152,311 +225,152 @@ __device__ __forceinline__ int bytes_for_df(uint32_t df)
     return 1;
 }
 
-template <int FMT>
-__device__ __forceinline__ void load_group(const MsdScanParams &P, int64_t n, uint32_t (&mg)[8],
-                                           const uint16_t *lut)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
-    /* n: absolute sample index of the first of 8 samples (multiple of 8) */
-    constexpr int BPS = (FMT == MSD_FMT_UC8) ? 2 : (FMT == MSD_FMT_MAG16 ? 2 : 4);
-    const int64_t rel = n - (int64_t)P.batch_first;
+    uint32_t x = v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        mg[k] = 0;
-    const uint8_t *src;
-    int avail = 8;
-    if (rel < 0) {
-        if (!P.have_prev)
-            return; /* before the start of the stream / after a discontinuity: zero magnitudes */
-        src = P.prev_tail + (rel + FRONT) * BPS;
-    } else {
-        const int64_t left = (int64_t)P.nsamples - rel;
-        if (left <= 0)
-            return;
-        if (left < 8)
-            avail = (int)left;
-        src = P.iq + rel * BPS;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o)
+            x += y;
     }
-
-    uint32_t w[8]; /* 32 bytes of raw input, zero padded */
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        w[k] = 0;
-    if (avail == 8) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(src);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-        if (BPS == 4) {
-            const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
-            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-        }
-    } else { /* ragged end of the capture */
-        for (int k = 0; k < avail * BPS / 2; ++k) {
-            const uint32_t h = *reinterpret_cast<const uint16_t *>(src + 2 * k);
-            w[k >> 1] |= h << (16 * (k & 1));
-        }
-    }
-
-    if (FMT == MSD_FMT_UC8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t pair = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu; /* I | Q << 8 */
-            mg[k] = lut[fold8(pair >> 8) * LUT_STRIDE + fold8(pair & 0xffu)];
-        }
-    } else if (FMT == MSD_FMT_MAG16) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            mg[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-    } else {
-        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int I = (int)(int16_t)(w[k] & 0xffffu), Q = (int)(int16_t)(w[k] >> 16);
-            mg[k] = mag_from_s16(I, Q, inv);
-        }
-    }
-    if (avail < 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k >= avail)
-                mg[k] = 0;
-    }
+    return x;
 }
 
-template <int FMT>
-__global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
+/* order LDS traffic between lanes of one wavefront (they run in lock step; this only stops the
+ * compiler from moving accesses across the exchange point) */
+__device__ __forceinline__ void wave_lds_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *mags = reinterpret_cast<uint16_t *>(smem + OFF_MAGS);
-    uint8_t *mask = smem + OFF_MASK;
-    uint32_t *crc_tab = reinterpret_cast<uint32_t *>(smem + OFF_CRC);
-    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);
-    uint32_t *hitlist = reinterpret_cast<uint32_t *>(smem + OFF_HITS);
-    uint32_t *hit_nlive = reinterpret_cast<uint32_t *>(smem + OFF_NLIVE);
-    uint8_t *try_msg = smem + OFF_TMSG;
-    uint32_t *try_addr = reinterpret_cast<uint32_t *>(smem + OFF_TADDR);
-    uint32_t *try_crc = reinterpret_cast<uint32_t *>(smem + OFF_TCRC);
-    uint8_t *try_nb = smem + OFF_TNB;
-    uint8_t *try_err = smem + OFF_TERR;
-    uint16_t *surv = reinterpret_cast<uint16_t *>(smem + OFF_SURV);
-    uint16_t *live = reinterpret_cast<uint16_t *>(smem + OFF_LIVE);
-    unsigned long long *power = reinterpret_cast<unsigned long long *>(smem + OFF_POWER);
-    uint32_t *scr = reinterpret_cast<uint32_t *>(smem + OFF_SCR);
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    const int tid = threadIdx.x;
-    const uint32_t wg = blockIdx.x;
+/* The wave-autonomous candidate stage for one round of up to HROUND hits held in lanes
+ * 0..nh-1 (hit = tile-relative position | mask << 13). */
+__device__ __forceinline__ void candidate_round(const MsdScanParams &P, const uint16_t *mags,
+                                                const uint32_t *crc_tab, const uint32_t *syn,
+                                                unsigned char *wscr, uint32_t *wg_try_cursor, int lane,
+                                                uint32_t nh, uint32_t hit, uint64_t tile_pos0,
+                                                msd_hit *hit_out, msd_try *my_tries)
+{
+    uint32_t *hit_nlive = reinterpret_cast<uint32_t *>(wscr + WAVE_NLIVE);
+    uint32_t *hit_first = reinterpret_cast<uint32_t *>(wscr + WAVE_FIRST);
+    uint32_t *smeta = reinterpret_cast<uint32_t *>(wscr + WAVE_SMETA);
+    uint8_t *smsg = wscr + WAVE_SMSG;
 
-    /* constant tables -> LDS, once per persistent workgroup */
-    for (int i = tid; i < 256; i += NT)
-        crc_tab[i] = P.crc_tab[i];
-    for (int i = tid; i < 160; i += NT)
-        syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
-                          : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
-    if (FMT == MSD_FMT_UC8) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
-        uint4 *l = reinterpret_cast<uint4 *>(lut);
-        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
-            l[i] = g[i];
+    const bool has_hit = (uint32_t)lane < nh;
+    const uint32_t pos = hit & 0x1fffu, mask = (hit >> 13) & 7u;
+    const uint16_t *pa = mags + pos + 2; /* pa[d] = m[j + d]; the tile stages 328 = 326 + 2 ahead */
+    if (lane < HROUND) {
+        hit_nlive[lane] = 0;
+        hit_first[lane] = 0xffffffffu;
     }
-    __syncthreads();
 
-    const uint32_t tile_lo = wg * P.tiles_per_wg;
-    uint32_t tile_hi = tile_lo + P.tiles_per_wg;
-    if (tile_hi > P.ntiles)
-        tile_hi = P.ntiles;
-    const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
+    /* ---- step A: first byte of every tried phase (demod_2400.c:183-205).  The trial phase is
+     *      the loop variable, so phase and sample offset are compile-time constants. ---- */
+    uint32_t b0[5], nb[5];
+#define MSD_STEP_A(Q)                                                                          \
+    {                                                                                          \
+        constexpr int tp = 4 + (Q), t0 = 95 + tp;                                              \
+        const bool tried = has_hit && (((Q) < 2) ? (mask & 1u) : (((Q) < 4) ? (mask & 2u) : (mask & 4u))); \
+        b0[Q] = 0;                                                                             \
+        nb[Q] = 0;                                                                             \
+        if (tried) {                                                                           \
+            b0[Q] = slice_byte_phase<t0 % 5>(pa + t0 / 5);                                     \
+            nb[Q] = bytes_for_df(b0[Q] >> 3);                                                  \
+        }                                                                                      \
+    }
+    MSD_STEP_A(0) MSD_STEP_A(1) MSD_STEP_A(2) MSD_STEP_A(3) MSD_STEP_A(4)
+#undef MSD_STEP_A
 
-    uint32_t hcur = 0, tcur = 0; /* workgroup-uniform cursors into this workgroup's regions */
-    msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
-    msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
-
-    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
-        const uint64_t a0 = P.batch_first + (uint64_t)tile * T; /* first scan position */
-        const int64_t n0 = (int64_t)a0 - FRONT;                 /* sample staged at mags[0] */
-
-        /* ---- stage 1: IQ -> magnitudes in LDS, and this tile's share of the buffer sums ---- */
-        uint32_t sum_level = 0;
-        unsigned long long sum_power = 0;
-        for (int g = tid; g < NGROUP; g += NT) {
-            uint32_t mg[8];
-            load_group<FMT>(P, n0 + 8 * g, mg, lut);
-            uint4 packed;
-            packed.x = mg[0] | (mg[1] << 16);
-            packed.y = mg[2] | (mg[3] << 16);
-            packed.z = mg[4] | (mg[5] << 16);
-            packed.w = mg[6] | (mg[7] << 16);
-            *reinterpret_cast<uint4 *>(mags + 8 * g) = packed;
-            if (g >= FRONT / 8 && g < FRONT / 8 + T / 8) { /* samples this tile owns */
+    /* survivors (known DF), ordered by (hit, phase) */
+    uint32_t cnt = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    sum_level += mg[k];
-                    sum_power += (unsigned long long)(mg[k] * mg[k]);
+    for (int q = 0; q < 5; ++q)
+        cnt += nb[q] > 1 ? 1u : 0u;
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const uint32_t nsurv = __shfl(incl, 63);
+    if (nsurv == 0) {
+        if (has_hit) /* every try of these hits scores -2 whatever the filter holds */
+            hit_out[lane] = (tile_pos0 + pos) | ((msd_hit)mask << 28);
+        return;
+    }
+    {
+        uint32_t r = incl - cnt;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (nb[q] > 1) {
+                smeta[r] = pos | ((uint32_t)q << 13) | (nb[q] << 16) | ((uint32_t)lane << 20); /* q = tp - 4 */
+                smsg[16 * r] = (uint8_t)b0[q];
+                ++r;
+            }
+        }
+    }
+    wave_lds_sync();
+
+    /* ---- step B: the remaining bytes, one lane per (survivor, byte) with the lanes of one pass
+     *      all at the same PPM phase d = (tp + byte) mod 5 ---- */
+#define MSD_STEP_B(D)                                                                          \
+    for (uint32_t ub = 0; ub < nsurv; ub += 21) {                                              \
+        const uint32_t u = ub + (uint32_t)lane / 3u, m = (uint32_t)lane % 3u;                  \
+        if (lane < 63 && u < nsurv) {                                                          \
+            const uint32_t me = smeta[u];                                                      \
+            const uint32_t tp = 4u + ((me >> 13) & 7u), nbytes = (me >> 16) & 15u;             \
+            const uint32_t b = (((D) + 10u - tp) % 5u) + 5u * m;                               \
+            if (b >= 1 && b < nbytes) {                                                        \
+                const uint32_t t0 = 95u + tp + 96u * b; /* t0 % 5 == D */                      \
+                smsg[16 * u + b] = (uint8_t)slice_byte_phase<(D)>(mags + (me & 0x1fffu) + 2 + t0 / 5u); \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    MSD_STEP_B(0) MSD_STEP_B(1) MSD_STEP_B(2) MSD_STEP_B(3) MSD_STEP_B(4)
+#undef MSD_STEP_B
+    wave_lds_sync();
+
+    /* ---- step C: CRC-24 (crc.c:67-82) and the part of scoreModesMessage that needs no filter
+     *      (mode_s.c:311-409); one lane per survivor, two blocks of 64 ---- */
+    uint32_t rank_base = 0;
+    uint32_t rec_addr[2], rec_crc[2], rec_rank[2];
+    bool rec_live[2];
+    uint4 rec_msg[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const uint32_t u = 64u * blk + (uint32_t)lane;
+        bool alive = false;
+        rec_addr[blk] = rec_crc[blk] = rec_rank[blk] = 0;
+        rec_msg[blk] = make_uint4(0, 0, 0, 0);
+        if (64u * blk < nsurv) { /* wave-uniform */
+            if (u < nsurv) {
+                const uint32_t me = smeta[u];
+                const int n = (int)((me >> 16) & 15u);
+                const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
+                uint32_t w[4] = {m4.x, m4.y, m4.z, m4.w};
+                if (n == 7) { /* bytes 7.. were never sliced */
+                    w[1] &= 0x00ffffffu;
+                    w[2] = 0;
+                    w[3] = 0;
+                } else {
+                    w[3] &= 0x0000ffffu;
                 }
-            }
-        }
-        if (P.chunk_sums) {
-            unsigned long long sl = sum_level;
+                const uint32_t orall = w[0] | w[1] | w[2] | w[3];
+                uint32_t rem = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                sl += __shfl_down(sl, o);
-                sum_power += __shfl_down(sum_power, o);
-            }
-            if ((tid & 63) == 0 && (sl | sum_power)) {
-                /* owned samples are [a0, a0+T): one buffer, because T divides the buffer length */
-                const uint64_t c = (a0 - P.batch_first) / MSD_CHUNK_SAMPLES;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * c]), sl);
-                atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * c + 1]), sum_power);
-            }
-        }
-        __syncthreads();
-        if (P.debug_flags & 2)
-            continue;
-
-        /* ---- stage 2: preamble tests for every scan position (demod_2400.c:257-335) ---- */
-        uint32_t nz = 0; /* positions of mine with a test that fired */
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int p0 = it * (NT * 8) + tid * 8;
-            uint32_t v[16];
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(mags + p0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint4 q = src[k];
-                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-                }
-            }
-            uint32_t mlo = 0, mhi = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                /* pa[d] = mags[p + 2 + d]: the tile stages 328 samples ahead, the reference's
-                 * overlap is 326 */
-#define PA(d) ((int)((v[(q + 2 + (d)) >> 1] >> (16 * ((q + 2 + (d)) & 1))) & 0xffffu))
-                uint32_t m = 0;
-                if (PA(1) > PA(7) && PA(12) > PA(14) && PA(12) > PA(15)) {
-                    const int base_noise = PA(5) + PA(8) + PA(16) + PA(17) + PA(18);
-                    const int ref_level = (base_noise * P.threshold) >> 5;
-                    const int diff_2_3 = PA(2) - PA(3);
-                    const int sum_1_4 = PA(1) + PA(4);
-                    const int diff_10_11 = PA(10) - PA(11);
-                    const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
-                    if (common3456 - diff_10_11 >= ref_level)
-                        m |= 1u;
-                    if (common3456 + diff_10_11 >= ref_level)
-                        m |= 2u;
-                    if (sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level)
-                        m |= 4u;
-                }
-#undef PA
-                if (a0 + (uint64_t)(p0 + q) >= batch_end)
-                    m = 0; /* past the last position the reference scans */
-                if (q < 4)
-                    mlo |= m << (8 * q);
-                else
-                    mhi |= m << (8 * (q - 4));
-            }
-            *reinterpret_cast<uint2 *>(mask + p0) = make_uint2(mlo, mhi);
-            nz |= mlo | mhi;
-        }
-        /* most tiles of a quiet band have no hit at all: skip the bookkeeping then */
-        const int any = __syncthreads_or(nz != 0);
-        if (!any || (P.debug_flags & 1))
-            continue;
-
-        /* ---- stage 3: ordered hit list ---- */
-        uint32_t mymask[4];
-        {
-            const uint4 q = *reinterpret_cast<const uint4 *>(mask + 16 * tid);
-            mymask[0] = q.x; mymask[1] = q.y; mymask[2] = q.z; mymask[3] = q.w;
-        }
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            cnt += ((mymask[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u;
-        uint32_t H;
-        const uint32_t rank0 = block_excl_scan(cnt, &H, scr);
-
-        for (uint32_t lo = 0; lo < H; lo += HPASS) {
-            const uint32_t nh = (H - lo < (uint32_t)HPASS) ? (H - lo) : (uint32_t)HPASS;
-            {
-                uint32_t r = rank0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t m = (mymask[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                    if (m) {
-                        if (r >= lo && r < lo + HPASS)
-                            hitlist[r - lo] = (uint32_t)(16 * tid + k) | (m << 12);
-                        ++r;
+                for (int i = 0; i < 11; ++i) {
+                    if (i < n - 3) {
+                        const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        rem = ((rem << 8) ^ crc_tab[byte ^ (rem >> 16)]) & 0xffffffu;
                     }
                 }
-            }
-            if (tid < HPASS)
-                hit_nlive[tid] = 0;
-            __syncthreads();
-
-            /* ---- stage 4a: first byte of every tried phase -> DF -> length ---- */
-            for (uint32_t s = tid; s < nh * 5; s += NT) {
-                const uint32_t hit = s / 5, q = s - 5 * hit;
-                const uint32_t e = hitlist[hit];
-                const uint32_t m = e >> 12;
-                const bool tried = (q < 2) ? (m & 1u) : ((q < 4) ? (m & 2u) : (m & 4u));
-                uint32_t nb = 0;
-                if (tried) {
-                    const uint32_t b0 = slice_byte(mags + (e & 0xfffu) + 2, 4 + (int)q, 0);
-                    nb = (uint32_t)bytes_for_df(b0 >> 3);
-                    try_msg[16 * s] = (uint8_t)b0;
-                }
-                try_nb[s] = (uint8_t)nb;
-            }
-            __syncthreads();
-
-            /* ---- stage 4b: tries with a known DF slice their remaining bytes, one lane per
-             *      (try, byte) so that the short list still fills wavefronts ---- */
-            uint32_t nsurv;
-            {
-                uint32_t c = 0;
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) {
-                    const uint32_t s = tid * SPT + i;
-                    if (s < nh * 5 && try_nb[s] > 1)
-                        ++c;
-                }
-                uint32_t r = block_excl_scan(c, &nsurv, scr);
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) {
-                    const uint32_t s = tid * SPT + i;
-                    if (s < nh * 5 && try_nb[s] > 1)
-                        surv[r++] = (uint16_t)s;
-                }
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < nsurv * 13; i += NT) {
-                const uint32_t u = i / 13, b = 1 + (i - 13 * u);
-                const uint32_t s = surv[u];
-                if (b < try_nb[s]) {
-                    const uint32_t hit = s / 5, q = s - 5 * hit;
-                    const uint32_t pos = hitlist[hit] & 0xfffu;
-                    try_msg[16 * s + b] = (uint8_t)slice_byte(mags + pos + 2, 4 + (int)q, (int)b);
-                }
-            }
-            __syncthreads();
-
-            /* ---- stage 4c: CRC + the part of scoreModesMessage that needs no filter ---- */
-            for (uint32_t u = tid; u < nsurv; u += NT) {
-                const uint32_t s = surv[u];
-                const uint8_t *msg = try_msg + 16 * s;
-                const int n = try_nb[s];
-                uint32_t orall = 0, rem = 0;
-                for (int i = 0; i < n - 3; ++i) {
-                    const uint32_t byte = msg[i];
-                    orall |= byte;
-                    rem = ((rem << 8) ^ crc_tab[byte ^ (rem >> 16)]) & 0xffffffu;
-                }
-                const uint32_t tail = ((uint32_t)msg[n - 3] << 16) | ((uint32_t)msg[n - 2] << 8) | msg[n - 1];
-                orall |= tail;
+                uint32_t tail;
+                if (n == 7) /* bytes 4,5,6 */
+                    tail = ((w[1] & 0xffu) << 16) | (w[1] & 0xff00u) | ((w[1] >> 16) & 0xffu);
+                else        /* bytes 11,12,13 */
+                    tail = (((w[2] >> 24) & 0xffu) << 16) | ((w[3] & 0xffu) << 8) | ((w[3] >> 8) & 0xffu);
                 const uint32_t crc = rem ^ tail;
-                const uint32_t df = msg[0] >> 3;
-                const uint32_t aa = ((uint32_t)msg[1] << 16) | ((uint32_t)msg[2] << 8) | msg[3];
-                bool alive = (orall != 0); /* mode_s.c:325 */
+                const uint32_t df = (w[0] & 0xffu) >> 3;
+                const uint32_t aa = (((w[0] >> 8) & 0xffu) << 16) | (((w[0] >> 16) & 0xffu) << 8) | (w[0] >> 24);
+                alive = (orall != 0); /* mode_s.c:325 */
                 uint32_t addr = crc, errbit = 0xffu;
                 if (alive && (df == 11 || df == 17 || df == 18)) {
                     addr = aa;
@@ -484,95 +398,300 @@ __global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
                             addr ^= 1u << (31 - errbit); /* correct_aa_field, mode_s.c:266-281 */
                     }
                 }
-                if (alive) {
-                    try_nb[s] = (uint8_t)(n | 0x80);
-                    try_addr[s] = addr;
-                    try_crc[s] = crc;
-                    try_err[s] = (uint8_t)errbit;
-                    atomicAdd(&hit_nlive[s / 5], 1u);
-                }
+                rec_addr[blk] = addr;
+                rec_crc[blk] = crc;
+                const uint32_t tp = 4u + ((me >> 13) & 7u);
+                rec_msg[blk] = make_uint4(w[0], w[1], w[2], (w[3] & 0xffffu) | (tp << 16) | (errbit << 24));
             }
-            __syncthreads();
-
-            /* ---- stage 4d: ordered list of live tries, their signal power, and the records ---- */
-            uint32_t nlive;
-            {
-                uint32_t c = 0;
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) {
-                    const uint32_t s = tid * SPT + i;
-                    if (s < nh * 5 && (try_nb[s] & 0x80))
-                        ++c;
-                }
-                uint32_t r = block_excl_scan(c, &nlive, scr);
-#pragma unroll
-                for (int i = 0; i < SPT; ++i) {
-                    const uint32_t s = tid * SPT + i;
-                    if (s < nh * 5 && (try_nb[s] & 0x80)) {
-                        live[r] = (uint16_t)s;
-                        power[r] = 0;
-                        ++r;
-                    }
-                }
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < nlive * 17; i += NT) {
-                const uint32_t l = i / 17, g = i - 17 * l;
-                const uint32_t s = live[l];
-                const int len = ((try_nb[s] & 0x7f) == 14) ? 268 : 134; /* msglen*12/5 */
-                const uint16_t *m19 = mags + (hitlist[s / 5] & 0xfffu) + 2 + 19;
-                unsigned long long acc = 0;
-                const int k1 = ((int)g * 16 + 16 < len) ? (int)g * 16 + 16 : len;
-                for (int k = (int)g * 16; k < k1; ++k) {
-                    const uint32_t x = m19[k];
-                    acc += (unsigned long long)(x * x);
-                }
-                if (acc)
-                    atomicAdd(&power[l], acc);
-            }
-            __syncthreads();
-            for (uint32_t l = tid; l < nlive; l += NT) {
-                const uint32_t s = live[l];
-                const uint32_t q = s - 5 * (s / 5);
-                const uint4 *m4 = reinterpret_cast<const uint4 *>(try_msg + 16 * s);
-                uint4 lo4 = *m4;
-                if ((try_nb[s] & 0x7f) == 7) { /* short message: bytes 7..13 were never sliced */
-                    lo4.y &= 0x00ffffffu;
-                    lo4.z = 0;
-                    lo4.w = 0;
-                }
-                /* bytes 14,15 of the first half carry tp and errbit */
-                lo4.w = (lo4.w & 0xffffu) | ((4u + q) << 16) | ((uint32_t)try_err[s] << 24);
-                uint4 hi4;
-                hi4.x = try_addr[s];
-                hi4.y = try_crc[s];
-                const unsigned long long pw = power[l];
-                hi4.z = (uint32_t)pw;
-                hi4.w = (uint32_t)(pw >> 32);
-                if (tcur + l < P.tcap) {
-                    uint4 *dst = reinterpret_cast<uint4 *>(my_tries + tcur + l);
-                    dst[0] = lo4;
-                    dst[1] = hi4;
-                }
-            }
-            for (uint32_t i = tid; i < nh; i += NT) {
-                const uint32_t e = hitlist[i];
-                const msd_hit rec = (a0 + (e & 0xfffu)) | ((msd_hit)(e >> 12) << 40) |
-                                    ((msd_hit)hit_nlive[i] << 43);
-                if (hcur + lo + i < P.hcap)
-                    my_hits[hcur + lo + i] = rec;
-            }
-            tcur += nlive;
-            __syncthreads();
+            const unsigned long long bal = __ballot(alive);
+            rec_rank[blk] = rank_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            rank_base += (uint32_t)__popcll(bal);
         }
-        hcur += H;
+        rec_live[blk] = alive;
+    }
+    const uint32_t total_live = rank_base;
+
+    /* ---- step D: reserve space for the try records, write them, then the hit records ---- */
+    if (total_live) {
+        uint32_t tbase = 0;
+        if (lane == 0)
+            tbase = atomicAdd(wg_try_cursor, total_live);
+        tbase = __shfl(tbase, 0);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            if (rec_live[blk]) {
+                const uint32_t u = 64u * blk + (uint32_t)lane;
+                const uint32_t me = smeta[u];
+                const uint32_t idx = tbase + rec_rank[blk];
+                const uint32_t h = me >> 20;
+                atomicAdd(&hit_nlive[h], 1u);
+                atomicMin(&hit_first[h], idx);
+                if (idx < P.tcap) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
+                    dst[0] = rec_msg[blk];
+                    dst[1] = make_uint4(rec_addr[blk], rec_crc[blk], (uint32_t)(tile_pos0 + (me & 0x1fffu)), 0u);
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    if (has_hit) {
+        const uint32_t nl = hit_nlive[lane];
+        msd_hit rec = (tile_pos0 + pos) | ((msd_hit)mask << 28) | ((msd_hit)nl << 31);
+        if (nl)
+            rec |= (msd_hit)hit_first[lane] << 34;
+        hit_out[lane] = rec;
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *mags = reinterpret_cast<uint16_t *>(smem + OFF_MAGS);
+    uint32_t *crc_tab = reinterpret_cast<uint32_t *>(smem + OFF_CRC);
+    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + OFF_MISC);
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wg = blockIdx.x;
+    unsigned char *wscr = smem + OFF_WAVE + wave * WAVE_BYTES;
+    uint32_t *hitbuf = reinterpret_cast<uint32_t *>(wscr + WAVE_HITBUF);
+    uint32_t *wave_hits = misc;         /* [2][NW], double buffered by tile parity */
+    uint32_t *wg_try_cursor = misc + 32; /* [1] */
+
+    /* constant tables -> LDS, once per persistent workgroup */
+    for (int i = tid; i < 256; i += NT)
+        crc_tab[i] = P.crc_tab[i];
+    for (int i = tid; i < 160; i += NT)
+        syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
+                          : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
+    if (FMT == MSD_FMT_UC8) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
+        uint4 *l = reinterpret_cast<uint4 *>(lut);
+        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
+            l[i] = g[i];
+    }
+    if (tid == 0)
+        *wg_try_cursor = 0;
+
+    const uint32_t tile_lo = wg * P.tiles_per_wg;
+    uint32_t tile_hi = tile_lo + P.tiles_per_wg;
+    if (tile_hi > P.ntiles)
+        tile_hi = P.ntiles;
+    if (tile_lo >= tile_hi) { /* workgroup-uniform */
+        if (tid == 0) {
+            msd_wg_counts c = {0, 0, 0, 0};
+            P.counts[wg] = c;
+        }
+        return;
+    }
+    __syncthreads();
+    const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
+
+    uint32_t hcur = 0; /* workgroup-uniform cursor into this workgroup's hit region */
+    msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
+    msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
+
+    /* running buffer sums (convert.c:78-110), flushed when the workgroup moves to another buffer */
+    uint32_t sum_level = 0;
+    unsigned long long sum_power = 0;
+    uint64_t sum_chunk = (uint64_t)tile_lo * T / MSD_CHUNK_SAMPLES;
+
+    /* look-behind of the first tile: samples [a0-328, a0) */
+    {
+        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * T;
+        if (tid < FRONT / 8) {
+            RawGroup<FMT> r;
+            const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * tid, r);
+            uint32_t mg[8];
+            convert_group<FMT>(r, valid, lut, mg);
+            *reinterpret_cast<uint4 *>(mags + 8 * tid) = pack8(mg);
+        }
+    }
+    RawGroup<FMT> cur[GPT], nxt[GPT];
+    uint32_t cur_valid[GPT], nxt_valid[GPT];
+    {
+        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * T;
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            cur_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + 8 * (tid + NT * k), cur[k]);
+            nxt_valid[k] = 0;
+            nxt[k] = cur[k];
+        }
     }
 
+    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const uint64_t tile_pos0 = (uint64_t)tile * T; /* first scan position, batch-relative */
+        const uint64_t a0 = P.batch_first + tile_pos0;
+
+        /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
+        {
+            const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
+            if (c != sum_chunk) { /* workgroup-uniform */
+                if (P.chunk_sums) {
+                    unsigned long long sl = sum_level, sp = sum_power;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        sl += __shfl_down(sl, o);
+                        sp += __shfl_down(sp, o);
+                    }
+                    if (lane == 0 && (sl | sp)) {
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
+                    }
+                }
+                sum_level = 0;
+                sum_power = 0;
+                sum_chunk = c;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            uint32_t mg[8];
+            convert_group<FMT>(cur[k], cur_valid[k], lut, mg);
+            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (tid + NT * k)) = pack8(mg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sum_level += mg[i];
+                sum_power += (unsigned long long)(mg[i] * mg[i]);
+            }
+        }
+        if (tile + 1 < tile_hi) {
+#pragma unroll
+            for (int k = 0; k < GPT; ++k)
+                nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + T + 8 * (tid + NT * k), nxt[k]);
+        }
+        __syncthreads();
+
+        if (!(P.debug_flags & 2)) {
+            /* ---- stage 2: preamble tests for my 16 consecutive positions (demod_2400.c:257-335) ---- */
+            uint32_t v[20];
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(mags + 16 * tid);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const uint4 q = src[k];
+                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+                }
+            }
+            uint64_t nib = 0; /* 4 bits per position: which tests fired */
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                /* pa[d] = mags[p + 2 + d]: the tile stages 328 samples ahead, the reference's
+                 * overlap is 326 */
+#define PA(d) ((int)((v[(q + 2 + (d)) >> 1] >> (16 * ((q + 2 + (d)) & 1))) & 0xffffu))
+                uint32_t m = 0;
+                if (PA(1) > PA(7) && PA(12) > PA(14) && PA(12) > PA(15)) {
+                    const int base_noise = PA(5) + PA(8) + PA(16) + PA(17) + PA(18);
+                    const int ref_level = (base_noise * P.threshold) >> 5;
+                    const int diff_2_3 = PA(2) - PA(3);
+                    const int sum_1_4 = PA(1) + PA(4);
+                    const int diff_10_11 = PA(10) - PA(11);
+                    const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
+                    if (common3456 - diff_10_11 >= ref_level)
+                        m |= 1u;
+                    if (common3456 + diff_10_11 >= ref_level)
+                        m |= 2u;
+                    if (sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level)
+                        m |= 4u;
+                }
+#undef PA
+                nib |= (uint64_t)m << (4 * q);
+            }
+            /* positions past the last one the reference scans */
+            {
+                const uint64_t first = a0 + 16ull * tid;
+                if (first + 16 > batch_end) {
+                    const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
+                    nib = keep ? (nib & ((1ull << (4 * keep)) - 1ull)) : 0ull;
+                }
+            }
+
+            /* ---- stage 3: ordered hit bookkeeping ---- */
+            uint32_t cnt;
+            {
+                uint64_t x = nib | (nib >> 1) | (nib >> 2); /* non-zero nibbles */
+                x &= 0x1111111111111111ull;
+                cnt = (uint32_t)__popcll(x);
+            }
+            const uint32_t incl = wave_incl_scan(cnt, lane);
+            const uint32_t wave_total = __shfl(incl, 63);
+            uint32_t *wh = wave_hits + NW * (tile & 1u);
+            if (lane == 0)
+                wh[wave] = wave_total;
+            __syncthreads();
+            uint32_t wave_base = 0, H = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t s = wh[i];
+                if (i < wave)
+                    wave_base += s;
+                H += s;
+            }
+
+            if (!(P.debug_flags & 1) && wave_total) {
+                /* ---- stage 4: wave-autonomous candidate rounds ---- */
+                const uint32_t my_rank0 = incl - cnt;
+                for (uint32_t r0 = 0; r0 < wave_total; r0 += HROUND) {
+                    const uint32_t nh = (wave_total - r0 < (uint32_t)HROUND) ? (wave_total - r0) : (uint32_t)HROUND;
+                    if (cnt && my_rank0 < r0 + HROUND && my_rank0 + cnt > r0) {
+                        uint32_t r = my_rank0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const uint32_t m = (uint32_t)(nib >> (4 * q)) & 7u;
+                            if (m) {
+                                if (r >= r0 && r < r0 + HROUND)
+                                    hitbuf[r - r0] = (uint32_t)(16 * tid + q) | (m << 13);
+                                ++r;
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    const uint32_t hit = (uint32_t)lane < nh ? hitbuf[lane] : 0u;
+                    const uint32_t out0 = hcur + wave_base + r0;
+                    if (out0 + nh <= P.hcap) /* wave-uniform; an overflow is reported via counts */
+                        candidate_round(P, mags, crc_tab, syn, wscr, wg_try_cursor, lane, nh, hit, tile_pos0,
+                                        my_hits + out0, my_tries);
+                    wave_lds_sync();
+                }
+            }
+            hcur += H;
+        }
+
+        /* ---- carry the last 328 magnitudes over as the next tile's look-behind ---- */
+        uint4 carry = make_uint4(0, 0, 0, 0);
+        if (tid < FRONT / 8)
+            carry = *reinterpret_cast<const uint4 *>(mags + T + 8 * tid);
+        __syncthreads();
+        if (tid < FRONT / 8)
+            *reinterpret_cast<uint4 *>(mags + 8 * tid) = carry;
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            cur[k] = nxt[k];
+            cur_valid[k] = nxt_valid[k];
+        }
+    }
+
+    if (P.chunk_sums) {
+        unsigned long long sl = sum_level, sp = sum_power;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sl += __shfl_down(sl, o);
+            sp += __shfl_down(sp, o);
+        }
+        if (lane == 0 && (sl | sp)) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
         msd_wg_counts c;
         c.nhits = hcur;
-        c.ntries = tcur;
-        c.overflow = (hcur > P.hcap || tcur > P.tcap) ? 1u : 0u;
+        c.ntries = *wg_try_cursor;
+        c.overflow = (hcur > P.hcap || c.ntries > P.tcap) ? 1u : 0u;
         c.pad = 0;
         P.counts[wg] = c;
     }
@@ -625,7 +744,8 @@ __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *c
     }
 }
 
-/* dense[offset[w] + i] = region[w][i]; grid = nwg workgroups */
+/* dense[offset[w] + i] = region[w][i]; the try index inside a hit record is made dense too.
+ * grid = nwg workgroups */
 __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *counts,
                                                          const uint64_t *offsets, const msd_hit *hits,
                                                          const msd_try *tries, uint32_t hcap,
@@ -638,14 +758,72 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *co
     const uint32_t nt = counts[w].ntries < tcap ? counts[w].ntries : tcap;
     const uint64_t ho = offsets[2 * w], to = offsets[2 * w + 1];
     const msd_hit *hs = hits + (size_t)w * hcap;
-    for (uint32_t i = threadIdx.x; i < nh; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < nh; i += blockDim.x) {
+        msd_hit h = hs[i];
+        if (MSD_HIT_NLIVE(h))
+            h += (msd_hit)to << 34;
         if (ho + i < dense_hcap)
-            dense_hits[ho + i] = hs[i];
+            dense_hits[ho + i] = h;
+    }
     const uint4 *ts = reinterpret_cast<const uint4 *>(tries + (size_t)w * tcap);
     uint4 *td = reinterpret_cast<uint4 *>(dense_tries);
     for (uint32_t i = threadIdx.x; i < 2 * nt; i += blockDim.x)
         if (to + (i >> 1) < dense_tcap)
             td[2 * to + i] = ts[i];
+}
+
+/* one magnitude of the stream, by absolute sample index (used by the small follow-up kernels) */
+template <int FMT>
+__device__ __forceinline__ uint32_t stream_mag(const MsdScanParams &P, int64_t n, const uint16_t *lut_g)
+{
+    constexpr int BPS = RawGroup<FMT>::WORDS / 2;
+    const int64_t rel = n - (int64_t)P.batch_first;
+    const uint8_t *src;
+    if (rel < 0) {
+        if (!P.have_prev || rel < -(int64_t)FRONT)
+            return 0;
+        src = P.prev_tail + (rel + FRONT) * BPS;
+    } else {
+        if (rel >= (int64_t)P.nsamples)
+            return 0;
+        src = P.iq + rel * BPS;
+    }
+    if (FMT == MSD_FMT_UC8) {
+        const uint32_t pair = *reinterpret_cast<const uint16_t *>(src);
+        return lut_g[fold8(pair >> 8) * LUT_STRIDE + fold8(pair & 0xffu)];
+    } else if (FMT == MSD_FMT_MAG16) {
+        return *reinterpret_cast<const uint16_t *>(src);
+    } else {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(src);
+        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        return mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
+    }
+}
+
+/* Signal power of the accepted messages (demod_2400.c:386-399): sum of m[j+19+k]^2 over
+ * msglen*12/5 samples.  Only accepted messages need it, so it runs after the resolve stage on
+ * their positions: one wavefront per message. */
+template <int FMT>
+__global__ void __launch_bounds__(256) msd_power_kernel(const MsdScanParams P, const uint64_t *req /* pos << 16 | len */,
+                                                        uint32_t nreq, unsigned long long *out)
+{
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= nreq)
+        return;
+    const uint64_t rq = req[i];
+    const int len = (int)(rq & 0xffffu);
+    const int64_t n0 = (int64_t)P.batch_first + (int64_t)(rq >> 16) - (int64_t)MSD_OVERLAP + 19;
+    unsigned long long acc = 0;
+    for (int k = lane; k < len; k += 64) {
+        const uint32_t x = stream_mag<FMT>(P, n0 + k, P.lut);
+        acc += (unsigned long long)(x * x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        acc += __shfl_down(acc, o);
+    if (lane == 0)
+        out[i] = acc;
 }
 
 /* IQ -> magnitude only, for the iq_convert_fn-shaped entry point (convert.h:33-38): writes the
@@ -655,7 +833,7 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
                                                           const uint16_t *lut_g, uint16_t *mag,
                                                           unsigned long long *sums)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[128 * LUT_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[(FMT == MSD_FMT_UC8) ? 128 * LUT_STRIDE : 8];
     if (FMT == MSD_FMT_UC8) {
         const uint4 *g = reinterpret_cast<const uint4 *>(lut_g);
         uint4 *l = reinterpret_cast<uint4 *>(lut);
@@ -671,8 +849,10 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
     unsigned long long sl = 0, sp = 0;
     const uint32_t ngroups = (nsamples + 7) / 8;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        RawGroup<FMT> r;
+        const uint32_t valid = fetch_group<FMT>(P, (int64_t)g * 8, r);
         uint32_t mg[8];
-        load_group<FMT>(P, (int64_t)g * 8, mg, lut);
+        convert_group<FMT>(r, valid, lut, mg);
         for (int k = 0; k < 8; ++k) {
             if (g * 8 + k < nsamples)
                 mag[g * 8 + k] = (uint16_t)mg[k];
@@ -734,32 +914,27 @@ extern "C" size_t msd_scan_lds_bytes(int format)
     return format == MSD_FMT_UC8 ? (size_t)LDS_UC8 : (size_t)LDS_COMMON;
 }
 
+template <int FMT>
+static int launch_scan_fmt(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
+{
+    const size_t lds = msd_scan_lds_bytes(FMT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+        return -5;
+    hipLaunchKernelGGL(msd_scan_kernel<FMT>, dim3(nwg), dim3(NT), lds, stream, *p);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream)
 {
-    const size_t lds = msd_scan_lds_bytes(format);
-    hipError_t e = hipSuccess;
     switch (format) {
-    case MSD_FMT_UC8:
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<MSD_FMT_UC8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            hipLaunchKernelGGL(msd_scan_kernel<MSD_FMT_UC8>, dim3(nwg), dim3(NT), lds, stream, *p);
-        break;
-    case MSD_FMT_SC16:
-        hipLaunchKernelGGL(msd_scan_kernel<MSD_FMT_SC16>, dim3(nwg), dim3(NT), lds, stream, *p);
-        break;
-    case MSD_FMT_SC16Q11:
-        hipLaunchKernelGGL(msd_scan_kernel<MSD_FMT_SC16Q11>, dim3(nwg), dim3(NT), lds, stream, *p);
-        break;
-    case MSD_FMT_MAG16:
-        hipLaunchKernelGGL(msd_scan_kernel<MSD_FMT_MAG16>, dim3(nwg), dim3(NT), lds, stream, *p);
-        break;
-    default:
-        return -22;
+    case MSD_FMT_UC8: return launch_scan_fmt<MSD_FMT_UC8>(p, nwg, stream);
+    case MSD_FMT_SC16: return launch_scan_fmt<MSD_FMT_SC16>(p, nwg, stream);
+    case MSD_FMT_SC16Q11: return launch_scan_fmt<MSD_FMT_SC16Q11>(p, nwg, stream);
+    case MSD_FMT_MAG16: return launch_scan_fmt<MSD_FMT_MAG16>(p, nwg, stream);
+    default: return -22;
     }
-    if (e == hipSuccess)
-        e = hipGetLastError();
-    return e == hipSuccess ? 0 : -5;
 }
 
 extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets,
@@ -771,6 +946,31 @@ extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint
     hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, counts, nwg, offsets, totals);
     hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, offsets, hits, tries,
                        hcap, tcap, dense_hits, dense_hcap, dense_tries, dense_tcap);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
+                                unsigned long long *d_out, hipStream_t stream)
+{
+    if (nreq == 0)
+        return 0;
+    const dim3 grid((nreq + 3) / 4), block(256);
+    switch (format) {
+    case MSD_FMT_UC8:
+        hipLaunchKernelGGL(msd_power_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, d_req, nreq, d_out);
+        break;
+    case MSD_FMT_SC16:
+        hipLaunchKernelGGL(msd_power_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, d_req, nreq, d_out);
+        break;
+    case MSD_FMT_SC16Q11:
+        hipLaunchKernelGGL(msd_power_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, d_req, nreq, d_out);
+        break;
+    case MSD_FMT_MAG16:
+        hipLaunchKernelGGL(msd_power_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, d_req, nreq, d_out);
+        break;
+    default:
+        return -22;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -118,17 +118,17 @@ static int score_try(const msd_try *t, int known)
     }
 }
 
-/* One buffer of demodulate2400 (demod_2400.c:236-428) over hits[*hi..] / tries[*ti..]. */
-static void resolve_mode_s(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint64_t sample_ts,
-                           uint64_t sys_ts, double mean_power, const msd_hit *hits, uint64_t nhits,
-                           uint64_t *hi, const msd_try *tries, uint64_t *ti, msd_emit_fn emit,
-                           void *user)
+/* One buffer of demodulate2400 (demod_2400.c:236-428) over hits[*hi..]; everything except the
+ * signal-power bookkeeping, which msd_resolve_power() adds once the sums are known. */
+static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, uint32_t mlen,
+                           uint64_t sample_ts, uint64_t sys_ts, const msd_hit *hits, uint64_t nhits,
+                           uint64_t *hi, const msd_try *tries, msd_emit_fn emit, void *user)
 {
     msd_stats *st = r->stats;
-    const uint64_t base = chunk * MSD_CHUNK_SAMPLES;
+    (void)batch_chunk0;
+    const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES; /* batch-relative */
     const uint64_t end = base + mlen;
     uint64_t resume = base; /* first position not covered by a skip-ahead */
-    uint64_t sum_scaled_signal_power = 0;
 
     r->ifile_now = sys_ts; /* demod_2400.c:252-255 */
 
@@ -137,9 +137,6 @@ static void resolve_mode_s(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint6
         const uint64_t a = MSD_HIT_POS(h);
         if (a >= end)
             break;
-        const unsigned nlive = MSD_HIT_NLIVE(h);
-        const msd_try *t = &tries[*ti];
-        *ti += nlive;
         if (a < resume)
             continue; /* inside the previous message (demod_2400.c:416) */
 
@@ -151,6 +148,8 @@ static void resolve_mode_s(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint6
 
         /* best phase: strict '>' so the first-tried phase wins ties (demod_2400.c:218); every
          * try that is not in the list scores -2 whatever the filter holds */
+        const unsigned nlive = MSD_HIT_NLIVE(h);
+        const msd_try *t = tries + MSD_HIT_TRY(h);
         int bestscore = -2, known_best = 0;
         const msd_try *best = 0;
         for (unsigned k = 0; k < nlive; ++k) {
@@ -220,36 +219,19 @@ static void resolve_mode_s(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint6
         st->demod_accepted[mm.correctedbits]++;
         st->demod_bestPhase[best->tp - 4]++;
 
-        { /* demod_2400.c:386-408 */
-            const int signal_len = msgbits * 12 / 5;
-            const double signal_power = best->power / 65535.0 / 65535.0;
-            mm.signalLevel = signal_power / signal_len;
-            st->signal_power_sum += signal_power;
-            st->signal_power_count += (uint64_t)signal_len;
-            sum_scaled_signal_power += best->power;
-            if (mm.signalLevel > st->peak_signal_power)
-                st->peak_signal_power = mm.signalLevel;
-            if (mm.signalLevel > 0.50119)
-                st->strong_signal_count++;
-            resume = a + (uint64_t)signal_len + 1; /* j += len, then the loop's ++ */
-        }
-        emit(&mm, user);
-    }
-
-    { /* demod_2400.c:422-427 */
-        double sum_signal_power = sum_scaled_signal_power / 65535.0 / 65535.0;
-        st->noise_power_sum += (mean_power * mlen - sum_signal_power);
-        st->noise_power_count += mlen;
+        const int signal_len = msgbits * 12 / 5;
+        resume = a + (uint64_t)signal_len + 1; /* j += len (demod_2400.c:416), then the loop's ++ */
+        emit(&mm, (a << 16) | (uint64_t)signal_len, b, user);
     }
 }
 
 /* The skip-ahead part of demodulate2400AC (demod_2400.c:522-708): every candidate in `ac` has
  * already passed all level/bit tests on the GPU. */
-static void resolve_mode_ac(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint64_t sample_ts,
+static void resolve_mode_ac(msd_resolver *r, uint32_t b, uint32_t mlen, uint64_t sample_ts,
                             uint64_t sys_ts, const msd_ac_hit *ac, uint64_t nac, uint64_t *ai,
                             msd_emit_fn emit, void *user)
 {
-    const uint64_t base = chunk * MSD_CHUNK_SAMPLES;
+    const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES; /* batch-relative, like msd_ac_hit.pos */
     const uint64_t end = base + mlen;
     uint64_t resume = base;
     for (; *ai < nac; ++*ai) {
@@ -267,22 +249,20 @@ static void resolve_mode_ac(msd_resolver *r, uint64_t chunk, uint32_t mlen, uint
         mm.msg[0] = (uint8_t)(c->modeac >> 8);
         mm.msg[1] = (uint8_t)c->modeac;
         mm.addr = (c->modeac & 0x0000FF7Fu) | (1u << 24);
-        emit(&mm, user);
+        emit(&mm, 0, b, user);
         resume = c->pos + (20 * 87 / 25) + 1; /* demod_2400.c:705 plus the loop's ++ */
         r->stats->demod_modeac++;
     }
 }
 
 void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
-                       const uint32_t *valid, const double *means, const msd_hit *hits,
-                       uint64_t nhits, const msd_try *tries, uint64_t ntries,
-                       const msd_ac_hit *ac, uint64_t nac, const uint64_t *ts_override,
-                       msd_emit_fn emit, void *user)
+                       const uint32_t *valid, const msd_hit *hits, uint64_t nhits,
+                       const msd_try *tries, uint64_t ntries, const msd_ac_hit *ac, uint64_t nac,
+                       const uint64_t *ts_override, msd_emit_fn emit, void *user)
 {
-    uint64_t hi = 0, ti = 0, ai = 0;
+    uint64_t hi = 0, ai = 0;
     (void)ntries;
     for (uint32_t b = 0; b < nbuffers; ++b) {
-        const uint64_t chunk = first_chunk + b;
         /* sdr_ifile.c:187-190 with startup_time = 0 */
         uint64_t sample_ts = (uint64_t)(r->sample_counter * 12e6 / 2400000.0);
         uint64_t sys_ts = sample_ts / 12000u;
@@ -292,14 +272,46 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         }
         const uint32_t mlen = valid[b];
 
-        resolve_mode_s(r, chunk, mlen, sample_ts, sys_ts, means[2 * b + 1], hits, nhits, &hi,
-                       tries, &ti, emit, user);
+        resolve_mode_s(r, first_chunk, b, mlen, sample_ts, sys_ts, hits, nhits, &hi, tries, emit, user);
         if (r->mode_ac)
-            resolve_mode_ac(r, chunk, mlen, sample_ts, sys_ts, ac, nac, &ai, emit, user);
+            resolve_mode_ac(r, b, mlen, sample_ts, sys_ts, ac, nac, &ai, emit, user);
 
         r->stats->samples_processed += (uint64_t)mlen + MSD_OVERLAP; /* readsb.c:835 */
         r->stats->buffers++;
         r->sample_counter += mlen;
         filter_expire(&r->filter, r->ifile_now); /* readsb.c:331, after the buffer */
+    }
+}
+
+void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
+                       msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
+                       const uint64_t *power, uint64_t nmsgs)
+{
+    msd_stats *st = r->stats;
+    uint64_t i = 0;
+    for (uint32_t b = 0; b < nbuffers; ++b) {
+        uint64_t sum_scaled_signal_power = 0;
+        for (; i < nmsgs && buffer[i] == b; ++i) {
+            if (!power_req[i])
+                continue; /* Mode A/C */
+            const int signal_len = (int)(power_req[i] & 0xffffu);
+            const uint64_t scaled = power[i];
+            /* demod_2400.c:386-408 */
+            const double signal_power = scaled / 65535.0 / 65535.0;
+            msgs[i].signalLevel = signal_power / signal_len;
+            st->signal_power_sum += signal_power;
+            st->signal_power_count += (uint64_t)signal_len;
+            sum_scaled_signal_power += scaled;
+            if (msgs[i].signalLevel > st->peak_signal_power)
+                st->peak_signal_power = msgs[i].signalLevel;
+            if (msgs[i].signalLevel > 0.50119)
+                st->strong_signal_count++;
+        }
+        { /* demod_2400.c:422-427 */
+            const uint32_t mlen = valid[b];
+            const double sum_signal_power = sum_scaled_signal_power / 65535.0 / 65535.0;
+            st->noise_power_sum += (means[2 * b + 1] * mlen - sum_signal_power);
+            st->noise_power_count += mlen;
+        }
     }
 }

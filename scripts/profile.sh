@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_profiler.json 2> $OUT/rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_profiler.json 2> $OUT/rocprof.log
 find $OUT/trace -name "*kernel_stats*" | head -3
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 for f in $(find $OUT/trace -name "*kernel_trace.csv"); do head -1 $f > $OUT/kernel_trace_head.csv; grep msd_scan $f | head -40 >> $OUT/kernel_trace_head.csv; done
