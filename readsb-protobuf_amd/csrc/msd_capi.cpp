@@ -34,6 +34,7 @@ constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
 
 struct Slot {
     bool busy = false;
+    bool download_started = false;
     /* batch description */
     const uint8_t *d_iq = nullptr;
     const uint8_t *d_prev = nullptr;
@@ -258,10 +259,12 @@ int enqueue(msd_ctx *c, Slot &s, int format)
     return 0;
 }
 
-/* Wait for a batch, download its candidate lists, resolve in order, deliver messages. */
-int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
-           const uint64_t *ts_override, const double *means_override, uint64_t resolver_first_chunk)
+/* Stage 1 of finishing a batch: once its totals are known, start the download of its candidate
+ * lists on the copy stream.  Idempotent; blocks only until the batch's kernels are done. */
+int start_download(msd_ctx *c, Slot &s, int format)
 {
+    if (s.download_started)
+        return 0;
     HIPCHK(c, hipEventSynchronize(s.ev_totals));
     const uint64_t H = s.h_totals[0], Tn = s.h_totals[1], ovf = s.h_totals[2];
     if (ovf)
@@ -283,7 +286,29 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
                                      hipMemcpyDeviceToHost, c->copy_stream));
     }
     HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
+    s.download_started = true;
+    return 0;
+}
+
+/* Wait for a batch's lists, resolve in order, deliver messages. */
+int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
+           const uint64_t *ts_override, const double *means_override, uint64_t resolver_first_chunk)
+{
+    int rc = start_download(c, s, format);
+    if (rc)
+        return rc;
+    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
     HIPCHK(c, hipEventSynchronize(s.ev_copy1));
+    s.download_started = false;
+    /* the following batch's lists can come down while this one is resolved on the host */
+    if (c->outstanding > 1) {
+        Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
+        if (&nx != &s && nx.busy) {
+            rc = start_download(c, nx, c->cfg.format);
+            if (rc)
+                return rc;
+        }
+    }
 
     /* per-buffer sample counts and means (mag_buf.validLength-overlap, .mean_level, .mean_power) */
     c->valid.assign(s.nbuffers, 0);
@@ -455,6 +480,7 @@ void destroy(msd_ctx *c)
         (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
+    msd_resolver_free(&c->resolver);
     free(c->tables);
     delete c;
 }

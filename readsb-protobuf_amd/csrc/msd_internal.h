@@ -81,6 +81,8 @@ typedef struct msd_filter {
     uint32_t slot[2][8192];
     int active;
     uint64_t next_flip;
+    uint64_t set_hash;  /* xor of a mix of every known address (identity of the membership) */
+    uint32_t set_count; /* number of known addresses */
 } msd_filter;
 
 /* ---- resolve stage (msd_resolve.c) ---- */
@@ -91,7 +93,9 @@ typedef struct msd_resolver {
     uint64_t ifile_now;      /* Modes.ifile_now, readsb.h:289 */
     uint64_t sample_counter; /* samples consumed so far (sdr_ifile.c:172) */
     int mode_ac;
+    int threads; /* host threads of the speculative batch resolve; 0 = MSD_RESOLVE_THREADS or 16 */
     struct msd_stats *stats;
+    struct msd_batch_state *batch; /* scratch of msd_resolve_batch, owned by the resolver */
 } msd_resolver;
 
 /* Receives every accepted message in order.  Mode S messages still lack their signal level:
@@ -100,6 +104,7 @@ typedef struct msd_resolver {
 typedef void (*msd_emit_fn)(const struct msd_message *mm, uint64_t power_req, uint32_t buffer, void *user);
 
 void msd_resolver_reset(msd_resolver *r);
+void msd_resolver_free(msd_resolver *r);
 /* Replays the buffers [first_chunk, first_chunk + nbuffers) of a batch.  hits/tries (Mode S) and
  * ac (Mode A/C) are the batch's ordered candidate lists; valid[i] is the i-th buffer's number of
  * new samples; ts_override, if not NULL, holds

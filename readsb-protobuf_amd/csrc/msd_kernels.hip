@@ -131,9 +131,13 @@ __device__ __forceinline__ uint32_t fetch_group(const MsdScanParams &P, int64_t 
         }
         return 0xffu;
     }
-    for (int k = 0; k < avail * BPS / 2; ++k) { /* ragged end of the capture */
-        const uint32_t h = *reinterpret_cast<const uint16_t *>(src + 2 * k);
-        r.w[(k >> 1) % RawGroup<FMT>::WORDS] |= h << (16 * (k & 1));
+    /* ragged end of the capture: 16-bit pieces, statically indexed so the group stays in VGPRs */
+#pragma unroll
+    for (int k = 0; k < 2 * RawGroup<FMT>::WORDS; ++k) {
+        if (k < avail * BPS / 2) {
+            const uint32_t h = *reinterpret_cast<const uint16_t *>(src + 2 * k);
+            r.w[k >> 1] |= h << (16 * (k & 1));
+        }
     }
     return (1u << avail) - 1u;
 }
@@ -445,7 +449,7 @@ __device__ __forceinline__ void candidate_round(const MsdScanParams &P, const ui
 }
 
 template <int FMT>
-__global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
+__global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *mags = reinterpret_cast<uint16_t *>(smem + OFF_MAGS);

@@ -2,14 +2,27 @@
  * msd_resolve.c -- the ordered resolve stage: replays demodulate2400's sequential state machine
  * (skip-ahead, ICAO filter, ifile clock, counters) over the candidate lists the GPU produced.
  *
- * Host C on purpose: this is a few hundred nanoseconds of pointer-chasing per candidate with a
- * strict order dependence; the data-parallel work (IQ->magnitude, preamble tests, bit slicing,
- * CRC, syndrome lookup, signal power) is all done on the GPU before this runs.
+ * What is sequential here, and how it is still run on many host cores:
+ *   - the skip-ahead after an accepted message never crosses a buffer boundary
+ *     (demod_2400.c:257,416), so buffers are independent except for the ICAO filter;
+ *   - the filter is only written by accepted clean DF17 / DF11(II=0) messages
+ *     (mode_s.c:717-726) and aged between buffers (readsb.c:331), and its *membership* changes
+ *     rarely (a new aircraft, or a 60 s flip that drops a silent one).
+ * So a batch is resolved speculatively: every buffer is resolved in parallel against a snapshot
+ * of the filter (plus the addresses the buffer itself adds); a cheap sequential pass then replays
+ * the adds and flips, giving every buffer the membership "version" it should have seen; buffers
+ * resolved against another version are redone.  The earliest stale buffer always has correct
+ * inputs, so this converges to exactly the sequential result (usually in one or two passes).
+ *
+ * Host C on purpose (the north star keeps the host in C): the data-parallel work -- IQ->magnitude,
+ * preamble tests, bit slicing, CRC, syndrome lookup, signal power -- is done on the GPU.
  */
 #include "msd_internal.h"
 #include "modes_hip.h"
 
-#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------------------------------- */
@@ -31,79 +44,352 @@ static uint32_t hash24(uint32_t a) /* icao_filter.c:44-65 */
     return h & (SLOTS - 1);
 }
 
+static int table_has(const uint32_t *t, uint32_t addr, uint32_t start);
+
 static void filter_init(msd_filter *f) /* icao_filter.c:67-71 */
 {
     memset(f->slot, 0xFF, sizeof f->slot);
     f->active = 0;
     f->next_flip = 0;
+    f->set_hash = 0;
+    f->set_count = 0;
 }
 
-static void filter_add(msd_filter *f, uint32_t addr) /* icao_filter.c:76-97 */
+/* exact comparison of two filters' membership (used to confirm a set-hash match) */
+static int same_members(const msd_filter *x, const msd_filter *y)
+{
+    if (x->set_count != y->set_count)
+        return 0;
+    for (int w = 0; w < 2; ++w)
+        for (uint32_t i = 0; i < SLOTS; ++i) {
+            const uint32_t v = x->slot[w][i];
+            if (v != VACANT && !(table_has(y->slot[0], v, hash24(v)) || table_has(y->slot[1], v, hash24(v))))
+                return 0;
+        }
+    return 1; /* x is a subset of y and the sizes agree */
+}
+
+static int table_has(const uint32_t *t, uint32_t addr, uint32_t start)
+{
+    uint32_t h = start;
+    while (t[h] != VACANT && t[h] != addr) {
+        h = (h + 1) & (SLOTS - 1);
+        if (h == start)
+            break;
+    }
+    return t[h] == addr;
+}
+
+static int filter_test(const msd_filter *f, uint32_t addr) /* icao_filter.c:99-119 */
+{
+    const uint32_t start = hash24(addr);
+    return table_has(f->slot[0], addr, start) || table_has(f->slot[1], addr, start);
+}
+
+static uint64_t mix_addr(uint32_t a)
+{
+    uint64_t z = (uint64_t)a + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+/* slot index at which a probe for addr ends (its primary copy if present) */
+static uint32_t probe_index(const uint32_t *t, uint32_t addr)
+{
+    const uint32_t start = hash24(addr);
+    uint32_t h = start;
+    while (t[h] != VACANT && t[h] != addr) {
+        h = (h + 1) & (SLOTS - 1);
+        if (h == start)
+            break;
+    }
+    return h;
+}
+
+static int filter_add_raw(msd_filter *f, uint32_t addr);
+
+/* icao_filter.c:76-97, plus bookkeeping of the membership (set hash and size).
+ * Returns 1 if the set of known addresses grew. */
+static int filter_add(msd_filter *f, uint32_t addr)
+{
+    /* already in the active table: both inserts are no-ops (entries are never removed one by one) */
+    if (table_has(f->slot[f->active], addr, hash24(addr)))
+        return 0;
+    const int was_known = filter_test(f, addr);
+    filter_add_raw(f, addr);
+    if (!was_known && filter_test(f, addr)) {
+        f->set_hash ^= mix_addr(addr);
+        f->set_count++;
+        return 1;
+    }
+    return 0;
+}
+
+static int filter_add_raw(msd_filter *f, uint32_t addr)
 {
     uint32_t *t = f->slot[f->active];
     uint32_t start = hash24(addr), h = start;
     while (t[h] != VACANT && t[h] != addr) {
         h = (h + 1) & (SLOTS - 1);
         if (h == start)
-            return; /* table full: the reference gives up on both inserts */
+            return 0; /* table full: the reference gives up on both inserts */
     }
     if (t[h] == VACANT)
         t[h] = addr;
 
-    uint32_t low = addr & 0xffffu;
+    /* second copy keyed by the low 16 bits (icao_filter.c:89-97) */
+    const uint32_t low = addr & 0xffffu;
     start = h = hash24(low);
     while (t[h] != VACANT && (t[h] & 0xffffu) != low) {
         h = (h + 1) & (SLOTS - 1);
         if (h == start)
-            return;
+            return 0;
     }
     if (t[h] == VACANT)
         t[h] = addr;
+    return 1;
 }
 
-static int filter_test(const msd_filter *f, uint32_t addr) /* icao_filter.c:99-119 */
+/* icao_filter.c:150-164.  Returns 1 if the flip dropped an address (membership shrank). */
+static int filter_expire(msd_filter *f, uint64_t now)
 {
-    uint32_t start = hash24(addr);
-    for (int w = 0; w < 2; ++w) {
-        const uint32_t *t = f->slot[w];
-        uint32_t h = start;
-        while (t[h] != VACANT && t[h] != addr) {
-            h = (h + 1) & (SLOTS - 1);
-            if (h == start)
-                break;
+    if (now < f->next_flip)
+        return 0;
+    const int other = f->active ^ 1;
+    int dropped = 0;
+    const uint32_t *gone = f->slot[other], *stay = f->slot[f->active];
+    for (uint32_t i = 0; i < SLOTS; ++i) {
+        const uint32_t v = gone[i];
+        /* every address is stored twice (icao_filter.c:89-97): count its primary copy only */
+        if (v != VACANT && probe_index(gone, v) == i && !table_has(stay, v, hash24(v))) {
+            f->set_hash ^= mix_addr(v);
+            f->set_count--;
+            dropped = 1;
         }
-        if (t[h] == addr)
+    }
+    memset(f->slot[other], 0xFF, sizeof f->slot[other]);
+    f->active = other;
+    f->next_flip = now + 60000u;
+    return dropped;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* the addresses one buffer has added so far (consulted on top of the snapshot)             */
+/* ---------------------------------------------------------------------------------------- */
+
+#define LOCAL_SLOTS 4096u /* a buffer holds at most 131072/135 < 1024 accepted messages */
+
+typedef struct local_set {
+    uint32_t slot[LOCAL_SLOTS];
+    uint32_t n;
+} local_set;
+
+static void local_init(local_set *s)
+{
+    memset(s->slot, 0xFF, sizeof s->slot);
+    s->n = 0;
+}
+
+static int local_has(const local_set *s, uint32_t addr)
+{
+    if (!s->n)
+        return 0;
+    uint32_t h = (addr * 2654435761u) >> 20;
+    while (s->slot[h] != VACANT) {
+        if (s->slot[h] == addr)
             return 1;
+        h = (h + 1) & (LOCAL_SLOTS - 1);
     }
     return 0;
 }
 
-static void filter_expire(msd_filter *f, uint64_t now) /* icao_filter.c:150-164 */
+static int local_add(local_set *s, uint32_t addr) /* returns 1 if newly added */
 {
-    if (now >= f->next_flip) {
-        int other = f->active ^ 1;
-        memset(f->slot[other], 0xFF, sizeof f->slot[other]);
-        f->active = other;
-        f->next_flip = now + 60000u;
+    uint32_t h = (addr * 2654435761u) >> 20;
+    while (s->slot[h] != VACANT) {
+        if (s->slot[h] == addr)
+            return 0;
+        h = (h + 1) & (LOCAL_SLOTS - 1);
     }
+    s->slot[h] = addr;
+    s->n++;
+    return 1;
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* thread pool                                                                              */
+/* ---------------------------------------------------------------------------------------- */
 
-void msd_resolver_reset(msd_resolver *r)
+typedef void (*pool_fn)(void *arg, uint32_t index);
+
+struct msd_pool {
+    pthread_t *threads;
+    int nthreads; /* workers besides the caller */
+    pthread_mutex_t mu;
+    pthread_cond_t start, done;
+    uint64_t generation;
+    int running, shutdown;
+    pool_fn fn;
+    void *arg;
+    uint32_t count;
+    atomic_uint next;
+};
+
+static void pool_drain(struct msd_pool *p)
 {
-    filter_init(&r->filter);
-    r->ifile_now = 0;
-    r->sample_counter = 0;
-    if (r->stats)
-        memset(r->stats, 0, sizeof *r->stats);
+    for (;;) {
+        const uint32_t i = atomic_fetch_add(&p->next, 1u);
+        if (i >= p->count)
+            break;
+        p->fn(p->arg, i);
+    }
+}
+
+static void *pool_main(void *arg)
+{
+    struct msd_pool *p = arg;
+    uint64_t seen = 0;
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->shutdown && p->generation == seen)
+            pthread_cond_wait(&p->start, &p->mu);
+        if (p->shutdown)
+            break;
+        seen = p->generation;
+        pthread_mutex_unlock(&p->mu);
+        pool_drain(p);
+        pthread_mutex_lock(&p->mu);
+        if (--p->running == 0)
+            pthread_cond_signal(&p->done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+
+static struct msd_pool *pool_create(int nworkers)
+{
+    struct msd_pool *p = calloc(1, sizeof *p);
+    if (!p)
+        return NULL;
+    pthread_mutex_init(&p->mu, NULL);
+    pthread_cond_init(&p->start, NULL);
+    pthread_cond_init(&p->done, NULL);
+    p->threads = calloc((size_t)(nworkers > 0 ? nworkers : 1), sizeof p->threads[0]);
+    for (int i = 0; i < nworkers; ++i) {
+        if (pthread_create(&p->threads[p->nthreads], NULL, pool_main, p) != 0)
+            break;
+        p->nthreads++;
+    }
+    return p;
+}
+
+static void pool_run(struct msd_pool *p, pool_fn fn, void *arg, uint32_t count)
+{
+    if (!p || p->nthreads == 0 || count < 2) {
+        for (uint32_t i = 0; i < count; ++i)
+            fn(arg, i);
+        return;
+    }
+    pthread_mutex_lock(&p->mu);
+    p->fn = fn;
+    p->arg = arg;
+    p->count = count;
+    atomic_store(&p->next, 0u);
+    p->running = p->nthreads;
+    p->generation++;
+    pthread_cond_broadcast(&p->start);
+    pthread_mutex_unlock(&p->mu);
+    pool_drain(p); /* the caller works too */
+    pthread_mutex_lock(&p->mu);
+    while (p->running)
+        pthread_cond_wait(&p->done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
+static void pool_destroy(struct msd_pool *p)
+{
+    if (!p)
+        return;
+    pthread_mutex_lock(&p->mu);
+    p->shutdown = 1;
+    pthread_cond_broadcast(&p->start);
+    pthread_mutex_unlock(&p->mu);
+    for (int i = 0; i < p->nthreads; ++i)
+        pthread_join(p->threads[i], NULL);
+    pthread_mutex_destroy(&p->mu);
+    pthread_cond_destroy(&p->start);
+    pthread_cond_destroy(&p->done);
+    free(p->threads);
+    free(p);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* one buffer                                                                               */
+/* ---------------------------------------------------------------------------------------- */
+
+enum { C_PREAMBLES, C_BAD, C_UNKNOWN, C_ACC0, C_ACC1, C_ACC2, C_PPHASE0, C_BPHASE0 = C_PPHASE0 + 5,
+       C_MODEAC = C_BPHASE0 + 5, C_COUNT };
+
+typedef struct buf_result {
+    uint32_t version_used;
+    uint64_t end_now; /* Modes.ifile_now when the buffer is done */
+    uint64_t ctr[C_COUNT];
+    msd_message *msgs;
+    uint64_t *reqs;
+    uint32_t nmsgs, cap_msgs;
+    uint32_t *adds; /* unique addresses passed to icaoFilterAdd, in order */
+    uint32_t nadds, cap_adds;
+} buf_result;
+
+struct msd_batch_state {
+    struct msd_pool *pool;
+    buf_result *res;
+    uint32_t res_cap;
+    msd_filter *snaps; /* membership versions of the filter within the current batch */
+    uint32_t nsnaps, cap_snaps;
+    uint32_t *want;    /* version each buffer should see */
+    uint64_t *hit_begin, *ac_begin, *ts; /* per buffer */
+    /* inputs of the running batch */
+    const uint32_t *valid;
+    const msd_hit *hits;
+    uint64_t nhits;
+    const msd_try *tries;
+    const msd_ac_hit *ac;
+    uint64_t nac;
+    int mode_ac;
+    uint32_t *todo;
+    uint32_t ntodo;
+};
+
+static void push_msg(buf_result *br, const msd_message *mm, uint64_t req)
+{
+    if (br->nmsgs == br->cap_msgs) {
+        const uint32_t cap = br->cap_msgs ? br->cap_msgs * 2 : 64;
+        br->msgs = realloc(br->msgs, (size_t)cap * sizeof br->msgs[0]);
+        br->reqs = realloc(br->reqs, (size_t)cap * sizeof br->reqs[0]);
+        br->cap_msgs = cap;
+    }
+    br->msgs[br->nmsgs] = *mm;
+    br->reqs[br->nmsgs] = req;
+    br->nmsgs++;
+}
+
+static void push_add(buf_result *br, uint32_t addr)
+{
+    if (br->nadds == br->cap_adds) {
+        const uint32_t cap = br->cap_adds ? br->cap_adds * 2 : 64;
+        br->adds = realloc(br->adds, (size_t)cap * sizeof br->adds[0]);
+        br->cap_adds = cap;
+    }
+    br->adds[br->nadds++] = addr;
 }
 
 /* scoreModesMessage (mode_s.c:311-409) given what the GPU already derived for this try */
 static int score_try(const msd_try *t, int known)
 {
-    int df = t->msg[0] >> 3;
-    int nerr = (t->errbit != 0xff);
+    const int df = t->msg[0] >> 3;
+    const int nerr = (t->errbit != 0xff);
     switch (df) {
     case 11:
         if ((t->crc & 0x7f) == 0)
@@ -118,22 +404,29 @@ static int score_try(const msd_try *t, int known)
     }
 }
 
-/* One buffer of demodulate2400 (demod_2400.c:236-428) over hits[*hi..]; everything except the
- * signal-power bookkeeping, which msd_resolve_power() adds once the sums are known. */
-static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, uint32_t mlen,
-                           uint64_t sample_ts, uint64_t sys_ts, const msd_hit *hits, uint64_t nhits,
-                           uint64_t *hi, const msd_try *tries, msd_emit_fn emit, void *user)
+/* demodulate2400 (demod_2400.c:236-428) for buffer b, everything except the signal-power
+ * bookkeeping (msd_resolve_power), then the skip-ahead part of demodulate2400AC (:522-708). */
+static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const msd_filter *snap,
+                           uint32_t version, buf_result *br)
 {
-    msd_stats *st = r->stats;
-    (void)batch_chunk0;
+    local_set local;
+    local_init(&local);
+    memset(br->ctr, 0, sizeof br->ctr);
+    br->nmsgs = 0;
+    br->nadds = 0;
+    br->version_used = version;
+
+    const uint32_t mlen = bs->valid[b];
+    const uint64_t sample_ts = bs->ts[2 * b], sys_ts = bs->ts[2 * b + 1];
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES; /* batch-relative */
     const uint64_t end = base + mlen;
     uint64_t resume = base; /* first position not covered by a skip-ahead */
+    uint64_t now = sys_ts;  /* demod_2400.c:252-255 */
 
-    r->ifile_now = sys_ts; /* demod_2400.c:252-255 */
-
-    for (; *hi < nhits; ++*hi) {
-        const msd_hit h = hits[*hi];
+    const msd_hit *hits = bs->hits;
+    const msd_try *tries = bs->tries;
+    for (uint64_t hi = bs->hit_begin[b]; hi < bs->nhits; ++hi) {
+        const msd_hit h = hits[hi];
         const uint64_t a = MSD_HIT_POS(h);
         if (a >= end)
             break;
@@ -141,10 +434,10 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
             continue; /* inside the previous message (demod_2400.c:416) */
 
         const unsigned mask = MSD_HIT_MASK(h);
-        if (mask & 1) { st->demod_preamblePhase[0]++; st->demod_preamblePhase[1]++; }
-        if (mask & 2) { st->demod_preamblePhase[2]++; st->demod_preamblePhase[3]++; }
-        if (mask & 4) { st->demod_preamblePhase[4]++; }
-        st->demod_preambles++;
+        if (mask & 1) { br->ctr[C_PPHASE0 + 0]++; br->ctr[C_PPHASE0 + 1]++; }
+        if (mask & 2) { br->ctr[C_PPHASE0 + 2]++; br->ctr[C_PPHASE0 + 3]++; }
+        if (mask & 4) { br->ctr[C_PPHASE0 + 4]++; }
+        br->ctr[C_PREAMBLES]++;
 
         /* best phase: strict '>' so the first-tried phase wins ties (demod_2400.c:218); every
          * try that is not in the list scores -2 whatever the filter holds */
@@ -153,8 +446,8 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
         int bestscore = -2, known_best = 0;
         const msd_try *best = 0;
         for (unsigned k = 0; k < nlive; ++k) {
-            int known = filter_test(&r->filter, t[k].addr);
-            int s = score_try(&t[k], known);
+            const int known = filter_test(snap, t[k].addr) || local_has(&local, t[k].addr);
+            const int s = score_try(&t[k], known);
             if (s > bestscore) {
                 bestscore = s;
                 best = &t[k];
@@ -162,10 +455,7 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
             }
         }
         if (bestscore < 0) {
-            if (bestscore == -1)
-                st->demod_rejected_unknown_icao++;
-            else
-                st->demod_rejected_bad++;
+            br->ctr[bestscore == -1 ? C_UNKNOWN : C_BAD]++;
             continue;
         }
 
@@ -177,7 +467,7 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
         memset(&mm, 0, sizeof mm);
         mm.timestampMsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + best->tp;
         mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-        r->ifile_now = mm.sysTimestampMsg; /* demod_2400.c:363-366, before decode */
+        now = mm.sysTimestampMsg; /* demod_2400.c:363-366, before decode */
         mm.score = bestscore;
         mm.bestphase = best->tp;
 
@@ -205,7 +495,7 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
             break;
         }
         if (verdict < 0) {
-            st->demod_rejected_unknown_icao++;
+            br->ctr[C_UNKNOWN]++;
             continue;
         }
         if (nerr) {
@@ -213,46 +503,156 @@ static void resolve_mode_s(msd_resolver *r, uint64_t batch_chunk0, uint32_t b, u
             mm.msg[best->errbit >> 3] ^= (uint8_t)(0x80u >> (best->errbit & 7)); /* crc.c:417-425 */
         }
         mm.addr = best->addr; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
-        if (!nerr && (df == 17 || (df == 11 && mm.iid == 0)))
-            filter_add(&r->filter, mm.addr); /* mode_s.c:717-726 */
+        if (!nerr && (df == 17 || (df == 11 && mm.iid == 0))) /* mode_s.c:717-726 */
+            if (local_add(&local, mm.addr))
+                push_add(br, mm.addr);
 
-        st->demod_accepted[mm.correctedbits]++;
-        st->demod_bestPhase[best->tp - 4]++;
+        br->ctr[C_ACC0 + mm.correctedbits]++;
+        br->ctr[C_BPHASE0 + best->tp - 4]++;
 
         const int signal_len = msgbits * 12 / 5;
         resume = a + (uint64_t)signal_len + 1; /* j += len (demod_2400.c:416), then the loop's ++ */
-        emit(&mm, (a << 16) | (uint64_t)signal_len, b, user);
+        push_msg(br, &mm, (a << 16) | (uint64_t)signal_len);
+    }
+    br->end_now = now;
+
+    if (bs->mode_ac) {
+        resume = base;
+        for (uint64_t ai = bs->ac_begin[b]; ai < bs->nac; ++ai) {
+            const msd_ac_hit *c = &bs->ac[ai];
+            if (c->pos >= end)
+                break;
+            if (c->pos < resume)
+                continue;
+            msd_message mm;
+            memset(&mm, 0, sizeof mm);
+            mm.timestampMsg = sample_ts + c->f2_clock / 5; /* demod_2400.c:695 */
+            mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+            mm.msgtype = 32; /* mode_ac.c:168-202 */
+            mm.msgbits = 16;
+            mm.msg[0] = (uint8_t)(c->modeac >> 8);
+            mm.msg[1] = (uint8_t)c->modeac;
+            mm.addr = (c->modeac & 0x0000FF7Fu) | (1u << 24);
+            push_msg(br, &mm, 0);
+            resume = c->pos + (20 * 87 / 25) + 1; /* demod_2400.c:705 plus the loop's ++ */
+            br->ctr[C_MODEAC]++;
+        }
     }
 }
 
-/* The skip-ahead part of demodulate2400AC (demod_2400.c:522-708): every candidate in `ac` has
- * already passed all level/bit tests on the GPU. */
-static void resolve_mode_ac(msd_resolver *r, uint32_t b, uint32_t mlen, uint64_t sample_ts,
-                            uint64_t sys_ts, const msd_ac_hit *ac, uint64_t nac, uint64_t *ai,
-                            msd_emit_fn emit, void *user)
+static void job_resolve(void *arg, uint32_t index)
 {
-    const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES; /* batch-relative, like msd_ac_hit.pos */
-    const uint64_t end = base + mlen;
-    uint64_t resume = base;
-    for (; *ai < nac; ++*ai) {
-        const msd_ac_hit *c = &ac[*ai];
-        if (c->pos >= end)
-            break;
-        if (c->pos < resume)
-            continue;
-        msd_message mm;
-        memset(&mm, 0, sizeof mm);
-        mm.timestampMsg = sample_ts + c->f2_clock / 5; /* demod_2400.c:695 */
-        mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-        mm.msgtype = 32; /* mode_ac.c:168-202 */
-        mm.msgbits = 16;
-        mm.msg[0] = (uint8_t)(c->modeac >> 8);
-        mm.msg[1] = (uint8_t)c->modeac;
-        mm.addr = (c->modeac & 0x0000FF7Fu) | (1u << 24);
-        emit(&mm, 0, b, user);
-        resume = c->pos + (20 * 87 / 25) + 1; /* demod_2400.c:705 plus the loop's ++ */
-        r->stats->demod_modeac++;
+    struct msd_batch_state *bs = arg;
+    const uint32_t b = bs->todo[index];
+    const uint32_t v = bs->want[b];
+    resolve_buffer(bs, b, &bs->snaps[v], v, &bs->res[b]);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+static int default_threads(void)
+{
+    const char *e = getenv("MSD_RESOLVE_THREADS");
+    if (e && atoi(e) > 0)
+        return atoi(e);
+    return 16;
+}
+
+void msd_resolver_reset(msd_resolver *r)
+{
+    filter_init(&r->filter);
+    r->ifile_now = 0;
+    r->sample_counter = 0;
+    if (r->stats)
+        memset(r->stats, 0, sizeof *r->stats);
+}
+
+void msd_resolver_free(msd_resolver *r)
+{
+    struct msd_batch_state *bs = r->batch;
+    if (!bs)
+        return;
+    pool_destroy(bs->pool);
+    for (uint32_t i = 0; i < bs->res_cap; ++i) {
+        free(bs->res[i].msgs);
+        free(bs->res[i].reqs);
+        free(bs->res[i].adds);
     }
+    free(bs->res);
+    free(bs->snaps);
+    free(bs->want);
+    free(bs->hit_begin);
+    free(bs->ac_begin);
+    free(bs->ts);
+    free(bs->todo);
+    free(bs);
+    r->batch = NULL;
+}
+
+static struct msd_batch_state *batch_state(msd_resolver *r, uint32_t nbuffers)
+{
+    struct msd_batch_state *bs = r->batch;
+    if (!bs) {
+        bs = calloc(1, sizeof *bs);
+        if (!bs)
+            return NULL;
+        const int n = r->threads > 0 ? r->threads : default_threads();
+        bs->pool = pool_create(n - 1);
+        r->batch = bs;
+    }
+    if (nbuffers > bs->res_cap) {
+        bs->res = realloc(bs->res, (size_t)nbuffers * sizeof bs->res[0]);
+        memset(bs->res + bs->res_cap, 0, (size_t)(nbuffers - bs->res_cap) * sizeof bs->res[0]);
+        bs->want = realloc(bs->want, (size_t)nbuffers * sizeof bs->want[0]);
+        bs->hit_begin = realloc(bs->hit_begin, (size_t)nbuffers * sizeof bs->hit_begin[0]);
+        bs->ac_begin = realloc(bs->ac_begin, (size_t)nbuffers * sizeof bs->ac_begin[0]);
+        bs->ts = realloc(bs->ts, (size_t)nbuffers * 2 * sizeof bs->ts[0]);
+        bs->todo = realloc(bs->todo, (size_t)nbuffers * sizeof bs->todo[0]);
+        bs->res_cap = nbuffers;
+    }
+    return bs;
+}
+
+/* index of a stored snapshot with exactly this membership, adding one if there is none; ids stay
+ * valid for the whole batch, so "resolved against version v" can be compared across passes */
+static uint32_t push_snapshot(struct msd_batch_state *bs, const msd_filter *f)
+{
+    for (uint32_t i = 0; i < bs->nsnaps; ++i)
+        if (bs->snaps[i].set_hash == f->set_hash && same_members(&bs->snaps[i], f))
+            return i;
+    if (bs->nsnaps == bs->cap_snaps) {
+        const uint32_t cap = bs->cap_snaps ? bs->cap_snaps * 2 : 4;
+        bs->snaps = realloc(bs->snaps, (size_t)cap * sizeof bs->snaps[0]);
+        bs->cap_snaps = cap;
+    }
+    bs->snaps[bs->nsnaps] = *f;
+    return bs->nsnaps++;
+}
+
+static uint64_t lower_bound_hit(const msd_hit *hits, uint64_t n, uint64_t pos)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (MSD_HIT_POS(hits[mid]) < pos)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+static uint64_t lower_bound_ac(const msd_ac_hit *ac, uint64_t n, uint64_t pos)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ac[mid].pos < pos)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
 }
 
 void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
@@ -260,27 +660,107 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
                        const msd_try *tries, uint64_t ntries, const msd_ac_hit *ac, uint64_t nac,
                        const uint64_t *ts_override, msd_emit_fn emit, void *user)
 {
-    uint64_t hi = 0, ai = 0;
+    (void)first_chunk;
     (void)ntries;
-    for (uint32_t b = 0; b < nbuffers; ++b) {
-        /* sdr_ifile.c:187-190 with startup_time = 0 */
-        uint64_t sample_ts = (uint64_t)(r->sample_counter * 12e6 / 2400000.0);
-        uint64_t sys_ts = sample_ts / 12000u;
-        if (ts_override) {
-            sample_ts = ts_override[2 * b];
-            sys_ts = ts_override[2 * b + 1];
+    if (nbuffers == 0)
+        return;
+    struct msd_batch_state *bs = batch_state(r, nbuffers);
+    if (!bs)
+        return;
+    bs->valid = valid;
+    bs->hits = hits;
+    bs->nhits = nhits;
+    bs->tries = tries;
+    bs->ac = ac;
+    bs->nac = nac;
+    bs->mode_ac = r->mode_ac;
+
+    { /* per-buffer clocks (sdr_ifile.c:187-190, startup_time = 0) and candidate ranges */
+        uint64_t counter = r->sample_counter;
+        for (uint32_t b = 0; b < nbuffers; ++b) {
+            uint64_t sample_ts = (uint64_t)(counter * 12e6 / 2400000.0);
+            uint64_t sys_ts = sample_ts / 12000u;
+            if (ts_override) {
+                sample_ts = ts_override[2 * b];
+                sys_ts = ts_override[2 * b + 1];
+            }
+            bs->ts[2 * b] = sample_ts;
+            bs->ts[2 * b + 1] = sys_ts;
+            counter += valid[b];
+            bs->hit_begin[b] = lower_bound_hit(hits, nhits, (uint64_t)b * MSD_CHUNK_SAMPLES);
+            bs->ac_begin[b] = ac ? lower_bound_ac(ac, nac, (uint64_t)b * MSD_CHUNK_SAMPLES) : 0;
         }
-        const uint32_t mlen = valid[b];
-
-        resolve_mode_s(r, first_chunk, b, mlen, sample_ts, sys_ts, hits, nhits, &hi, tries, emit, user);
-        if (r->mode_ac)
-            resolve_mode_ac(r, b, mlen, sample_ts, sys_ts, ac, nac, &ai, emit, user);
-
-        r->stats->samples_processed += (uint64_t)mlen + MSD_OVERLAP; /* readsb.c:835 */
-        r->stats->buffers++;
-        r->sample_counter += mlen;
-        filter_expire(&r->filter, r->ifile_now); /* readsb.c:331, after the buffer */
     }
+
+    const int serial = !bs->pool || bs->pool->nthreads == 0 || nbuffers < 4;
+    msd_filter work;
+    if (serial) {
+        /* plain sequential replay: the live filter is the snapshot and a buffer's adds are applied
+         * when it is done -- equal to the reference because, inside a buffer, the filter is only
+         * read through "snapshot or this buffer's own adds" */
+        work = r->filter;
+        for (uint32_t b = 0; b < nbuffers; ++b) {
+            buf_result *br = &bs->res[b];
+            resolve_buffer(bs, b, &work, 0, br);
+            for (uint32_t i = 0; i < br->nadds; ++i)
+                filter_add(&work, br->adds[i]);
+            filter_expire(&work, br->end_now); /* readsb.c:331, after the buffer */
+        }
+    } else {
+        bs->nsnaps = 0;
+        push_snapshot(bs, &r->filter);
+        for (uint32_t b = 0; b < nbuffers; ++b) {
+            bs->want[b] = 0;
+            bs->todo[b] = b;
+        }
+        bs->ntodo = nbuffers;
+        for (uint32_t pass = 0;; ++pass) {
+            pool_run(bs->pool, job_resolve, bs, bs->ntodo);
+            /* replay adds and flips in order; find the membership version every buffer must see */
+            work = r->filter;
+            uint32_t version = 0;
+            bs->ntodo = 0;
+            for (uint32_t b = 0; b < nbuffers; ++b) {
+                buf_result *br = &bs->res[b];
+                bs->want[b] = version;
+                if (br->version_used != version)
+                    bs->todo[bs->ntodo++] = b;
+                int changed = 0;
+                for (uint32_t i = 0; i < br->nadds; ++i)
+                    changed |= filter_add(&work, br->adds[i]);
+                changed |= filter_expire(&work, br->end_now);
+                if (changed && b + 1 < nbuffers)
+                    version = push_snapshot(bs, &work);
+            }
+            if (bs->ntodo == 0)
+                break;
+            if (pass > nbuffers)
+                abort(); /* cannot happen: each pass fixes at least the earliest stale buffer */
+        }
+    }
+
+    /* commit, in order */
+    msd_stats *st = r->stats;
+    for (uint32_t b = 0; b < nbuffers; ++b) {
+        const buf_result *br = &bs->res[b];
+        st->demod_preambles += br->ctr[C_PREAMBLES];
+        st->demod_rejected_bad += br->ctr[C_BAD];
+        st->demod_rejected_unknown_icao += br->ctr[C_UNKNOWN];
+        for (int k = 0; k < 3; ++k)
+            st->demod_accepted[k] += br->ctr[C_ACC0 + k];
+        for (int k = 0; k < 5; ++k) {
+            st->demod_preamblePhase[k] += br->ctr[C_PPHASE0 + k];
+            st->demod_bestPhase[k] += br->ctr[C_BPHASE0 + k];
+        }
+        st->demod_modeac += br->ctr[C_MODEAC];
+        st->samples_processed += (uint64_t)valid[b] + MSD_OVERLAP; /* readsb.c:835 */
+        st->buffers++;
+        r->sample_counter += valid[b];
+        for (uint32_t i = 0; i < br->nmsgs; ++i)
+            emit(&br->msgs[i], br->reqs[i], b, user);
+    }
+    r->filter = work;
+    r->ifile_now = bs->res[nbuffers - 1].end_now;
 }
 
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
