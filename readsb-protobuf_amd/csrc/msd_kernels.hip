@@ -44,8 +44,8 @@ constexpr int NW = NT / 64;
 constexpr int T = MSD_TILE;           /* 8192 scan positions per tile */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
 constexpr int GPT = T / 8 / NT;       /* 8-sample load groups per thread per tile (2) */
-constexpr int HROUND = 16;            /* hits per candidate round (one per lane 0..15) */
-constexpr int SURV_CAP = HROUND * 5;
+constexpr int HCAP = 128;             /* hits per candidate round */
+constexpr int SCAP = HCAP * 5;        /* tries with a known DF per round, worst case */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
 static_assert(T == NT * 16, "each thread scans 16 consecutive positions");
@@ -57,18 +57,19 @@ constexpr int OFF_MAGS = 0;                               /* u16[FRONT + T + 8] 
 constexpr int OFF_CRC = OFF_MAGS + (FRONT + T + 8) * 2;   /* u32[256] */
 constexpr int OFF_SYN = OFF_CRC + 1024;                   /* u32[160] */
 constexpr int OFF_MISC = OFF_SYN + 640;                   /* u32[64]: wave hit counts, try cursor */
-constexpr int OFF_WAVE = OFF_MISC + 256;                  /* per-wave scratch */
-constexpr int WAVE_HITBUF = 0;                            /* u32[16] */
-constexpr int WAVE_NLIVE = 64;                            /* u32[16] */
-constexpr int WAVE_FIRST = 128;                           /* u32[16] */
-constexpr int WAVE_SMETA = 192;                           /* u32[SURV_CAP] */
-constexpr int WAVE_SMSG = WAVE_SMETA + SURV_CAP * 4;      /* u8[SURV_CAP][16] */
-constexpr int WAVE_BYTES = WAVE_SMSG + SURV_CAP * 16;     /* 1792 */
-constexpr int OFF_LUT = OFF_WAVE + NW * WAVE_BYTES;       /* u16[128 * LUT_STRIDE], UC8 only */
+constexpr int OFF_CAND = OFF_MISC + 256;                  /* candidate-stage scratch */
+constexpr int CS_HITS = 0;                                /* u32[HCAP]: position | mask << 13 */
+constexpr int CS_SIDX = CS_HITS + HCAP * 4;               /* u16[HCAP][5]: try slot or 0xffff */
+constexpr int CS_SMETA = CS_SIDX + HCAP * 5 * 2;          /* u32[SCAP] */
+constexpr int CS_SMSG = CS_SMETA + SCAP * 4;              /* u8[SCAP][16] */
+constexpr int CS_SRES = CS_SMSG + SCAP * 16;              /* u32[SCAP][2]: addr, crc */
+constexpr int CS_MISC = CS_SRES + SCAP * 8;               /* u32[16] */
+constexpr int CS_BYTES = CS_MISC + 64;
+constexpr int OFF_LUT = OFF_CAND + CS_BYTES;              /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
 constexpr int LDS_UC8 = OFF_LUT + 128 * LUT_STRIDE * 2;
-static_assert(OFF_CRC % 16 == 0 && OFF_WAVE % 16 == 0 && WAVE_BYTES % 16 == 0 && WAVE_SMSG % 16 == 0 &&
-              OFF_LUT % 16 == 0, "LDS carve offsets must stay 16-byte aligned");
+static_assert(OFF_CRC % 16 == 0 && OFF_CAND % 16 == 0 && CS_SMSG % 16 == 0 && CS_SRES % 16 == 0 &&
+              CS_BYTES % 16 == 0 && OFF_LUT % 16 == 0, "LDS carve offsets must stay 16-byte aligned");
 
 /* (b - 127.5)^2 only depends on k = b-128 (b >= 128) or 127-b (b < 128) */
 __device__ __forceinline__ uint32_t fold8(uint32_t b)
@@ -193,26 +194,35 @@ __device__ __forceinline__ int correlate(int m0, int m1, int m2, int m3)
     return 4 * m0 + 15 * m1 - 20 * m2 + m3;
 }
 
-/* One message byte whose first bit sits at PPM phase PH (0..4) of sample p[0]: bit k is
- * correlator (PH + 12k) % 5 at p[(PH + 12k) / 5]  (demod_2400.c:98-177 in closed form).  With PH
- * uniform across the wavefront every tap is a constant LDS offset and the 21 samples the eight
- * correlators share are read once. */
+/* One message byte whose first bit sits at PPM phase PH (0..4) of sample mags[first]: bit k is
+ * correlator (PH + 12k) % 5 at sample first + (PH + 12k) / 5  (demod_2400.c:98-177 in closed
+ * form).  With PH uniform across the wavefront every tap is a compile-time offset.  The 21 samples
+ * the eight correlators share are fetched as 11 naturally aligned dwords and shifted by the
+ * parity of `first` (unaligned wide LDS reads are replayed at 64 cycles each on gfx950). */
 template <int PH>
-__device__ __forceinline__ uint32_t slice_byte_phase(const uint16_t *p)
+__device__ __forceinline__ uint32_t slice_byte_phase(const uint16_t *mags, uint32_t first)
 {
-    int s[21];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(mags + (first & ~1u));
+    const uint32_t sh = (first & 1u) * 16u;
+    uint32_t d[11], a[11];
 #pragma unroll
-    for (int k = 0; k < 21; ++k)
-        s[k] = p[k];
+    for (int k = 0; k < 11; ++k)
+        d[k] = w[k];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+        a[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+    a[10] = d[10] >> sh;
+#define MSD_S(K) ((int)((a[(K) >> 1] >> (16 * ((K) & 1))) & 0xffffu))
     uint32_t v = 0;
 #define MSD_BIT(K)                                                                                   \
     {                                                                                                \
         constexpr int t = PH + 12 * (K);                                                             \
         constexpr int i = t / 5, c = t % 5;                                                          \
-        v = (v << 1) | (correlate<c>(s[i], s[i + 1], s[i + 2], s[(i + 3 > 20) ? 20 : i + 3]) > 0 ? 1u : 0u); \
+        v = (v << 1) | (correlate<c>(MSD_S(i), MSD_S(i + 1), MSD_S(i + 2), MSD_S((i + 3 > 20) ? 20 : i + 3)) > 0 ? 1u : 0u); \
     }
     MSD_BIT(0) MSD_BIT(1) MSD_BIT(2) MSD_BIT(3) MSD_BIT(4) MSD_BIT(5) MSD_BIT(6) MSD_BIT(7)
 #undef MSD_BIT
+#undef MSD_S
     return v;
 }
 
@@ -250,202 +260,207 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* The wave-autonomous candidate stage for one round of up to HROUND hits held in lanes
- * 0..nh-1 (hit = tile-relative position | mask << 13). */
-__device__ __forceinline__ void candidate_round(const MsdScanParams &P, const uint16_t *mags,
-                                                const uint32_t *crc_tab, const uint32_t *syn,
-                                                unsigned char *wscr, uint32_t *wg_try_cursor, int lane,
-                                                uint32_t nh, uint32_t hit, uint64_t tile_pos0,
-                                                msd_hit *hit_out, msd_try *my_tries)
+/* The workgroup-cooperative candidate stage for one round of up to HCAP hits (hitlist[0..nh), in
+ * position order).  All NT threads call it; `tcur` is the workgroup-uniform try cursor.
+ *
+ *   step A  first byte of every tried phase -> DF -> message length.  Work is laid out as
+ *           (phase q, hit) so that each wavefront pass has one trial phase: every correlator tap
+ *           is then a compile-time LDS offset (demod_2400.c:183-205).
+ *   step B  remaining bytes of the tries with a known DF, one lane per (try, byte), passes grouped
+ *           by PPM phase class d = (tp + byte) mod 5 for the same reason (demod_2400.c:98-177).
+ *   step C  CRC-24, syndrome lookup and the filter-independent part of scoreModesMessage, one lane
+ *           per try (crc.c:67-82,389-412; mode_s.c:311-409).
+ *   step D  records out: per hit, its live tries in phase order at consecutive indices. */
+__device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, const uint16_t *mags,
+                                                    const uint32_t *crc_tab, const uint32_t *syn,
+                                                    unsigned char *cs, int tid, uint32_t nh, uint64_t tile_pos0,
+                                                    msd_hit *hit_out, bool hits_fit, msd_try *my_tries,
+                                                    uint32_t tcur)
 {
-    uint32_t *hit_nlive = reinterpret_cast<uint32_t *>(wscr + WAVE_NLIVE);
-    uint32_t *hit_first = reinterpret_cast<uint32_t *>(wscr + WAVE_FIRST);
-    uint32_t *smeta = reinterpret_cast<uint32_t *>(wscr + WAVE_SMETA);
-    uint8_t *smsg = wscr + WAVE_SMSG;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t *hitlist = reinterpret_cast<const uint32_t *>(cs + CS_HITS);
+    uint16_t *survidx = reinterpret_cast<uint16_t *>(cs + CS_SIDX);
+    uint32_t *smeta = reinterpret_cast<uint32_t *>(cs + CS_SMETA);
+    uint8_t *smsg = cs + CS_SMSG;
+    uint32_t *sres = reinterpret_cast<uint32_t *>(cs + CS_SRES);
+    uint32_t *nsurv_p = reinterpret_cast<uint32_t *>(cs + CS_MISC);
+    uint32_t *wtot = nsurv_p + 4;
 
-    const bool has_hit = (uint32_t)lane < nh;
-    const uint32_t pos = hit & 0x1fffu, mask = (hit >> 13) & 7u;
-    const uint16_t *pa = mags + pos + 2; /* pa[d] = m[j + d]; the tile stages 328 = 326 + 2 ahead */
-    if (lane < HROUND) {
-        hit_nlive[lane] = 0;
-        hit_first[lane] = 0xffffffffu;
+    /* ---- step A ---- */
+    for (int c = wave; c < 5 * (HCAP / 64); c += NW) { /* chunk c: phase q = c / (HCAP/64) */
+        const int q = c / (HCAP / 64);
+        const uint32_t h = (uint32_t)(c % (HCAP / 64)) * 64u + (uint32_t)lane;
+        if (h < nh) {
+            const uint32_t e = hitlist[h];
+            const uint32_t pos = e & 0x1fffu, mask = e >> 13;
+            const bool tried = (q < 2) ? (mask & 1u) : ((q < 4) ? (mask & 2u) : (mask & 4u));
+            if (tried) {
+                /* pa[d] = mags[pos + 2 + d]; first data sample of trial phase tp = 4 + q is at
+                 * pa + (95 + tp) / 5 with PPM phase (95 + tp) % 5 = (4 + q) % 5 */
+                const uint32_t first = pos + 2u + (uint32_t)(99 + q) / 5u;
+                uint32_t b0;
+                switch (q) { /* wave-uniform */
+                case 0: b0 = slice_byte_phase<4>(mags, first); break;
+                case 1: b0 = slice_byte_phase<0>(mags, first); break;
+                case 2: b0 = slice_byte_phase<1>(mags, first); break;
+                case 3: b0 = slice_byte_phase<2>(mags, first); break;
+                default: b0 = slice_byte_phase<3>(mags, first); break;
+                }
+                const uint32_t nb = bytes_for_df(b0 >> 3);
+                if (nb > 1) {
+                    const uint32_t u = atomicAdd(nsurv_p, 1u);
+                    smeta[u] = pos | ((uint32_t)q << 13) | (nb << 16) | (h << 20);
+                    smsg[16 * u] = (uint8_t)b0;
+                    survidx[h * 5 + (uint32_t)q] = (uint16_t)u;
+                }
+            }
+        }
     }
+    __syncthreads();
+    const uint32_t nsurv = *nsurv_p;
 
-    /* ---- step A: first byte of every tried phase (demod_2400.c:183-205).  The trial phase is
-     *      the loop variable, so phase and sample offset are compile-time constants. ---- */
-    uint32_t b0[5], nb[5];
-#define MSD_STEP_A(Q)                                                                          \
-    {                                                                                          \
-        constexpr int tp = 4 + (Q), t0 = 95 + tp;                                              \
-        const bool tried = has_hit && (((Q) < 2) ? (mask & 1u) : (((Q) < 4) ? (mask & 2u) : (mask & 4u))); \
-        b0[Q] = 0;                                                                             \
-        nb[Q] = 0;                                                                             \
-        if (tried) {                                                                           \
-            b0[Q] = slice_byte_phase<t0 % 5>(pa + t0 / 5);                                     \
-            nb[Q] = bytes_for_df(b0[Q] >> 3);                                                  \
-        }                                                                                      \
-    }
-    MSD_STEP_A(0) MSD_STEP_A(1) MSD_STEP_A(2) MSD_STEP_A(3) MSD_STEP_A(4)
-#undef MSD_STEP_A
-
-    /* survivors (known DF), ordered by (hit, phase) */
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-        cnt += nb[q] > 1 ? 1u : 0u;
-    const uint32_t incl = wave_incl_scan(cnt, lane);
-    const uint32_t nsurv = __shfl(incl, 63);
-    if (nsurv == 0) {
-        if (has_hit) /* every try of these hits scores -2 whatever the filter holds */
-            hit_out[lane] = (tile_pos0 + pos) | ((msd_hit)mask << 28);
-        return;
-    }
+    /* ---- step B ---- */
     {
-        uint32_t r = incl - cnt;
+        const uint32_t nchunk = (nsurv + 20u) / 21u;
+        for (uint32_t x = (uint32_t)wave; x < 5u * nchunk; x += NW) {
+            const uint32_t d = x % 5u, chunk = x / 5u;
+            const uint32_t u = chunk * 21u + (uint32_t)lane / 3u, m = (uint32_t)lane % 3u;
+            if (lane < 63 && u < nsurv) {
+                const uint32_t me = smeta[u];
+                const uint32_t tp = 4u + ((me >> 13) & 7u), nbytes = (me >> 16) & 15u;
+                const uint32_t b = ((d + 10u - tp) % 5u) + 5u * m;
+                if (b >= 1 && b < nbytes) {
+                    const uint32_t t0 = 95u + tp + 96u * b; /* t0 % 5 == d */
+                    const uint32_t first = (me & 0x1fffu) + 2u + t0 / 5u;
+                    uint32_t v;
+                    switch (d) { /* wave-uniform */
+                    case 0: v = slice_byte_phase<0>(mags, first); break;
+                    case 1: v = slice_byte_phase<1>(mags, first); break;
+                    case 2: v = slice_byte_phase<2>(mags, first); break;
+                    case 3: v = slice_byte_phase<3>(mags, first); break;
+                    default: v = slice_byte_phase<4>(mags, first); break;
+                    }
+                    smsg[16 * u + b] = (uint8_t)v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- step C ---- */
+    for (uint32_t u = (uint32_t)tid; u < nsurv; u += NT) {
+        const uint32_t me = smeta[u];
+        const int n = (int)((me >> 16) & 15u);
+        const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
+        uint32_t w[4] = {m4.x, m4.y, m4.z, m4.w};
+        if (n == 7) { /* bytes 7.. were never sliced */
+            w[1] &= 0x00ffffffu;
+            w[2] = 0;
+            w[3] = 0;
+        } else {
+            w[3] &= 0x0000ffffu;
+        }
+        const uint32_t orall = w[0] | w[1] | w[2] | w[3];
+        uint32_t rem = 0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            if (i < n - 3) {
+                const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                rem = ((rem << 8) ^ crc_tab[byte ^ (rem >> 16)]) & 0xffffffu;
+            }
+        }
+        uint32_t tail;
+        if (n == 7) /* bytes 4,5,6 */
+            tail = ((w[1] & 0xffu) << 16) | (w[1] & 0xff00u) | ((w[1] >> 16) & 0xffu);
+        else        /* bytes 11,12,13 */
+            tail = (((w[2] >> 24) & 0xffu) << 16) | ((w[3] & 0xffu) << 8) | ((w[3] >> 8) & 0xffu);
+        const uint32_t crc = rem ^ tail;
+        const uint32_t df = (w[0] & 0xffu) >> 3;
+        const uint32_t aa = (((w[0] >> 8) & 0xffu) << 16) | (((w[0] >> 16) & 0xffu) << 8) | (w[0] >> 24);
+        bool alive = (orall != 0); /* mode_s.c:325 */
+        uint32_t addr = crc, errbit = 0xffu;
+        if (alive && (df == 11 || df == 17 || df == 18)) {
+            addr = aa;
+            const uint32_t syndrome = (df == 11) ? (crc & 0xffff80u) : crc;
+            if (syndrome != 0) {
+                /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted single-bit
+                 * table, or give up */
+                const uint32_t *tab = (df == 11) ? syn : syn + 51;
+                int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
+                alive = false;
+                while (lo2 < hi2) {
+                    const int mid = (lo2 + hi2) >> 1;
+                    const uint32_t e = tab[mid];
+                    if ((e & 0xffffffu) == syndrome) {
+                        errbit = e >> 24;
+                        alive = true;
+                        break;
+                    }
+                    if ((e & 0xffffffu) < syndrome)
+                        lo2 = mid + 1;
+                    else
+                        hi2 = mid;
+                }
+                if (alive && errbit >= 8 && errbit <= 31)
+                    addr ^= 1u << (31 - errbit); /* correct_aa_field, mode_s.c:266-281 */
+            }
+        }
+        const uint32_t q = (me >> 13) & 7u, h = me >> 20;
+        if (alive) {
+            *reinterpret_cast<uint4 *>(smsg + 16 * u) =
+                make_uint4(w[0], w[1], w[2], (w[3] & 0xffffu) | ((4u + q) << 16) | (errbit << 24));
+            sres[2 * u] = addr;
+            sres[2 * u + 1] = crc;
+        } else {
+            survidx[h * 5 + q] = 0xffffu; /* scores -2 whatever the filter holds */
+        }
+    }
+    __syncthreads();
+
+    /* ---- step D ---- */
+    uint32_t nl = 0, mask = 0, pos = 0;
+    if ((uint32_t)tid < nh) {
+        const uint32_t e = hitlist[tid];
+        pos = e & 0x1fffu;
+        mask = e >> 13;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            nl += survidx[tid * 5 + q] != 0xffffu ? 1u : 0u;
+    }
+    const uint32_t incl = wave_incl_scan(nl, lane);
+    if (lane == 63)
+        wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t s = wtot[i];
+        if (i < wave)
+            before += s;
+        total += s;
+    }
+    if ((uint32_t)tid < nh) {
+        uint32_t idx = tcur + before + incl - nl;
+        if (hits_fit) {
+            msd_hit rec = (tile_pos0 + pos) | ((msd_hit)mask << 28) | ((msd_hit)nl << 31);
+            if (nl)
+                rec |= (msd_hit)idx << 34;
+            hit_out[tid] = rec;
+        }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            if (nb[q] > 1) {
-                smeta[r] = pos | ((uint32_t)q << 13) | (nb[q] << 16) | ((uint32_t)lane << 20); /* q = tp - 4 */
-                smsg[16 * r] = (uint8_t)b0[q];
-                ++r;
-            }
-        }
-    }
-    wave_lds_sync();
-
-    /* ---- step B: the remaining bytes, one lane per (survivor, byte) with the lanes of one pass
-     *      all at the same PPM phase d = (tp + byte) mod 5 ---- */
-#define MSD_STEP_B(D)                                                                          \
-    for (uint32_t ub = 0; ub < nsurv; ub += 21) {                                              \
-        const uint32_t u = ub + (uint32_t)lane / 3u, m = (uint32_t)lane % 3u;                  \
-        if (lane < 63 && u < nsurv) {                                                          \
-            const uint32_t me = smeta[u];                                                      \
-            const uint32_t tp = 4u + ((me >> 13) & 7u), nbytes = (me >> 16) & 15u;             \
-            const uint32_t b = (((D) + 10u - tp) % 5u) + 5u * m;                               \
-            if (b >= 1 && b < nbytes) {                                                        \
-                const uint32_t t0 = 95u + tp + 96u * b; /* t0 % 5 == D */                      \
-                smsg[16 * u + b] = (uint8_t)slice_byte_phase<(D)>(mags + (me & 0x1fffu) + 2 + t0 / 5u); \
-            }                                                                                  \
-        }                                                                                      \
-    }
-    MSD_STEP_B(0) MSD_STEP_B(1) MSD_STEP_B(2) MSD_STEP_B(3) MSD_STEP_B(4)
-#undef MSD_STEP_B
-    wave_lds_sync();
-
-    /* ---- step C: CRC-24 (crc.c:67-82) and the part of scoreModesMessage that needs no filter
-     *      (mode_s.c:311-409); one lane per survivor, two blocks of 64 ---- */
-    uint32_t rank_base = 0;
-    uint32_t rec_addr[2], rec_crc[2], rec_rank[2];
-    bool rec_live[2];
-    uint4 rec_msg[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const uint32_t u = 64u * blk + (uint32_t)lane;
-        bool alive = false;
-        rec_addr[blk] = rec_crc[blk] = rec_rank[blk] = 0;
-        rec_msg[blk] = make_uint4(0, 0, 0, 0);
-        if (64u * blk < nsurv) { /* wave-uniform */
-            if (u < nsurv) {
-                const uint32_t me = smeta[u];
-                const int n = (int)((me >> 16) & 15u);
-                const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
-                uint32_t w[4] = {m4.x, m4.y, m4.z, m4.w};
-                if (n == 7) { /* bytes 7.. were never sliced */
-                    w[1] &= 0x00ffffffu;
-                    w[2] = 0;
-                    w[3] = 0;
-                } else {
-                    w[3] &= 0x0000ffffu;
-                }
-                const uint32_t orall = w[0] | w[1] | w[2] | w[3];
-                uint32_t rem = 0;
-#pragma unroll
-                for (int i = 0; i < 11; ++i) {
-                    if (i < n - 3) {
-                        const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                        rem = ((rem << 8) ^ crc_tab[byte ^ (rem >> 16)]) & 0xffffffu;
-                    }
-                }
-                uint32_t tail;
-                if (n == 7) /* bytes 4,5,6 */
-                    tail = ((w[1] & 0xffu) << 16) | (w[1] & 0xff00u) | ((w[1] >> 16) & 0xffu);
-                else        /* bytes 11,12,13 */
-                    tail = (((w[2] >> 24) & 0xffu) << 16) | ((w[3] & 0xffu) << 8) | ((w[3] >> 8) & 0xffu);
-                const uint32_t crc = rem ^ tail;
-                const uint32_t df = (w[0] & 0xffu) >> 3;
-                const uint32_t aa = (((w[0] >> 8) & 0xffu) << 16) | (((w[0] >> 16) & 0xffu) << 8) | (w[0] >> 24);
-                alive = (orall != 0); /* mode_s.c:325 */
-                uint32_t addr = crc, errbit = 0xffu;
-                if (alive && (df == 11 || df == 17 || df == 18)) {
-                    addr = aa;
-                    const uint32_t syndrome = (df == 11) ? (crc & 0xffff80u) : crc;
-                    if (syndrome != 0) {
-                        /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted
-                         * single-bit table, or give up */
-                        const uint32_t *tab = (df == 11) ? syn : syn + 51;
-                        int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
-                        alive = false;
-                        while (lo2 < hi2) {
-                            const int mid = (lo2 + hi2) >> 1;
-                            const uint32_t e = tab[mid];
-                            if ((e & 0xffffffu) == syndrome) {
-                                errbit = e >> 24;
-                                alive = true;
-                                break;
-                            }
-                            if ((e & 0xffffffu) < syndrome)
-                                lo2 = mid + 1;
-                            else
-                                hi2 = mid;
-                        }
-                        if (alive && errbit >= 8 && errbit <= 31)
-                            addr ^= 1u << (31 - errbit); /* correct_aa_field, mode_s.c:266-281 */
-                    }
-                }
-                rec_addr[blk] = addr;
-                rec_crc[blk] = crc;
-                const uint32_t tp = 4u + ((me >> 13) & 7u);
-                rec_msg[blk] = make_uint4(w[0], w[1], w[2], (w[3] & 0xffffu) | (tp << 16) | (errbit << 24));
-            }
-            const unsigned long long bal = __ballot(alive);
-            rec_rank[blk] = rank_base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            rank_base += (uint32_t)__popcll(bal);
-        }
-        rec_live[blk] = alive;
-    }
-    const uint32_t total_live = rank_base;
-
-    /* ---- step D: reserve space for the try records, write them, then the hit records ---- */
-    if (total_live) {
-        uint32_t tbase = 0;
-        if (lane == 0)
-            tbase = atomicAdd(wg_try_cursor, total_live);
-        tbase = __shfl(tbase, 0);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            if (rec_live[blk]) {
-                const uint32_t u = 64u * blk + (uint32_t)lane;
-                const uint32_t me = smeta[u];
-                const uint32_t idx = tbase + rec_rank[blk];
-                const uint32_t h = me >> 20;
-                atomicAdd(&hit_nlive[h], 1u);
-                atomicMin(&hit_first[h], idx);
+            const uint32_t u = survidx[tid * 5 + q];
+            if (u != 0xffffu) {
                 if (idx < P.tcap) {
                     uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
-                    dst[0] = rec_msg[blk];
-                    dst[1] = make_uint4(rec_addr[blk], rec_crc[blk], (uint32_t)(tile_pos0 + (me & 0x1fffu)), 0u);
+                    dst[0] = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
+                    dst[1] = make_uint4(sres[2 * u], sres[2 * u + 1], (uint32_t)(tile_pos0 + pos), 0u);
                 }
+                ++idx;
             }
         }
     }
-    wave_lds_sync();
-    if (has_hit) {
-        const uint32_t nl = hit_nlive[lane];
-        msd_hit rec = (tile_pos0 + pos) | ((msd_hit)mask << 28) | ((msd_hit)nl << 31);
-        if (nl)
-            rec |= (msd_hit)hit_first[lane] << 34;
-        hit_out[lane] = rec;
-    }
+    return total;
 }
 
 template <int FMT>
@@ -460,10 +475,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wg = blockIdx.x;
-    unsigned char *wscr = smem + OFF_WAVE + wave * WAVE_BYTES;
-    uint32_t *hitbuf = reinterpret_cast<uint32_t *>(wscr + WAVE_HITBUF);
+    unsigned char *cs = smem + OFF_CAND;
     uint32_t *wave_hits = misc;         /* [2][NW], double buffered by tile parity */
-    uint32_t *wg_try_cursor = misc + 32; /* [1] */
 
     /* constant tables -> LDS, once per persistent workgroup */
     for (int i = tid; i < 256; i += NT)
@@ -477,8 +490,6 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
         for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
             l[i] = g[i];
     }
-    if (tid == 0)
-        *wg_try_cursor = 0;
 
     const uint32_t tile_lo = wg * P.tiles_per_wg;
     uint32_t tile_hi = tile_lo + P.tiles_per_wg;
@@ -494,7 +505,7 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     __syncthreads();
     const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
 
-    uint32_t hcur = 0; /* workgroup-uniform cursor into this workgroup's hit region */
+    uint32_t hcur = 0, tcur = 0; /* workgroup-uniform cursors into this workgroup's regions */
     msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
     msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
 
@@ -621,10 +632,9 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 cnt = (uint32_t)__popcll(x);
             }
             const uint32_t incl = wave_incl_scan(cnt, lane);
-            const uint32_t wave_total = __shfl(incl, 63);
             uint32_t *wh = wave_hits + NW * (tile & 1u);
-            if (lane == 0)
-                wh[wave] = wave_total;
+            if (lane == 63)
+                wh[wave] = incl;
             __syncthreads();
             uint32_t wave_base = 0, H = 0;
 #pragma unroll
@@ -635,30 +645,34 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 H += s;
             }
 
-            if (!(P.debug_flags & 1) && wave_total) {
-                /* ---- stage 4: wave-autonomous candidate rounds ---- */
-                const uint32_t my_rank0 = incl - cnt;
-                for (uint32_t r0 = 0; r0 < wave_total; r0 += HROUND) {
-                    const uint32_t nh = (wave_total - r0 < (uint32_t)HROUND) ? (wave_total - r0) : (uint32_t)HROUND;
-                    if (cnt && my_rank0 < r0 + HROUND && my_rank0 + cnt > r0) {
+            if (!(P.debug_flags & 1) && H) {
+                /* ---- stage 4: workgroup-cooperative candidate rounds ---- */
+                const uint32_t my_rank0 = wave_base + incl - cnt;
+                uint32_t *hitlist = reinterpret_cast<uint32_t *>(cs + CS_HITS);
+                uint32_t *sidx32 = reinterpret_cast<uint32_t *>(cs + CS_SIDX);
+                for (uint32_t r0 = 0; r0 < H; r0 += HCAP) {
+                    const uint32_t nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
+                    if (cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
                         uint32_t r = my_rank0;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
                             const uint32_t m = (uint32_t)(nib >> (4 * q)) & 7u;
                             if (m) {
-                                if (r >= r0 && r < r0 + HROUND)
-                                    hitbuf[r - r0] = (uint32_t)(16 * tid + q) | (m << 13);
+                                if (r >= r0 && r < r0 + HCAP)
+                                    hitlist[r - r0] = (uint32_t)(16 * tid + q) | (m << 13);
                                 ++r;
                             }
                         }
                     }
-                    wave_lds_sync();
-                    const uint32_t hit = (uint32_t)lane < nh ? hitbuf[lane] : 0u;
-                    const uint32_t out0 = hcur + wave_base + r0;
-                    if (out0 + nh <= P.hcap) /* wave-uniform; an overflow is reported via counts */
-                        candidate_round(P, mags, crc_tab, syn, wscr, wg_try_cursor, lane, nh, hit, tile_pos0,
-                                        my_hits + out0, my_tries);
-                    wave_lds_sync();
+                    for (int i = tid; i < HCAP * 5 / 2; i += NT)
+                        sidx32[i] = 0xffffffffu;
+                    if (tid == 0)
+                        *reinterpret_cast<uint32_t *>(cs + CS_MISC) = 0;
+                    __syncthreads();
+                    const uint32_t out0 = hcur + r0;
+                    tcur += candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0, my_hits + out0,
+                                            out0 + nh <= P.hcap, my_tries, tcur);
+                    __syncthreads();
                 }
             }
             hcur += H;
@@ -694,8 +708,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     if (tid == 0) {
         msd_wg_counts c;
         c.nhits = hcur;
-        c.ntries = *wg_try_cursor;
-        c.overflow = (hcur > P.hcap || c.ntries > P.tcap) ? 1u : 0u;
+        c.ntries = tcur;
+        c.overflow = (hcur > P.hcap || tcur > P.tcap) ? 1u : 0u;
         c.pad = 0;
         P.counts[wg] = c;
     }
