@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <cmath>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -57,6 +58,11 @@ struct Slot {
     size_t h_hits_cap = 0;
     msd_try *h_tries = nullptr;
     size_t h_tries_cap = 0;
+    /* Mode A/C candidates */
+    msd_ac_hit *d_ac = nullptr;
+    uint64_t *d_ac_totals = nullptr, *h_ac_totals = nullptr;
+    msd_ac_hit *h_ac = nullptr;
+    size_t h_ac_cap = 0;
     /* deferred signal power of the accepted messages */
     uint64_t *d_req = nullptr, *d_pow = nullptr, *h_req = nullptr, *h_pow = nullptr;
     size_t req_cap = 0;
@@ -81,6 +87,13 @@ struct msd_ctx {
     msd_wg_counts *d_counts = nullptr;
     uint64_t *d_offsets = nullptr;
     uint32_t max_wg = 0, max_buffers = 0;
+    /* Mode A/C candidate regions */
+    msd_ac_hit *d_ac_regions = nullptr;
+    uint64_t ac_arena = 0;
+    msd_wg_counts *d_ac_counts = nullptr;
+    uint64_t *d_ac_offsets = nullptr;
+    uint32_t *d_noise = nullptr;
+    uint32_t ac_max_wg = 0;
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -195,7 +208,7 @@ int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
 }
 
 /* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
-int enqueue(msd_ctx *c, Slot &s, int format)
+int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise = nullptr)
 {
     const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
     const uint32_t ntiles = (uint32_t)ntiles64;
@@ -209,6 +222,8 @@ int enqueue(msd_ctx *c, Slot &s, int format)
 
     HIPCHK(c, hipMemsetAsync(s.d_sums, 0, sizeof(uint64_t) * 2 * (s.nbuffers ? s.nbuffers : 1), c->stream));
     HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
+    if (c->cfg.mode_ac)
+        HIPCHK(c, hipMemsetAsync(s.d_ac_totals, 0, sizeof(uint64_t) * 4, c->stream));
     HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
     if (nwg) {
         MsdScanParams p{};
@@ -249,12 +264,27 @@ int enqueue(msd_ctx *c, Slot &s, int format)
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
     }
+    if (c->cfg.mode_ac && s.nbuffers) {
+        if (host_noise)
+            HIPCHK(c, hipMemcpyAsync(c->d_noise, host_noise, sizeof(uint32_t) * s.nbuffers, hipMemcpyHostToDevice,
+                                     c->stream));
+        MsdScanParams p{};
+        fill_params(c, s, p);
+        int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise, host_noise != nullptr,
+                               c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
+                               c->ac_arena, c->ac_max_wg, c->stream);
+        if (rc)
+            return fail(c, rc, "Mode A/C kernel launch failed");
+    }
     HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
 
     /* download of the totals on the copy stream, behind this batch's kernels only */
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.ev_kernels, 0));
     HIPCHK(c, hipMemcpyAsync(s.h_totals, s.d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost,
                              c->copy_stream));
+    if (c->cfg.mode_ac)
+        HIPCHK(c, hipMemcpyAsync(s.h_ac_totals, s.d_ac_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost,
+                                 c->copy_stream));
     HIPCHK(c, hipEventRecord(s.ev_totals, c->copy_stream));
     return 0;
 }
@@ -284,6 +314,24 @@ int start_download(msd_ctx *c, Slot &s, int format)
         if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11)
             HIPCHK(c, hipMemcpyAsync(s.h_fmeans, s.d_fmeans, sizeof(float) * 2 * s.nbuffers,
                                      hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    if (c->cfg.mode_ac) {
+        const uint64_t nac = s.h_ac_totals[0];
+        if (s.h_ac_totals[2])
+            return fail(c, -EOVERFLOW, "Mode A/C candidate arena overflow (%llu)", (unsigned long long)nac);
+        if (nac > s.h_ac_cap) {
+            size_t cap = s.h_ac_cap ? s.h_ac_cap : (size_t)1 << 14;
+            while (cap < nac)
+                cap *= 2;
+            if (s.h_ac)
+                (void)hipHostFree(s.h_ac);
+            s.h_ac = nullptr;
+            s.h_ac_cap = 0;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_ac), cap * sizeof(msd_ac_hit)));
+            s.h_ac_cap = cap;
+        }
+        if (nac)
+            HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->copy_stream));
     }
     HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
     s.download_started = true;
@@ -338,7 +386,8 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     c->out_req.clear();
     c->out_buf.clear();
     msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
-                      nullptr, 0, ts_override, emit_thunk, c);
+                      c->cfg.mode_ac ? s.h_ac : nullptr, c->cfg.mode_ac ? s.h_ac_totals[0] : 0, ts_override,
+                      emit_thunk, c);
     auto t1 = std::chrono::steady_clock::now();
 
     /* signal power of the accepted messages: a small follow-up kernel on the copy stream */
@@ -465,6 +514,9 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
+        (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals);
+        if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
+        if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
         for (hipEvent_t *e : evs)
             if (*e)
@@ -472,6 +524,8 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_offsets);
+    (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
+    (void)hipFree(c->d_noise);
     for (uint8_t *t : c->d_tail)
         (void)hipFree(t);
     (void)hipFree(c->d_stage);
@@ -568,6 +622,14 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_wg_counts)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_offsets), c->max_wg * 2 * sizeof(uint64_t)));
+    if (cfg->mode_ac) {
+        c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
+        c->ac_max_wg = (uint32_t)c->cu_count * 4u;
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_regions), c->ac_arena * sizeof(msd_ac_hit)));
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_counts), c->ac_max_wg * sizeof(msd_wg_counts)));
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_offsets), c->ac_max_wg * 2 * sizeof(uint64_t)));
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_noise), c->max_buffers * sizeof(uint32_t)));
+    }
     for (uint8_t *&t : c->d_tail) {
         CK(hipMalloc(reinterpret_cast<void **>(&t), (size_t)TAIL_SAMPLES * 4));
         CK(hipMemset(t, 0, (size_t)TAIL_SAMPLES * 4));
@@ -579,6 +641,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_fmeans), 2 * sizeof(float) * c->max_buffers));
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
+        if (cfg->mode_ac) {
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac), c->ac_arena * sizeof(msd_ac_hit)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac_totals), 4 * sizeof(uint64_t)));
+            CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ac_totals), 4 * sizeof(uint64_t)));
+        }
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_sums), 2 * sizeof(uint64_t) * c->max_buffers));
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_fmeans), 2 * sizeof(float) * c->max_buffers));
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
@@ -778,7 +845,10 @@ int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength
     s.nsamples = mlen;
     s.nbuffers = 1;
     s.last = 1;
-    int rc = enqueue(c, s, MSD_FMT_MAG16);
+    /* demod_2400.c:530-531 from the caller's mag_buf.mean_level / .mean_power */
+    const double noise_stddev = sqrt(mean_power - mean_level * mean_level);
+    const uint32_t host_noise = mlen ? (uint32_t)((mean_power + noise_stddev) * 65535 + 0.5) : 0u;
+    int rc = enqueue(c, s, MSD_FMT_MAG16, c->cfg.mode_ac ? &host_noise : nullptr);
     if (rc) {
         s.busy = false;
         return rc;

@@ -51,7 +51,7 @@ typedef struct msd_try {
 /* Mode A/C candidate: every f1_sample that passes all tests of demod_2400.c:581-668; only the
  * 69-sample skip-ahead (:705) is left to the resolve stage. */
 typedef struct msd_ac_hit {
-    uint64_t pos;      /* chunk*131072 + f1_sample */
+    uint64_t pos;      /* batch-relative: buffer*131072 + f1_sample */
     uint32_t f2_clock; /* 60 MHz, relative to the buffer start (demod_2400.c:604) */
     uint32_t modeac;   /* demod_2400.c:672-685 */
 } msd_ac_hit;

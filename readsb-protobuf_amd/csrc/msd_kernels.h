@@ -44,6 +44,12 @@ int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offse
                       uint64_t dense_tcap, hipStream_t stream);
 int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
                      unsigned long long *d_out, hipStream_t stream);
+/* Mode A/C candidate stage: noise levels (unless noise_ready), candidate kernel, ordered gather.
+ * d_totals[0] receives the number of candidates, d_totals[2] an overflow flag. */
+int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, const float *d_fmeans,
+                  uint32_t nbuffers, uint32_t *d_noise, int noise_ready, msd_ac_hit *d_regions,
+                  uint64_t region_total, msd_wg_counts *d_counts, uint64_t *d_offsets, uint64_t *d_totals,
+                  msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,

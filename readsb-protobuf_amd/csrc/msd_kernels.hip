@@ -921,6 +921,200 @@ __global__ void __launch_bounds__(64) msd_float_means_kernel(const uint8_t *iq, 
     out[2 * b + 1] = sum_power;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Mode A/C (demodulate2400AC, demod_2400.c:522-708)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* noise_level of every buffer (demod_2400.c:530-531) from the buffer sums the scan kernel left:
+ *   UC8 / MAG16: integer sums -> mean_level = sum/65536/n, mean_power = sum/65535^2/n (convert.c:104-110)
+ *   SC16 / SC16Q11: the sequential float sums of msd_float_means_kernel, float division by n.
+ * All arithmetic is IEEE double (division and sqrt are correctly rounded on gfx950). */
+__global__ void __launch_bounds__(64) msd_ac_noise_kernel(const uint64_t *sums, const float *fmeans, int use_float,
+                                                           uint64_t nsamples, uint32_t nbuffers, uint32_t *noise_level)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuffers)
+        return;
+    const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
+    uint64_t n = nsamples > first ? nsamples - first : 0;
+    if (n > MSD_CHUNK_SAMPLES)
+        n = MSD_CHUNK_SAMPLES;
+    double mean_level, mean_power;
+    if (use_float) {
+        mean_level = (double)(fmeans[2 * b] / (float)(unsigned)n);
+        mean_power = (double)(fmeans[2 * b + 1] / (float)(unsigned)n);
+    } else {
+        mean_level = (double)sums[2 * b] / 65536.0 / (double)(unsigned)n;
+        mean_power = (double)sums[2 * b + 1] / 65535.0 / 65535.0 / (double)(unsigned)n;
+    }
+    const double level_sq = mean_level * mean_level;
+    const double noise_stddev = sqrt(mean_power - level_sq);
+    const double scaled = (mean_power + noise_stddev) * 65535;
+    noise_level[b] = n ? (uint32_t)(scaled + 0.5) : 0u;
+}
+
+constexpr int ACNT = 256;                    /* threads per workgroup */
+constexpr int ACT = 4096;                    /* F1 positions per tile */
+constexpr int AC_LOAD = ACT + 72;            /* samples staged from m[j0 - 2]; bit 19 of the last position ends at +71 */
+static_assert(AC_LOAD % 8 == 0 && MSD_CHUNK_SAMPLES % ACT == 0, "whole groups, tiles inside one buffer");
+
+/* Every F1 position that passes all tests of demod_2400.c:581-668; the 69-sample skip-ahead after
+ * a decode (:705) is left to the resolve stage.  One thread per position, magnitudes staged in
+ * LDS like in the Mode S scan; output appended in position order to a workgroup-private region. */
+template <int FMT>
+__global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
+                                                      const uint32_t *noise_levels, msd_ac_hit *out,
+                                                      uint32_t cap, msd_wg_counts *counts)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t mags[AC_LOAD + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[(FMT == MSD_FMT_UC8) ? 128 * LUT_STRIDE : 8];
+    __shared__ uint32_t wcount[ACNT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wg = blockIdx.x;
+    if (FMT == MSD_FMT_UC8) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
+        uint4 *l = reinterpret_cast<uint4 *>(lut);
+        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += ACNT)
+            l[i] = g[i];
+    }
+    __syncthreads();
+
+    const uint32_t tile_lo = wg * tiles_per_wg;
+    uint32_t tile_hi = tile_lo + tiles_per_wg;
+    if (tile_hi > ntiles)
+        tile_hi = ntiles;
+    uint32_t cur = 0; /* workgroup-uniform output cursor */
+    msd_ac_hit *const mine = out + (size_t)wg * cap;
+
+    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const uint64_t pos0 = (uint64_t)tile * ACT; /* batch-relative */
+        const uint64_t a0 = P.batch_first + pos0;
+        for (int g = tid; g < AC_LOAD / 8; g += ACNT) {
+            RawGroup<FMT> r;
+            const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * g, r);
+            uint32_t mg[8];
+            convert_group<FMT>(r, valid, lut, mg);
+            *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
+        }
+        __syncthreads();
+
+        const uint32_t b = (uint32_t)(pos0 / MSD_CHUNK_SAMPLES);
+        const uint32_t j0 = (uint32_t)(pos0 % MSD_CHUNK_SAMPLES);
+        const uint64_t bfirst = (uint64_t)b * MSD_CHUNK_SAMPLES;
+        uint64_t mlen64 = P.nsamples > bfirst ? P.nsamples - bfirst : 0;
+        const uint32_t mlen = mlen64 > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : (uint32_t)mlen64;
+        const uint32_t noise_level = noise_levels[b];
+
+        for (int sub = 0; sub < ACT; sub += ACNT) {
+            const int p = sub + tid;
+            const uint32_t f1_sample = j0 + (uint32_t)p;
+            /* m[x] = mags[p + 2 + (x - f1_sample)]: the tile stages 328 = 326 + 2 samples behind */
+#define ACM(x) ((uint32_t)mags[p + 2 + (int)((x) - f1_sample)])
+            bool found = false;
+            uint32_t f2_clock = 0, modeac = 0;
+            if (f1_sample >= 1 && f1_sample < mlen) {
+                const uint32_t m0 = ACM(f1_sample), m1 = ACM(f1_sample + 1), m2 = ACM(f1_sample + 2);
+                const uint32_t f1_level = (m0 + m1) / 2;
+                if (ACM(f1_sample - 1) < m0 && !(m2 > m0 || m2 > m1) && !(noise_level * 2 > f1_level)) {
+                    const float f1a_power = (float)m0 * (float)m0;
+                    const float f1b_power = (float)m1 * (float)m1;
+                    const float fsum = f1a_power + f1b_power;
+                    const float fraction = f1b_power / fsum;
+                    const float frac2 = fraction * fraction;
+                    const float fpos = (float)f1_sample + frac2;
+                    const float fclk = 25.0f * fpos;
+                    const uint32_t f1_clock = (uint32_t)((double)fclk + 0.5);
+                    f2_clock = f1_clock + (87 * 14);
+                    const uint32_t f2_sample = f2_clock / 25;
+                    const uint32_t n0 = ACM(f2_sample), n1 = ACM(f2_sample + 1), n2 = ACM(f2_sample + 2);
+                    const uint32_t f2_level = (n0 + n1) / 2;
+                    if (ACM(f2_sample - 1) < n0 && !(n2 > n0 || n2 > n1) && !(noise_level * 2 > f2_level)) {
+                        const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
+                        const float midpoint = __builtin_sqrtf((float)(noise_level * f1f2_level)); /* u32 product */
+                        const double up = (double)midpoint * 1.41421356237309504880;
+                        const double down = (double)midpoint / 1.41421356237309504880;
+                        const uint32_t signal_threshold = (uint32_t)(up + 0.5);
+                        const uint32_t noise_threshold = (uint32_t)(down + 0.5);
+                        uint32_t bits = 0, bad = 0;
+                        uint32_t clock = f1_clock;
+                        for (int bit = 0; bit < 20; ++bit, clock += 87) {
+                            const uint32_t s = clock / 25;
+                            const uint32_t x0 = ACM(s), x1 = ACM(s + 1), x2 = ACM(s + 2);
+                            bits <<= 1;
+                            if (x2 >= signal_threshold)
+                                bad = 1; /* noisy quiet period */
+                            if (x0 >= signal_threshold || x1 >= signal_threshold)
+                                bits |= 1;
+                            else if (x0 > noise_threshold && x1 > noise_threshold)
+                                bad = 1; /* uncertain bit */
+                        }
+                        if ((bits & 0x80020u) == 0x80020u && (bits & 0x0101Bu) == 0 && !bad) {
+                            /* demod_2400.c:672-685: 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 */
+                            modeac = ((bits & 0x40000u) ? 0x0010u : 0) | ((bits & 0x20000u) ? 0x1000u : 0) |
+                                     ((bits & 0x10000u) ? 0x0020u : 0) | ((bits & 0x08000u) ? 0x2000u : 0) |
+                                     ((bits & 0x04000u) ? 0x0040u : 0) | ((bits & 0x02000u) ? 0x4000u : 0) |
+                                     ((bits & 0x00800u) ? 0x0100u : 0) | ((bits & 0x00400u) ? 0x0001u : 0) |
+                                     ((bits & 0x00200u) ? 0x0200u : 0) | ((bits & 0x00100u) ? 0x0002u : 0) |
+                                     ((bits & 0x00080u) ? 0x0400u : 0) | ((bits & 0x00040u) ? 0x0004u : 0) |
+                                     ((bits & 0x00004u) ? 0x0080u : 0);
+                            found = true;
+                        }
+                    }
+                }
+            }
+#undef ACM
+            /* ordered append */
+            const unsigned long long bal = __ballot(found);
+            if (lane == 0)
+                wcount[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < ACNT / 64; ++i) {
+                const uint32_t s = wcount[i];
+                if (i < wave)
+                    before += s;
+                total += s;
+            }
+            if (found) {
+                const uint32_t idx = cur + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (idx < cap) {
+                    msd_ac_hit h;
+                    h.pos = pos0 + (uint64_t)p;
+                    h.f2_clock = f2_clock;
+                    h.modeac = modeac;
+                    mine[idx] = h;
+                }
+            }
+            cur += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        msd_wg_counts c;
+        c.nhits = cur;
+        c.ntries = 0;
+        c.overflow = cur > cap ? 1u : 0u;
+        c.pad = 0;
+        counts[wg] = c;
+    }
+}
+
+/* dense[offset[w] + i] = region[w][i] for the Mode A/C list (offsets from msd_offsets_kernel) */
+__global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts *counts, const uint64_t *offsets,
+                                                            const msd_ac_hit *regions, uint32_t cap,
+                                                            msd_ac_hit *dense, uint64_t dense_cap)
+{
+    const uint32_t w = blockIdx.x;
+    const uint32_t n = counts[w].nhits < cap ? counts[w].nhits : cap;
+    const uint64_t o = offsets[2 * w];
+    const uint4 *src = reinterpret_cast<const uint4 *>(regions + (size_t)w * cap);
+    uint4 *dst = reinterpret_cast<uint4 *>(dense);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (o + i < dense_cap)
+            dst[o + i] = src[i];
+}
+
 } /* namespace */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -989,6 +1183,57 @@ extern "C" int msd_launch_power(const MsdScanParams *p, int format, const uint64
     default:
         return -22;
     }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, const float *d_fmeans,
+                             uint32_t nbuffers, uint32_t *d_noise, int noise_ready, msd_ac_hit *d_regions,
+                             uint64_t region_total, msd_wg_counts *d_counts, uint64_t *d_offsets,
+                             uint64_t *d_totals, msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg,
+                             hipStream_t stream)
+{
+    if (nbuffers == 0)
+        return 0;
+    if (!noise_ready) {
+        const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11);
+        hipLaunchKernelGGL(msd_ac_noise_kernel, dim3((nbuffers + 63) / 64), dim3(64), 0, stream, d_sums, d_fmeans,
+                           use_float, p->nsamples, nbuffers, d_noise);
+    }
+    const uint32_t ntiles = (uint32_t)((p->nsamples + ACT - 1) / ACT);
+    if (ntiles == 0) {
+        (void)hipMemsetAsync(d_totals, 0, 4 * sizeof(uint64_t), stream);
+        return 0;
+    }
+    uint32_t tpw = (ntiles + max_wg - 1) / max_wg;
+    if (tpw == 0)
+        tpw = 1;
+    const uint32_t nwg = (ntiles + tpw - 1) / tpw;
+    uint64_t cap = region_total / nwg;
+    if (cap > (uint64_t)tpw * ACT)
+        cap = (uint64_t)tpw * ACT;
+    switch (format) {
+    case MSD_FMT_UC8:
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_UC8>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
+                           d_regions, (uint32_t)cap, d_counts);
+        break;
+    case MSD_FMT_SC16:
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
+                           d_regions, (uint32_t)cap, d_counts);
+        break;
+    case MSD_FMT_SC16Q11:
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16Q11>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
+                           d_regions, (uint32_t)cap, d_counts);
+        break;
+    case MSD_FMT_MAG16:
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_MAG16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
+                           d_regions, (uint32_t)cap, d_counts);
+        break;
+    default:
+        return -22;
+    }
+    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, d_counts, nwg, d_offsets, d_totals);
+    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nwg), dim3(256), 0, stream, d_counts, d_offsets, d_regions,
+                       (uint32_t)cap, d_dense, dense_cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

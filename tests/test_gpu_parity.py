@@ -22,17 +22,18 @@ def assert_same(got, gstats, want, wstats):
         assert np.array_equal(np.float64(gstats[k]), np.float64(wstats[k]), equal_nan=True), (k, gstats[k], wstats[k])
 
 
-def run_case(pkg, oracle, torch, fmt, n, seed, nfix, batch=None, **cfgkw):
+def run_case(pkg, oracle, torch, fmt, n, seed, nfix, batch=None, mode_ac=0, **cfgkw):
     cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, **cfgkw)
     iq = pkg.siggen.generate(cfg, n)
     d_iq = torch.from_numpy(iq).to("cuda:0")
     max_batch = batch or max(pkg.CHUNK, ((n + pkg.CHUNK - 1) // pkg.CHUNK) * pkg.CHUNK)
-    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, max_batch_samples=max_batch, message_capacity=1 << 18)
+    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=max_batch,
+                          message_capacity=1 << 18)
     if batch:
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
     else:
         got = dem.submit_device(d_iq.data_ptr(), n, last=True)
-    want, wstats = oracle.Oracle(fmt, 58, nfix, 0).replay(iq, cap=1 << 18)
+    want, wstats = oracle.Oracle(fmt, 58, nfix, mode_ac).replay(iq, cap=1 << 18)
     assert len(want) > 0
     assert_same(got, dem.stats(), want, wstats)
     return got, dem
@@ -54,3 +55,18 @@ def test_uc8_pipelined_batches(pkg, oracle, torch_cuda):
 def test_s16_formats(pkg, oracle, torch_cuda, fmt):
     f = pkg.FMT_SC16 if fmt == "sc16" else pkg.FMT_SC16Q11
     run_case(pkg, oracle, torch_cuda, f, 3 * 131072 + 77, seed=10920, nfix=1)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16q11"])
+def test_mode_s_plus_mode_ac_fix(pkg, oracle, torch_cuda, fmt):
+    """BASELINE.json configs[4]: Mode S + Mode A/C combined (demodulate2400AC) with --fix."""
+    f = pkg.FMT_UC8 if fmt == "uc8" else pkg.FMT_SC16Q11
+    got, dem = run_case(pkg, oracle, torch_cuda, f, 6 * 131072 + 31, seed=44, nfix=1, mode_ac=1, msgs_per_sec=200,
+                        ac_per_sec=2000)
+    assert dem.stats()["demod_modeac"] > 300
+    assert (got["msgtype"] == 32).sum() == dem.stats()["demod_modeac"]
+
+
+def test_mode_ac_pipelined(pkg, oracle, torch_cuda):
+    run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 12 * 131072, seed=45, nfix=1, mode_ac=1, msgs_per_sec=2000,
+             ac_per_sec=1000, batch=4 * 131072)
