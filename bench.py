@@ -72,7 +72,7 @@ def main():
     batch = max(pkg.CHUNK, (batch // pkg.CHUNK) * pkg.CHUNK)
 
     # ---- synthetic capture, generated on the host from a seed, then made resident in HBM ----
-    seed = 10901 + rank
+    seed = pkg.sharding.capture_seed(rank)
     cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec)
     t0 = time.time()
     iq = pkg.siggen.generate(cfg, n)
@@ -128,18 +128,9 @@ def main():
         nmsg = one_step(timings)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([nmsg], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        nmsg_total = int(c.item())
-    else:
-        nmsg_total = nmsg
+    elapsed, nmsg_total, total_samples = pkg.sharding.reduce_job(elapsed, nmsg, n, device=dev)
 
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    total_samples = n * world
     value = total_samples / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
 
     # ---- roofline of the dominant kernel, from HIP events around every launch in the timed region ----

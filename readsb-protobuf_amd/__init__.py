@@ -4,6 +4,6 @@ The product is csrc/libmodes_hip.so (hand-written gfx950 HIP kernels behind the 
 include/modes_hip.h).  This package only binds it; torch is used by bench.py/tests for device
 memory and streams, never for compute.
 """
-from . import capi, siggen  # noqa: F401
+from . import capi, sharding, siggen  # noqa: F401
 from .capi import (CHUNK, FMT_MAG16, FMT_SC16, FMT_SC16Q11, FMT_UC8, MESSAGE_DTYPE, OVERLAP, Demodulator,  # noqa: F401
                    MsdError, replay_device)

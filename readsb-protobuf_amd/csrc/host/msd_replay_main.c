@@ -1,0 +1,93 @@
+/*
+ * msd_replay -- `readsb --device-type ifile --ifile F --iformat X [--fix|--no-fix]
+ * [--preamble-threshold N] [--modeac] --raw --quiet-ish` for the part of readsb this repository
+ * implements: replays a capture through the GPU receive path and prints one `*hex;` line per
+ * accepted message like displayModesMessage does in --raw mode (mode_s.c:1786-1798), or
+ * `@<12 hex digit timestamp>hex;` with --mlat.  Counters go to stderr with --stats.
+ */
+#define _GNU_SOURCE
+#include <inttypes.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "msd_sdr_ifile.h"
+
+static int g_mlat;
+static uint64_t g_count;
+
+static void print_raw(const msd_message *mm, void *user)
+{
+    FILE *out = user;
+    if (g_mlat && mm->timestampMsg)
+        fprintf(out, "@%012" PRIX64, mm->timestampMsg);
+    else
+        fputc('*', out);
+    for (int j = 0; j < mm->msgbits / 8; j++)
+        fprintf(out, "%02x", mm->msg[j]);
+    fputs(";\n", out);
+    g_count++;
+}
+
+int main(int argc, char **argv)
+{
+    msd_receiver_options rx;
+    memset(&rx, 0, sizeof rx);
+    rx.preamble_threshold = 58;
+    rx.nfix_crc = 1;
+    rx.batch_buffers = 64;
+    rx.sink = print_raw;
+    rx.sink_user = stdout;
+    int want_stats = 0;
+
+    msd_ifileInitConfig();
+    for (int i = 1; i < argc; ++i) {
+        const char *a = argv[i];
+        char *next = (i + 1 < argc) ? argv[i + 1] : NULL;
+        if (!strcmp(a, "--ifile") && next) { msd_ifileHandleOption(MSD_OPT_IFILE_NAME, next); ++i; }
+        else if (!strcmp(a, "--iformat") && next) {
+            if (!msd_ifileHandleOption(MSD_OPT_IFILE_FORMAT, next)) { fprintf(stderr, "%s\n", msd_ifileLastError()); return 1; }
+            ++i;
+        }
+        else if (!strcmp(a, "--throttle")) msd_ifileHandleOption(MSD_OPT_IFILE_THROTTLE, NULL);
+        else if (!strcmp(a, "--path") && next) { msd_ifileHandleOption(MSD_OPT_IFILE_MODE, next); ++i; }
+        else if (!strcmp(a, "--fix")) rx.nfix_crc = 1;
+        else if (!strcmp(a, "--no-fix")) rx.nfix_crc = 0;
+        else if (!strcmp(a, "--modeac")) rx.mode_ac = 1;
+        else if (!strcmp(a, "--mlat")) g_mlat = 1;
+        else if (!strcmp(a, "--stats")) want_stats = 1;
+        else if (!strcmp(a, "--raw") || !strcmp(a, "--quiet")) { /* this tool only has the raw dump */ }
+        else if (!strcmp(a, "--device-type") && next) { ++i; /* always ifile */ }
+        else if (!strcmp(a, "--device") && next) { rx.device = atoi(next); ++i; }
+        else if (!strcmp(a, "--batch-buffers") && next) { rx.batch_buffers = (unsigned)atoi(next); ++i; }
+        else if (!strcmp(a, "--preamble-threshold") && next) {
+            long v = strtol(next, NULL, 10); /* readsb.c:503-505 clamps to 40..400 */
+            rx.preamble_threshold = (int)(v < 40 ? 40 : (v > 400 ? 400 : v));
+            ++i;
+        } else {
+            fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix] "
+                            "[--preamble-threshold N] [--modeac] [--mlat] [--stats] [--path fused|magbuf] [--device N]\n");
+            return 2;
+        }
+    }
+    msd_ifileSetReceiver(&rx);
+    if (!msd_ifileOpen()) {
+        fprintf(stderr, "%s\n", msd_ifileLastError());
+        return 1;
+    }
+    msd_ifileRun();
+    if (msd_ifileLastError()[0])
+        fprintf(stderr, "%s\n", msd_ifileLastError());
+    if (want_stats) {
+        msd_stats st;
+        if (msd_ifileGetStats(&st) == 0) {
+            fprintf(stderr, "messages %" PRIu64 "\npreambles %" PRIu64 "\nrejected_bad %" PRIu64
+                            "\nrejected_unknown_icao %" PRIu64 "\naccepted %" PRIu64 " %" PRIu64 "\nmodeac %" PRIu64
+                            "\nbuffers %" PRIu64 "\n",
+                    g_count, st.demod_preambles, st.demod_rejected_bad, st.demod_rejected_unknown_icao,
+                    st.demod_accepted[0], st.demod_accepted[1], st.demod_modeac, st.buffers);
+        }
+    }
+    msd_ifileClose();
+    return 0;
+}

@@ -1,0 +1,236 @@
+/* msd_sdr_ifile.c -- see msd_sdr_ifile.h.  Host C, like the reference's sdr_ifile.c; all the
+ * signal processing happens behind the C-ABI of modes_hip.h. */
+#define _GNU_SOURCE
+#include "msd_sdr_ifile.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <unistd.h>
+
+#include "msd_fifo.h"
+
+static struct {
+    char *filename;
+    int format; /* MSD_FMT_* */
+    int mode;
+    bool throttle; /* accepted for compatibility; replay is never slowed down here */
+    int fd;
+    unsigned bytes_per_sample;
+    char *readbuf;
+    size_t readbuf_bytes;
+    msd_receiver_options rx;
+    msd_ctx *ctx;
+    char err[256];
+    volatile int exit_flag;
+} F;
+
+const char *msd_ifileLastError(void)
+{
+    return F.err;
+}
+
+void msd_ifileInitConfig(void)
+{
+    memset(&F, 0, sizeof F);
+    F.format = MSD_FMT_UC8;
+    F.fd = -1;
+    F.rx.preamble_threshold = 58; /* PREAMBLE_THRESHOLD_DEFAULT, demod_2400.h:31 */
+    F.rx.nfix_crc = 1;            /* readsb.c:169 */
+    F.rx.batch_buffers = 64;
+}
+
+void msd_ifileSetReceiver(const msd_receiver_options *opt)
+{
+    F.rx = *opt;
+    if (!F.rx.batch_buffers)
+        F.rx.batch_buffers = 64;
+}
+
+bool msd_ifileHandleOption(int key, char *arg)
+{
+    switch (key) {
+    case MSD_OPT_IFILE_NAME:
+        free(F.filename);
+        F.filename = strdup(arg);
+        break;
+    case MSD_OPT_IFILE_FORMAT:
+        if (!strcasecmp(arg, "uc8"))
+            F.format = MSD_FMT_UC8;
+        else if (!strcasecmp(arg, "sc16"))
+            F.format = MSD_FMT_SC16;
+        else if (!strcasecmp(arg, "sc16q11"))
+            F.format = MSD_FMT_SC16Q11;
+        else {
+            snprintf(F.err, sizeof F.err, "Input format '%s' not understood (supported values: UC8, SC16, SC16Q11)", arg);
+            return false;
+        }
+        break;
+    case MSD_OPT_IFILE_THROTTLE:
+        F.throttle = true;
+        break;
+    case MSD_OPT_IFILE_MODE:
+        F.mode = (!strcasecmp(arg, "magbuf")) ? MSD_IFILE_MAGBUF : MSD_IFILE_FUSED;
+        break;
+    }
+    return true;
+}
+
+bool msd_ifileOpen(void)
+{
+    if (!F.filename) {
+        snprintf(F.err, sizeof F.err, "SDR type 'ifile' requires an --ifile argument");
+        return false;
+    }
+    if (!strcmp(F.filename, "-"))
+        F.fd = STDIN_FILENO;
+    else if ((F.fd = open(F.filename, O_RDONLY)) < 0) {
+        snprintf(F.err, sizeof F.err, "ifile: could not open %s: %s", F.filename, strerror(errno));
+        return false;
+    }
+    F.bytes_per_sample = (F.format == MSD_FMT_UC8) ? 2 : 4;
+    const unsigned nbuf = (F.mode == MSD_IFILE_FUSED) ? F.rx.batch_buffers : 1;
+    F.readbuf_bytes = (size_t)F.bytes_per_sample * MSD_CHUNK_SAMPLES * nbuf;
+    if (posix_memalign((void **)&F.readbuf, 64, F.readbuf_bytes)) {
+        snprintf(F.err, sizeof F.err, "ifile: failed to allocate read buffer");
+        msd_ifileClose();
+        return false;
+    }
+    msd_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.device = F.rx.device;
+    cfg.format = F.format;
+    cfg.preamble_threshold = F.rx.preamble_threshold;
+    cfg.nfix_crc = F.rx.nfix_crc;
+    cfg.mode_ac = F.rx.mode_ac;
+    cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * nbuf;
+    int rc = msd_create(&cfg, &F.ctx);
+    if (rc) {
+        snprintf(F.err, sizeof F.err, "ifile: msd_create failed: %s", strerror(-rc));
+        msd_ifileClose();
+        return false;
+    }
+    return true;
+}
+
+static size_t read_fully(char *dst, size_t want)
+{
+    size_t got = 0;
+    while (got < want) {
+        ssize_t n = read(F.fd, dst + got, want - got);
+        if (n <= 0)
+            break; /* EOF or error: a short read ends the capture (sdr_ifile.c:197-209) */
+        got += (size_t)n;
+    }
+    return got;
+}
+
+/* the reference's main-thread consumer loop (readsb.c:820-855) for the mag_buf mode */
+static void *magbuf_consumer(void *arg)
+{
+    (void)arg;
+    for (;;) {
+        struct msd_mag_buf *buf = msd_fifo_dequeue(100);
+        if (!buf) {
+            if (F.exit_flag)
+                break;
+            continue;
+        }
+        int rc = msd_demodulate_magbuf(F.ctx, buf->data, buf->validLength, buf->overlap, buf->sampleTimestamp,
+                                       buf->sysTimestamp, buf->mean_level, buf->mean_power, F.rx.sink,
+                                       F.rx.sink_user);
+        if (rc)
+            snprintf(F.err, sizeof F.err, "demodulate: %s", msd_last_error(F.ctx));
+        msd_fifo_release(buf);
+    }
+    return NULL;
+}
+
+static void run_magbuf(void)
+{
+    if (!msd_fifo_create(12, MSD_CHUNK_SAMPLES + MSD_OVERLAP, MSD_OVERLAP)) { /* readsb.c:200 */
+        snprintf(F.err, sizeof F.err, "Out of memory allocating FIFO");
+        return;
+    }
+    pthread_t consumer;
+    F.exit_flag = 0;
+    pthread_create(&consumer, NULL, magbuf_consumer, NULL);
+    uint64_t sample_counter = 0;
+    bool eof = false;
+    while (!eof) {
+        struct msd_mag_buf *out = msd_fifo_acquire(100);
+        if (!out)
+            continue;
+        out->sampleTimestamp = (uint64_t)(sample_counter * 12e6 / 2400000.0); /* sdr_ifile.c:187 */
+        out->sysTimestamp = out->sampleTimestamp / 12000U;                    /* startup_time = 0 */
+        const size_t want = (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample;
+        const size_t got = read_fully(F.readbuf, want);
+        if (got < want)
+            eof = true;
+        const unsigned samples = (unsigned)(got / F.bytes_per_sample);
+        int rc = msd_convert(F.ctx, F.readbuf, &out->data[out->overlap], samples, &out->mean_level, &out->mean_power);
+        if (rc)
+            snprintf(F.err, sizeof F.err, "convert: %s", msd_last_error(F.ctx));
+        out->validLength = out->overlap + samples;
+        out->flags = 0;
+        msd_fifo_enqueue(out);
+        /* the GPU context is shared by msd_convert (here) and msd_demodulate_magbuf (consumer):
+         * hand buffers over one at a time, which is also the lossless feed of SURVEY.md 8(b) */
+        msd_fifo_drain();
+        sample_counter += samples;
+    }
+    msd_fifo_drain();
+    F.exit_flag = 1;
+    pthread_join(consumer, NULL);
+    msd_fifo_destroy();
+}
+
+static void run_fused(void)
+{
+    bool eof = false;
+    while (!eof) {
+        const size_t got = read_fully(F.readbuf, F.readbuf_bytes);
+        if (got < F.readbuf_bytes)
+            eof = true;
+        const uint64_t samples = got / F.bytes_per_sample;
+        int rc = msd_submit_host(F.ctx, F.readbuf, samples, eof ? 1 : 0, F.rx.sink, F.rx.sink_user);
+        if (rc) {
+            snprintf(F.err, sizeof F.err, "submit: %s", msd_last_error(F.ctx));
+            return;
+        }
+    }
+}
+
+void msd_ifileRun(void)
+{
+    if (F.fd < 0 || !F.ctx)
+        return;
+    if (F.mode == MSD_IFILE_MAGBUF)
+        run_magbuf();
+    else
+        run_fused();
+}
+
+int msd_ifileGetStats(msd_stats *st)
+{
+    return F.ctx ? msd_get_stats(F.ctx, st) : -EINVAL;
+}
+
+void msd_ifileClose(void)
+{
+    if (F.ctx) {
+        msd_destroy(F.ctx);
+        F.ctx = NULL;
+    }
+    free(F.readbuf);
+    F.readbuf = NULL;
+    if (F.fd >= 0 && F.fd != STDIN_FILENO)
+        close(F.fd);
+    F.fd = -1;
+    free(F.filename);
+    F.filename = NULL;
+}

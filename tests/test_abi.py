@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/modes_hip.h
+declares, and refuses to work without a device (no CPU fallback)."""
+import ctypes as C
+import errno
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "modes_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("msd_create", "msd_destroy", "msd_submit_device", "msd_submit_host", "msd_launch_device",
+                 "msd_collect", "msd_convert", "msd_demodulate_magbuf", "msd_get_stats", "msd_reset"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.lib()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in modes_hip.h but not exported"
+    assert sorted(pkg.capi.EXPORTS) == declared_functions()
+
+
+def test_host_boundary_library_exports(pkg):
+    host = C.CDLL(os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "libmsd_host.so"))
+    for name in ("msd_fifo_create", "msd_fifo_destroy", "msd_fifo_drain", "msd_fifo_halt", "msd_fifo_acquire",
+                 "msd_fifo_enqueue", "msd_fifo_dequeue", "msd_fifo_release", "msd_ifileInitConfig",
+                 "msd_ifileHandleOption", "msd_ifileOpen", "msd_ifileRun", "msd_ifileClose"):
+        assert hasattr(host, name), name
+
+
+def test_message_struct_layout_matches_numpy_mirror(pkg, oracle):
+    assert pkg.MESSAGE_DTYPE == oracle.MESSAGE_DTYPE
+    assert pkg.MESSAGE_DTYPE.itemsize == 56
+    assert pkg.MESSAGE_DTYPE.fields["msg"][1] == 40 and pkg.MESSAGE_DTYPE.fields["iid"][1] == 54
+
+
+def test_no_cpu_fallback_without_a_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.MsdError) as e:
+        pkg.Demodulator()
+    assert str(-errno.ENODEV) in str(e.value) or "No such device" in str(e.value)
+
+
+def test_bad_configuration_is_rejected(pkg):
+    lib = pkg.capi.lib()
+    h = C.c_void_p()
+    for kw in (dict(format=9), dict(nfix_crc=2), dict(preamble_threshold=0)):
+        cfg = pkg.capi.Config(device=0, format=0, preamble_threshold=58, nfix_crc=1, mode_ac=0, reserved0=0,
+                              max_batch_samples=131072, stream=None)
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        assert lib.msd_create(C.byref(cfg), C.byref(h)) == -errno.EINVAL
+    assert lib.msd_create(None, C.byref(h)) == -errno.EINVAL

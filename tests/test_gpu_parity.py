@@ -70,3 +70,22 @@ def test_mode_s_plus_mode_ac_fix(pkg, oracle, torch_cuda, fmt):
 def test_mode_ac_pipelined(pkg, oracle, torch_cuda):
     run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 12 * 131072, seed=45, nfix=1, mode_ac=1, msgs_per_sec=2000,
              ac_per_sec=1000, batch=4 * 131072)
+
+
+@pytest.mark.parametrize("path", ["fused", "magbuf"])
+def test_replay_cli_matches_oracle(pkg, oracle, torch_cuda, tmp_path, path):
+    """BASELINE.json configs[0]: --ifile replay through the sdr.h-handler / mag_buf boundary (host C)."""
+    import os
+    import subprocess
+    n = 24_000_000 if path == "fused" else 12 * 131072 + 5000   # 10 s of signal for the fast path
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=1090), n)
+    f = tmp_path / "capture.uc8"
+    iq.tofile(f)
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "msd_replay")
+    out = subprocess.run([exe, "--device-type", "ifile", "--ifile", str(f), "--iformat", "uc8", "--fix", "--mlat",
+                          "--raw", "--path", path], capture_output=True, text=True, check=True)
+    want, _ = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 17)
+    lines = out.stdout.split()
+    assert len(lines) == len(want) > 0
+    for line, m in zip(lines, want):
+        assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())

@@ -1,0 +1,205 @@
+"""Pins the oracle (oracle/modes_oracle.c) against every known answer available without the
+reference binary (which cannot be built in this image): public Mode S frames, the values recorded in
+SURVEY.md Appendix C from the reference itself, and direct restatements of single reference
+expressions.  See oracle/modes_oracle.h for what remains unpinned."""
+import math
+import struct
+
+import numpy as np
+import pytest
+
+
+# CRC-valid extended squitters that appear throughout the public ADS-B literature
+PUBLIC_DF17 = ["8D4840D6202CC371C32CE0576098", "8D40621D58C382D690C8AC2863A7", "8D485020994409940838175B284F",
+               "8DA05F219B06B6AF189400CBC33F"]
+
+
+def test_crc_public_frames(oracle):
+    for h in PUBLIC_DF17:
+        assert oracle.checksum(bytes.fromhex(h)) == 0, h
+
+
+def test_crc_survey_appendix_c_frames(oracle):
+    # SURVEY.md Appendix C, last row: outputs of the reference itself
+    assert oracle.checksum(bytes.fromhex("5dabcdef8a6ab3")) == 0          # clean DF11, II=0
+    assert oracle.checksum(bytes.fromhex("20000c3862a0b4")) == 0xABCDEF   # DF4 with AP = address
+
+
+def test_crc_bitwise_definition(oracle):
+    """crc.c:31,42-82: table-driven remainder == bit-serial long division by 0xFFF409."""
+    rng = np.random.default_rng(1)
+
+    def slow(msg):
+        reg = 0
+        for i in range(len(msg) * 8 - 24):
+            bit = (msg[i >> 3] >> (7 - (i & 7))) & 1
+            top = (reg >> 23) & 1
+            reg = (reg << 1) & 0xFFFFFF
+            if top ^ bit:
+                reg ^= 0xFFF409
+        return reg ^ (msg[-3] << 16 | msg[-2] << 8 | msg[-1])
+
+    for n in (7, 14):
+        for _ in range(200):
+            m = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            assert oracle.checksum(m) == slow(m)
+
+
+def test_single_bit_syndrome_table_self_check(oracle):
+    """crc.c:309-333: every table entry must reproduce its syndrome when its bit is flipped in an
+    all-zero message, and the DF field (bits 0..4) is never corrected."""
+    o = oracle.Oracle(nfix_crc=1)
+    for bits in (56, 112):
+        for b in range(bits):
+            msg = bytearray(bits // 8)
+            msg[b >> 3] ^= 0x80 >> (b & 7)
+            syn = oracle.checksum(bytes(msg))
+            n, where = o.diagnose(syn, bits)
+            if b < 5:
+                assert n == -1
+            else:
+                assert (n, where[0]) == (1, b)
+    assert o.diagnose(0, 56)[0] == 0
+    assert oracle.Oracle(nfix_crc=0).diagnose(0x123456, 112)[0] == -1  # --no-fix: no tables
+
+
+def test_uc8_table_matches_convert_c_expression(oracle):
+    """convert.c:35-61 evaluated with numpy float32 arithmetic (IEEE, no FMA)."""
+    t = oracle.uc8_table().reshape(256, 256)
+    v = ((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32)
+    magsq = (v[:, None] * v[:, None] + v[None, :] * v[None, :]).astype(np.float32)
+    magsq = np.minimum(magsq, np.float32(1))
+    mag = np.sqrt(magsq, dtype=np.float32)
+    want = (mag * np.float32(65535.0) + np.float32(0.5)).astype(np.uint16)
+    assert np.array_equal(t, want)
+    assert np.array_equal(t, t.T)                     # I/Q symmetric
+    k = np.where(np.arange(256) >= 128, np.arange(256) - 128, 127 - np.arange(256))
+    assert np.array_equal(t, t[128:, 128:][k][:, k])  # folds to 128 x 128
+    assert t[127, 127] == 363 and t[0, 0] == 65535
+
+
+def test_uc8_means_use_65536_and_65535(oracle):
+    """convert.c:105,109."""
+    o = oracle.Oracle()
+    iq = np.full(2 * 64, 255, dtype=np.uint8)
+    mag, ml, mp = o.convert(iq, 64)
+    assert (mag == 65535).all()
+    assert ml == 65535 * 64 / 65536.0 / 64 and mp == (65535 ** 2 * 64) / 65535.0 / 65535.0 / 64
+
+
+@pytest.mark.parametrize("fmt,scale", [("sc16", 32768.0), ("sc16q11", 2048.0)])
+def test_s16_converters_against_numpy(oracle, fmt, scale):
+    """convert.c:215-253 / :332-370: float path, sequential float sums."""
+    f = oracle.FMT_SC16 if fmt == "sc16" else oracle.FMT_SC16Q11
+    o = oracle.Oracle(fmt=f)
+    rng = np.random.default_rng(2)
+    lim = 32767 if fmt == "sc16" else 2047
+    iq = rng.integers(-lim, lim + 1, size=2 * 5000).astype("<i2")
+    iq[:8] = [lim, lim, -lim, 0, 0, 0, 1, -1]
+    mag, ml, mp = o.convert(iq.view(np.uint8), 5000)
+    fi = (iq[0::2].astype(np.float32) / np.float32(scale))
+    fq = (iq[1::2].astype(np.float32) / np.float32(scale))
+    magsq = np.minimum((fi * fi).astype(np.float32) + (fq * fq).astype(np.float32), np.float32(1)).astype(np.float32)
+    m = np.sqrt(magsq, dtype=np.float32)
+    assert np.array_equal(mag, (m * np.float32(65535.0) + np.float32(0.5)).astype(np.uint16))
+    sl = np.float32(0)
+    sp = np.float32(0)
+    for a, b in zip(m, magsq):
+        sp = np.float32(sp + b)
+        sl = np.float32(sl + a)
+    assert ml == float(np.float32(sl / np.float32(5000))) and mp == float(np.float32(sp / np.float32(5000)))
+
+
+def test_slicer_plan_equals_closed_form(oracle):
+    """demod_2400.c:98-177 (per-phase offset tables) == bit k at t = 95 + tp + 12k."""
+    rng = np.random.default_rng(3)
+    mag = rng.integers(0, 65536, size=700).astype(np.uint16)
+    coef = {0: (18, -15, -3, 0), 1: (14, -5, -9, 0), 2: (16, 5, -20, 0), 3: (7, 11, -18, 0), 4: (4, 15, -20, 1)}
+    for j in (0, 5, 123, 400):
+        for tp in range(4, 9):
+            got = oracle.slice_bytes(mag, j, tp, 14)
+            bits = []
+            for k in range(112):
+                t = 95 + tp + 12 * k
+                p = j + t // 5
+                c = coef[t % 5]
+                bits.append(int(sum(int(ci) * int(mag[p + i]) for i, ci in enumerate(c)) > 0))
+            want = np.packbits(np.array(bits, dtype=np.uint8))
+            assert np.array_equal(got, want), (j, tp)
+            assert j + (95 + tp + 12 * 111) // 5 + 3 <= j + 289 + 1  # highest sample the slicer can touch
+
+
+def test_score_table_and_filter_dependence(oracle):
+    """mode_s.c:311-409 scores and the SURVEY.md Appendix C acceptance sequence."""
+    o = oracle.Oracle(nfix_crc=1)
+    df11 = bytes.fromhex("5dabcdef8a6ab3")
+    df4 = bytes.fromhex("20000c3862a0b4")
+    bad = bytearray(df11)
+    bad[2] ^= 0x10                                  # one flipped AA bit
+    assert o.score(df4) == -1                       # AP address unknown
+    assert o.score(bytes(bad)) == 750 // 2          # 1-bit error, unknown address -> 375 (rejected later in decode)
+    assert o.score(df11) == 750                     # clean, unknown
+    o.filter_add(0xABCDEF)
+    assert o.filter_test(0xABCDEF) and not o.filter_test(0xABCDEE)
+    assert o.score(df11) == 1600 and o.score(bytes(bad)) == 800 and o.score(df4) == 1000
+    assert o.score(bytes(14)) == -2 and o.score(bytes(7)) == -2          # all-zero
+    assert o.score(bytes.fromhex(PUBLIC_DF17[0])) == 1400                # clean DF17, unknown
+    o.filter_add(0x4840D6)
+    assert o.score(bytes.fromhex(PUBLIC_DF17[0])) == 1800
+    one = bytearray(bytes.fromhex(PUBLIC_DF17[0]))
+    one[9] ^= 0x04
+    assert o.score(bytes(one)) == 900
+    assert oracle.Oracle(nfix_crc=0).score(bytes(one)) == -2             # --no-fix cannot repair
+    assert o.score(bytes.fromhex("f8000000000000")) == -2                # DF31 is a long format: 56 valid bits are too few
+    df20_unknown = bytes.fromhex("a0000000000000000000000000ff")
+    assert o.score(df20_unknown) == -2                                   # DF20/21 unknown address is -2, not -1
+
+
+def test_filter_generations(oracle):
+    """icao_filter.c:150-164: an address survives one flip and is gone after the second."""
+    o = oracle.Oracle()
+    data = np.zeros(326 + 16, dtype=np.uint16)
+
+    def tick(ms):  # one empty buffer at signal time ms (drives icaoFilterExpire)
+        o.demod_buffer(data, sample_ts=ms * 12000, sys_ts=ms)
+
+    tick(0)                    # first call always flips (next_flip starts at 0)
+    o.filter_add(0x123456)
+    tick(59999)
+    assert o.filter_test(0x123456)
+    tick(60000)                # flip 2: address now only in the inactive table
+    assert o.filter_test(0x123456)
+    tick(120000)               # flip 3: that table is cleared
+    assert not o.filter_test(0x123456)
+
+
+def _ppm_frame(msg_hex, j0, phase_units, amp=20000, noise=200, n=1200, seed=0):
+    """Ideal 2.4 MSPS magnitude trace of one Mode S frame starting phase_units/5 samples after j0."""
+    rng = np.random.default_rng(seed)
+    hi = np.zeros(n * 5, dtype=np.float64)
+    bits = np.unpackbits(np.frombuffer(bytes.fromhex(msg_hex), dtype=np.uint8))
+    start = j0 * 5 + phase_units
+    for p in (0, 12, 42, 54):                       # preamble pulses, 12 MHz ticks
+        hi[start + p // 1: start + p + 6] = 1       # each tick here is 1/5 sample * ... (5 ticks per sample)
+    for k, b in enumerate(bits):
+        t = start + 96 + 12 * k + (0 if b else 6)
+        hi[t:t + 6] = 1
+    mag = hi.reshape(n, 5).mean(axis=1) * amp + rng.integers(0, noise, n)
+    return mag.astype(np.uint16)
+
+
+def test_timestamp_and_skip_ahead_on_a_constructed_frame(oracle):
+    """demod_2400.c:358: timestamp = sampleTimestamp + 5 j + 768 + phase; :416: skip ahead."""
+    o = oracle.Oracle(nfix_crc=0)
+    mag = np.zeros(326 + 2000, dtype=np.uint16)
+    frame = _ppm_frame(PUBLIC_DF17[0], 0, 0, n=400)
+    mag[500:900] = frame
+    msgs = o.demod_buffer(mag, sample_ts=1_000_000, sys_ts=77)
+    assert len(msgs) == 1
+    m = msgs[0]
+    assert bytes(m["msg"]).hex().upper() == PUBLIC_DF17[0]
+    j_units = int(m["timestampMsg"]) - 1_000_000 - 768
+    assert 5 * 498 <= j_units <= 5 * 501 + 8      # within a sample of where the frame was placed
+    assert m["msgtype"] == 17 and m["addr"] == 0x4840D6 and m["score"] == 1400 and m["correctedbits"] == 0
+    assert o.filter_test(0x4840D6)                # mode_s.c:717-726
+    assert m["sysTimestampMsg"] == 77 + (int(m["timestampMsg"]) - 1_000_000) // 12000
