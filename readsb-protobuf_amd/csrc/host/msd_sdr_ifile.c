@@ -27,6 +27,10 @@ static struct {
     msd_ctx *ctx;
     char err[256];
     volatile int exit_flag;
+    /* buffers handed to the consumer and not yet demodulated (the GPU context is shared) */
+    pthread_mutex_t mu;
+    pthread_cond_t idle;
+    int in_flight;
 } F;
 
 const char *msd_ifileLastError(void)
@@ -146,6 +150,10 @@ static void *magbuf_consumer(void *arg)
         if (rc)
             snprintf(F.err, sizeof F.err, "demodulate: %s", msd_last_error(F.ctx));
         msd_fifo_release(buf);
+        pthread_mutex_lock(&F.mu);
+        F.in_flight--;
+        pthread_cond_signal(&F.idle);
+        pthread_mutex_unlock(&F.mu);
     }
     return NULL;
 }
@@ -158,6 +166,9 @@ static void run_magbuf(void)
     }
     pthread_t consumer;
     F.exit_flag = 0;
+    pthread_mutex_init(&F.mu, NULL);
+    pthread_cond_init(&F.idle, NULL);
+    F.in_flight = 0;
     pthread_create(&consumer, NULL, magbuf_consumer, NULL);
     uint64_t sample_counter = 0;
     bool eof = false;
@@ -177,10 +188,17 @@ static void run_magbuf(void)
             snprintf(F.err, sizeof F.err, "convert: %s", msd_last_error(F.ctx));
         out->validLength = out->overlap + samples;
         out->flags = 0;
+        pthread_mutex_lock(&F.mu);
+        F.in_flight++;
+        pthread_mutex_unlock(&F.mu);
         msd_fifo_enqueue(out);
         /* the GPU context is shared by msd_convert (here) and msd_demodulate_magbuf (consumer):
-         * hand buffers over one at a time, which is also the lossless feed of SURVEY.md 8(b) */
-        msd_fifo_drain();
+         * wait until the consumer is done with the buffer before converting the next one, which
+         * is also the lossless, depth-one feed of SURVEY.md 8(b) */
+        pthread_mutex_lock(&F.mu);
+        while (F.in_flight)
+            pthread_cond_wait(&F.idle, &F.mu);
+        pthread_mutex_unlock(&F.mu);
         sample_counter += samples;
     }
     msd_fifo_drain();
