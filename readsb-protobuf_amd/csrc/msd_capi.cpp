@@ -385,6 +385,8 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     c->out_msgs.clear();
     c->out_req.clear();
     c->out_buf.clear();
+    const char *dbgflags = getenv("MSD_DEBUG_FLAGS"); /* perf experiments with incomplete candidates */
+    if (!(dbgflags && (atoi(dbgflags) & 0x1c)))
     msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
                       c->cfg.mode_ac ? s.h_ac : nullptr, c->cfg.mode_ac ? s.h_ac_totals[0] : 0, ts_override,
                       emit_thunk, c);

@@ -317,10 +317,10 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
         }
     }
     __syncthreads();
-    const uint32_t nsurv = *nsurv_p;
+    const uint32_t nsurv = (P.debug_flags & 4) ? 0u : *nsurv_p;
 
     /* ---- step B ---- */
-    {
+    if (!(P.debug_flags & 8)) {
         const uint32_t nchunk = (nsurv + 20u) / 21u;
         for (uint32_t x = (uint32_t)wave; x < 5u * nchunk; x += NW) {
             const uint32_t d = x % 5u, chunk = x / 5u;
@@ -348,7 +348,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
     __syncthreads();
 
     /* ---- step C ---- */
-    for (uint32_t u = (uint32_t)tid; u < nsurv; u += NT) {
+    for (uint32_t u = (uint32_t)tid; u < ((P.debug_flags & 16) ? 0u : nsurv); u += NT) {
         const uint32_t me = smeta[u];
         const int n = (int)((me >> 16) & 15u);
         const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg + 16 * u);

@@ -178,6 +178,7 @@ static int filter_expire(msd_filter *f, uint64_t now)
 /* the addresses one buffer has added so far (consulted on top of the snapshot)             */
 /* ---------------------------------------------------------------------------------------- */
 
+#define MAX_SPECULATIVE_PASSES 4u
 #define LOCAL_SLOTS 4096u /* a buffer holds at most 131072/135 < 1024 accepted messages */
 
 typedef struct local_set {
@@ -718,13 +719,18 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
             pool_run(bs->pool, job_resolve, bs, bs->ntodo);
             /* replay adds and flips in order; find the membership version every buffer must see */
             work = r->filter;
-            uint32_t version = 0;
+            uint32_t version = 0, first_stale = nbuffers;
             bs->ntodo = 0;
             for (uint32_t b = 0; b < nbuffers; ++b) {
                 buf_result *br = &bs->res[b];
                 bs->want[b] = version;
-                if (br->version_used != version)
+                if (br->version_used != version) {
+                    if (first_stale == nbuffers)
+                        first_stale = b;
                     bs->todo[bs->ntodo++] = b;
+                }
+                if (pass >= MAX_SPECULATIVE_PASSES && first_stale != nbuffers)
+                    break; /* `work` is now the exact state in front of the first stale buffer */
                 int changed = 0;
                 for (uint32_t i = 0; i < br->nadds; ++i)
                     changed |= filter_add(&work, br->adds[i]);
@@ -734,8 +740,19 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
             }
             if (bs->ntodo == 0)
                 break;
-            if (pass > nbuffers)
-                abort(); /* cannot happen: each pass fixes at least the earliest stale buffer */
+            if (pass >= MAX_SPECULATIVE_PASSES) {
+                /* membership keeps changing (every pass is exact up to its first stale buffer, but
+                 * an input whose adds shift from pass to pass would need one pass per buffer):
+                 * finish the tail with the plain sequential replay */
+                for (uint32_t b = first_stale; b < nbuffers; ++b) {
+                    buf_result *br = &bs->res[b];
+                    resolve_buffer(bs, b, &work, 0, br);
+                    for (uint32_t i = 0; i < br->nadds; ++i)
+                        filter_add(&work, br->adds[i]);
+                    filter_expire(&work, br->end_now);
+                }
+                break;
+            }
         }
     }
 

@@ -89,3 +89,12 @@ def test_replay_cli_matches_oracle(pkg, oracle, torch_cuda, tmp_path, path):
     assert len(lines) == len(want) > 0
     for line, m in zip(lines, want):
         assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_resolve_threads_and_membership_churn(pkg, oracle, torch_cuda, monkeypatch, threads):
+    """The speculative buffer-parallel resolve must equal the sequential one for any thread count,
+    also when new aircraft appear in nearly every buffer (forces re-resolution and the serial tail)."""
+    monkeypatch.setenv("MSD_RESOLVE_THREADS", threads)
+    run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 40 * 131072 + 17, seed=77, nfix=1, n_aircraft=30000,
+             msgs_per_sec=4000)
