@@ -44,8 +44,9 @@ constexpr int NW = NT / 64;
 constexpr int T = MSD_TILE;           /* 8192 scan positions per tile */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
 constexpr int GPT = T / 8 / NT;       /* 8-sample load groups per thread per tile (2) */
-constexpr int HCAP = 128;             /* hits per candidate round */
-constexpr int SCAP = HCAP * 5;        /* tries with a known DF per round, worst case */
+constexpr int HCAP = 256;             /* hits per candidate round */
+constexpr int SCAP = 512;             /* tries with a known DF per round; a round that would need
+                                         more is retried with half the hits (5 * 102 < 512) */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
 static_assert(T == NT * 16, "each thread scans 16 consecutive positions");
@@ -60,11 +61,12 @@ constexpr int OFF_MISC = OFF_SYN + 640;                   /* u32[64]: wave hit c
 constexpr int OFF_CAND = OFF_MISC + 256;                  /* candidate-stage scratch */
 constexpr int CS_HITS = 0;                                /* u32[HCAP]: position | mask << 13 */
 constexpr int CS_SIDX = CS_HITS + HCAP * 4;               /* u16[HCAP][5]: try slot or 0xffff */
-constexpr int CS_SMETA = CS_SIDX + HCAP * 5 * 2;          /* u32[SCAP] */
+constexpr int CS_PLIST = CS_SIDX + HCAP * 5 * 2;          /* u8[5][HCAP]: hits that try phase q */
+constexpr int CS_SMETA = CS_PLIST + HCAP * 5;             /* u32[SCAP] */
 constexpr int CS_SMSG = CS_SMETA + SCAP * 4;              /* u8[SCAP][16] */
 constexpr int CS_SRES = CS_SMSG + SCAP * 16;              /* u32[SCAP][2]: addr, crc */
-constexpr int CS_MISC = CS_SRES + SCAP * 8;               /* u32[16] */
-constexpr int CS_BYTES = CS_MISC + 64;
+constexpr int CS_MISC = CS_SRES + SCAP * 8;               /* u32[32]: counters */
+constexpr int CS_BYTES = CS_MISC + 128;
 constexpr int OFF_LUT = OFF_CAND + CS_BYTES;              /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
 constexpr int LDS_UC8 = OFF_LUT + 128 * LUT_STRIDE * 2;
@@ -285,38 +287,41 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
     uint32_t *sres = reinterpret_cast<uint32_t *>(cs + CS_SRES);
     uint32_t *nsurv_p = reinterpret_cast<uint32_t *>(cs + CS_MISC);
     uint32_t *wtot = nsurv_p + 4;
+    const uint32_t *pcount = nsurv_p + 16;
+    const uint8_t *plist = cs + CS_PLIST;
 
     /* ---- step A ---- */
-    for (int c = wave; c < 5 * (HCAP / 64); c += NW) { /* chunk c: phase q = c / (HCAP/64) */
-        const int q = c / (HCAP / 64);
-        const uint32_t h = (uint32_t)(c % (HCAP / 64)) * 64u + (uint32_t)lane;
-        if (h < nh) {
-            const uint32_t e = hitlist[h];
-            const uint32_t pos = e & 0x1fffu, mask = e >> 13;
-            const bool tried = (q < 2) ? (mask & 1u) : ((q < 4) ? (mask & 2u) : (mask & 4u));
-            if (tried) {
-                /* pa[d] = mags[pos + 2 + d]; first data sample of trial phase tp = 4 + q is at
-                 * pa + (95 + tp) / 5 with PPM phase (95 + tp) % 5 = (4 + q) % 5 */
-                const uint32_t first = pos + 2u + (uint32_t)(99 + q) / 5u;
-                uint32_t b0;
-                switch (q) { /* wave-uniform */
-                case 0: b0 = slice_byte_phase<4>(mags, first); break;
-                case 1: b0 = slice_byte_phase<0>(mags, first); break;
-                case 2: b0 = slice_byte_phase<1>(mags, first); break;
-                case 3: b0 = slice_byte_phase<2>(mags, first); break;
-                default: b0 = slice_byte_phase<3>(mags, first); break;
-                }
-                const uint32_t nb = bytes_for_df(b0 >> 3);
-                if (nb > 1) {
-                    const uint32_t u = atomicAdd(nsurv_p, 1u);
-                    smeta[u] = pos | ((uint32_t)q << 13) | (nb << 16) | (h << 20);
-                    smsg[16 * u] = (uint8_t)b0;
-                    survidx[h * 5 + (uint32_t)q] = (uint16_t)u;
-                }
-            }
+    {
+        /* chunk c covers 64 entries of one phase list; chunks are dealt to the wavefronts round robin */
+        uint32_t c = 0;
+#define MSD_STEP_A(Q)                                                                                   \
+        {                                                                                                   \
+            const uint32_t n = pcount[Q];                                                                   \
+            for (uint32_t off = 0; off < n; off += 64, ++c) {                                               \
+                if ((c % NW) != (uint32_t)wave || off + (uint32_t)lane >= n)                                \
+                    continue;                                                                               \
+                const uint32_t h = plist[(Q) * HCAP + off + (uint32_t)lane];                                \
+                const uint32_t pos = hitlist[h] & 0x1fffu;                                                  \
+                /* pa[d] = mags[pos + 2 + d]; the first data sample of trial phase tp = 4 + Q is at */      \
+                /* pa + (95 + tp) / 5 with PPM phase (95 + tp) % 5 */                                       \
+                const uint32_t b0 = slice_byte_phase<(99 + (Q)) % 5>(mags, pos + 2u + (99u + (Q)) / 5u);    \
+                const uint32_t nb = bytes_for_df(b0 >> 3);                                                  \
+                if (nb > 1) {                                                                               \
+                    const uint32_t u = atomicAdd(nsurv_p, 1u);                                              \
+                    if (u < (uint32_t)SCAP) {                                                               \
+                        smeta[u] = pos | ((uint32_t)(Q) << 13) | (nb << 16) | (h << 20);                    \
+                        smsg[16 * u] = (uint8_t)b0;                                                         \
+                        survidx[h * 5 + (Q)] = (uint16_t)u;                                                 \
+                    }                                                                                       \
+                }                                                                                           \
+            }                                                                                               \
         }
+        MSD_STEP_A(0) MSD_STEP_A(1) MSD_STEP_A(2) MSD_STEP_A(3) MSD_STEP_A(4)
+#undef MSD_STEP_A
     }
     __syncthreads();
+    if (*nsurv_p > (uint32_t)SCAP)
+        return 0xffffffffu; /* workgroup-uniform: the caller retries with fewer hits */
     const uint32_t nsurv = (P.debug_flags & 4) ? 0u : *nsurv_p;
 
     /* ---- step B ---- */
@@ -650,29 +655,53 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 const uint32_t my_rank0 = wave_base + incl - cnt;
                 uint32_t *hitlist = reinterpret_cast<uint32_t *>(cs + CS_HITS);
                 uint32_t *sidx32 = reinterpret_cast<uint32_t *>(cs + CS_SIDX);
-                for (uint32_t r0 = 0; r0 < H; r0 += HCAP) {
-                    const uint32_t nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
-                    if (cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
+                uint8_t *plist = cs + CS_PLIST;
+                uint32_t *cmisc = reinterpret_cast<uint32_t *>(cs + CS_MISC);
+                uint32_t r0 = 0;
+                bool fill = true;
+                uint32_t nh = (H < (uint32_t)HCAP) ? H : (uint32_t)HCAP;
+                while (r0 < H) {
+                    if (fill && cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
+                        /* my hits with rank in [r0, r0 + HCAP) -> hitlist, in position order */
+                        uint64_t x = (nib | (nib >> 1) | (nib >> 2)) & 0x1111111111111111ull;
                         uint32_t r = my_rank0;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const uint32_t m = (uint32_t)(nib >> (4 * q)) & 7u;
-                            if (m) {
-                                if (r >= r0 && r < r0 + HCAP)
-                                    hitlist[r - r0] = (uint32_t)(16 * tid + q) | (m << 13);
-                                ++r;
-                            }
+                        while (x) {
+                            const int q = (__ffsll((unsigned long long)x) - 1) >> 2;
+                            x &= x - 1;
+                            if (r >= r0 && r < r0 + HCAP)
+                                hitlist[r - r0] = (uint32_t)(16 * tid + q) | (((uint32_t)(nib >> (4 * q)) & 7u) << 13);
+                            ++r;
                         }
                     }
                     for (int i = tid; i < HCAP * 5 / 2; i += NT)
                         sidx32[i] = 0xffffffffu;
-                    if (tid == 0)
-                        *reinterpret_cast<uint32_t *>(cs + CS_MISC) = 0;
+                    if (tid < 32)
+                        cmisc[tid] = 0;
+                    __syncthreads();
+                    /* per-phase lists of the hits that try that phase (order is irrelevant here) */
+                    if ((uint32_t)tid < nh) {
+                        const uint32_t m = hitlist[tid] >> 13;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            const bool tried = (q < 2) ? (m & 1u) : ((q < 4) ? (m & 2u) : (m & 4u));
+                            if (tried)
+                                plist[q * HCAP + atomicAdd(&cmisc[16 + q], 1u)] = (uint8_t)tid;
+                        }
+                    }
                     __syncthreads();
                     const uint32_t out0 = hcur + r0;
-                    tcur += candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0, my_hits + out0,
-                                            out0 + nh <= P.hcap, my_tries, tcur);
+                    const uint32_t got = candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
+                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, tcur);
                     __syncthreads();
+                    if (got == 0xffffffffu) { /* too many tries with a known DF: halve the round */
+                        nh = (nh + 1) / 2;
+                        fill = false;
+                        continue;
+                    }
+                    tcur += got;
+                    r0 += nh;
+                    nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
+                    fill = true;
                 }
             }
             hcur += H;
