@@ -277,7 +277,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
                                                     const uint32_t *crc_tab, const uint32_t *syn,
                                                     unsigned char *cs, int tid, uint32_t nh, uint64_t tile_pos0,
                                                     msd_hit *hit_out, bool hits_fit, msd_try *my_tries,
-                                                    uint32_t tcur)
+                                                    uint32_t *try_cursor)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t *hitlist = reinterpret_cast<const uint32_t *>(cs + CS_HITS);
@@ -286,7 +286,6 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
     uint8_t *smsg = cs + CS_SMSG;
     uint32_t *sres = reinterpret_cast<uint32_t *>(cs + CS_SRES);
     uint32_t *nsurv_p = reinterpret_cast<uint32_t *>(cs + CS_MISC);
-    uint32_t *wtot = nsurv_p + 4;
     const uint32_t *pcount = nsurv_p + 16;
     const uint8_t *plist = cs + CS_PLIST;
 
@@ -432,20 +431,18 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
         for (int q = 0; q < 5; ++q)
             nl += survidx[tid * 5 + q] != 0xffffu ? 1u : 0u;
     }
+    /* try indices need not be ordered across wavefronts (a hit record names its first try), so
+     * every wavefront reserves its own range from the workgroup cursor: no barrier */
     const uint32_t incl = wave_incl_scan(nl, lane);
-    if (lane == 63)
-        wtot[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const uint32_t s = wtot[i];
-        if (i < wave)
-            before += s;
-        total += s;
+    const uint32_t wave_total = __shfl(incl, 63);
+    uint32_t tbase = 0;
+    if (wave_total) {
+        if (lane == 0)
+            tbase = atomicAdd(try_cursor, wave_total);
+        tbase = __shfl(tbase, 0);
     }
     if ((uint32_t)tid < nh) {
-        uint32_t idx = tcur + before + incl - nl;
+        uint32_t idx = tbase + incl - nl;
         if (hits_fit) {
             msd_hit rec = (tile_pos0 + pos) | ((msd_hit)mask << 28) | ((msd_hit)nl << 31);
             if (nl)
@@ -465,7 +462,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             }
         }
     }
-    return total;
+    return 0;
 }
 
 template <int FMT>
@@ -482,6 +479,7 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     const uint32_t wg = blockIdx.x;
     unsigned char *cs = smem + OFF_CAND;
     uint32_t *wave_hits = misc;         /* [2][NW], double buffered by tile parity */
+    uint32_t *try_cursor = misc + 32;   /* workgroup cursor into its try region */
 
     /* constant tables -> LDS, once per persistent workgroup */
     for (int i = tid; i < 256; i += NT)
@@ -496,6 +494,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
             l[i] = g[i];
     }
 
+    if (tid == 0)
+        *try_cursor = 0;
     const uint32_t tile_lo = wg * P.tiles_per_wg;
     uint32_t tile_hi = tile_lo + P.tiles_per_wg;
     if (tile_hi > P.ntiles)
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     __syncthreads();
     const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
 
-    uint32_t hcur = 0, tcur = 0; /* workgroup-uniform cursors into this workgroup's regions */
+    uint32_t hcur = 0; /* workgroup-uniform cursor into this workgroup's hit region */
     msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
     msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
 
@@ -640,6 +640,13 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
             uint32_t *wh = wave_hits + NW * (tile & 1u);
             if (lane == 63)
                 wh[wave] = incl;
+            { /* clear the candidate round scratch (nobody reads it between here and the barrier) */
+                uint32_t *sidx32z = reinterpret_cast<uint32_t *>(cs + CS_SIDX);
+                for (int i = tid; i < HCAP * 5 / 2; i += NT)
+                    sidx32z[i] = 0xffffffffu;
+                if (tid < 32)
+                    reinterpret_cast<uint32_t *>(cs + CS_MISC)[tid] = 0;
+            }
             __syncthreads();
             uint32_t wave_base = 0, H = 0;
 #pragma unroll
@@ -661,24 +668,23 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 bool fill = true;
                 uint32_t nh = (H < (uint32_t)HCAP) ? H : (uint32_t)HCAP;
                 while (r0 < H) {
-                    if (fill && cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
-                        /* my hits with rank in [r0, r0 + HCAP) -> hitlist, in position order */
-                        uint64_t x = (nib | (nib >> 1) | (nib >> 2)) & 0x1111111111111111ull;
-                        uint32_t r = my_rank0;
-                        while (x) {
-                            const int q = (__ffsll((unsigned long long)x) - 1) >> 2;
-                            x &= x - 1;
-                            if (r >= r0 && r < r0 + HCAP)
-                                hitlist[r - r0] = (uint32_t)(16 * tid + q) | (((uint32_t)(nib >> (4 * q)) & 7u) << 13);
-                            ++r;
+                    /* (the round's counters and try-slot table were cleared before the last barrier) */
+                    if (fill) {
+                        if (cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
+                            /* my hits with rank in [r0, r0 + HCAP) -> hitlist, in position order */
+                            uint64_t x = (nib | (nib >> 1) | (nib >> 2)) & 0x1111111111111111ull;
+                            uint32_t r = my_rank0;
+                            while (x) {
+                                const int q = (__ffsll((unsigned long long)x) - 1) >> 2;
+                                x &= x - 1;
+                                if (r >= r0 && r < r0 + HCAP)
+                                    hitlist[r - r0] = (uint32_t)(16 * tid + q) | (((uint32_t)(nib >> (4 * q)) & 7u) << 13);
+                                ++r;
+                            }
                         }
+                        __syncthreads();
                     }
-                    for (int i = tid; i < HCAP * 5 / 2; i += NT)
-                        sidx32[i] = 0xffffffffu;
-                    if (tid < 32)
-                        cmisc[tid] = 0;
-                    __syncthreads();
-                    /* per-phase lists of the hits that try that phase (order is irrelevant here) */
+                    /* per-phase lists of the hits that try that phase (any order), one thread per hit */
                     if ((uint32_t)tid < nh) {
                         const uint32_t m = hitlist[tid] >> 13;
 #pragma unroll
@@ -691,17 +697,23 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                     __syncthreads();
                     const uint32_t out0 = hcur + r0;
                     const uint32_t got = candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
-                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, tcur);
-                    __syncthreads();
+                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, try_cursor);
                     if (got == 0xffffffffu) { /* too many tries with a known DF: halve the round */
                         nh = (nh + 1) / 2;
                         fill = false;
-                        continue;
+                    } else {
+                        r0 += nh;
+                        nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
+                        fill = true;
                     }
-                    tcur += got;
-                    r0 += nh;
-                    nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
-                    fill = true;
+                    if (r0 < H) { /* another round: clear its scratch behind a barrier */
+                        __syncthreads();
+                        for (int i = tid; i < HCAP * 5 / 2; i += NT)
+                            sidx32[i] = 0xffffffffu;
+                        if (tid < 32)
+                            cmisc[tid] = 0;
+                        __syncthreads();
+                    }
                 }
             }
             hcur += H;
@@ -737,8 +749,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     if (tid == 0) {
         msd_wg_counts c;
         c.nhits = hcur;
-        c.ntries = tcur;
-        c.overflow = (hcur > P.hcap || tcur > P.tcap) ? 1u : 0u;
+        c.ntries = *try_cursor;
+        c.overflow = (hcur > P.hcap || c.ntries > P.tcap) ? 1u : 0u;
         c.pad = 0;
         P.counts[wg] = c;
     }
