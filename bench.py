@@ -94,7 +94,7 @@ def main():
             m = min(batch, n - off)
             last = off + m >= n
             if inflight == pkg.capi.PIPELINE_DEPTH:
-                msgs = dem.collect()
+                msgs = dem.collect(copy=False)
                 nmsg += len(msgs)
                 first = msgs if first is None else first
                 if collect_timing is not None:
@@ -106,7 +106,7 @@ def main():
             if last:
                 break
         while inflight:
-            msgs = dem.collect()
+            msgs = dem.collect(copy=False)
             nmsg += len(msgs)
             if collect_timing is not None:
                 collect_timing.append(dem.timing())

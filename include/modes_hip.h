@@ -123,7 +123,7 @@ int msd_reset(msd_ctx *ctx);
 /* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the
  * oldest outstanding batch, runs the ordered resolve and delivers its messages.  At most
  * MSD_PIPELINE_DEPTH batches may be outstanding. ---- */
-#define MSD_PIPELINE_DEPTH 2
+#define MSD_PIPELINE_DEPTH 3
 int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
 int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmodes_hip.so")
 FMT_UC8, FMT_SC16, FMT_SC16Q11, FMT_MAG16 = 0, 1, 2, 3
 CHUNK = 131072
 OVERLAP = 326
-PIPELINE_DEPTH = 2
+PIPELINE_DEPTH = 3
 
 MESSAGE_DTYPE = np.dtype(
     [
@@ -188,14 +188,15 @@ class Demodulator:
         if rc != 0:
             raise MsdError(f"{lib().msd_last_error(self._h).decode()} ({os.strerror(-rc)}, {rc})")
 
-    def _run(self, call):
-        """Run one C call that delivers messages; returns them as a structured array."""
+    def _run(self, call, copy=True):
+        """Run one C call that delivers messages; returns them as a structured array (a view into the
+        context's message buffer, valid until the next call, when copy=False)."""
         while True:
             st = _SinkState(self._buf.ctypes.data, self._buf.size, 0)
             rc = call(self._sink_fn, C.byref(st))
             self._check(rc)
             if st.count <= self._buf.size:
-                return self._buf[: st.count].copy()
+                return self._buf[: st.count].copy() if copy else self._buf[: st.count]
             # a context is stateful, so a too-small array cannot simply be retried: grow ahead of time
             raise MsdError(f"message array too small ({st.count} > {self._buf.size}); "
                            "construct the Demodulator with a larger message_capacity")
@@ -217,8 +218,8 @@ class Demodulator:
     def launch_device(self, dptr, nsamples, last=False):
         self._check(lib().msd_launch_device(self._h, C.c_void_p(dptr), nsamples, int(last)))
 
-    def collect(self):
-        return self._run(lambda fn, st: lib().msd_collect(self._h, fn, st))
+    def collect(self, copy=True):
+        return self._run(lambda fn, st: lib().msd_collect(self._h, fn, st), copy=copy)
 
     def reset(self):
         self._check(lib().msd_reset(self._h))

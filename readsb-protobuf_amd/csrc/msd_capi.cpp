@@ -6,8 +6,10 @@
  *   compute stream : memset sums -> scan kernel -> offsets+gather [-> float means] (per batch)
  *   copy stream    : waits on the batch's "kernels done" event, then D2H totals / lists / sums,
  *                    so a batch's download overlaps the next batch's kernels.
- * The host resolve of batch k runs while the GPU works on batch k+1 (msd_launch_device /
- * msd_collect); msd_submit_* is the depth-1 synchronous form.
+ *   aux stream     : the signal-power round trip of the batch being resolved.
+ * With three batches in flight (msd_launch_device / msd_collect), while the host resolves batch k
+ * the lists of batch k+1 come down and the GPU scans batch k+2; msd_submit_* is the depth-1
+ * synchronous form.
  */
 #include <hip/hip_runtime.h>
 
@@ -74,7 +76,7 @@ struct Slot {
 
 struct msd_ctx {
     msd_config cfg{};
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, aux_stream = nullptr;
     bool own_stream = false;
     int bps = 2;
     msd_tables *tables = nullptr;
@@ -136,12 +138,12 @@ int fail(msd_ctx *c, int code, const char *fmt, ...)
             return fail((c), -EIO, "%s failed: %s", #call, hipGetErrorString(e_));              \
     } while (0)
 
-void emit_thunk(const msd_message *mm, uint64_t power_req, uint32_t buffer, void *user)
+void emit_thunk(const msd_message *mm, const uint64_t *power_req, uint32_t count, uint32_t buffer, void *user)
 {
     msd_ctx *c = static_cast<msd_ctx *>(user);
-    c->out_msgs.push_back(*mm);
-    c->out_req.push_back(power_req);
-    c->out_buf.push_back(buffer);
+    c->out_msgs.insert(c->out_msgs.end(), mm, mm + count);
+    c->out_req.insert(c->out_req.end(), power_req, power_req + count);
+    c->out_buf.insert(c->out_buf.end(), count, buffer);
 }
 
 int ensure_req(msd_ctx *c, Slot &s, size_t n)
@@ -342,17 +344,19 @@ int start_download(msd_ctx *c, Slot &s, int format)
 int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
            const uint64_t *ts_override, const double *means_override, uint64_t resolver_first_chunk)
 {
+    auto ta = std::chrono::steady_clock::now();
     int rc = start_download(c, s, format);
     if (rc)
         return rc;
     const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
     HIPCHK(c, hipEventSynchronize(s.ev_copy1));
+    auto tb = std::chrono::steady_clock::now();
     s.download_started = false;
     /* the following batch's lists can come down while this one is resolved on the host */
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy) {
-            rc = start_download(c, nx, c->cfg.format);
+        if (&nx != &s && nx.busy && hipEventQuery(nx.ev_totals) == hipSuccess) {
+            rc = start_download(c, nx, c->cfg.format); /* its kernels are done: does not block */
             if (rc)
                 return rc;
         }
@@ -391,6 +395,14 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
                       c->cfg.mode_ac ? s.h_ac : nullptr, c->cfg.mode_ac ? s.h_ac_totals[0] : 0, ts_override,
                       emit_thunk, c);
     auto t1 = std::chrono::steady_clock::now();
+    if (c->outstanding > 1) { /* if the next batch was still running before the resolve, fetch it now */
+        Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
+        if (&nx != &s && nx.busy && !nx.download_started) {
+            rc = start_download(c, nx, c->cfg.format);
+            if (rc)
+                return rc;
+        }
+    }
 
     /* signal power of the accepted messages: a small follow-up kernel on the copy stream */
     const size_t nm = c->out_msgs.size();
@@ -399,15 +411,16 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         if (rc)
             return rc;
         memcpy(s.h_req, c->out_req.data(), nm * sizeof(uint64_t));
-        HIPCHK(c, hipMemcpyAsync(s.d_req, s.h_req, nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+        /* its own stream: the copy stream may already be busy downloading the next batch's lists */
+        HIPCHK(c, hipMemcpyAsync(s.d_req, s.h_req, nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->aux_stream));
         MsdScanParams p{};
         fill_params(c, s, p);
         rc = msd_launch_power(&p, format, s.d_req, (uint32_t)nm, reinterpret_cast<unsigned long long *>(s.d_pow),
-                              c->copy_stream);
+                              c->aux_stream);
         if (rc)
             return fail(c, rc, "power kernel launch failed");
-        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, nm * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, nm * sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipStreamSynchronize(c->aux_stream));
     }
     msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(),
                       c->out_req.data(), c->out_buf.data(), s.h_pow, nm);
@@ -415,7 +428,12 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     if (sink)
         for (size_t i = 0; i < nm; ++i)
             sink(&c->out_msgs[i], user);
-    (void)t2;
+    if (getenv("MSD_RESOLVE_TRACE")) {
+        auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "finish: wait-download %.3f  next-download+means %.3f  resolve %.3f  power %.3f  sink %.3f ms\n",
+                ms(ta, tb), ms(tb, t0), ms(t0, t1), ms(t1, t2), ms(t2, t3));
+    }
 
     float ms = 0;
     c->timing.hits = H;
@@ -534,6 +552,8 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_mag);
     if (c->copy_stream)
         (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream)
+        (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
     msd_resolver_free(&c->resolver);
@@ -595,6 +615,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->own_stream = true;
     }
     CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
     if (!c->tables) {

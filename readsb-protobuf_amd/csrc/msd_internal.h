@@ -93,15 +93,16 @@ typedef struct msd_resolver {
     uint64_t ifile_now;      /* Modes.ifile_now, readsb.h:289 */
     uint64_t sample_counter; /* samples consumed so far (sdr_ifile.c:172) */
     int mode_ac;
-    int threads; /* host threads of the speculative batch resolve; 0 = MSD_RESOLVE_THREADS or 16 */
+    int threads; /* host threads of the speculative batch resolve; 0 = MSD_RESOLVE_THREADS or ncpu/8 */
     struct msd_stats *stats;
     struct msd_batch_state *batch; /* scratch of msd_resolve_batch, owned by the resolver */
 } msd_resolver;
 
-/* Receives every accepted message in order.  Mode S messages still lack their signal level:
- * power_req = (batch-relative position << 16) | number of samples to sum, 0 for Mode A/C;
+/* Receives the accepted messages of one buffer, in order.  Mode S messages still lack their signal
+ * level: power_req[i] = (batch-relative position << 16) | number of samples to sum, 0 for Mode A/C;
  * buffer = index of the buffer within the batch. */
-typedef void (*msd_emit_fn)(const struct msd_message *mm, uint64_t power_req, uint32_t buffer, void *user);
+typedef void (*msd_emit_fn)(const struct msd_message *mm, const uint64_t *power_req, uint32_t count,
+                            uint32_t buffer, void *user);
 
 void msd_resolver_reset(msd_resolver *r);
 void msd_resolver_free(msd_resolver *r);

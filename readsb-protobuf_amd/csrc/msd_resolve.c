@@ -17,6 +17,7 @@
  * Host C on purpose (the north star keeps the host in C): the data-parallel work -- IQ->magnitude,
  * preamble tests, bit slicing, CRC, syndrome lookup, signal power -- is done on the GPU.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "msd_internal.h"
 #include "modes_hip.h"
 
@@ -24,6 +25,9 @@
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
+#include <unistd.h>
 
 /* ---------------------------------------------------------------------------------------- */
 /* ICAO address filter -- icao_filter.c semantics                                           */
@@ -551,12 +555,21 @@ static void job_resolve(void *arg, uint32_t index)
 
 /* ---------------------------------------------------------------------------------------- */
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 static int default_threads(void)
 {
     const char *e = getenv("MSD_RESOLVE_THREADS");
     if (e && atoi(e) > 0)
         return atoi(e);
-    return 16;
+    /* an eighth of the host's CPUs (an 8-GPU node runs 8 contexts), between 4 and 64 */
+    long n = sysconf(_SC_NPROCESSORS_ONLN) / 8;
+    return (int)(n < 4 ? 4 : (n > 64 ? 64 : n));
 }
 
 void msd_resolver_reset(msd_resolver *r)
@@ -695,6 +708,9 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
 
     const int serial = !bs->pool || bs->pool->nthreads == 0 || nbuffers < 4;
     msd_filter work;
+    const int trace = getenv("MSD_RESOLVE_TRACE") != NULL;
+    double t_par = 0, t_seq = 0, t0 = trace ? now_ms() : 0;
+    uint32_t npass = 0;
     if (serial) {
         /* plain sequential replay: the live filter is the snapshot and a buffer's adds are applied
          * when it is done -- equal to the reference because, inside a buffer, the filter is only
@@ -716,7 +732,11 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         }
         bs->ntodo = nbuffers;
         for (uint32_t pass = 0;; ++pass) {
+            double ta = trace ? now_ms() : 0;
             pool_run(bs->pool, job_resolve, bs, bs->ntodo);
+            double tb = trace ? now_ms() : 0;
+            t_par += tb - ta;
+            ++npass;
             /* replay adds and flips in order; find the membership version every buffer must see */
             work = r->filter;
             uint32_t version = 0, first_stale = nbuffers;
@@ -756,6 +776,11 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         }
     }
 
+    if (trace) {
+        t_seq = now_ms() - t0 - t_par;
+        fprintf(stderr, "resolve: %u buffers %u passes parallel %.3f ms, setup+replay %.3f ms\n", nbuffers, npass, t_par, t_seq);
+    }
+    const double tc = trace ? now_ms() : 0;
     /* commit, in order */
     msd_stats *st = r->stats;
     for (uint32_t b = 0; b < nbuffers; ++b) {
@@ -773,11 +798,13 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         st->samples_processed += (uint64_t)valid[b] + MSD_OVERLAP; /* readsb.c:835 */
         st->buffers++;
         r->sample_counter += valid[b];
-        for (uint32_t i = 0; i < br->nmsgs; ++i)
-            emit(&br->msgs[i], br->reqs[i], b, user);
+        if (br->nmsgs)
+            emit(br->msgs, br->reqs, br->nmsgs, b, user);
     }
     r->filter = work;
     r->ifile_now = bs->res[nbuffers - 1].end_now;
+    if (trace)
+        fprintf(stderr, "resolve: commit %.3f ms\n", now_ms() - tc);
 }
 
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
