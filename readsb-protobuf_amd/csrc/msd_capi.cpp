@@ -210,7 +210,7 @@ int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
 }
 
 /* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
-int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise = nullptr)
+int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
     const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
     const uint32_t ntiles = (uint32_t)ntiles64;
@@ -293,47 +293,162 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise = nullpt
 
 /* Stage 1 of finishing a batch: once its totals are known, start the download of its candidate
  * lists on the copy stream.  Idempotent; blocks only until the batch's kernels are done. */
+int ensure_ac_host(msd_ctx *c, Slot &s, size_t nac)
+{
+    if (nac <= s.h_ac_cap)
+        return 0;
+    size_t cap = s.h_ac_cap ? s.h_ac_cap : (size_t)1 << 14;
+    while (cap < nac)
+        cap *= 2;
+    if (s.h_ac)
+        (void)hipHostFree(s.h_ac);
+    s.h_ac = nullptr;
+    s.h_ac_cap = 0;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_ac), cap * sizeof(msd_ac_hit)));
+    s.h_ac_cap = cap;
+    return 0;
+}
+
+int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise);
+
+/* A batch whose candidate lists did not fit its arenas (an interference storm: a large share of
+ * all positions look like preambles) is scanned again in pieces -- halves, quarters, ... down to
+ * single buffers, which always fit -- and the pieces' lists are stitched together on the host.
+ * Synchronous and slow on purpose; nothing is ever dropped. */
+int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
+{
+    const uint64_t total_buffers = s.nbuffers;
+    for (uint64_t pieces = 2;; pieces *= 2) {
+        uint64_t piece = ((s.nsamples + pieces - 1) / pieces + MSD_CHUNK_SAMPLES - 1) / MSD_CHUNK_SAMPLES *
+                         MSD_CHUNK_SAMPLES;
+        if (piece < MSD_CHUNK_SAMPLES)
+            piece = MSD_CHUNK_SAMPLES;
+        std::vector<msd_hit> hits;
+        std::vector<msd_try> tries;
+        std::vector<msd_ac_hit> acs;
+        bool again = false;
+        for (uint64_t off = 0; off < s.nsamples || (off == 0 && s.nsamples == 0); off += piece) {
+            Slot t = s; /* shares the device buffers and events of s */
+            const uint64_t n = s.nsamples - off < piece ? s.nsamples - off : piece;
+            const bool is_last = off + n >= s.nsamples;
+            const uint64_t b0 = off / MSD_CHUNK_SAMPLES;
+            t.d_iq = s.d_iq + off * c->bps;
+            if (off) {
+                t.d_prev = s.d_iq + (off - TAIL_SAMPLES) * c->bps;
+                t.have_prev = 1;
+            }
+            t.batch_first = s.batch_first + off;
+            t.nsamples = n;
+            t.nbuffers = (uint32_t)((is_last ? total_buffers : (off + n) / MSD_CHUNK_SAMPLES) - b0);
+            t.d_sums = s.d_sums + 2 * b0;
+            t.d_fmeans = s.d_fmeans + 2 * b0;
+            int rc = enqueue(c, t, format, nullptr);
+            if (rc)
+                return rc;
+            HIPCHK(c, hipEventSynchronize(t.ev_totals));
+            const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
+            const uint64_t nac = c->cfg.mode_ac ? s.h_ac_totals[0] : 0;
+            if (s.h_totals[2] || (c->cfg.mode_ac && s.h_ac_totals[2])) {
+                if (piece == MSD_CHUNK_SAMPLES)
+                    return fail(c, -EOVERFLOW, "candidate arena overflow on a single buffer");
+                again = true;
+                break;
+            }
+            rc = ensure_host(c, s, H, Tn);
+            if (!rc)
+                rc = ensure_ac_host(c, s, nac);
+            if (rc)
+                return rc;
+            if (H)
+                HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->copy_stream));
+            if (Tn)
+                HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->copy_stream));
+            if (nac)
+                HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+            const uint64_t try0 = tries.size();
+            for (uint64_t i = 0; i < H; ++i) {
+                msd_hit h = s.h_hits[i] + off; /* position is the low field: no carry into the mask */
+                if (MSD_HIT_NLIVE(h))
+                    h += (msd_hit)try0 << 34;
+                hits.push_back(h);
+            }
+            for (uint64_t i = 0; i < Tn; ++i) {
+                msd_try tr = s.h_tries[i];
+                tr.pos += (uint32_t)off;
+                tries.push_back(tr);
+            }
+            for (uint64_t i = 0; i < nac; ++i) {
+                msd_ac_hit a = s.h_ac[i];
+                a.pos += off;
+                acs.push_back(a);
+            }
+            if (s.nsamples == 0)
+                break;
+        }
+        if (again)
+            continue;
+        int rc = ensure_host(c, s, hits.size(), tries.size());
+        if (!rc)
+            rc = ensure_ac_host(c, s, acs.size());
+        if (rc)
+            return rc;
+        if (!hits.empty())
+            memcpy(s.h_hits, hits.data(), hits.size() * sizeof(msd_hit));
+        if (!tries.empty())
+            memcpy(s.h_tries, tries.data(), tries.size() * sizeof(msd_try));
+        if (!acs.empty())
+            memcpy(s.h_ac, acs.data(), acs.size() * sizeof(msd_ac_hit));
+        s.h_totals[0] = hits.size();
+        s.h_totals[1] = tries.size();
+        s.h_totals[2] = 0;
+        if (c->cfg.mode_ac) {
+            s.h_ac_totals[0] = acs.size();
+            s.h_ac_totals[2] = 0;
+        }
+        c->timing.reruns++;
+        return 0;
+    }
+}
+
+/* Stage 1 of finishing a batch: once its totals are known, start the download of its candidate
+ * lists on the copy stream.  Idempotent; blocks only until the batch's kernels are done. */
 int start_download(msd_ctx *c, Slot &s, int format)
 {
     if (s.download_started)
         return 0;
     HIPCHK(c, hipEventSynchronize(s.ev_totals));
-    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1], ovf = s.h_totals[2];
-    if (ovf)
-        return fail(c, -EOVERFLOW, "candidate arena overflow (%llu hits, %llu tries)",
-                    (unsigned long long)H, (unsigned long long)Tn);
-    int rc = ensure_host(c, s, H, Tn);
-    if (rc)
-        return rc;
+    const bool overflow = s.h_totals[2] || (c->cfg.mode_ac && s.h_ac_totals[2]);
+    if (overflow) {
+        int rc = rerun_in_pieces(c, s, format);
+        if (rc)
+            return rc;
+    }
+    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
     HIPCHK(c, hipEventRecord(s.ev_copy0, c->copy_stream));
-    if (H)
-        HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->copy_stream));
-    if (Tn)
-        HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->copy_stream));
+    if (!overflow) {
+        int rc = ensure_host(c, s, H, Tn);
+        if (rc)
+            return rc;
+        if (H)
+            HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->copy_stream));
+        if (Tn)
+            HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->copy_stream));
+        if (c->cfg.mode_ac) {
+            const uint64_t nac = s.h_ac_totals[0];
+            rc = ensure_ac_host(c, s, nac);
+            if (rc)
+                return rc;
+            if (nac)
+                HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->copy_stream));
+        }
+    }
     if (s.nbuffers) {
         HIPCHK(c, hipMemcpyAsync(s.h_sums, s.d_sums, sizeof(uint64_t) * 2 * s.nbuffers, hipMemcpyDeviceToHost,
                                  c->copy_stream));
         if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11)
             HIPCHK(c, hipMemcpyAsync(s.h_fmeans, s.d_fmeans, sizeof(float) * 2 * s.nbuffers,
                                      hipMemcpyDeviceToHost, c->copy_stream));
-    }
-    if (c->cfg.mode_ac) {
-        const uint64_t nac = s.h_ac_totals[0];
-        if (s.h_ac_totals[2])
-            return fail(c, -EOVERFLOW, "Mode A/C candidate arena overflow (%llu)", (unsigned long long)nac);
-        if (nac > s.h_ac_cap) {
-            size_t cap = s.h_ac_cap ? s.h_ac_cap : (size_t)1 << 14;
-            while (cap < nac)
-                cap *= 2;
-            if (s.h_ac)
-                (void)hipHostFree(s.h_ac);
-            s.h_ac = nullptr;
-            s.h_ac_cap = 0;
-            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_ac), cap * sizeof(msd_ac_hit)));
-            s.h_ac_cap = cap;
-        }
-        if (nac)
-            HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->copy_stream));
     }
     HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
     s.download_started = true;
@@ -483,7 +598,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
     s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
-    rc = enqueue(c, s, c->cfg.format);
+    rc = enqueue(c, s, c->cfg.format, nullptr);
     if (rc) {
         s.busy = false;
         return rc;
@@ -637,8 +752,16 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMemcpy(c->d_syn112, c->tables->syn112, sizeof c->tables->syn112, hipMemcpyHostToDevice));
 
     const uint64_t B = c->cfg.max_batch_samples;
-    c->hit_arena = B / 8 > MIN_HIT_ARENA ? B / 8 : MIN_HIT_ARENA;
-    c->try_arena = B / 16 > MIN_TRY_ARENA ? B / 16 : MIN_TRY_ARENA;
+    uint64_t hit_want = B / 8, try_want = B / 16;
+    if (const char *scale = getenv("MSD_ARENA_SCALE_PERMILLE")) { /* test knob: provoke the overflow path */
+        const uint64_t pm = (uint64_t)atoi(scale);
+        if (pm > 0) {
+            hit_want = hit_want * pm / 1000;
+            try_want = try_want * pm / 1000;
+        }
+    }
+    c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
+    c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
     c->max_wg = (uint32_t)c->cu_count * 2u;
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));

@@ -98,3 +98,22 @@ def test_resolve_threads_and_membership_churn(pkg, oracle, torch_cuda, monkeypat
     monkeypatch.setenv("MSD_RESOLVE_THREADS", threads)
     run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 40 * 131072 + 17, seed=77, nfix=1, n_aircraft=30000,
              msgs_per_sec=4000)
+
+
+def test_interference_storm_overflows_and_is_rerun_in_pieces(pkg, oracle, torch_cuda, monkeypatch):
+    """strong wideband interference makes a large share of all positions candidates.
+    The candidate arenas then overflow; the batch must be rescanned in pieces, never truncated."""
+    rng = np.random.default_rng(5)
+    n = 128 * 131072
+    on = rng.random(n) < 0.3
+    i = np.where(on, 128 + 100 * rng.choice([-1, 1], n), 128 + rng.integers(-2, 3, n)).clip(0, 255).astype(np.uint8)
+    q = (128 + rng.integers(-3, 4, n)).clip(0, 255).astype(np.uint8)
+    iq = np.stack([i, q], 1).reshape(-1).copy()
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "200")  # arenas sized for a fifth of the default density
+    dem = pkg.Demodulator(fmt=pkg.FMT_UC8, nfix_crc=1, max_batch_samples=n, message_capacity=1 << 16)
+    got = dem.submit_device(d.data_ptr(), n, last=True)
+    assert dem.timing()["reruns"] >= 1, dem.timing()
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)
+    assert_same(got, dem.stats(), want, wstats)
+    assert wstats["demod_preambles"] > 0.05 * n
