@@ -60,6 +60,7 @@ struct Slot {
     size_t h_hits_cap = 0;
     msd_try *h_tries = nullptr;
     size_t h_tries_cap = 0;
+    uint8_t *d_ragged = nullptr; /* zero-padded copy of a partially filled last 8-sample group */
     /* Mode A/C candidates */
     msd_ac_hit *d_ac = nullptr;
     uint64_t *d_ac_totals = nullptr, *h_ac_totals = nullptr;
@@ -96,6 +97,7 @@ struct msd_ctx {
     uint64_t *d_ac_offsets = nullptr;
     uint32_t *d_noise = nullptr;
     uint32_t ac_max_wg = 0;
+    unsigned long long *d_timers = nullptr; /* MSD_KERNEL_TIMING experiments */
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -170,6 +172,7 @@ void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
 {
     p.iq = s.d_iq;
     p.prev_tail = s.d_prev;
+    p.ragged = s.d_ragged;
     p.have_prev = s.have_prev;
     p.threshold = c->cfg.preamble_threshold;
     p.batch_first = s.batch_first;
@@ -222,6 +225,12 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         tpw = 1;
     uint32_t nwg = ntiles ? (ntiles + tpw - 1) / tpw : 0;
 
+    if (s.nsamples & 7u) { /* the last, partially filled 8-sample group: a zero-padded private copy */
+        const size_t bps = (format == MSD_FMT_UC8 || format == MSD_FMT_MAG16) ? 2 : 4;
+        HIPCHK(c, hipMemsetAsync(s.d_ragged, 0, 64, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s.d_ragged, s.d_iq + (s.nsamples & ~7ull) * bps, (s.nsamples & 7u) * bps,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(s.d_sums, 0, sizeof(uint64_t) * 2 * (s.nbuffers ? s.nbuffers : 1), c->stream));
     HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
     if (c->cfg.mode_ac)
@@ -244,6 +253,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.tcap = (uint32_t)tcap;
         p.counts = c->d_counts;
         p.chunk_sums = s.d_sums;
+        p.timers = c->d_timers;
         {
             const char *dbg = getenv("MSD_DEBUG_FLAGS");
             p.debug_flags = dbg ? atoi(dbg) : 0;
@@ -639,6 +649,16 @@ void destroy(msd_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream)
         (void)hipStreamSynchronize(c->copy_stream);
+    if (c->d_timers) {
+        unsigned long long t[16];
+        if (hipMemcpy(t, c->d_timers, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "kernel section cycles (sum over wavefronts):");
+            for (int k = 0; k < 12; ++k)
+                fprintf(stderr, " [%d]=%llu", k, t[k]);
+            fprintf(stderr, "\n");
+        }
+        (void)hipFree(c->d_timers);
+    }
     for (Slot &s : c->slots) {
         (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
         if (s.h_totals) (void)hipHostFree(s.h_totals);
@@ -649,7 +669,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
-        (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals);
+        (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
@@ -784,6 +804,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_ragged), 64));
+        CK(hipMemset(s.d_ragged, 0, 64));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_fmeans), 2 * sizeof(float) * c->max_buffers));
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
@@ -799,6 +821,10 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipEventCreate(e));
     }
 #undef CK
+    if (getenv("MSD_KERNEL_TIMING")) {
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_timers), 16 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(c->d_timers, 0, 16 * sizeof(unsigned long long));
+    }
     c->resolver.stats = &c->stats;
     c->resolver.mode_ac = cfg->mode_ac;
     msd_resolver_reset(&c->resolver);

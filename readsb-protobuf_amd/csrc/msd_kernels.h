@@ -13,6 +13,7 @@
 typedef struct MsdScanParams {
     const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */
     const uint8_t *prev_tail; /* the MSD_HALO_FRONT samples before it */
+    const uint8_t *ragged;    /* 32 readable bytes holding the last nsamples % 8 samples, zero padded */
     int have_prev;            /* 0: start of stream or discontinuity -> zero magnitudes (fifo.c:180) */
     int threshold;            /* Modes.preambleThreshold */
     uint64_t batch_first;     /* absolute index of iq[0]; multiple of MSD_CHUNK_SAMPLES */
@@ -29,6 +30,7 @@ typedef struct MsdScanParams {
     uint32_t hcap, tcap; /* per-workgroup region capacities */
     msd_wg_counts *counts;
     uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
+    unsigned long long *timers; /* MSD_KERNEL_TIMING builds only */
     int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
                              2 = stop after the conversion (results are then incomplete) */
 } MsdScanParams;

@@ -37,6 +37,20 @@
  * to plain operators and the native sqrt). */
 #pragma clang fp contract(off)
 
+#ifdef MSD_KERNEL_TIMING
+/* section timers for experiments (never in the shipped build): wall cycles per wavefront */
+__device__ unsigned long long g_msd_tlast_dummy;
+#define TDECL unsigned long long tacc_[12] = {0}; unsigned long long tlast_ = __builtin_readcyclecounter();
+#define TMARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); tacc_[k] += n_ - tlast_; tlast_ = n_; }
+#define TMARKF(k) { const unsigned long long n_ = __builtin_readcyclecounter(); tacc[k] += n_ - *tlast; *tlast = n_; }
+#define TFLUSH if (P.timers && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&P.timers[k_], tacc_[k_]); }
+#else
+#define TDECL
+#define TMARK(k)
+#define TMARKF(k)
+#define TFLUSH
+#endif
+
 namespace {
 
 constexpr int NT = MSD_SCAN_THREADS;  /* 512 threads = 8 wavefronts */
@@ -101,48 +115,40 @@ struct RawGroup { /* the raw bytes of 8 consecutive samples */
 
 /* Fetch the raw bytes of samples [n, n+8); n is a multiple of 8.  Returns a bit per sample that
  * exists; samples outside the stream (before its start / after a discontinuity / past the end)
- * have magnitude zero (fifo.c:179-182). */
+ * have magnitude zero (fifo.c:179-182).
+ * Always exactly one unconditional vector load from a *selected* address: a load inside a branch
+ * forces the compiler to wait for it at the join (s_waitcnt vmcnt(0) right behind the load), which
+ * would expose the full HBM latency of the next tile's prefetch.  A partially valid last group is
+ * read from P.ragged, a 32-byte zero-padded copy prepared by the host; groups that do not exist
+ * read the (always present) lookup table and are masked out. */
 template <int FMT>
 __device__ __forceinline__ uint32_t fetch_group(const MsdScanParams &P, int64_t n, RawGroup<FMT> &r)
 {
     constexpr int BPS = RawGroup<FMT>::WORDS / 2;
     const int64_t rel = n - (int64_t)P.batch_first;
-#pragma unroll
-    for (int k = 0; k < RawGroup<FMT>::WORDS; ++k)
-        r.w[k] = 0;
-    const uint8_t *src;
-    int avail = 8;
+    const int64_t left = (int64_t)P.nsamples - rel;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(P.lut);
+    uint32_t valid = 0;
     if (rel < 0) {
-        if (!P.have_prev || rel < -(int64_t)FRONT)
-            return 0;
-        src = P.prev_tail + (rel + FRONT) * BPS;
-    } else {
-        const int64_t left = (int64_t)P.nsamples - rel;
-        if (left <= 0)
-            return 0;
-        if (left < 8)
-            avail = (int)left;
+        if (P.have_prev && rel >= -(int64_t)FRONT) {
+            src = P.prev_tail + (rel + FRONT) * BPS;
+            valid = 0xffu;
+        }
+    } else if (left >= 8) {
         src = P.iq + rel * BPS;
+        valid = 0xffu;
+    } else if (left > 0) {
+        src = P.ragged;
+        valid = (1u << (int)left) - 1u;
     }
-    if (avail == 8) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(src);
-        r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
-        if (BPS == 4) {
-            const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
-            r.w[4 % RawGroup<FMT>::WORDS] = b.x; r.w[5 % RawGroup<FMT>::WORDS] = b.y;
-            r.w[6 % RawGroup<FMT>::WORDS] = b.z; r.w[7 % RawGroup<FMT>::WORDS] = b.w;
-        }
-        return 0xffu;
+    const uint4 a = *reinterpret_cast<const uint4 *>(src);
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+    if (BPS == 4) {
+        const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
+        r.w[4 % RawGroup<FMT>::WORDS] = b.x; r.w[5 % RawGroup<FMT>::WORDS] = b.y;
+        r.w[6 % RawGroup<FMT>::WORDS] = b.z; r.w[7 % RawGroup<FMT>::WORDS] = b.w;
     }
-    /* ragged end of the capture: 16-bit pieces, statically indexed so the group stays in VGPRs */
-#pragma unroll
-    for (int k = 0; k < 2 * RawGroup<FMT>::WORDS; ++k) {
-        if (k < avail * BPS / 2) {
-            const uint32_t h = *reinterpret_cast<const uint16_t *>(src + 2 * k);
-            r.w[k >> 1] |= h << (16 * (k & 1));
-        }
-    }
-    return (1u << avail) - 1u;
+    return valid;
 }
 
 template <int FMT>
@@ -241,6 +247,15 @@ __device__ __forceinline__ uint32_t bytes_for_df(uint32_t df)
     return 1;
 }
 
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector memory
+ * counter (s_waitcnt vmcnt(0)), which would make every barrier wait for the IQ prefetch of the next
+ * tile and for the candidate-record stores; nothing in this kernel hands global data from one
+ * thread to another, so waiting for LDS (lgkmcnt) is all the ordering it needs. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
     uint32_t x = v;
@@ -277,7 +292,11 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
                                                     const uint32_t *crc_tab, const uint32_t *syn,
                                                     unsigned char *cs, int tid, uint32_t nh, uint64_t tile_pos0,
                                                     msd_hit *hit_out, bool hits_fit, msd_try *my_tries,
-                                                    uint32_t *try_cursor)
+                                                    uint32_t *try_cursor
+#ifdef MSD_KERNEL_TIMING
+                                                    , unsigned long long *tacc, unsigned long long *tlast
+#endif
+                                                    )
 {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t *hitlist = reinterpret_cast<const uint32_t *>(cs + CS_HITS);
@@ -318,11 +337,12 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
         MSD_STEP_A(0) MSD_STEP_A(1) MSD_STEP_A(2) MSD_STEP_A(3) MSD_STEP_A(4)
 #undef MSD_STEP_A
     }
-    __syncthreads();
+    lds_barrier();
     if (*nsurv_p > (uint32_t)SCAP)
         return 0xffffffffu; /* workgroup-uniform: the caller retries with fewer hits */
     const uint32_t nsurv = (P.debug_flags & 4) ? 0u : *nsurv_p;
 
+    TMARKF(6); /* step A + barrier */
     /* ---- step B ---- */
     if (!(P.debug_flags & 8)) {
         const uint32_t nchunk = (nsurv + 20u) / 21u;
@@ -349,8 +369,9 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    TMARKF(7); /* step B + barrier */
     /* ---- step C ---- */
     for (uint32_t u = (uint32_t)tid; u < ((P.debug_flags & 16) ? 0u : nsurv); u += NT) {
         const uint32_t me = smeta[u];
@@ -419,8 +440,9 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             survidx[h * 5 + q] = 0xffffu; /* scores -2 whatever the filter holds */
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    TMARKF(8); /* step C + barrier */
     /* ---- step D ---- */
     uint32_t nl = 0, mask = 0, pos = 0;
     if ((uint32_t)tid < nh) {
@@ -507,10 +529,11 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
         }
         return;
     }
-    __syncthreads();
+    lds_barrier();
     const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
 
     uint32_t hcur = 0; /* workgroup-uniform cursor into this workgroup's hit region */
+    TDECL
     msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
     msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
 
@@ -546,6 +569,7 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
         const uint64_t tile_pos0 = (uint64_t)tile * T; /* first scan position, batch-relative */
         const uint64_t a0 = P.batch_first + tile_pos0;
 
+        TMARK(0); /* loop top */
         /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
         {
             const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
@@ -583,7 +607,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
             for (int k = 0; k < GPT; ++k)
                 nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + T + 8 * (tid + NT * k), nxt[k]);
         }
-        __syncthreads();
+        lds_barrier();
+        TMARK(1); /* conversion + barrier */
 
         if (!(P.debug_flags & 2)) {
             /* ---- stage 2: preamble tests for my 16 consecutive positions (demod_2400.c:257-335) ---- */
@@ -629,6 +654,7 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 }
             }
 
+            TMARK(2); /* tests */
             /* ---- stage 3: ordered hit bookkeeping ---- */
             uint32_t cnt;
             {
@@ -647,7 +673,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                 if (tid < 32)
                     reinterpret_cast<uint32_t *>(cs + CS_MISC)[tid] = 0;
             }
-            __syncthreads();
+            lds_barrier();
+            TMARK(3); /* hit bookkeeping + barrier */
             uint32_t wave_base = 0, H = 0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -682,7 +709,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                                 ++r;
                             }
                         }
-                        __syncthreads();
+                        lds_barrier();
+                        TMARK(4); /* fill + barrier */
                     }
                     /* per-phase lists of the hits that try that phase (any order), one thread per hit */
                     if ((uint32_t)tid < nh) {
@@ -694,10 +722,15 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                                 plist[q * HCAP + atomicAdd(&cmisc[16 + q], 1u)] = (uint8_t)tid;
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
+                    TMARK(5); /* plist + barrier */
                     const uint32_t out0 = hcur + r0;
                     const uint32_t got = candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
-                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, try_cursor);
+                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, try_cursor
+#ifdef MSD_KERNEL_TIMING
+                                                         , tacc_, &tlast_
+#endif
+                                                         );
                     if (got == 0xffffffffu) { /* too many tries with a known DF: halve the round */
                         nh = (nh + 1) / 2;
                         fill = false;
@@ -707,23 +740,25 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                         fill = true;
                     }
                     if (r0 < H) { /* another round: clear its scratch behind a barrier */
-                        __syncthreads();
+                        lds_barrier();
                         for (int i = tid; i < HCAP * 5 / 2; i += NT)
                             sidx32[i] = 0xffffffffu;
                         if (tid < 32)
                             cmisc[tid] = 0;
-                        __syncthreads();
+                        lds_barrier();
                     }
                 }
             }
             hcur += H;
         }
 
+        TMARK(10); /* candidates: rest */
         /* ---- carry the last 328 magnitudes over as the next tile's look-behind ---- */
         uint4 carry = make_uint4(0, 0, 0, 0);
         if (tid < FRONT / 8)
             carry = *reinterpret_cast<const uint4 *>(mags + T + 8 * tid);
-        __syncthreads();
+        lds_barrier();
+        TMARK(11); /* carry barrier */
         if (tid < FRONT / 8)
             *reinterpret_cast<uint4 *>(mags + 8 * tid) = carry;
 #pragma unroll
@@ -745,7 +780,8 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
             atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
         }
     }
-    __syncthreads();
+    TFLUSH
+    lds_barrier();
     if (tid == 0) {
         msd_wg_counts c;
         c.nhits = hcur;
@@ -905,6 +941,8 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
     P.nsamples = nsamples;
     P.batch_first = 0;
     P.have_prev = 0;
+    P.lut = lut_g;
+    P.ragged = iq + (size_t)(nsamples & ~7u) * (RawGroup<FMT>::WORDS / 2); /* the staging buffer is padded */
     unsigned long long sl = 0, sp = 0;
     const uint32_t ngroups = (nsamples + 7) / 8;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
