@@ -2,7 +2,7 @@
 # Builds libmodes_hip.so (HIP kernels + C-ABI + host resolve) and libmsd_siggen.so for gfx950.
 set -e
 cd "$(dirname "$0")"
-INC="-I. -I../../include"
+INC="-I. -I../../include $MSD_EXTRA_DEFS"
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC -ffp-contract=off $INC -c msd_tables.c -o msd_tables.o
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC -ffp-contract=off $INC -c msd_resolve.c -o msd_resolve.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $MSD_EXTRA_HIPFLAGS $INC -c msd_kernels.hip -o msd_kernels.o

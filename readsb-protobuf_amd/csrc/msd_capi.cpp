@@ -217,7 +217,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
     const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
     const uint32_t ntiles = (uint32_t)ntiles64;
-    uint32_t target_wg = (uint32_t)c->cu_count * 2u;
+    uint32_t target_wg = (uint32_t)c->cu_count * MSD_WGS_PER_CU;
     if (target_wg > c->max_wg)
         target_wg = c->max_wg;
     uint32_t tpw = ntiles ? (ntiles + target_wg - 1) / target_wg : 1;
@@ -782,7 +782,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     }
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
-    c->max_wg = (uint32_t)c->cu_count * 2u;
+    c->max_wg = (uint32_t)c->cu_count * MSD_WGS_PER_CU;
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));

@@ -23,7 +23,17 @@
 extern "C" {
 #endif
 
-#define MSD_TILE 8192u          /* scan positions per tile */
+/* geometry of the scan kernel (overridable at build time for experiments) */
+#ifndef MSD_SCAN_THREADS
+#define MSD_SCAN_THREADS 512 /* threads per workgroup */
+#endif
+#ifndef MSD_WGS_PER_CU
+#define MSD_WGS_PER_CU 2
+#endif
+#ifndef MSD_LUT_GLOBAL
+#define MSD_LUT_GLOBAL 0 /* 1: read the UC8 table through the vector cache instead of LDS */
+#endif
+#define MSD_TILE (16u * MSD_SCAN_THREADS) /* scan positions per tile: 16 per thread */
 #define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */
 #define MSD_MAX_BATCH_SAMPLES (1ull << 28) /* hit positions are 28-bit, batch-relative */
 

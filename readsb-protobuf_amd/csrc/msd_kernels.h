@@ -8,7 +8,6 @@
 #include "modes_hip.h"
 #include "msd_internal.h"
 
-#define MSD_SCAN_THREADS 512
 
 typedef struct MsdScanParams {
     const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */

@@ -58,9 +58,9 @@ constexpr int NW = NT / 64;
 constexpr int T = MSD_TILE;           /* 8192 scan positions per tile */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
 constexpr int GPT = T / 8 / NT;       /* 8-sample load groups per thread per tile (2) */
-constexpr int HCAP = 256;             /* hits per candidate round */
-constexpr int SCAP = 512;             /* tries with a known DF per round; a round that would need
-                                         more is retried with half the hits (5 * 102 < 512) */
+constexpr int HCAP = NT / 2;          /* hits per candidate round */
+constexpr int SCAP = NT;               /* tries with a known DF per round; a round that would need
+                                         more is retried with half the hits (5 * HCAP / 4 < SCAP) */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
 static_assert(T == NT * 16, "each thread scans 16 consecutive positions");
@@ -83,7 +83,7 @@ constexpr int CS_MISC = CS_SRES + SCAP * 8;               /* u32[32]: counters *
 constexpr int CS_BYTES = CS_MISC + 128;
 constexpr int OFF_LUT = OFF_CAND + CS_BYTES;              /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
-constexpr int LDS_UC8 = OFF_LUT + 128 * LUT_STRIDE * 2;
+constexpr int LDS_UC8 = OFF_LUT + (MSD_LUT_GLOBAL ? 0 : 128 * LUT_STRIDE * 2);
 static_assert(OFF_CRC % 16 == 0 && OFF_CAND % 16 == 0 && CS_SMSG % 16 == 0 && CS_SRES % 16 == 0 &&
               CS_BYTES % 16 == 0 && OFF_LUT % 16 == 0, "LDS carve offsets must stay 16-byte aligned");
 
@@ -488,14 +488,15 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
 }
 
 template <int FMT>
-__global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
+__global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *mags = reinterpret_cast<uint16_t *>(smem + OFF_MAGS);
     uint32_t *crc_tab = reinterpret_cast<uint32_t *>(smem + OFF_CRC);
     uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + OFF_MISC);
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
+    uint16_t *lds_lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
+    const uint16_t *lut = MSD_LUT_GLOBAL ? P.lut : lds_lut;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wg = blockIdx.x;
@@ -509,9 +510,9 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
     for (int i = tid; i < 160; i += NT)
         syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
                           : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
-    if (FMT == MSD_FMT_UC8) {
+    if (FMT == MSD_FMT_UC8 && !MSD_LUT_GLOBAL) {
         const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
-        uint4 *l = reinterpret_cast<uint4 *>(lut);
+        uint4 *l = reinterpret_cast<uint4 *>(lds_lut);
         for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
             l[i] = g[i];
     }
@@ -621,30 +622,38 @@ __global__ void __launch_bounds__(NT, 4) msd_scan_kernel(const MsdScanParams P)
                     v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
                 }
             }
-            uint64_t nib = 0; /* 4 bits per position: which tests fired */
+            /* all 36 samples this lane's 16 positions touch, unpacked once */
+            int sm[40];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                sm[2 * k] = (int)(v[k] & 0xffffu);
+                sm[2 * k + 1] = (int)(v[k] >> 16);
+            }
+            uint32_t nib_lo = 0, nib_hi = 0; /* 4 bits per position: which tests fired */
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 /* pa[d] = mags[p + 2 + d]: the tile stages 328 samples ahead, the reference's
-                 * overlap is 326 */
-#define PA(d) ((int)((v[(q + 2 + (d)) >> 1] >> (16 * ((q + 2 + (d)) & 1))) & 0xffffu))
+                 * overlap is 326.  Branch-free on purpose: with 64 lanes some lane almost always
+                 * passes the pre-check, so a branch only adds exec-mask bookkeeping. */
+#define PA(d) (sm[q + 2 + (d)])
+                const bool pre = (PA(1) > PA(7)) & (PA(12) > PA(14)) & (PA(12) > PA(15));
+                const uint32_t base_noise = (uint32_t)(PA(5) + PA(8) + PA(16) + PA(17) + PA(18));
+                const int ref_level = (int)(__umul24(base_noise, (uint32_t)P.threshold) >> 5); /* < 2^24 each */
+                const int diff_2_3 = PA(2) - PA(3);
+                const int sum_1_4 = PA(1) + PA(4);
+                const int diff_10_11 = PA(10) - PA(11);
+                const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
                 uint32_t m = 0;
-                if (PA(1) > PA(7) && PA(12) > PA(14) && PA(12) > PA(15)) {
-                    const int base_noise = PA(5) + PA(8) + PA(16) + PA(17) + PA(18);
-                    const int ref_level = (base_noise * P.threshold) >> 5;
-                    const int diff_2_3 = PA(2) - PA(3);
-                    const int sum_1_4 = PA(1) + PA(4);
-                    const int diff_10_11 = PA(10) - PA(11);
-                    const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
-                    if (common3456 - diff_10_11 >= ref_level)
-                        m |= 1u;
-                    if (common3456 + diff_10_11 >= ref_level)
-                        m |= 2u;
-                    if (sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level)
-                        m |= 4u;
-                }
+                m |= (pre & (common3456 - diff_10_11 >= ref_level)) ? 1u : 0u;
+                m |= (pre & (common3456 + diff_10_11 >= ref_level)) ? 2u : 0u;
+                m |= (pre & (sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level)) ? 4u : 0u;
 #undef PA
-                nib |= (uint64_t)m << (4 * q);
+                if (q < 8)
+                    nib_lo |= m << (4 * q);
+                else
+                    nib_hi |= m << (4 * (q - 8));
             }
+            uint64_t nib = (uint64_t)nib_lo | ((uint64_t)nib_hi << 32);
             /* positions past the last one the reference scans */
             {
                 const uint64_t first = a0 + 16ull * tid;
