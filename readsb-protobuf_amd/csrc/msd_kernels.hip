@@ -298,7 +298,8 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
 #endif
                                                     )
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    /* the wavefront index is uniform: keep it (and everything derived from it) in scalar registers */
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t *hitlist = reinterpret_cast<const uint32_t *>(cs + CS_HITS);
     uint16_t *survidx = reinterpret_cast<uint16_t *>(cs + CS_SIDX);
     uint32_t *smeta = reinterpret_cast<uint32_t *>(cs + CS_SMETA);
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
     uint16_t *lds_lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
     const uint16_t *lut = MSD_LUT_GLOBAL ? P.lut : lds_lut;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wg = blockIdx.x;
     unsigned char *cs = smem + OFF_CAND;
     uint32_t *wave_hits = misc;         /* [2][NW], double buffered by tile parity */
