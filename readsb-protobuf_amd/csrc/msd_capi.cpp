@@ -38,6 +38,13 @@ constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
 struct Slot {
     bool busy = false;
     bool download_started = false;
+    bool gpu_resolve = false; /* the candidate lists stay in HBM: resolved there (msd_resolve_kernels.hip) */
+    bool resolve_inflight = false; /* its first resolve pass was launched while the previous batch finished */
+    uint32_t resolve_ntodo = 0;
+    msd_rbuf *d_rbuf = nullptr, *h_rbuf = nullptr;
+    msd_acc *d_acc = nullptr;
+    uint32_t *d_adds = nullptr;
+    uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] | offsets[n+1] */
     /* batch description */
     const uint8_t *d_iq = nullptr;
     const uint8_t *d_prev = nullptr;
@@ -98,6 +105,14 @@ struct msd_ctx {
     uint32_t *d_noise = nullptr;
     uint32_t ac_max_wg = 0;
     unsigned long long *d_timers = nullptr; /* MSD_KERNEL_TIMING experiments */
+    /* GPU resolve stage: per-buffer reports, accepted-message records, filter snapshots, control arrays */
+    bool gpu_resolve = false;
+    uint32_t *h_adds = nullptr; /* complete add lists, fetched only when a buffer needs them */
+    uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
+    uint32_t snaps_uploaded = 0;
+    msd_message *d_msgs = nullptr, *h_msgs = nullptr;
+    size_t msgs_cap = 0;
+    hipEvent_t ev_emit = nullptr;
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -436,7 +451,8 @@ int start_download(msd_ctx *c, Slot &s, int format)
     }
     const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
     HIPCHK(c, hipEventRecord(s.ev_copy0, c->copy_stream));
-    if (!overflow) {
+    s.gpu_resolve = c->gpu_resolve && !overflow && !c->cfg.mode_ac && s.nbuffers >= 4;
+    if (!overflow && !s.gpu_resolve) {
         int rc = ensure_host(c, s, H, Tn);
         if (rc)
             return rc;
@@ -462,6 +478,214 @@ int start_download(msd_ctx *c, Slot &s, int format)
     }
     HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
     s.download_started = true;
+    return 0;
+}
+
+constexpr uint32_t SNAP_CAP = 64; /* filter membership versions of one batch kept on the device */
+
+int ensure_msgs(msd_ctx *c, size_t n)
+{
+    if (n <= c->msgs_cap)
+        return 0;
+    size_t cap = c->msgs_cap ? c->msgs_cap : (size_t)1 << 14;
+    while (cap < n)
+        cap *= 2;
+    (void)hipFree(c->d_msgs);
+    if (c->h_msgs)
+        (void)hipHostFree(c->h_msgs);
+    c->d_msgs = c->h_msgs = nullptr;
+    c->msgs_cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_msgs), cap * sizeof(msd_message)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_msgs), cap * sizeof(msd_message)));
+    c->msgs_cap = cap;
+    return 0;
+}
+
+/* The resolve stage with the candidate lists left in HBM: one workgroup per buffer against a
+ * snapshot of the ICAO filter; the host only replays the buffers' add lists to find the snapshot
+ * every buffer has to see (msd_resolve.c) and re-launches the ones that saw another. */
+struct GpuCtl {
+    uint64_t *h_ts;
+    uint32_t *h_valid, *h_snap, *h_todo, *h_off;
+    const uint64_t *d_ts;
+    const uint32_t *d_valid, *d_snap, *d_todo, *d_off;
+    size_t bytes;
+};
+
+GpuCtl gpu_ctl(const msd_ctx *c, const Slot &s)
+{
+    const size_t N = c->max_buffers;
+    GpuCtl g;
+    g.bytes = 32 * N + 64;
+    g.h_ts = reinterpret_cast<uint64_t *>(s.h_ctl);
+    g.h_valid = reinterpret_cast<uint32_t *>(s.h_ctl + 16 * N);
+    g.h_snap = g.h_valid + N;
+    g.h_todo = g.h_snap + N;
+    g.h_off = g.h_todo + N;
+    g.d_ts = reinterpret_cast<const uint64_t *>(s.d_ctl);
+    g.d_valid = reinterpret_cast<const uint32_t *>(s.d_ctl + 16 * N);
+    g.d_snap = g.d_valid + N;
+    g.d_todo = g.d_snap + N;
+    g.d_off = g.d_todo + N;
+    return g;
+}
+
+void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
+{
+    const GpuCtl g = gpu_ctl(c, s);
+    rp.hits = s.d_hits;
+    rp.tries = s.d_tries;
+    rp.nhits = s.h_totals[0];
+    rp.valid = g.d_valid;
+    rp.ts = g.d_ts;
+    rp.snaps = c->d_snaps;
+    rp.snap_idx = g.d_snap;
+    rp.todo = g.d_todo;
+    rp.rbuf = s.d_rbuf;
+    rp.acc = s.d_acc;
+    rp.adds = s.d_adds;
+}
+
+uint32_t slot_valid(const Slot &s, uint32_t b)
+{
+    const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
+    uint64_t n = s.nsamples > first ? s.nsamples - first : 0;
+    return (uint32_t)(n > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : n);
+}
+
+/* one resolve pass over s.resolve_ntodo buffers, and the download of the reports; asynchronous */
+int gpu_launch_pass(msd_ctx *c, Slot &s)
+{
+    const GpuCtl g = gpu_ctl(c, s);
+    const uint32_t nsn = msd_gpu_resolve_nsnaps(&c->resolver);
+    for (uint32_t i = c->snaps_uploaded; i < nsn; ++i) {
+        uint32_t *stage = c->h_snaps + (size_t)i * MSD_SNAP_WORDS;
+        memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i), sizeof(uint32_t) * MSD_SNAP_WORDS);
+        HIPCHK(c, hipMemcpyAsync(c->d_snaps + (size_t)i * MSD_SNAP_WORDS, stage, sizeof(uint32_t) * MSD_SNAP_WORDS,
+                                 hipMemcpyHostToDevice, c->aux_stream));
+    }
+    c->snaps_uploaded = nsn;
+    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
+    MsdResolveParams rp{};
+    gpu_params(c, s, rp);
+    int rc = msd_launch_resolve(&rp, s.resolve_ntodo, c->aux_stream);
+    if (rc)
+        return fail(c, rc, "resolve kernel launch failed");
+    HIPCHK(c, hipMemcpyAsync(s.h_rbuf, s.d_rbuf, sizeof(msd_rbuf) * s.nbuffers, hipMemcpyDeviceToHost, c->aux_stream));
+    return 0;
+}
+
+/* clocks, snapshot 0 = the live filter, first pass over every buffer.  The previous batch must
+ * have been committed: this is the earliest moment its successor can start. */
+int gpu_begin(msd_ctx *c, Slot &s)
+{
+    const GpuCtl g = gpu_ctl(c, s);
+    for (uint32_t b = 0; b < s.nbuffers; ++b)
+        g.h_valid[b] = slot_valid(s, b);
+    msd_gpu_resolve_begin(&c->resolver, s.nbuffers, g.h_valid, g.h_ts, g.h_snap, g.h_todo, &s.resolve_ntodo);
+    c->snaps_uploaded = 0;
+    int rc = gpu_launch_pass(c, s);
+    s.resolve_inflight = rc == 0;
+    return rc;
+}
+
+/* Returns 1 when the batch has to go through the host resolver instead (nothing committed). */
+int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
+{
+    const uint32_t n = s.nbuffers;
+    const GpuCtl g = gpu_ctl(c, s);
+    const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double t_kernel = 0, t_replay = 0;
+    uint32_t npass = 0;
+    const bool early = s.resolve_inflight;
+    if (!s.resolve_inflight) {
+        int rc = gpu_begin(c, s);
+        if (rc)
+            return rc;
+    }
+    for (uint32_t pass = 0;; ++pass) {
+        auto k0 = tnow();
+        ++npass;
+        HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+        bool long_lists = false;
+        for (uint32_t b = 0; b < n && !long_lists; ++b)
+            long_lists = s.h_rbuf[b].nadds > MSD_RB_ADD_INLINE;
+        if (long_lists) {
+            HIPCHK(c, hipMemcpyAsync(c->h_adds, s.d_adds, sizeof(uint32_t) * MSD_RB_MSG_CAP * n, hipMemcpyDeviceToHost,
+                                     c->aux_stream));
+            HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+        }
+        auto k1 = tnow();
+        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, pass, SNAP_CAP, g.h_snap, g.h_todo,
+                                        &s.resolve_ntodo);
+        t_kernel += tms(k0, k1);
+        t_replay += tms(k1, tnow());
+        if (rc == 0)
+            break;
+        if (rc < 0) {
+            s.resolve_inflight = false;
+            return 1;
+        }
+        rc = gpu_launch_pass(c, s);
+        if (rc)
+            return rc;
+    }
+    s.resolve_inflight = false;
+    auto e0 = tnow();
+    msd_gpu_resolve_commit(&c->resolver, n, g.h_valid, s.h_rbuf);
+
+    uint32_t total = 0;
+    c->out_buf.clear();
+    for (uint32_t b = 0; b < n; ++b) {
+        g.h_off[b] = total;
+        total += s.h_rbuf[b].nmsgs;
+        c->out_buf.insert(c->out_buf.end(), s.h_rbuf[b].nmsgs, b);
+    }
+    g.h_off[n] = total;
+    if (total) { /* message records and their signal power, asynchronously */
+        int rc = ensure_req(c, s, total);
+        if (!rc)
+            rc = ensure_msgs(c, total);
+        if (rc)
+            return rc;
+        MsdResolveParams rp{};
+        gpu_params(c, s, rp);
+        HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
+        rc = msd_launch_emit(&rp, n, g.d_off, c->d_msgs, s.d_req, c->aux_stream);
+        if (rc)
+            return fail(c, rc, "emit kernel launch failed");
+        MsdScanParams p{};
+        fill_params(c, s, p);
+        rc = msd_launch_power(&p, format, s.d_req, total, reinterpret_cast<unsigned long long *>(s.d_pow), c->aux_stream);
+        if (rc)
+            return fail(c, rc, "power kernel launch failed");
+        HIPCHK(c, hipMemcpyAsync(c->h_msgs, c->d_msgs, sizeof(msd_message) * total, hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipMemcpyAsync(s.h_req, s.d_req, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, c->aux_stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_emit, c->aux_stream));
+    /* the filter is final for this batch: the next one can start its first pass behind the copies */
+    if (c->outstanding > 1) {
+        Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
+        if (&nx != &s && nx.busy && nx.download_started && nx.gpu_resolve && !nx.resolve_inflight) {
+            int rc = gpu_begin(c, nx);
+            if (rc)
+                return rc;
+        }
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_emit));
+    auto e1 = tnow();
+    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), c->h_msgs, s.h_req, c->out_buf.data(), s.h_pow,
+                      total);
+    if (trace)
+        fprintf(stderr, "gpu resolve: %u passes%s, wait+copies %.3f ms, replay %.3f ms, commit+emit+power+download %.3f ms, "
+                "power stats %.3f ms\n", npass, early ? " (first one launched early)" : "", t_kernel, t_replay, tms(e0, e1),
+                tms(e1, tnow()));
+    if (sink)
+        for (uint32_t i = 0; i < total; ++i)
+            sink(&c->h_msgs[i], user);
     return 0;
 }
 
@@ -511,11 +735,55 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     }
 
     auto t0 = std::chrono::steady_clock::now();
+    const char *dbgflags = getenv("MSD_DEBUG_FLAGS"); /* perf experiments with incomplete candidates */
+    const bool skip_resolve = dbgflags && (atoi(dbgflags) & 0x1c);
+    if (s.gpu_resolve) {
+        rc = (ts_override || skip_resolve) ? 1 : finish_gpu(c, s, format, sink, user);
+        if (rc < 0)
+            return rc;
+        if (rc == 0) {
+            auto t1 = std::chrono::steady_clock::now();
+            if (c->outstanding > 1) {
+                Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
+                if (&nx != &s && nx.busy && !nx.download_started) {
+                    rc = start_download(c, nx, c->cfg.format);
+                    if (rc)
+                        return rc;
+                }
+            }
+            if (getenv("MSD_RESOLVE_TRACE")) {
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                fprintf(stderr, "finish: wait-download %.3f  means %.3f  gpu resolve+power+sink %.3f ms\n", ms(ta, tb),
+                        ms(tb, t0), ms(t0, t1));
+            }
+            float ms = 0;
+            c->timing.hits = H;
+            c->timing.tries = Tn;
+            if (hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
+                c->timing.scan_kernel_ms = ms;
+            if (hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
+                c->timing.other_kernels_ms = ms;
+            if (hipEventElapsedTime(&ms, s.ev_copy0, s.ev_copy1) == hipSuccess)
+                c->timing.d2h_ms = ms;
+            c->timing.resolve_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+            s.busy = false;
+            return 0;
+        }
+        /* the host resolver takes the batch: it needs the lists after all */
+        rc = ensure_host(c, s, H, Tn);
+        if (rc)
+            return rc;
+        if (H)
+            HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->aux_stream));
+        if (Tn)
+            HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->aux_stream));
+        HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+        c->timing.reruns++;
+    }
     c->out_msgs.clear();
     c->out_req.clear();
     c->out_buf.clear();
-    const char *dbgflags = getenv("MSD_DEBUG_FLAGS"); /* perf experiments with incomplete candidates */
-    if (!(dbgflags && (atoi(dbgflags) & 0x1c)))
+    if (!skip_resolve)
     msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
                       c->cfg.mode_ac ? s.h_ac : nullptr, c->cfg.mode_ac ? s.h_ac_totals[0] : 0, ts_override,
                       emit_thunk, c);
@@ -608,11 +876,15 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
     s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
+    auto tl0 = std::chrono::steady_clock::now();
     rc = enqueue(c, s, c->cfg.format, nullptr);
     if (rc) {
         s.busy = false;
         return rc;
     }
+    if (getenv("MSD_RESOLVE_TRACE"))
+        fprintf(stderr, "launch: enqueue %.3f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     if (nsamples >= (uint64_t)TAIL_SAMPLES) {
         const int nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
         HIPCHK(c, hipMemcpyAsync(c->d_tail[nxt], s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
@@ -649,6 +921,8 @@ void destroy(msd_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream)
         (void)hipStreamSynchronize(c->copy_stream);
+    if (c->aux_stream)
+        (void)hipStreamSynchronize(c->aux_stream);
     if (c->d_timers) {
         unsigned long long t[16];
         if (hipMemcpy(t, c->d_timers, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -670,6 +944,9 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
+        (void)hipFree(s.d_rbuf); (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl);
+        if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
+        if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
@@ -681,6 +958,11 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_offsets);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
+    (void)hipFree(c->d_snaps); (void)hipFree(c->d_msgs);
+    if (c->h_adds) (void)hipHostFree(c->h_adds);
+    if (c->h_snaps) (void)hipHostFree(c->h_snaps);
+    if (c->h_msgs) (void)hipHostFree(c->h_msgs);
+    if (c->ev_emit) (void)hipEventDestroy(c->ev_emit);
     for (uint8_t *t : c->d_tail)
         (void)hipFree(t);
     (void)hipFree(c->d_stage);
@@ -750,7 +1032,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->own_stream = true;
     }
     CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    { /* the resolve/power follow-ups are short and on the critical path: let them jump the queued scans */
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
+    }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
     if (!c->tables) {
@@ -819,6 +1105,26 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
         for (hipEvent_t *e : evs)
             CK(hipEventCreate(e));
+    }
+    {
+        const char *g = getenv("MSD_GPU_RESOLVE");
+        c->gpu_resolve = g ? atoi(g) != 0 : false;
+    }
+    if (c->gpu_resolve && !cfg->mode_ac) {
+        const size_t ctl_bytes = (size_t)32 * c->max_buffers + 64;
+        for (Slot &s : c->slots) {
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rbuf), sizeof(msd_rbuf) * c->max_buffers));
+            CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_rbuf), sizeof(msd_rbuf) * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));
+            CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
+            memset(s.h_ctl, 0, ctl_bytes);
+        }
+        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
+        CK(hipEventCreate(&c->ev_emit));
     }
 #undef CK
     if (getenv("MSD_KERNEL_TIMING")) {

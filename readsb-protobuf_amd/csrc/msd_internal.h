@@ -74,6 +74,29 @@ typedef struct msd_wg_counts {
     uint32_t pad;
 } msd_wg_counts;
 
+/* ---- GPU resolve stage (msd_resolve_kernels.hip) ---- */
+#define MSD_RB_MSG_CAP 1024u   /* accepted Mode S messages of one buffer: at most 131072/135 = 970 */
+#define MSD_RB_ADD_INLINE 232u /* unique icaoFilterAdd addresses of one buffer reported inline */
+#define MSD_SNAP_WORDS 16384u  /* a filter snapshot on the device: slot[2][8192] */
+/* what the resolve kernel reports per buffer; 1 KiB */
+typedef struct msd_rbuf {
+    uint32_t ctr[16]; /* 0 preambles, 1 bad, 2 unknown, 3/4 accepted with 0/1 fixes, 6-10 preamble phases,
+                         11-15 best phases */
+    uint32_t nmsgs, nadds;
+    uint32_t version_used; /* index of the snapshot it was resolved against */
+    uint32_t fallback;     /* the buffer needs the host path (cannot happen with valid candidate lists) */
+    uint64_t end_now;      /* Modes.ifile_now when the buffer is done */
+    uint64_t pad;
+    uint32_t adds[MSD_RB_ADD_INLINE]; /* addresses passed to icaoFilterAdd, first occurrence order */
+} msd_rbuf;
+/* an accepted message before it is turned into a msd_message */
+typedef struct msd_acc {
+    uint32_t pos; /* batch-relative scan position */
+    uint32_t try_index;
+    int32_t score;
+    uint32_t pad;
+} msd_acc;
+
 /* ---- host tables (msd_tables.c) ---- */
 #define MSD_LUT_STRIDE 136u /* folded UC8 table row pitch in u16 (bank spread) */
 typedef struct msd_tables {
@@ -130,6 +153,22 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
                        struct msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
                        const uint64_t *power, uint64_t nmsgs);
+
+/* ---- host half of the GPU resolve (msd_resolve.c): the cross-buffer replay ----
+ * begin: clocks, snapshot 0 (= the live filter), every buffer on the to-do list.
+ * replay: after a kernel pass, walks the buffers' add lists (rb[b].adds, or all_adds[b][MSD_RB_MSG_CAP]
+ * for a buffer with more than MSD_RB_ADD_INLINE) and flip times in order, decides which
+ * membership version each buffer has to see; returns 0 when every buffer saw the right one,
+ * 1 when `todo` (and maybe new snapshots) need another pass, -1 when the batch must go through
+ * msd_resolve_batch instead (nothing has been committed in that case).
+ * commit: counters, clocks and the filter, once replay returned 0. */
+void msd_gpu_resolve_begin(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, uint64_t *ts,
+                           uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
+uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r);
+const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index);
+int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
+                           uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
+void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
 
 #ifdef __cplusplus
 }

@@ -34,9 +34,26 @@ typedef struct MsdScanParams {
                              2 = stop after the conversion (results are then incomplete) */
 } MsdScanParams;
 
+typedef struct MsdResolveParams {
+    const msd_hit *hits; /* the batch's ordered candidate lists, as the gather kernel left them */
+    const msd_try *tries;
+    uint64_t nhits;
+    const uint32_t *valid;    /* [buffer] new samples */
+    const uint64_t *ts;       /* [buffer][2] sampleTimestamp, sysTimestamp */
+    const uint32_t *snaps;    /* [snapshot][MSD_SNAP_WORDS] */
+    const uint32_t *snap_idx; /* [buffer] snapshot to resolve against */
+    const uint32_t *todo;     /* [workgroup] buffer to resolve */
+    msd_rbuf *rbuf;           /* [buffer] */
+    msd_acc *acc;             /* [buffer][MSD_RB_MSG_CAP] */
+    uint32_t *adds;           /* [buffer][MSD_RB_MSG_CAP]: the complete add lists (msd_rbuf holds the first ones) */
+} MsdResolveParams;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
+int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const uint32_t *d_offsets,
+                    msd_message *dense, uint64_t *dense_req, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets, uint64_t *totals,

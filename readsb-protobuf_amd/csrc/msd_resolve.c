@@ -365,6 +365,7 @@ struct msd_batch_state {
     int mode_ac;
     uint32_t *todo;
     uint32_t ntodo;
+    msd_filter work; /* GPU resolve: the filter behind the last replayed buffer */
 };
 
 static void push_msg(buf_result *br, const msd_message *mm, uint64_t req)
@@ -805,6 +806,90 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
     r->ifile_now = bs->res[nbuffers - 1].end_now;
     if (trace)
         fprintf(stderr, "resolve: commit %.3f ms\n", now_ms() - tc);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* host half of the GPU resolve: only the cross-buffer replay stays here                     */
+/* ---------------------------------------------------------------------------------------- */
+
+void msd_gpu_resolve_begin(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, uint64_t *ts,
+                           uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo)
+{
+    struct msd_batch_state *bs = batch_state(r, nbuffers);
+    uint64_t counter = r->sample_counter;
+    for (uint32_t b = 0; b < nbuffers; ++b) { /* sdr_ifile.c:187-190, startup_time = 0 */
+        const uint64_t sample_ts = (uint64_t)(counter * 12e6 / 2400000.0);
+        ts[2 * b] = sample_ts;
+        ts[2 * b + 1] = sample_ts / 12000u;
+        counter += valid[b];
+        snap_idx[b] = 0;
+        todo[b] = b;
+    }
+    *ntodo = nbuffers;
+    bs->nsnaps = 0;
+    push_snapshot(bs, &r->filter);
+}
+
+uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r)
+{
+    return r->batch ? r->batch->nsnaps : 0;
+}
+
+const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index)
+{
+    return &r->batch->snaps[index].slot[0][0];
+}
+
+int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
+                           uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo)
+{
+    struct msd_batch_state *bs = r->batch;
+    bs->work = r->filter;
+    uint32_t version = 0, n = 0;
+    for (uint32_t b = 0; b < nbuffers; ++b) {
+        const msd_rbuf *br = &rb[b];
+        if (br->fallback)
+            return -1;
+        snap_idx[b] = version;
+        if (br->version_used != version)
+            todo[n++] = b;
+        int changed = 0;
+        const uint32_t *adds = br->nadds > MSD_RB_ADD_INLINE ? all_adds + (size_t)b * MSD_RB_MSG_CAP : br->adds;
+        for (uint32_t i = 0; i < br->nadds; ++i)
+            changed |= filter_add(&bs->work, adds[i]);
+        changed |= filter_expire(&bs->work, br->end_now); /* readsb.c:331, after the buffer */
+        if (changed && b + 1 < nbuffers) {
+            version = push_snapshot(bs, &bs->work);
+            if (bs->nsnaps > max_snaps)
+                return -1;
+        }
+    }
+    *ntodo = n;
+    if (n == 0)
+        return 0;
+    return pass >= MAX_SPECULATIVE_PASSES ? -1 : 1;
+}
+
+void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb)
+{
+    msd_stats *st = r->stats;
+    for (uint32_t b = 0; b < nbuffers; ++b) {
+        const msd_rbuf *br = &rb[b];
+        st->demod_preambles += br->ctr[C_PREAMBLES];
+        st->demod_rejected_bad += br->ctr[C_BAD];
+        st->demod_rejected_unknown_icao += br->ctr[C_UNKNOWN];
+        for (int k = 0; k < 3; ++k)
+            st->demod_accepted[k] += br->ctr[C_ACC0 + k];
+        for (int k = 0; k < 5; ++k) {
+            st->demod_preamblePhase[k] += br->ctr[C_PPHASE0 + k];
+            st->demod_bestPhase[k] += br->ctr[C_BPHASE0 + k];
+        }
+        st->samples_processed += (uint64_t)valid[b] + MSD_OVERLAP; /* readsb.c:835 */
+        st->buffers++;
+        r->sample_counter += valid[b];
+    }
+    r->filter = r->batch->work;
+    r->ifile_now = rb[nbuffers - 1].end_now;
 }
 
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,

@@ -1,0 +1,477 @@
+/*
+ * msd_resolve_kernels.hip -- the ordered resolve stage on the GPU: one workgroup per buffer replays
+ * demodulate2400's state machine (skip-ahead, ICAO filter reads, accept/reject, counters,
+ * demod_2400.c:236-428 + mode_s.c:311-409,424-555,717-726) over the candidate lists the scan
+ * kernel left in HBM, against a snapshot of the ICAO filter.  The host keeps only what is really
+ * sequential *across* buffers: replaying the ~50 filter adds per buffer and the 60 s flips to
+ * decide which snapshot ("membership version") each buffer must see, and re-running the few
+ * buffers that saw another one (msd_resolve.c explains why that converges to the exact result).
+ *
+ * Inside a buffer two things are sequential: the skip-ahead (an accepted message hides the next
+ * 134/268 positions) and addresses the buffer itself adds.  Both are cheap once the expensive,
+ * independent part -- hashing and probing the filter for every try, scoring, picking the best
+ * phase -- has been done for all hits in parallel (phase P).  Phase S then walks the hits in order
+ * on one lane, only re-evaluating a hit when one of the buffer's own *new* addresses (not in the
+ * snapshot) could change its score; phase E builds the message records in parallel.
+ */
+#include <hip/hip_runtime.h>
+
+#include "modes_hip.h"
+#include "msd_internal.h"
+#include "msd_kernels.h"
+
+namespace {
+
+constexpr int RT = 256;    /* threads per workgroup (one workgroup per buffer) */
+constexpr int SEG = 1024;  /* hits staged per segment */
+constexpr uint32_t VACANT = 0xFFFFFFFFu;
+constexpr uint32_t SLOTS = 8192u;
+
+__device__ __forceinline__ uint32_t hash24(uint32_t a) /* icao_filter.c:44-65 */
+{
+    uint32_t h = 0;
+    h += a & 0xff;         h += h << 10; h ^= h >> 6;
+    h += (a >> 8) & 0xff;  h += h << 10; h ^= h >> 6;
+    h += (a >> 16) & 0xff; h += h << 10; h ^= h >> 6;
+    h += h << 3;
+    h ^= h >> 11;
+    h += h << 15;
+    return h & (SLOTS - 1);
+}
+
+__device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint32_t start)
+{
+    uint32_t h = start;
+    for (;;) {
+        const uint32_t v = t[h];
+        if (v == addr)
+            return true;
+        if (v == VACANT)
+            return false;
+        h = (h + 1) & (SLOTS - 1);
+        if (h == start)
+            return false;
+    }
+}
+
+/* icaoFilterTest (icao_filter.c:99-119) against a snapshot: two tables of 8192 slots */
+__device__ __forceinline__ bool snap_known(const uint32_t *snap, uint32_t addr)
+{
+    const uint32_t start = hash24(addr);
+    return table_has(snap, addr, start) || table_has(snap + SLOTS, addr, start);
+}
+
+struct TryView {
+    uint32_t w0, w3; /* message bytes 0..3 and 12..15 (tp, errbit in the top half) */
+    uint32_t addr, crc;
+};
+
+__device__ __forceinline__ TryView load_try(const msd_try *t)
+{
+    const uint4 lo = *reinterpret_cast<const uint4 *>(t);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
+    TryView v;
+    v.w0 = lo.x;
+    v.w3 = lo.w;
+    v.addr = hi.x;
+    v.crc = hi.y;
+    return v;
+}
+
+/* A try as phase P keeps it in LDS (everything the score and the verdict need):
+ *   19 address known   20-24 DF   25-27 phase-4   28-35 corrected bit (0xff none)
+ *   36 DF11 with IID 0   40-63 address
+ * and the best phase of a hit: the same word plus  0-15 score (int16)   16-18 offset of the try. */
+__device__ __forceinline__ uint64_t pack_try(const TryView &v, bool known)
+{
+    const uint32_t df = (v.w0 & 0xffu) >> 3, tp = (v.w3 >> 16) & 0xffu, errbit = v.w3 >> 24;
+    return ((uint64_t)(known ? 1u : 0u) << 19) | ((uint64_t)df << 20) | ((uint64_t)(tp - 4) << 25) |
+           ((uint64_t)errbit << 28) | ((uint64_t)((v.crc & 0x7fu) == 0 ? 1u : 0u) << 36) |
+           ((uint64_t)(v.addr & 0xffffffu) << 40);
+}
+
+/* scoreModesMessage (mode_s.c:311-409) on a packed try */
+__device__ __forceinline__ int score_packed(uint64_t t)
+{
+    const uint32_t df = (uint32_t)(t >> 20) & 31u;
+    const bool known = (t >> 19) & 1u;
+    const int nerr = (((uint32_t)(t >> 28) & 0xffu) != 0xffu) ? 1 : 0;
+    switch (df) {
+    case 11:
+        if ((t >> 36) & 1u)
+            return (known ? 1600 : 750) / (nerr + 1);
+        return known ? 1000 / (nerr + 1) : -1;
+    case 17: case 18:
+        return (known ? 1800 : 1400) / (nerr + 1);
+    case 20: case 21:
+        return known ? 1000 : -2;
+    default: /* 0, 4, 5, 16, 24: address/parity */
+        return known ? 1000 : -1;
+    }
+}
+
+__device__ __forceinline__ uint32_t res_len(uint64_t r) /* samples hidden by the message */
+{
+    return (((uint32_t)(r >> 20) & 0x10u) ? 112u : 56u) * 12u / 5u;
+}
+
+constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
+
+__device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr)
+{
+    uint32_t hs = (addr * 2654435761u) >> 21;
+    for (;;) {
+        const uint32_t v = addset[hs];
+        if (v == addr)
+            return true;
+        if (v == VACANT)
+            return false;
+        hs = (hs + 1) & (ADDSET - 1);
+    }
+}
+
+__global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams P)
+{
+    __shared__ msd_hit seg_hits[SEG];
+    __shared__ uint64_t seg_res[SEG];
+    __shared__ uint64_t seg_try[5 * SEG];
+    __shared__ uint16_t seg_toff[SEG + 1];
+    __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
+    __shared__ uint32_t cand[SEG / 32]; /* hits whose best phase scores >= 0 */
+    __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
+    __shared__ uint32_t sh_ctr[16];
+    __shared__ uint32_t sh_wsum[RT / 64];
+    __shared__ uint64_t sh_range[2];
+    __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_next, sh_nacc, sh_newaddr;
+
+    const int tid = threadIdx.x;
+    const uint32_t b = P.todo[blockIdx.x];
+    const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * (2 * SLOTS);
+    const uint32_t mlen = P.valid[b];
+    const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
+    const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
+    msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
+    uint32_t *adds = P.adds + (size_t)b * MSD_RB_MSG_CAP;
+    msd_rbuf *rb = P.rbuf + b;
+
+    for (int i = tid; i < (int)ADDSET; i += RT)
+        addset[i] = VACANT;
+    if (tid < 16)
+        sh_ctr[tid] = 0;
+    if (tid < 2) { /* range of this buffer's hits in the ordered list */
+        const uint64_t want = base + (tid ? MSD_CHUNK_SAMPLES : 0);
+        uint64_t lo = 0, hi = P.nhits;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (MSD_HIT_POS(P.hits[mid]) < want)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        sh_range[tid] = lo;
+    }
+    if (tid == 0) {
+        sh_resume = base;
+        sh_now = sys_ts; /* demod_2400.c:252-255 */
+        sh_nmsgs = sh_nadds = 0;
+    }
+    __syncthreads();
+    const uint64_t hb = sh_range[0], he = sh_range[1];
+
+    for (uint64_t s0 = hb; s0 < he; s0 += SEG) {
+        const uint32_t n = (he - s0 < (uint64_t)SEG) ? (uint32_t)(he - s0) : (uint32_t)SEG;
+        for (uint32_t i = tid; i < n; i += RT)
+            seg_hits[i] = P.hits[s0 + i];
+        if (tid == 0) {
+            sh_seg_resume = sh_resume;
+            sh_nacc = 0;
+        }
+        __syncthreads();
+        /* ---- phase P: stage every try of the segment in LDS with its filter verdict ---- */
+        constexpr uint32_t PER = SEG / RT; /* consecutive hits per thread */
+        uint32_t nl[PER], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = tid * PER + k;
+            nl[k] = i < n ? MSD_HIT_NLIVE(seg_hits[i]) : 0u;
+            mine += nl[k];
+        }
+        uint32_t incl = mine; /* block-wide exclusive prefix of the try counts */
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += up;
+        }
+        if ((tid & 63) == 63)
+            sh_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = incl - mine;
+        for (int w = 0; w < (tid >> 6); ++w)
+            off += sh_wsum[w];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = tid * PER + k;
+            if (i <= n)
+                seg_toff[i] = (uint16_t)off; /* entry n = all tries of the segment */
+            if (nl[k]) {
+                const msd_try *t = P.tries + MSD_HIT_TRY(seg_hits[i]);
+                for (uint32_t q = 0; q < nl[k]; ++q) {
+                    const TryView v = load_try(t + q);
+                    const bool known = snap_known(snap, v.addr) || addset_has(addset, v.addr);
+                    seg_try[off + q] = pack_try(v, known);
+                }
+            }
+            off += nl[k];
+        }
+        if (tid == RT - 1 && n == SEG)
+            seg_toff[SEG] = (uint16_t)off;
+        __syncthreads();
+        const uint32_t ntries = seg_toff[n];
+
+        uint32_t start = 0;
+        while (start < n) {
+            if (tid < (int)(SEG / 32))
+                cand[tid] = 0;
+            __syncthreads();
+            /* best phase of every remaining hit: strict '>' so the first-tried phase wins ties
+             * (demod_2400.c:218); a position without tries scores -2 */
+            for (uint32_t i = start + tid; i < n; i += RT) {
+                const uint32_t nlive = MSD_HIT_NLIVE(seg_hits[i]), o = seg_toff[i];
+                int bestscore = -2;
+                uint64_t best = 0;
+                for (uint32_t q = 0; q < nlive; ++q) {
+                    const uint64_t t = seg_try[o + q];
+                    const int sc = score_packed(t);
+                    if (sc > bestscore) {
+                        bestscore = sc;
+                        best = t | ((uint64_t)q << 16);
+                    }
+                }
+                seg_res[i] = best | ((uint64_t)bestscore & 0xffffu);
+                if (bestscore >= 0)
+                    atomicOr(&cand[i >> 5], 1u << (i & 31));
+            }
+            __syncthreads();
+            /* ---- phase S: the ordered walk over the hits that could be messages, on one lane ---- */
+            if (tid == 0) {
+                uint64_t resume = sh_resume, now = sh_now;
+                uint32_t nmsgs = sh_nmsgs, nadds = sh_nadds, nacc = sh_nacc;
+                uint32_t c_unk = 0, c_acc0 = 0, c_acc1 = 0, next = n;
+                bool stop = false;
+                for (uint32_t w = start >> 5; w < (n + 31) / 32 && !stop; ++w) {
+                    uint32_t m = cand[w];
+                    if (w == (start >> 5))
+                        m &= ~0u << (start & 31);
+                    while (m) {
+                        const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint64_t a = MSD_HIT_POS(seg_hits[i]);
+                        if (a >= end) {
+                            stop = true;
+                            break;
+                        }
+                        if (a < resume)
+                            continue; /* inside the previous message (demod_2400.c:416) */
+                        const uint64_t r = seg_res[i];
+                        const uint32_t known = (uint32_t)(r >> 19) & 1u, df = (uint32_t)(r >> 20) & 31u;
+                        const uint32_t tp = 4 + ((uint32_t)(r >> 25) & 7u), errbit = (uint32_t)(r >> 28) & 0xffu;
+                        const uint32_t addr = (uint32_t)(r >> 40);
+                        const uint32_t j = (uint32_t)(a - base);
+                        const uint64_t tsmsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
+                        now = sys_ts + (tsmsg - sample_ts) / 12000u; /* demod_2400.c:363-366, before decode */
+                        /* acceptance part of decodeModesMessage (mode_s.c:424-555) */
+                        const bool nerr = errbit != 0xffu;
+                        bool reject;
+                        if (df == 11)
+                            reject = nerr && !known; /* mode_s.c:492-498 */
+                        else if (df == 17 || df == 18)
+                            reject = nerr && errbit >= 8 && errbit <= 31 && !known; /* mode_s.c:522-526 */
+                        else
+                            reject = !known;
+                        if (reject) {
+                            c_unk++;
+                            continue;
+                        }
+                        bool fresh = false;
+                        if (!nerr && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) { /* mode_s.c:717-726 */
+                            uint32_t hs = (addr * 2654435761u) >> 21;
+                            bool seen = false;
+                            while (addset[hs] != VACANT) {
+                                if (addset[hs] == addr) {
+                                    seen = true;
+                                    break;
+                                }
+                                hs = (hs + 1) & (ADDSET - 1);
+                            }
+                            if (!seen) {
+                                addset[hs] = addr;
+                                if (nadds < MSD_RB_ADD_INLINE)
+                                    rb->adds[nadds] = addr;
+                                if (nadds < MSD_RB_MSG_CAP)
+                                    adds[nadds] = addr;
+                                nadds++;
+                                fresh = !known; /* a new aircraft: the hits behind it must see it */
+                            }
+                        }
+                        if (nerr)
+                            c_acc1++;
+                        else
+                            c_acc0++;
+                        sh_ctr[11 + tp - 4]++;
+                        if (nmsgs < MSD_RB_MSG_CAP) {
+                            msd_acc rec;
+                            rec.pos = (uint32_t)a;
+                            rec.try_index = (uint32_t)(MSD_HIT_TRY(seg_hits[i]) + ((uint32_t)(r >> 16) & 7u));
+                            rec.score = (int32_t)(int16_t)(r & 0xffffu);
+                            rec.pad = 0;
+                            acc[nmsgs] = rec;
+                        }
+                        nmsgs++;
+                        accidx[nacc++] = (uint16_t)i;
+                        resume = a + res_len(r) + 1; /* j += len, then the loop's ++ */
+                        if (fresh) {
+                            sh_newaddr = addr;
+                            next = i + 1;
+                            stop = true;
+                            break;
+                        }
+                    }
+                }
+                sh_resume = resume;
+                sh_now = now;
+                sh_nmsgs = nmsgs;
+                sh_nadds = nadds;
+                sh_nacc = nacc;
+                sh_next = next;
+                sh_ctr[2] += c_unk;
+                sh_ctr[3] += c_acc0;
+                sh_ctr[4] += c_acc1;
+            }
+            __syncthreads();
+            /* ---- phase C: the counters of every hit that no accepted message hides, in parallel ---- */
+            const uint32_t stop_at = sh_next, nacc = sh_nacc;
+            const uint64_t seg_resume = sh_seg_resume;
+            uint32_t c_pre = 0, c_bad = 0, c_unk = 0, c_p01 = 0, c_p23 = 0, c_p4 = 0;
+            for (uint32_t i = start + tid; i < stop_at; i += RT) {
+                const msd_hit h = seg_hits[i];
+                const uint64_t a = MSD_HIT_POS(h);
+                if (a >= end)
+                    continue;
+                uint32_t lo = 0, hi = nacc; /* number of accepted hits in front of i */
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (accidx[mid] < i)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                uint64_t resume = seg_resume;
+                if (lo) {
+                    const uint32_t k = accidx[lo - 1];
+                    resume = MSD_HIT_POS(seg_hits[k]) + res_len(seg_res[k]) + 1;
+                }
+                if (a < resume)
+                    continue;
+                const uint32_t mask = MSD_HIT_MASK(h);
+                c_pre++;
+                c_p01 += mask & 1u;
+                c_p23 += (mask >> 1) & 1u;
+                c_p4 += (mask >> 2) & 1u;
+                const uint32_t sc = (uint32_t)seg_res[i] & 0xffffu;
+                c_bad += sc == 0xfffeu;
+                c_unk += sc == 0xffffu;
+            }
+            if (c_pre) {
+                atomicAdd(&sh_ctr[0], c_pre);
+                if (c_bad) atomicAdd(&sh_ctr[1], c_bad);
+                if (c_unk) atomicAdd(&sh_ctr[2], c_unk);
+                if (c_p01) { atomicAdd(&sh_ctr[6], c_p01); atomicAdd(&sh_ctr[7], c_p01); }
+                if (c_p23) { atomicAdd(&sh_ctr[8], c_p23); atomicAdd(&sh_ctr[9], c_p23); }
+                if (c_p4) atomicAdd(&sh_ctr[10], c_p4);
+            }
+            start = stop_at;
+            if (start < n) { /* the walk stopped at a new aircraft: its later tries are known now */
+                const uint32_t x = sh_newaddr;
+                for (uint32_t t = tid; t < ntries; t += RT) {
+                    const uint64_t v = seg_try[t];
+                    if ((uint32_t)(v >> 40) == x)
+                        seg_try[t] = v | (1ull << 19);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (tid == 0) {
+        for (int k = 0; k < 16; ++k)
+            rb->ctr[k] = sh_ctr[k];
+        rb->nmsgs = sh_nmsgs;
+        rb->nadds = sh_nadds;
+        rb->version_used = P.snap_idx[b];
+        rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP) ? 1u : 0u;
+        rb->end_now = sh_now;
+    }
+}
+
+/* The accepted messages of buffer b as msd_message records at dense[offsets[b]..), plus the request
+ * list of the signal power kernel. */
+__global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const uint32_t *offsets,
+                                                       msd_message *dense, uint64_t *dense_req)
+{
+    const uint32_t b = blockIdx.x;
+    const uint32_t o = offsets[b], nm = offsets[b + 1] - o;
+    const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
+    const uint32_t base = b * MSD_CHUNK_SAMPLES;
+    const msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
+    for (uint32_t m = threadIdx.x; m < nm; m += blockDim.x) {
+        const msd_acc rec = acc[m];
+        const msd_try *t = P.tries + rec.try_index;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(t);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
+        const uint32_t df = (lo.x & 0xffu) >> 3, tp = (lo.w >> 16) & 0xffu, errbit = lo.w >> 24;
+        const uint32_t msgbits = (df & 0x10u) ? 112u : 56u;
+        const uint32_t j = rec.pos - base;
+        msd_message mm;
+        mm.timestampMsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
+        mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+        mm.signalLevel = 0.0;
+        mm.addr = hi.x; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
+        mm.crc = hi.y;
+        mm.score = rec.score;
+        mm.msgtype = (uint8_t)df;
+        mm.msgbits = (uint8_t)msgbits;
+        mm.correctedbits = errbit != 0xffu ? 1 : 0;
+        mm.bestphase = (uint8_t)tp;
+        uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w & 0xffffu};
+        if (errbit != 0xffu)
+            w[errbit >> 5] ^= (0x80u >> (errbit & 7u)) << (8 * ((errbit >> 3) & 3u)); /* crc.c:417-425 */
+#pragma unroll
+        for (int k = 0; k < 14; ++k)
+            mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
+        mm.pad = 0;
+        dense[o + m] = mm;
+        dense_req[o + m] = ((uint64_t)rec.pos << 16) | (uint64_t)(msgbits * 12 / 5);
+    }
+}
+
+} /* namespace */
+
+extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream)
+{
+    if (ntodo == 0)
+        return 0;
+    hipLaunchKernelGGL(msd_resolve_kernel, dim3(ntodo), dim3(RT), 0, stream, *p);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const uint32_t *d_offsets,
+                               msd_message *dense, uint64_t *dense_req, hipStream_t stream)
+{
+    if (nbuffers == 0)
+        return 0;
+    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, d_offsets, dense, dense_req);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
