@@ -82,10 +82,13 @@ typedef struct msd_timing {
     float scan_kernel_ms;   /* the fused convert+scan+slice+CRC kernel */
     float other_kernels_ms; /* compaction (+ Mode A/C, + float means) */
     float d2h_ms;
-    float resolve_ms; /* host, ordered resolve */
+    float resolve_ms; /* ordered resolve stage, wall clock on the calling thread */
     uint64_t hits;    /* preamble positions reported by the GPU */
     uint64_t tries;   /* state-dependent candidate records reported by the GPU */
     uint64_t reruns;  /* batches re-run in halves because a candidate arena overflowed */
+    uint64_t resolve_passes;   /* passes of the GPU resolve kernel over this batch; 0 = resolved on the host */
+    uint64_t resolve_fallback; /* batches the GPU resolve handed to the host resolver (since msd_reset) */
+    uint64_t resolve_long_lists; /* passes that had to fetch the complete per-buffer add lists (since msd_reset) */
 } msd_timing;
 
 typedef struct msd_ctx msd_ctx;

@@ -89,6 +89,9 @@ class Timing(C.Structure):
         ("hits", C.c_uint64),
         ("tries", C.c_uint64),
         ("reruns", C.c_uint64),
+        ("resolve_passes", C.c_uint64),
+        ("resolve_fallback", C.c_uint64),
+        ("resolve_long_lists", C.c_uint64),
     ]
 
     def as_dict(self):

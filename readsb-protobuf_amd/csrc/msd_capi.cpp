@@ -110,6 +110,7 @@ struct msd_ctx {
     uint32_t *h_adds = nullptr; /* complete add lists, fetched only when a buffer needs them */
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
+    uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
     msd_message *d_msgs = nullptr, *h_msgs = nullptr;
     size_t msgs_cap = 0;
     hipEvent_t ev_emit = nullptr;
@@ -611,14 +612,15 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
         bool long_lists = false;
         for (uint32_t b = 0; b < n && !long_lists; ++b)
-            long_lists = s.h_rbuf[b].nadds > MSD_RB_ADD_INLINE;
+            long_lists = s.h_rbuf[b].nadds > c->inline_adds;
         if (long_lists) {
+            c->timing.resolve_long_lists++;
             HIPCHK(c, hipMemcpyAsync(c->h_adds, s.d_adds, sizeof(uint32_t) * MSD_RB_MSG_CAP * n, hipMemcpyDeviceToHost,
                                      c->aux_stream));
             HIPCHK(c, hipStreamSynchronize(c->aux_stream));
         }
         auto k1 = tnow();
-        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, pass, SNAP_CAP, g.h_snap, g.h_todo,
+        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap, g.h_todo,
                                         &s.resolve_ntodo);
         t_kernel += tms(k0, k1);
         t_replay += tms(k1, tnow());
@@ -633,6 +635,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return rc;
     }
     s.resolve_inflight = false;
+    c->timing.resolve_passes = npass;
     auto e0 = tnow();
     msd_gpu_resolve_commit(&c->resolver, n, g.h_valid, s.h_rbuf);
 
@@ -778,8 +781,9 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         if (Tn)
             HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->aux_stream));
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
-        c->timing.reruns++;
+        c->timing.resolve_fallback++;
     }
+    c->timing.resolve_passes = 0;
     c->out_msgs.clear();
     c->out_req.clear();
     c->out_buf.clear();
@@ -1107,8 +1111,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipEventCreate(e));
     }
     {
-        const char *g = getenv("MSD_GPU_RESOLVE");
-        c->gpu_resolve = g ? atoi(g) != 0 : false;
+        const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
+        c->gpu_resolve = g ? atoi(g) != 0 : true;
+        const char *ia = getenv("MSD_RESOLVE_INLINE_ADDS");
+        if (ia && atoi(ia) >= 0 && (uint32_t)atoi(ia) < MSD_RB_ADD_INLINE)
+            c->inline_adds = (uint32_t)atoi(ia);
     }
     if (c->gpu_resolve && !cfg->mode_ac) {
         const size_t ctl_bytes = (size_t)32 * c->max_buffers + 64;

@@ -157,7 +157,7 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
 /* ---- host half of the GPU resolve (msd_resolve.c): the cross-buffer replay ----
  * begin: clocks, snapshot 0 (= the live filter), every buffer on the to-do list.
  * replay: after a kernel pass, walks the buffers' add lists (rb[b].adds, or all_adds[b][MSD_RB_MSG_CAP]
- * for a buffer with more than MSD_RB_ADD_INLINE) and flip times in order, decides which
+ * for a buffer with more than inline_adds <= MSD_RB_ADD_INLINE) and flip times in order, decides which
  * membership version each buffer has to see; returns 0 when every buffer saw the right one,
  * 1 when `todo` (and maybe new snapshots) need another pass, -1 when the batch must go through
  * msd_resolve_batch instead (nothing has been committed in that case).
@@ -167,7 +167,7 @@ void msd_gpu_resolve_begin(msd_resolver *r, uint32_t nbuffers, const uint32_t *v
 uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r);
 const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index);
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
-                           uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
+                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
 void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
 
 #ifdef __cplusplus

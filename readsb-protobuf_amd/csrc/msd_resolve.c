@@ -841,7 +841,7 @@ const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index)
 }
 
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
-                           uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo)
+                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo)
 {
     struct msd_batch_state *bs = r->batch;
     bs->work = r->filter;
@@ -854,7 +854,7 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
         if (br->version_used != version)
             todo[n++] = b;
         int changed = 0;
-        const uint32_t *adds = br->nadds > MSD_RB_ADD_INLINE ? all_adds + (size_t)b * MSD_RB_MSG_CAP : br->adds;
+        const uint32_t *adds = br->nadds > inline_adds ? all_adds + (size_t)b * MSD_RB_MSG_CAP : br->adds;
         for (uint32_t i = 0; i < br->nadds; ++i)
             changed |= filter_add(&bs->work, adds[i]);
         changed |= filter_expire(&bs->work, br->end_now); /* readsb.c:331, after the buffer */

@@ -11,6 +11,13 @@ FIELDS = ("timestampMsg", "sysTimestampMsg", "signalLevel", "addr", "crc", "scor
           "correctedbits", "bestphase", "iid")
 
 
+@pytest.fixture(params=["gpu-resolve", "host-resolve"], autouse=True)
+def resolve_stage(request, monkeypatch):
+    """Every parity case runs with the ordered resolve stage on the GPU (default) and on host threads."""
+    monkeypatch.setenv("MSD_GPU_RESOLVE", "1" if request.param == "gpu-resolve" else "0")
+    return request.param
+
+
 def assert_same(got, gstats, want, wstats):
     assert len(got) == len(want), (len(got), len(want))
     for f in FIELDS:
@@ -92,12 +99,40 @@ def test_replay_cli_matches_oracle(pkg, oracle, torch_cuda, tmp_path, path):
 
 
 @pytest.mark.parametrize("threads", ["1", "3", "16"])
-def test_resolve_threads_and_membership_churn(pkg, oracle, torch_cuda, monkeypatch, threads):
+def test_resolve_threads_and_membership_churn(pkg, oracle, torch_cuda, monkeypatch, threads, resolve_stage):
     """The speculative buffer-parallel resolve must equal the sequential one for any thread count,
-    also when new aircraft appear in nearly every buffer (forces re-resolution and the serial tail)."""
+    also when new aircraft appear in nearly every buffer (forces re-resolution and the serial tail;
+    the GPU resolve gives such a batch to the host resolver after its pass limit)."""
     monkeypatch.setenv("MSD_RESOLVE_THREADS", threads)
-    run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 40 * 131072 + 17, seed=77, nfix=1, n_aircraft=30000,
-             msgs_per_sec=4000)
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 40 * 131072 + 17, seed=77, nfix=1, n_aircraft=30000,
+                        msgs_per_sec=4000)
+    t = dem.timing()
+    if resolve_stage == "gpu-resolve":
+        assert t["resolve_passes"] > 1 or t["resolve_fallback"] >= 1, t
+    else:
+        assert t["resolve_passes"] == 0 and t["resolve_fallback"] == 0, t
+
+
+def test_gpu_resolve_runs_and_converges(pkg, oracle, torch_cuda, resolve_stage):
+    """A stable aircraft population: the first batch needs a second pass (everything is new), later
+    batches one; no batch falls back to the host."""
+    if resolve_stage != "gpu-resolve":
+        pytest.skip("GPU resolve only")
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 64 * 131072, seed=11, nfix=1, batch=16 * 131072,
+                        n_aircraft=300, msgs_per_sec=3000)
+    t = dem.timing()
+    assert t["resolve_passes"] >= 1 and t["resolve_fallback"] == 0, t
+
+
+def test_gpu_resolve_long_add_lists(pkg, oracle, torch_cuda, resolve_stage, monkeypatch):
+    """More unique addresses in one buffer than a per-buffer report holds inline (232; 40 here, the
+    synthetic traffic peaks near 150): the complete add lists are fetched instead."""
+    if resolve_stage != "gpu-resolve":
+        pytest.skip("GPU resolve only")
+    monkeypatch.setenv("MSD_RESOLVE_INLINE_ADDS", "40")
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 8 * 131072, seed=12, nfix=0, n_aircraft=1000,
+                        msgs_per_sec=8000, overlap_permille=0)
+    assert dem.timing()["resolve_long_lists"] >= 1, dem.timing()
 
 
 def test_interference_storm_overflows_and_is_rerun_in_pieces(pkg, oracle, torch_cuda, monkeypatch):
