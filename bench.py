@@ -87,6 +87,8 @@ def main():
     dem = pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=0, device=local_rank,
                           max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21)
 
+    DEPTH = int(os.environ.get("MSD_BENCH_DEPTH", pkg.capi.PIPELINE_DEPTH))
+
     def one_step(collect_timing=None):
         dem.reset()
         nmsg = 0
@@ -96,7 +98,7 @@ def main():
         while True:
             m = min(batch, n - off)
             last = off + m >= n
-            if inflight == pkg.capi.PIPELINE_DEPTH:
+            if inflight == DEPTH:
                 msgs = dem.collect(copy=False)
                 nmsg += len(msgs)
                 first = msgs if first is None else first

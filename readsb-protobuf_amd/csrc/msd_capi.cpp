@@ -39,12 +39,15 @@ struct Slot {
     bool busy = false;
     bool download_started = false;
     bool gpu_resolve = false; /* the candidate lists stay in HBM: resolved there (msd_resolve_kernels.hip) */
-    bool resolve_inflight = false; /* its first resolve pass was launched while the previous batch finished */
+    bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
     uint32_t resolve_ntodo = 0;
-    msd_rbuf *d_rbuf = nullptr, *h_rbuf = nullptr;
+    msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
-    uint32_t *d_adds = nullptr;
-    uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] | offsets[n+1] */
+    uint32_t *d_adds = nullptr, *d_nmsgs = nullptr, *d_off = nullptr;
+    uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
+    msd_message *d_msgs = nullptr, *h_msgs = nullptr; /* message records of the emit kernel and their pinned copy */
+    uint32_t copied_msgs = 0;      /* how many of them the queued download covers */
+    hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
     /* batch description */
     const uint8_t *d_iq = nullptr;
     const uint8_t *d_prev = nullptr;
@@ -111,9 +114,8 @@ struct msd_ctx {
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
-    msd_message *d_msgs = nullptr, *h_msgs = nullptr;
-    size_t msgs_cap = 0;
-    hipEvent_t ev_emit = nullptr;
+    hipEvent_t ev_aux = nullptr;
+    uint32_t est_msgs = 0; /* messages of the last batch: sizes the speculative download of the next */
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -174,12 +176,19 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
     if (s.h_req) (void)hipHostFree(s.h_req);
     if (s.h_pow) (void)hipHostFree(s.h_pow);
+    if (s.h_msgs) (void)hipHostFree(s.h_msgs);
+    (void)hipFree(s.d_msgs);
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
+    s.h_msgs = s.d_msgs = nullptr;
     s.req_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_pow), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_pow), cap * sizeof(uint64_t)));
+    if (c->gpu_resolve) {
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_msgs), cap * sizeof(msd_message)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_msgs), cap * sizeof(msd_message)));
+    }
     s.req_cap = cap;
     return 0;
 }
@@ -306,14 +315,16 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     }
     HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
 
-    /* download of the totals on the copy stream, behind this batch's kernels only */
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.ev_kernels, 0));
-    HIPCHK(c, hipMemcpyAsync(s.h_totals, s.d_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost,
-                             c->copy_stream));
-    if (c->cfg.mode_ac)
-        HIPCHK(c, hipMemcpyAsync(s.h_ac_totals, s.d_ac_totals, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost,
-                                 c->copy_stream));
-    HIPCHK(c, hipEventRecord(s.ev_totals, c->copy_stream));
+    /* totals and per-buffer sums go to pinned host memory from this stream, right behind the kernels */
+    {
+        const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11;
+        int rc = msd_launch_publish(s.d_totals, c->cfg.mode_ac ? s.d_ac_totals : nullptr, s.d_sums,
+                                    fm ? s.d_fmeans : nullptr, s.nbuffers, s.h_totals, s.h_ac_totals, s.h_sums,
+                                    s.h_fmeans, c->stream);
+        if (rc)
+            return fail(c, rc, "publish kernel launch failed");
+    }
+    HIPCHK(c, hipEventRecord(s.ev_totals, c->stream));
     return 0;
 }
 
@@ -368,6 +379,8 @@ int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
             t.nbuffers = (uint32_t)((is_last ? total_buffers : (off + n) / MSD_CHUNK_SAMPLES) - b0);
             t.d_sums = s.d_sums + 2 * b0;
             t.d_fmeans = s.d_fmeans + 2 * b0;
+            t.h_sums = s.h_sums + 2 * b0;
+            t.h_fmeans = s.h_fmeans + 2 * b0;
             int rc = enqueue(c, t, format, nullptr);
             if (rc)
                 return rc;
@@ -443,7 +456,16 @@ int start_download(msd_ctx *c, Slot &s, int format)
 {
     if (s.download_started)
         return 0;
+    const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+    auto td0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipEventSynchronize(s.ev_totals));
+    if (trace) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, s.ev_start, s.ev_scan);
+        (void)hipEventElapsedTime(&b, s.ev_start, s.ev_kernels);
+        fprintf(stderr, "start_download: waited %.3f ms for the totals; scan %.3f ms, all kernels %.3f ms after its start\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(), a, b);
+    }
     const bool overflow = s.h_totals[2] || (c->cfg.mode_ac && s.h_ac_totals[2]);
     if (overflow) {
         int rc = rerun_in_pieces(c, s, format);
@@ -452,7 +474,10 @@ int start_download(msd_ctx *c, Slot &s, int format)
     }
     const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
     HIPCHK(c, hipEventRecord(s.ev_copy0, c->copy_stream));
-    s.gpu_resolve = c->gpu_resolve && !overflow && !c->cfg.mode_ac && s.nbuffers >= 4;
+    if (overflow) { /* rescanned in pieces and stitched on the host: the host resolver takes it */
+        s.gpu_resolve = false;
+        s.resolve_inflight = false;
+    }
     if (!overflow && !s.gpu_resolve) {
         int rc = ensure_host(c, s, H, Tn);
         if (rc)
@@ -470,13 +495,6 @@ int start_download(msd_ctx *c, Slot &s, int format)
                 HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->copy_stream));
         }
     }
-    if (s.nbuffers) {
-        HIPCHK(c, hipMemcpyAsync(s.h_sums, s.d_sums, sizeof(uint64_t) * 2 * s.nbuffers, hipMemcpyDeviceToHost,
-                                 c->copy_stream));
-        if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11)
-            HIPCHK(c, hipMemcpyAsync(s.h_fmeans, s.d_fmeans, sizeof(float) * 2 * s.nbuffers,
-                                     hipMemcpyDeviceToHost, c->copy_stream));
-    }
     HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
     s.download_started = true;
     return 0;
@@ -484,32 +502,20 @@ int start_download(msd_ctx *c, Slot &s, int format)
 
 constexpr uint32_t SNAP_CAP = 64; /* filter membership versions of one batch kept on the device */
 
-int ensure_msgs(msd_ctx *c, size_t n)
-{
-    if (n <= c->msgs_cap)
-        return 0;
-    size_t cap = c->msgs_cap ? c->msgs_cap : (size_t)1 << 14;
-    while (cap < n)
-        cap *= 2;
-    (void)hipFree(c->d_msgs);
-    if (c->h_msgs)
-        (void)hipHostFree(c->h_msgs);
-    c->d_msgs = c->h_msgs = nullptr;
-    c->msgs_cap = 0;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_msgs), cap * sizeof(msd_message)));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_msgs), cap * sizeof(msd_message)));
-    c->msgs_cap = cap;
-    return 0;
-}
-
 /* The resolve stage with the candidate lists left in HBM: one workgroup per buffer against a
  * snapshot of the ICAO filter; the host only replays the buffers' add lists to find the snapshot
- * every buffer has to see (msd_resolve.c) and re-launches the ones that saw another. */
+ * every buffer has to see (msd_resolve.c) and re-launches the ones that saw another.
+ *
+ * Queueing: the first pass over a batch, the message records and their signal power are queued on
+ * the scan stream as soon as the previous batch is committed (often long before anybody waits for
+ * them), so they never share compute units with a scan kernel; everything they report lands in
+ * pinned host memory, the host waits for one event.  Only the rare further passes use the
+ * high-priority aux stream. */
 struct GpuCtl {
     uint64_t *h_ts;
-    uint32_t *h_valid, *h_snap, *h_todo, *h_off;
+    uint32_t *h_valid, *h_snap, *h_todo;
     const uint64_t *d_ts;
-    const uint32_t *d_valid, *d_snap, *d_todo, *d_off;
+    const uint32_t *d_valid, *d_snap, *d_todo;
     size_t bytes;
 };
 
@@ -517,17 +523,15 @@ GpuCtl gpu_ctl(const msd_ctx *c, const Slot &s)
 {
     const size_t N = c->max_buffers;
     GpuCtl g;
-    g.bytes = 32 * N + 64;
+    g.bytes = 28 * N;
     g.h_ts = reinterpret_cast<uint64_t *>(s.h_ctl);
     g.h_valid = reinterpret_cast<uint32_t *>(s.h_ctl + 16 * N);
     g.h_snap = g.h_valid + N;
     g.h_todo = g.h_snap + N;
-    g.h_off = g.h_todo + N;
     g.d_ts = reinterpret_cast<const uint64_t *>(s.d_ctl);
     g.d_valid = reinterpret_cast<const uint32_t *>(s.d_ctl + 16 * N);
     g.d_snap = g.d_valid + N;
     g.d_todo = g.d_snap + N;
-    g.d_off = g.d_todo + N;
     return g;
 }
 
@@ -536,13 +540,14 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     const GpuCtl g = gpu_ctl(c, s);
     rp.hits = s.d_hits;
     rp.tries = s.d_tries;
-    rp.nhits = s.h_totals[0];
+    rp.totals = s.d_totals;
     rp.valid = g.d_valid;
     rp.ts = g.d_ts;
     rp.snaps = c->d_snaps;
     rp.snap_idx = g.d_snap;
     rp.todo = g.d_todo;
-    rp.rbuf = s.d_rbuf;
+    rp.rbuf = s.h_rbuf;
+    rp.nmsgs = s.d_nmsgs;
     rp.acc = s.d_acc;
     rp.adds = s.d_adds;
 }
@@ -554,8 +559,8 @@ uint32_t slot_valid(const Slot &s, uint32_t b)
     return (uint32_t)(n > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : n);
 }
 
-/* one resolve pass over s.resolve_ntodo buffers, and the download of the reports; asynchronous */
-int gpu_launch_pass(msd_ctx *c, Slot &s)
+/* one resolve pass over the s.resolve_ntodo buffers of the to-do list, on `ks` */
+int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
 {
     const GpuCtl g = gpu_ctl(c, s);
     const uint32_t nsn = msd_gpu_resolve_nsnaps(&c->resolver);
@@ -563,31 +568,87 @@ int gpu_launch_pass(msd_ctx *c, Slot &s)
         uint32_t *stage = c->h_snaps + (size_t)i * MSD_SNAP_WORDS;
         memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i), sizeof(uint32_t) * MSD_SNAP_WORDS);
         HIPCHK(c, hipMemcpyAsync(c->d_snaps + (size_t)i * MSD_SNAP_WORDS, stage, sizeof(uint32_t) * MSD_SNAP_WORDS,
-                                 hipMemcpyHostToDevice, c->aux_stream));
+                                 hipMemcpyHostToDevice, ks));
     }
     c->snaps_uploaded = nsn;
-    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
+    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, ks));
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
-    int rc = msd_launch_resolve(&rp, s.resolve_ntodo, c->aux_stream);
+    int rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
     if (rc)
         return fail(c, rc, "resolve kernel launch failed");
-    HIPCHK(c, hipMemcpyAsync(s.h_rbuf, s.d_rbuf, sizeof(msd_rbuf) * s.nbuffers, hipMemcpyDeviceToHost, c->aux_stream));
     return 0;
 }
 
-/* clocks, snapshot 0 = the live filter, first pass over every buffer.  The previous batch must
- * have been committed: this is the earliest moment its successor can start. */
-int gpu_begin(msd_ctx *c, Slot &s)
+/* message records and signal power of every buffer on `ks`, then the download of the first `expect`
+ * of them on the aux stream (the count is not known on the host yet); ev_resolve marks the end of both */
+int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks, size_t expect)
+{
+    MsdResolveParams rp{};
+    gpu_params(c, s, rp);
+    int rc = msd_launch_emit(&rp, s.nbuffers, s.d_off, s.d_msgs, s.d_req, (uint32_t)s.req_cap, ks);
+    if (rc)
+        return fail(c, rc, "emit kernel launch failed");
+    MsdScanParams p{};
+    fill_params(c, s, p);
+    rc = msd_launch_power_buffers(&p, format, s.d_req, s.d_off, s.nbuffers, s.d_totals,
+                                  reinterpret_cast<unsigned long long *>(s.d_pow), (uint32_t)s.req_cap, ks);
+    if (rc)
+        return fail(c, rc, "power kernel launch failed");
+    if (expect > s.req_cap)
+        expect = s.req_cap;
+    hipStream_t cs = ks;
+    if (ks != c->aux_stream) {
+        HIPCHK(c, hipEventRecord(s.ev_records, ks));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, s.ev_records, 0));
+        cs = c->aux_stream;
+    }
+    if (expect) {
+        HIPCHK(c, hipMemcpyAsync(s.h_msgs, s.d_msgs, expect * sizeof(msd_message), hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, expect * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    }
+    s.copied_msgs = (uint32_t)expect;
+    HIPCHK(c, hipEventRecord(s.ev_resolve, cs));
+    return 0;
+}
+
+/* the records beyond the speculative download, if the batch held more messages than expected */
+int gpu_fetch_rest(msd_ctx *c, Slot &s, uint32_t total)
+{
+    if (total <= s.copied_msgs)
+        return 0;
+    const size_t o = s.copied_msgs, k = total - s.copied_msgs;
+    HIPCHK(c, hipMemcpyAsync(s.h_msgs + o, s.d_msgs + o, k * sizeof(msd_message), hipMemcpyDeviceToHost, c->aux_stream));
+    HIPCHK(c, hipMemcpyAsync(s.h_pow + o, s.d_pow + o, k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux_stream));
+    HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+    s.copied_msgs = total;
+    return 0;
+}
+
+/* Clocks, snapshot 0 = the live filter, first pass over every buffer and the (speculative) message
+ * records, all behind the batch's own kernels on the scan stream.  Every earlier batch must have
+ * been committed: this is the earliest moment its successor can start. */
+int gpu_begin(msd_ctx *c, Slot &s, int format)
 {
     const GpuCtl g = gpu_ctl(c, s);
     for (uint32_t b = 0; b < s.nbuffers; ++b)
         g.h_valid[b] = slot_valid(s, b);
     msd_gpu_resolve_begin(&c->resolver, s.nbuffers, g.h_valid, g.h_ts, g.h_snap, g.h_todo, &s.resolve_ntodo);
     c->snaps_uploaded = 0;
-    int rc = gpu_launch_pass(c, s);
-    s.resolve_inflight = rc == 0;
-    return rc;
+    int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
+    if (!rc)
+        rc = gpu_queue_pass(c, s, c->stream);
+    if (!rc)
+        rc = gpu_queue_emit(c, s, format, c->stream, c->est_msgs ? (size_t)c->est_msgs + c->est_msgs / 4 + 2048 : s.req_cap);
+    if (rc)
+        return rc;
+    s.resolve_inflight = true;
+    return 0;
+}
+
+bool gpu_eligible(const msd_ctx *c, const Slot &s)
+{
+    return c->gpu_resolve && !c->cfg.mode_ac && s.nbuffers >= 4;
 }
 
 /* Returns 1 when the batch has to go through the host resolver instead (nothing committed). */
@@ -598,18 +659,21 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    double t_kernel = 0, t_replay = 0;
+    double t_wait = 0, t_replay = 0;
     uint32_t npass = 0;
     const bool early = s.resolve_inflight;
     if (!s.resolve_inflight) {
-        int rc = gpu_begin(c, s);
+        int rc = gpu_begin(c, s, format);
         if (rc)
             return rc;
     }
+    s.resolve_inflight = false;
+    hipEvent_t wait_for = s.ev_resolve;
+    bool records_current = true; /* the message records in host memory belong to the latest pass */
     for (uint32_t pass = 0;; ++pass) {
         auto k0 = tnow();
         ++npass;
-        HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+        HIPCHK(c, hipEventSynchronize(wait_for));
         bool long_lists = false;
         for (uint32_t b = 0; b < n && !long_lists; ++b)
             long_lists = s.h_rbuf[b].nadds > c->inline_adds;
@@ -620,21 +684,23 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             HIPCHK(c, hipStreamSynchronize(c->aux_stream));
         }
         auto k1 = tnow();
-        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap, g.h_todo,
-                                        &s.resolve_ntodo);
-        t_kernel += tms(k0, k1);
+        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap,
+                                        g.h_todo, &s.resolve_ntodo);
+        t_wait += tms(k0, k1);
         t_replay += tms(k1, tnow());
         if (rc == 0)
             break;
-        if (rc < 0) {
-            s.resolve_inflight = false;
+        if (rc < 0)
             return 1;
-        }
-        rc = gpu_launch_pass(c, s);
+        /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
+        hipStream_t ps = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
+        rc = gpu_queue_pass(c, s, ps);
         if (rc)
             return rc;
+        HIPCHK(c, hipEventRecord(c->ev_aux, ps));
+        wait_for = c->ev_aux;
+        records_current = false;
     }
-    s.resolve_inflight = false;
     c->timing.resolve_passes = npass;
     auto e0 = tnow();
     msd_gpu_resolve_commit(&c->resolver, n, g.h_valid, s.h_rbuf);
@@ -642,53 +708,56 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     uint32_t total = 0;
     c->out_buf.clear();
     for (uint32_t b = 0; b < n; ++b) {
-        g.h_off[b] = total;
         total += s.h_rbuf[b].nmsgs;
         c->out_buf.insert(c->out_buf.end(), s.h_rbuf[b].nmsgs, b);
     }
-    g.h_off[n] = total;
-    if (total) { /* message records and their signal power, asynchronously */
+    if (total > s.req_cap) {
         int rc = ensure_req(c, s, total);
-        if (!rc)
-            rc = ensure_msgs(c, total);
         if (rc)
             return rc;
-        MsdResolveParams rp{};
-        gpu_params(c, s, rp);
-        HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
-        rc = msd_launch_emit(&rp, n, g.d_off, c->d_msgs, s.d_req, c->aux_stream);
-        if (rc)
-            return fail(c, rc, "emit kernel launch failed");
-        MsdScanParams p{};
-        fill_params(c, s, p);
-        rc = msd_launch_power(&p, format, s.d_req, total, reinterpret_cast<unsigned long long *>(s.d_pow), c->aux_stream);
-        if (rc)
-            return fail(c, rc, "power kernel launch failed");
-        HIPCHK(c, hipMemcpyAsync(c->h_msgs, c->d_msgs, sizeof(msd_message) * total, hipMemcpyDeviceToHost, c->aux_stream));
-        HIPCHK(c, hipMemcpyAsync(s.h_req, s.d_req, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, c->aux_stream));
-        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, sizeof(uint64_t) * total, hipMemcpyDeviceToHost, c->aux_stream));
+        records_current = false;
     }
-    HIPCHK(c, hipEventRecord(c->ev_emit, c->aux_stream));
-    /* the filter is final for this batch: the next one can start its first pass behind the copies */
+    hipStream_t rs = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
+    if (!records_current && total) {
+        int rc = gpu_queue_emit(c, s, format, rs, total);
+        if (rc)
+            return rc;
+    }
+    c->est_msgs = total;
+    /* the filter is final for this batch: its successor can start */
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy && nx.download_started && nx.gpu_resolve && !nx.resolve_inflight) {
-            int rc = gpu_begin(c, nx);
+        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight) {
+            int rc = gpu_begin(c, nx, c->cfg.format);
             if (rc)
                 return rc;
         }
     }
-    HIPCHK(c, hipEventSynchronize(c->ev_emit));
+    if (!records_current && total)
+        HIPCHK(c, hipEventSynchronize(s.ev_resolve));
+    {
+        int rc = gpu_fetch_rest(c, s, total);
+        if (rc)
+            return rc;
+    }
     auto e1 = tnow();
-    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), c->h_msgs, s.h_req, c->out_buf.data(), s.h_pow,
+    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), s.h_msgs, nullptr, c->out_buf.data(), s.h_pow,
                       total);
+    if (trace) {
+        double cyc[8] = {0};
+        for (uint32_t b = 0; b < n; ++b)
+            for (int k = 0; k < 8; ++k)
+                cyc[k] += s.h_rbuf[b].cyc[k];
+        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f stage %.1f eval %.1f walk %.1f count %.1f\n",
+                cyc[0] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100);
+    }
     if (trace)
-        fprintf(stderr, "gpu resolve: %u passes%s, wait+copies %.3f ms, replay %.3f ms, commit+emit+power+download %.3f ms, "
-                "power stats %.3f ms\n", npass, early ? " (first one launched early)" : "", t_kernel, t_replay, tms(e0, e1),
+        fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
+                "power stats %.3f ms\n", npass, early ? " (first one queued early)" : "", t_wait, t_replay, tms(e0, e1),
                 tms(e1, tnow()));
     if (sink)
         for (uint32_t i = 0; i < total; ++i)
-            sink(&c->h_msgs[i], user);
+            sink(&s.h_msgs[i], user);
     return 0;
 }
 
@@ -742,6 +811,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     const bool skip_resolve = dbgflags && (atoi(dbgflags) & 0x1c);
     if (s.gpu_resolve) {
         rc = (ts_override || skip_resolve) ? 1 : finish_gpu(c, s, format, sink, user);
+        s.resolve_inflight = false;
         if (rc < 0)
             return rc;
         if (rc == 0) {
@@ -886,9 +956,21 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         s.busy = false;
         return rc;
     }
-    if (getenv("MSD_RESOLVE_TRACE"))
-        fprintf(stderr, "launch: enqueue %.3f ms\n",
+    if (getenv("MSD_RESOLVE_TRACE")) {
+        static const auto t_origin = std::chrono::steady_clock::now();
+        fprintf(stderr, "launch: at %.3f ms, enqueue %.3f ms\n",
+                std::chrono::duration<double, std::milli>(tl0 - t_origin).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
+    }
+    s.gpu_resolve = gpu_eligible(c, s);
+    s.resolve_inflight = false;
+    if (s.gpu_resolve && c->outstanding == 0) { /* no earlier batch to wait for: resolve right behind the scan */
+        rc = gpu_begin(c, s, c->cfg.format);
+        if (rc) {
+            s.busy = false;
+            return rc;
+        }
+    }
     if (nsamples >= (uint64_t)TAIL_SAMPLES) {
         const int nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
         HIPCHK(c, hipMemcpyAsync(c->d_tail[nxt], s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
@@ -948,9 +1030,13 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_rbuf); (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl);
+        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_off);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
+        if (s.h_msgs) (void)hipHostFree(s.h_msgs);
+        if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
+        if (s.ev_records) (void)hipEventDestroy(s.ev_records);
+        (void)hipFree(s.d_msgs);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
@@ -962,11 +1048,10 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_offsets);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
-    (void)hipFree(c->d_snaps); (void)hipFree(c->d_msgs);
+    (void)hipFree(c->d_snaps);
     if (c->h_adds) (void)hipHostFree(c->h_adds);
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
-    if (c->h_msgs) (void)hipHostFree(c->h_msgs);
-    if (c->ev_emit) (void)hipEventDestroy(c->ev_emit);
+    if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     for (uint8_t *t : c->d_tail)
         (void)hipFree(t);
     (void)hipFree(c->d_stage);
@@ -1118,20 +1203,25 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             c->inline_adds = (uint32_t)atoi(ia);
     }
     if (c->gpu_resolve && !cfg->mode_ac) {
-        const size_t ctl_bytes = (size_t)32 * c->max_buffers + 64;
+        const size_t ctl_bytes = (size_t)28 * c->max_buffers;
         for (Slot &s : c->slots) {
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rbuf), sizeof(msd_rbuf) * c->max_buffers));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_rbuf), sizeof(msd_rbuf) * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_nmsgs), sizeof(uint32_t) * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_off), sizeof(uint32_t) * (c->max_buffers + 1)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
             memset(s.h_ctl, 0, ctl_bytes);
+            CK(hipEventCreateWithFlags(&s.ev_resolve, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&s.ev_records, hipEventDisableTiming));
         }
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
-        CK(hipEventCreate(&c->ev_emit));
+        CK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
+    } else {
+        c->gpu_resolve = false;
     }
 #undef CK
     if (getenv("MSD_KERNEL_TIMING")) {

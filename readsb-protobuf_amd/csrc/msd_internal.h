@@ -76,7 +76,7 @@ typedef struct msd_wg_counts {
 
 /* ---- GPU resolve stage (msd_resolve_kernels.hip) ---- */
 #define MSD_RB_MSG_CAP 1024u   /* accepted Mode S messages of one buffer: at most 131072/135 = 970 */
-#define MSD_RB_ADD_INLINE 232u /* unique icaoFilterAdd addresses of one buffer reported inline */
+#define MSD_RB_ADD_INLINE 224u /* unique icaoFilterAdd addresses of one buffer reported inline */
 #define MSD_SNAP_WORDS 16384u  /* a filter snapshot on the device: slot[2][8192] */
 /* what the resolve kernel reports per buffer; 1 KiB */
 typedef struct msd_rbuf {
@@ -87,6 +87,7 @@ typedef struct msd_rbuf {
     uint32_t fallback;     /* the buffer needs the host path (cannot happen with valid candidate lists) */
     uint64_t end_now;      /* Modes.ifile_now when the buffer is done */
     uint64_t pad;
+    uint32_t cyc[8]; /* wall-clock ticks (100 MHz) lane 0 spent per phase: setup, stage, eval, walk, count, rest */
     uint32_t adds[MSD_RB_ADD_INLINE]; /* addresses passed to icaoFilterAdd, first occurrence order */
 } msd_rbuf;
 /* an accepted message before it is turned into a msd_message */
@@ -149,7 +150,8 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
                        const msd_ac_hit *ac, uint64_t nac, const uint64_t *ts_override,
                        msd_emit_fn emit, void *user);
 /* Second half of demodulate2400's bookkeeping, once the signal power sums are known
- * (demod_2400.c:386-408,422-427): fills signalLevel and the power statistics, in order. */
+ * (demod_2400.c:386-408,422-427): fills signalLevel and the power statistics, in order.
+ * power_req may be NULL when every message is Mode S (the length follows from msgbits). */
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
                        struct msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
                        const uint64_t *power, uint64_t nmsgs);

@@ -37,13 +37,14 @@ typedef struct MsdScanParams {
 typedef struct MsdResolveParams {
     const msd_hit *hits; /* the batch's ordered candidate lists, as the gather kernel left them */
     const msd_try *tries;
-    uint64_t nhits;
+    const uint64_t *totals;   /* the batch's totals on the device: [0] hits, [2] arena overflow flag */
     const uint32_t *valid;    /* [buffer] new samples */
     const uint64_t *ts;       /* [buffer][2] sampleTimestamp, sysTimestamp */
     const uint32_t *snaps;    /* [snapshot][MSD_SNAP_WORDS] */
     const uint32_t *snap_idx; /* [buffer] snapshot to resolve against */
     const uint32_t *todo;     /* [workgroup] buffer to resolve */
-    msd_rbuf *rbuf;           /* [buffer] */
+    msd_rbuf *rbuf;           /* [buffer], pinned host memory: written, never read, by the kernels */
+    uint32_t *nmsgs;          /* [buffer] accepted messages, for the offsets of the emit kernel */
     msd_acc *acc;             /* [buffer][MSD_RB_MSG_CAP] */
     uint32_t *adds;           /* [buffer][MSD_RB_MSG_CAP]: the complete add lists (msd_rbuf holds the first ones) */
 } MsdResolveParams;
@@ -51,9 +52,19 @@ typedef struct MsdResolveParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* h_* are device-visible pinned host addresses */
+int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, const uint64_t *sums, const float *fmeans,
+                       uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums, float *h_fmeans,
+                       hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
-int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const uint32_t *d_offsets,
-                    msd_message *dense, uint64_t *dense_req, hipStream_t stream);
+/* offsets (device scratch, nbuffers + 1) from the buffers' message counts, then the message records
+ * and the request list of the power kernel; entries beyond cap are dropped (the host notices) */
+int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, uint32_t *d_offsets, msd_message *dense,
+                    uint64_t *dense_req, uint32_t cap, hipStream_t stream);
+/* signal power of the emitted messages, four workgroups per buffer: out[i] for i < cap */
+int msd_launch_power_buffers(const MsdScanParams *p, int format, const uint64_t *d_req, const uint32_t *d_offsets,
+                             uint32_t nbuffers, const uint64_t *totals, unsigned long long *out, uint32_t cap,
+                             hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets, uint64_t *totals,

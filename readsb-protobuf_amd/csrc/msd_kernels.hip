@@ -931,6 +931,34 @@ __global__ void __launch_bounds__(256) msd_power_kernel(const MsdScanParams P, c
         out[i] = acc;
 }
 
+/* The same for the GPU resolve stage, which does not know the number of messages on the host when
+ * it queues the kernel: four workgroups per buffer walk that buffer's slice of the request list. */
+template <int FMT>
+__global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const uint64_t *req,
+                                                                const uint32_t *offsets, const uint64_t *totals,
+                                                                unsigned long long *out, uint32_t cap)
+{
+    if (totals[2])
+        return;
+    const uint32_t b = blockIdx.x >> 2, end = offsets[b + 1] < cap ? offsets[b + 1] : cap;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = offsets[b] + (blockIdx.x & 3u) * 4 + (threadIdx.x >> 6); i < end; i += 16) {
+        const uint64_t rq = req[i];
+        const int len = (int)(rq & 0xffffu);
+        const int64_t n0 = (int64_t)P.batch_first + (int64_t)(rq >> 16) - (int64_t)MSD_OVERLAP + 19;
+        unsigned long long acc = 0;
+        for (int k = lane; k < len; k += 64) {
+            const uint32_t x = stream_mag<FMT>(P, n0 + k, P.lut);
+            acc += (unsigned long long)(x * x);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            acc += __shfl_down(acc, o);
+        if (lane == 0)
+            out[i] = acc;
+    }
+}
+
 /* IQ -> magnitude only, for the iq_convert_fn-shaped entry point (convert.h:33-38): writes the
  * u16 magnitudes and accumulates the integer level/power sums (UC8). */
 template <int FMT>
@@ -1268,6 +1296,32 @@ extern "C" int msd_launch_power(const MsdScanParams *p, int format, const uint64
         break;
     case MSD_FMT_MAG16:
         hipLaunchKernelGGL(msd_power_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, d_req, nreq, d_out);
+        break;
+    default:
+        return -22;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, const uint64_t *d_req,
+                                        const uint32_t *d_offsets, uint32_t nbuffers, const uint64_t *totals,
+                                        unsigned long long *out, uint32_t cap, hipStream_t stream)
+{
+    if (nbuffers == 0)
+        return 0;
+    const dim3 grid(nbuffers * 4), block(256);
+    switch (format) {
+    case MSD_FMT_UC8:
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        break;
+    case MSD_FMT_SC16:
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        break;
+    case MSD_FMT_SC16Q11:
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        break;
+    case MSD_FMT_MAG16:
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
         break;
     default:
         return -22;

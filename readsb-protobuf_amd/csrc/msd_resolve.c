@@ -901,9 +901,9 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
     for (uint32_t b = 0; b < nbuffers; ++b) {
         uint64_t sum_scaled_signal_power = 0;
         for (; i < nmsgs && buffer[i] == b; ++i) {
-            if (!power_req[i])
+            if (power_req && !power_req[i])
                 continue; /* Mode A/C */
-            const int signal_len = (int)(power_req[i] & 0xffffu);
+            const int signal_len = power_req ? (int)(power_req[i] & 0xffffu) : msgs[i].msgbits * 12 / 5;
             const uint64_t scaled = power[i];
             /* demod_2400.c:386-408 */
             const double signal_power = scaled / 65535.0 / 65535.0;

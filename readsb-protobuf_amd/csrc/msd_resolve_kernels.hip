@@ -97,12 +97,12 @@ __device__ __forceinline__ int score_packed(uint64_t t)
     const bool known = (t >> 19) & 1u;
     const int nerr = (((uint32_t)(t >> 28) & 0xffu) != 0xffu) ? 1 : 0;
     switch (df) {
-    case 11:
+    case 11: /* x / (nerr + 1) with nerr 0 or 1: a shift */
         if ((t >> 36) & 1u)
-            return (known ? 1600 : 750) / (nerr + 1);
-        return known ? 1000 / (nerr + 1) : -1;
+            return (known ? 1600 : 750) >> nerr;
+        return known ? 1000 >> nerr : -1;
     case 17: case 18:
-        return (known ? 1800 : 1400) / (nerr + 1);
+        return (known ? 1800 : 1400) >> nerr;
     case 20: case 21:
         return known ? 1000 : -2;
     default: /* 0, 4, 5, 16, 24: address/parity */
@@ -115,6 +115,7 @@ __device__ __forceinline__ uint32_t res_len(uint64_t r) /* samples hidden by the
     return (((uint32_t)(r >> 20) & 0x10u) ? 112u : 56u) * 12u / 5u;
 }
 
+constexpr uint32_t TCAP = 2048;   /* tries staged per segment; a segment is cut short where they would not fit */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
 
 __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr)
@@ -134,8 +135,10 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
 {
     __shared__ msd_hit seg_hits[SEG];
     __shared__ uint64_t seg_res[SEG];
-    __shared__ uint64_t seg_try[5 * SEG];
+    __shared__ uint64_t seg_try[TCAP];
     __shared__ uint16_t seg_toff[SEG + 1];
+    __shared__ uint16_t seg_thit[TCAP];       /* owner of each staged try */
+    __shared__ uint32_t out_adds[ADDSET / 2]; /* this buffer's adds, flushed at the end (half go to host memory) */
     __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
     __shared__ uint32_t cand[SEG / 32]; /* hits whose best phase scores >= 0 */
     __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
@@ -143,13 +146,19 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ uint64_t sh_range[2];
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
-    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_next, sh_nacc, sh_newaddr;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_next, sh_nacc, sh_newaddr, sh_nfit;
 
     const int tid = threadIdx.x;
+    uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = wall_clock64();
+#define PHASE(k) { const uint64_t n_ = wall_clock64(); cyc[k] += (uint32_t)(n_ - tlast); tlast = n_; }
+    if (P.totals[2])
+        return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
+    const uint64_t nhits = P.totals[0];
     const uint32_t b = P.todo[blockIdx.x];
     const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * (2 * SLOTS);
     const uint32_t mlen = P.valid[b];
-    const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
+    const uint64_t sys_ts = P.ts[2 * b + 1];
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
     msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
     uint32_t *adds = P.adds + (size_t)b * MSD_RB_MSG_CAP;
@@ -159,17 +168,26 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         addset[i] = VACANT;
     if (tid < 16)
         sh_ctr[tid] = 0;
-    if (tid < 2) { /* range of this buffer's hits in the ordered list */
-        const uint64_t want = base + (tid ? MSD_CHUNK_SAMPLES : 0);
-        uint64_t lo = 0, hi = P.nhits;
+    if (tid < 128) { /* range of this buffer's hits in the ordered list: a 64-ary search per wavefront */
+        const int lane = tid & 63;
+        const uint64_t want = base + ((tid >> 6) ? MSD_CHUNK_SAMPLES : 0);
+        uint64_t lo = 0, hi = nhits; /* lower_bound lies in [lo, hi] */
         while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (MSD_HIT_POS(P.hits[mid]) < want)
-                lo = mid + 1;
-            else
-                hi = mid;
+            const uint64_t step = (hi - lo + 63) / 64;
+            const uint64_t p = lo + (uint64_t)lane * step;
+            const bool below = p < hi && MSD_HIT_POS(P.hits[p]) < want;
+            const int k = __popcll(__ballot(below)); /* the first k probes are below: monotone */
+            if (k == 0) {
+                hi = lo;
+            } else {
+                const uint64_t nhi = lo + (uint64_t)k * step;
+                lo = lo + (uint64_t)(k - 1) * step + 1;
+                if (nhi < hi)
+                    hi = nhi;
+            }
         }
-        sh_range[tid] = lo;
+        if (lane == 0)
+            sh_range[tid >> 6] = lo;
     }
     if (tid == 0) {
         sh_resume = base;
@@ -178,14 +196,17 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     }
     __syncthreads();
     const uint64_t hb = sh_range[0], he = sh_range[1];
+    PHASE(0)
 
-    for (uint64_t s0 = hb; s0 < he; s0 += SEG) {
-        const uint32_t n = (he - s0 < (uint64_t)SEG) ? (uint32_t)(he - s0) : (uint32_t)SEG;
+    uint32_t n = 0;
+    for (uint64_t s0 = hb; s0 < he; s0 += n) {
+        n = (he - s0 < (uint64_t)SEG) ? (uint32_t)(he - s0) : (uint32_t)SEG;
         for (uint32_t i = tid; i < n; i += RT)
             seg_hits[i] = P.hits[s0 + i];
         if (tid == 0) {
             sh_seg_resume = sh_resume;
             sh_nacc = 0;
+            sh_nfit = n;
         }
         __syncthreads();
         /* ---- phase P: stage every try of the segment in LDS with its filter verdict ---- */
@@ -210,25 +231,42 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         uint32_t off = incl - mine;
         for (int w = 0; w < (tid >> 6); ++w)
             off += sh_wsum[w];
+        { /* cut the segment in front of the first hit whose tries do not fit (at least one hit always fits) */
+            uint32_t o = off;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                o += nl[k];
+                if (o > TCAP) {
+                    atomicMin(&sh_nfit, tid * PER + k);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        n = sh_nfit;
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = tid * PER + k;
+            if (i >= n)
+                nl[k] = 0;
             if (i <= n)
                 seg_toff[i] = (uint16_t)off; /* entry n = all tries of the segment */
-            if (nl[k]) {
-                const msd_try *t = P.tries + MSD_HIT_TRY(seg_hits[i]);
-                for (uint32_t q = 0; q < nl[k]; ++q) {
-                    const TryView v = load_try(t + q);
-                    const bool known = snap_known(snap, v.addr) || addset_has(addset, v.addr);
-                    seg_try[off + q] = pack_try(v, known);
-                }
-            }
+            for (uint32_t q = 0; q < nl[k]; ++q)
+                seg_thit[off + q] = (uint16_t)i;
             off += nl[k];
         }
         if (tid == RT - 1 && n == SEG)
             seg_toff[SEG] = (uint16_t)off;
         __syncthreads();
+        for (uint32_t t = tid; t < seg_toff[n]; t += RT) { /* one try per thread: the loads of a round overlap */
+            const uint32_t i = seg_thit[t];
+            const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
+            const bool known = snap_known(snap, v.addr) || addset_has(addset, v.addr);
+            seg_try[t] = pack_try(v, known);
+        }
+        __syncthreads();
         const uint32_t ntries = seg_toff[n];
+        PHASE(1)
 
         uint32_t start = 0;
         while (start < n) {
@@ -254,11 +292,13 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     atomicOr(&cand[i >> 5], 1u << (i & 31));
             }
             __syncthreads();
+            PHASE(2)
             /* ---- phase S: the ordered walk over the hits that could be messages, on one lane ---- */
             if (tid == 0) {
                 uint64_t resume = sh_resume, now = sh_now;
                 uint32_t nmsgs = sh_nmsgs, nadds = sh_nadds, nacc = sh_nacc;
                 uint32_t c_unk = 0, c_acc0 = 0, c_acc1 = 0, next = n;
+                uint64_t c_bp = 0; /* best-phase counters, 11 bits each */
                 bool stop = false;
                 for (uint32_t w = start >> 5; w < (n + 31) / 32 && !stop; ++w) {
                     uint32_t m = cand[w];
@@ -267,7 +307,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     while (m) {
                         const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(m);
                         m &= m - 1;
-                        const uint64_t a = MSD_HIT_POS(seg_hits[i]);
+                        const msd_hit h = seg_hits[i];
+                        const uint64_t a = MSD_HIT_POS(h);
                         if (a >= end) {
                             stop = true;
                             break;
@@ -278,9 +319,9 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                         const uint32_t known = (uint32_t)(r >> 19) & 1u, df = (uint32_t)(r >> 20) & 31u;
                         const uint32_t tp = 4 + ((uint32_t)(r >> 25) & 7u), errbit = (uint32_t)(r >> 28) & 0xffu;
                         const uint32_t addr = (uint32_t)(r >> 40);
-                        const uint32_t j = (uint32_t)(a - base);
-                        const uint64_t tsmsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
-                        now = sys_ts + (tsmsg - sample_ts) / 12000u; /* demod_2400.c:363-366, before decode */
+                        /* demod_2400.c:358-366, before decode: (timestampMsg - sampleTimestamp) / 12000 ms,
+                         * a 32-bit quotient (at most 131072 * 5 + 776) */
+                        now = sys_ts + ((uint32_t)(a - base) * 5u + (8 + 56) * 12 + tp) / 12000u;
                         /* acceptance part of decodeModesMessage (mode_s.c:424-555) */
                         const bool nerr = errbit != 0xffu;
                         bool reject;
@@ -307,10 +348,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                             }
                             if (!seen) {
                                 addset[hs] = addr;
-                                if (nadds < MSD_RB_ADD_INLINE)
-                                    rb->adds[nadds] = addr;
                                 if (nadds < MSD_RB_MSG_CAP)
-                                    adds[nadds] = addr;
+                                    out_adds[nadds] = addr;
                                 nadds++;
                                 fresh = !known; /* a new aircraft: the hits behind it must see it */
                             }
@@ -319,11 +358,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                             c_acc1++;
                         else
                             c_acc0++;
-                        sh_ctr[11 + tp - 4]++;
+                        c_bp += 1ull << (11 * (tp - 4));
                         if (nmsgs < MSD_RB_MSG_CAP) {
                             msd_acc rec;
                             rec.pos = (uint32_t)a;
-                            rec.try_index = (uint32_t)(MSD_HIT_TRY(seg_hits[i]) + ((uint32_t)(r >> 16) & 7u));
+                            rec.try_index = (uint32_t)(MSD_HIT_TRY(h) + ((uint32_t)(r >> 16) & 7u));
                             rec.score = (int32_t)(int16_t)(r & 0xffffu);
                             rec.pad = 0;
                             acc[nmsgs] = rec;
@@ -348,8 +387,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 sh_ctr[2] += c_unk;
                 sh_ctr[3] += c_acc0;
                 sh_ctr[4] += c_acc1;
+                for (int k = 0; k < 5; ++k)
+                    sh_ctr[11 + k] += (uint32_t)(c_bp >> (11 * k)) & 2047u;
             }
             __syncthreads();
+            PHASE(3)
             /* ---- phase C: the counters of every hit that no accepted message hides, in parallel ---- */
             const uint32_t stop_at = sh_next, nacc = sh_nacc;
             const uint64_t seg_resume = sh_seg_resume;
@@ -383,13 +425,23 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 c_bad += sc == 0xfffeu;
                 c_unk += sc == 0xffffu;
             }
-            if (c_pre) {
-                atomicAdd(&sh_ctr[0], c_pre);
-                if (c_bad) atomicAdd(&sh_ctr[1], c_bad);
-                if (c_unk) atomicAdd(&sh_ctr[2], c_unk);
-                if (c_p01) { atomicAdd(&sh_ctr[6], c_p01); atomicAdd(&sh_ctr[7], c_p01); }
-                if (c_p23) { atomicAdd(&sh_ctr[8], c_p23); atomicAdd(&sh_ctr[9], c_p23); }
-                if (c_p4) atomicAdd(&sh_ctr[10], c_p4);
+            { /* six counters of at most 4 per lane, packed ten bits apart, summed over the wavefront */
+                uint64_t pk = (uint64_t)c_pre | ((uint64_t)c_bad << 10) | ((uint64_t)c_unk << 20) | ((uint64_t)c_p01 << 30) |
+                              ((uint64_t)c_p23 << 40) | ((uint64_t)c_p4 << 50);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    pk += __shfl_down(pk, o, 64);
+                if ((tid & 63) == 0 && pk) {
+                    atomicAdd(&sh_ctr[0], (uint32_t)pk & 1023u);
+                    atomicAdd(&sh_ctr[1], (uint32_t)(pk >> 10) & 1023u);
+                    atomicAdd(&sh_ctr[2], (uint32_t)(pk >> 20) & 1023u);
+                    const uint32_t p01 = (uint32_t)(pk >> 30) & 1023u, p23 = (uint32_t)(pk >> 40) & 1023u;
+                    atomicAdd(&sh_ctr[6], p01);
+                    atomicAdd(&sh_ctr[7], p01);
+                    atomicAdd(&sh_ctr[8], p23);
+                    atomicAdd(&sh_ctr[9], p23);
+                    atomicAdd(&sh_ctr[10], (uint32_t)(pk >> 50) & 1023u);
+                }
             }
             start = stop_at;
             if (start < n) { /* the walk stopped at a new aircraft: its later tries are known now */
@@ -401,9 +453,19 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 }
             }
             __syncthreads();
+            PHASE(4)
         }
     }
 
+    { /* flush the lists, coalesced */
+        const uint32_t na = sh_nadds < MSD_RB_MSG_CAP ? sh_nadds : MSD_RB_MSG_CAP;
+        for (uint32_t i = tid; i < na; i += RT) {
+            const uint32_t a = out_adds[i];
+            adds[i] = a;
+            if (i < MSD_RB_ADD_INLINE)
+                rb->adds[i] = a;
+        }
+    }
     if (tid == 0) {
         for (int k = 0; k < 16; ++k)
             rb->ctr[k] = sh_ctr[k];
@@ -412,14 +474,46 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         rb->version_used = P.snap_idx[b];
         rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP) ? 1u : 0u;
         rb->end_now = sh_now;
+        for (int k = 0; k < 8; ++k)
+            rb->cyc[k] = cyc[k];
+        P.nmsgs[b] = sh_nmsgs < MSD_RB_MSG_CAP ? sh_nmsgs : MSD_RB_MSG_CAP;
+    }
+}
+
+/* offsets[b] = number of accepted messages in front of buffer b (one workgroup) */
+__global__ void __launch_bounds__(256) msd_msg_offsets_kernel(const uint32_t *nmsgs, uint32_t nbuffers, uint32_t *offsets)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t tid = threadIdx.x, per = (nbuffers + 255) / 256;
+    uint32_t sum = 0;
+    for (uint32_t i = tid * per; i < (tid + 1) * per && i < nbuffers; ++i)
+        sum += nmsgs[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t x = part[i];
+            part[i] = a;
+            a += x;
+        }
+        offsets[nbuffers] = a;
+    }
+    __syncthreads();
+    uint32_t o = part[tid];
+    for (uint32_t i = tid * per; i < (tid + 1) * per && i < nbuffers; ++i) {
+        offsets[i] = o;
+        o += nmsgs[i];
     }
 }
 
 /* The accepted messages of buffer b as msd_message records at dense[offsets[b]..), plus the request
  * list of the signal power kernel. */
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const uint32_t *offsets,
-                                                       msd_message *dense, uint64_t *dense_req)
+                                                       msd_message *dense, uint64_t *dense_req, uint32_t cap)
 {
+    if (P.totals[2])
+        return;
     const uint32_t b = blockIdx.x;
     const uint32_t o = offsets[b], nm = offsets[b + 1] - o;
     const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
@@ -452,12 +546,45 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
         mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
         mm.pad = 0;
+        if (o + m >= cap)
+            break; /* the host notices (total > cap), grows the arrays and emits again */
+        const uint64_t rq = ((uint64_t)rec.pos << 16) | (uint64_t)(msgbits * 12 / 5);
         dense[o + m] = mm;
-        dense_req[o + m] = ((uint64_t)rec.pos << 16) | (uint64_t)(msgbits * 12 / 5);
+        dense_req[o + m] = rq;
+    }
+}
+
+/* The small per-batch results the host waits for -- list totals and per-buffer level/power sums --
+ * written straight into pinned host memory at the end of the batch's kernels: a copy on another
+ * stream would queue behind the persistent scan kernels of the following batches. */
+__global__ void __launch_bounds__(256) msd_publish_kernel(const uint64_t *totals, const uint64_t *ac_totals,
+                                                          const uint64_t *sums, const float *fmeans, uint32_t nbuffers,
+                                                          uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums,
+                                                          float *h_fmeans)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid < 4) {
+        h_totals[tid] = totals[tid];
+        if (ac_totals)
+            h_ac_totals[tid] = ac_totals[tid];
+    }
+    for (uint32_t i = tid; i < 2 * nbuffers; i += blockDim.x) {
+        h_sums[i] = sums[i];
+        if (fmeans)
+            h_fmeans[i] = fmeans[i];
     }
 }
 
 } /* namespace */
+
+extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, const uint64_t *sums,
+                                  const float *fmeans, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals,
+                                  uint64_t *h_sums, float *h_fmeans, hipStream_t stream)
+{
+    hipLaunchKernelGGL(msd_publish_kernel, dim3(1), dim3(256), 0, stream, totals, ac_totals, sums, fmeans, nbuffers,
+                       h_totals, h_ac_totals, h_sums, h_fmeans);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
 
 extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream)
 {
@@ -467,11 +594,12 @@ extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hip
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const uint32_t *d_offsets,
-                               msd_message *dense, uint64_t *dense_req, hipStream_t stream)
+extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, uint32_t *d_offsets, msd_message *dense,
+                               uint64_t *dense_req, uint32_t cap, hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, d_offsets, dense, dense_req);
+    hipLaunchKernelGGL(msd_msg_offsets_kernel, dim3(1), dim3(256), 0, stream, p->nmsgs, nbuffers, d_offsets);
+    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, d_offsets, dense, dense_req, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
