@@ -566,7 +566,9 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
     const uint32_t nsn = msd_gpu_resolve_nsnaps(&c->resolver);
     for (uint32_t i = c->snaps_uploaded; i < nsn; ++i) {
         uint32_t *stage = c->h_snaps + (size_t)i * MSD_SNAP_WORDS;
-        memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i), sizeof(uint32_t) * MSD_SNAP_WORDS);
+        uint32_t active = 0;
+        memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i, &active), sizeof(uint32_t) * 16384);
+        stage[16384] = active;
         HIPCHK(c, hipMemcpyAsync(c->d_snaps + (size_t)i * MSD_SNAP_WORDS, stage, sizeof(uint32_t) * MSD_SNAP_WORDS,
                                  hipMemcpyHostToDevice, ks));
     }
@@ -674,18 +676,17 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         auto k0 = tnow();
         ++npass;
         HIPCHK(c, hipEventSynchronize(wait_for));
-        bool long_lists = false;
-        for (uint32_t b = 0; b < n && !long_lists; ++b)
-            long_lists = s.h_rbuf[b].nadds > c->inline_adds;
-        if (long_lists) {
+        auto k1 = tnow();
+        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, g.h_snap,
+                                        g.h_todo, &s.resolve_ntodo);
+        if (rc == -2) { /* a flip, or very many new addresses in one buffer: the complete add lists are needed */
             c->timing.resolve_long_lists++;
             HIPCHK(c, hipMemcpyAsync(c->h_adds, s.d_adds, sizeof(uint32_t) * MSD_RB_MSG_CAP * n, hipMemcpyDeviceToHost,
                                      c->aux_stream));
             HIPCHK(c, hipStreamSynchronize(c->aux_stream));
-        }
-        auto k1 = tnow();
-        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap,
+            rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap,
                                         g.h_todo, &s.resolve_ntodo);
+        }
         t_wait += tms(k0, k1);
         t_replay += tms(k1, tnow());
         if (rc == 0)

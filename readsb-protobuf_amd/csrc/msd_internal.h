@@ -76,19 +76,21 @@ typedef struct msd_wg_counts {
 
 /* ---- GPU resolve stage (msd_resolve_kernels.hip) ---- */
 #define MSD_RB_MSG_CAP 1024u   /* accepted Mode S messages of one buffer: at most 131072/135 = 970 */
-#define MSD_RB_ADD_INLINE 224u /* unique icaoFilterAdd addresses of one buffer reported inline */
-#define MSD_SNAP_WORDS 16384u  /* a filter snapshot on the device: slot[2][8192] */
+#define MSD_RB_ADD_INLINE 224u /* icaoFilterAdd addresses of one buffer reported inline: those that are not in the
+                                  snapshot's active table already (the others cannot change the filter) */
+#define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[2][8192], then the index of the active table */
 /* what the resolve kernel reports per buffer; 1 KiB */
 typedef struct msd_rbuf {
     uint32_t ctr[16]; /* 0 preambles, 1 bad, 2 unknown, 3/4 accepted with 0/1 fixes, 6-10 preamble phases,
                          11-15 best phases */
-    uint32_t nmsgs, nadds;
+    uint32_t nmsgs, nadds; /* nadds: all unique addresses added (the complete list stays in device memory) */
     uint32_t version_used; /* index of the snapshot it was resolved against */
     uint32_t fallback;     /* the buffer needs the host path (cannot happen with valid candidate lists) */
     uint64_t end_now;      /* Modes.ifile_now when the buffer is done */
-    uint64_t pad;
+    uint32_t nshort;       /* entries of adds[] below, if <= MSD_RB_ADD_INLINE; else use the complete list */
+    uint32_t pad;
     uint32_t cyc[8]; /* wall-clock ticks (100 MHz) lane 0 spent per phase: setup, stage, eval, walk, count, rest */
-    uint32_t adds[MSD_RB_ADD_INLINE]; /* addresses passed to icaoFilterAdd, first occurrence order */
+    uint32_t adds[MSD_RB_ADD_INLINE]; /* first occurrence order */
 } msd_rbuf;
 /* an accepted message before it is turned into a msd_message */
 typedef struct msd_acc {
@@ -158,16 +160,18 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
 
 /* ---- host half of the GPU resolve (msd_resolve.c): the cross-buffer replay ----
  * begin: clocks, snapshot 0 (= the live filter), every buffer on the to-do list.
- * replay: after a kernel pass, walks the buffers' add lists (rb[b].adds, or all_adds[b][MSD_RB_MSG_CAP]
- * for a buffer with more than inline_adds <= MSD_RB_ADD_INLINE) and flip times in order, decides which
- * membership version each buffer has to see; returns 0 when every buffer saw the right one,
- * 1 when `todo` (and maybe new snapshots) need another pass, -1 when the batch must go through
- * msd_resolve_batch instead (nothing has been committed in that case).
+ * replay: after a kernel pass, walks the buffers' add lists and flip times in order and decides which
+ * membership version each buffer has to see.  A buffer's short list (rb[b].adds) is enough while the
+ * active table of the snapshot it used is a subset of the live one; otherwise, or when it holds more
+ * than inline_adds <= MSD_RB_ADD_INLINE entries, the complete list all_adds[b][MSD_RB_MSG_CAP] is
+ * needed.  Returns 0 when every buffer saw the right version, 1 when `todo` (and maybe new snapshots)
+ * need another pass, -2 when all_adds is NULL but needed (fetch the lists and call again), -1 when the
+ * batch must go through msd_resolve_batch instead (nothing has been committed in that case).
  * commit: counters, clocks and the filter, once replay returned 0. */
 void msd_gpu_resolve_begin(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, uint64_t *ts,
                            uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
 uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r);
-const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index);
+const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index, uint32_t *active);
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
                            uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
 void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);

@@ -366,6 +366,7 @@ struct msd_batch_state {
     uint32_t *todo;
     uint32_t ntodo;
     msd_filter work; /* GPU resolve: the filter behind the last replayed buffer */
+    uint32_t *short_ok, cap_short;
 };
 
 static void push_msg(buf_result *br, const msd_message *mm, uint64_t req)
@@ -600,6 +601,7 @@ void msd_resolver_free(msd_resolver *r)
     free(bs->ac_begin);
     free(bs->ts);
     free(bs->todo);
+    free(bs->short_ok);
     free(bs);
     r->batch = NULL;
 }
@@ -835,17 +837,37 @@ uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r)
     return r->batch ? r->batch->nsnaps : 0;
 }
 
-const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index)
+const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index, uint32_t *active)
 {
+    *active = (uint32_t)r->batch->snaps[index].active;
     return &r->batch->snaps[index].slot[0][0];
 }
 
+/* every address of x's active table is in y's */
+static int active_subset(const msd_filter *x, const msd_filter *y)
+{
+    const uint32_t *xa = x->slot[x->active], *ya = y->slot[y->active];
+    for (uint32_t i = 0; i < SLOTS; ++i)
+        if (xa[i] != VACANT && !table_has(ya, xa[i], hash24(xa[i])))
+            return 0;
+    return 1;
+}
+
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
-                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo)
+                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo,
+                           uint32_t *ntodo)
 {
     struct msd_batch_state *bs = r->batch;
     bs->work = r->filter;
     uint32_t version = 0, n = 0;
+    /* short_ok[v]: 1 + the flip count at which "snapshot v's active table is a subset of the live
+     * one" was last verified; it stays true until the next flip (active tables only grow) */
+    uint32_t flips = 0;
+    if (bs->cap_snaps > bs->cap_short) {
+        bs->short_ok = realloc(bs->short_ok, (size_t)bs->cap_snaps * sizeof bs->short_ok[0]);
+        bs->cap_short = bs->cap_snaps;
+    }
+    memset(bs->short_ok, 0, (size_t)bs->cap_short * sizeof bs->short_ok[0]);
     for (uint32_t b = 0; b < nbuffers; ++b) {
         const msd_rbuf *br = &rb[b];
         if (br->fallback)
@@ -853,15 +875,33 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
         snap_idx[b] = version;
         if (br->version_used != version)
             todo[n++] = b;
+        const uint32_t v = br->version_used;
+        int use_short = br->nshort <= inline_adds && v < bs->nsnaps;
+        if (use_short && bs->short_ok[v] != flips + 1) {
+            if (active_subset(&bs->snaps[v], &bs->work))
+                bs->short_ok[v] = flips + 1;
+            else
+                use_short = 0;
+        }
+        if (!use_short && !all_adds && br->nadds)
+            return -2;
+        const uint32_t *adds = use_short ? br->adds : all_adds + (size_t)b * MSD_RB_MSG_CAP;
+        const uint32_t nadds = use_short ? br->nshort : br->nadds;
         int changed = 0;
-        const uint32_t *adds = br->nadds > inline_adds ? all_adds + (size_t)b * MSD_RB_MSG_CAP : br->adds;
-        for (uint32_t i = 0; i < br->nadds; ++i)
+        for (uint32_t i = 0; i < nadds; ++i)
             changed |= filter_add(&bs->work, adds[i]);
+        const int active_before = bs->work.active;
         changed |= filter_expire(&bs->work, br->end_now); /* readsb.c:331, after the buffer */
+        flips += bs->work.active != active_before;
         if (changed && b + 1 < nbuffers) {
             version = push_snapshot(bs, &bs->work);
             if (bs->nsnaps > max_snaps)
                 return -1;
+            if (bs->cap_snaps > bs->cap_short) { /* push_snapshot grew the array */
+                bs->short_ok = realloc(bs->short_ok, (size_t)bs->cap_snaps * sizeof bs->short_ok[0]);
+                memset(bs->short_ok + bs->cap_short, 0, (size_t)(bs->cap_snaps - bs->cap_short) * sizeof bs->short_ok[0]);
+                bs->cap_short = bs->cap_snaps;
+            }
         }
     }
     *ntodo = n;

@@ -54,11 +54,12 @@ __device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint
     }
 }
 
-/* icaoFilterTest (icao_filter.c:99-119) against a snapshot: two tables of 8192 slots */
-__device__ __forceinline__ bool snap_known(const uint32_t *snap, uint32_t addr)
+/* icaoFilterTest (icao_filter.c:99-119) against a snapshot: two tables of 8192 slots.
+ * bit 0: in table 0, bit 1: in table 1 */
+__device__ __forceinline__ uint32_t snap_probe(const uint32_t *snap, uint32_t addr)
 {
     const uint32_t start = hash24(addr);
-    return table_has(snap, addr, start) || table_has(snap + SLOTS, addr, start);
+    return (table_has(snap, addr, start) ? 1u : 0u) | (table_has(snap + SLOTS, addr, start) ? 2u : 0u);
 }
 
 struct TryView {
@@ -80,14 +81,14 @@ __device__ __forceinline__ TryView load_try(const msd_try *t)
 
 /* A try as phase P keeps it in LDS (everything the score and the verdict need):
  *   19 address known   20-24 DF   25-27 phase-4   28-35 corrected bit (0xff none)
- *   36 DF11 with IID 0   40-63 address
+ *   36 DF11 with IID 0   37 address in the snapshot's active table   40-63 address
  * and the best phase of a hit: the same word plus  0-15 score (int16)   16-18 offset of the try. */
-__device__ __forceinline__ uint64_t pack_try(const TryView &v, bool known)
+__device__ __forceinline__ uint64_t pack_try(const TryView &v, bool known, bool in_active)
 {
     const uint32_t df = (v.w0 & 0xffu) >> 3, tp = (v.w3 >> 16) & 0xffu, errbit = v.w3 >> 24;
     return ((uint64_t)(known ? 1u : 0u) << 19) | ((uint64_t)df << 20) | ((uint64_t)(tp - 4) << 25) |
            ((uint64_t)errbit << 28) | ((uint64_t)((v.crc & 0x7fu) == 0 ? 1u : 0u) << 36) |
-           ((uint64_t)(v.addr & 0xffffffu) << 40);
+           ((uint64_t)(in_active ? 1u : 0u) << 37) | ((uint64_t)(v.addr & 0xffffffu) << 40);
 }
 
 /* scoreModesMessage (mode_s.c:311-409) on a packed try */
@@ -138,7 +139,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint64_t seg_try[TCAP];
     __shared__ uint16_t seg_toff[SEG + 1];
     __shared__ uint16_t seg_thit[TCAP];       /* owner of each staged try */
-    __shared__ uint32_t out_adds[ADDSET / 2]; /* this buffer's adds, flushed at the end (half go to host memory) */
+    __shared__ uint32_t out_adds[ADDSET / 2]; /* this buffer's adds, flushed at the end */
+    __shared__ uint32_t out_short[MSD_RB_ADD_INLINE]; /* those the host must apply: not in the active table yet */
     __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
     __shared__ uint32_t cand[SEG / 32]; /* hits whose best phase scores >= 0 */
     __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ uint64_t sh_range[2];
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
-    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_next, sh_nacc, sh_newaddr, sh_nfit;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_newaddr, sh_nfit;
 
     const int tid = threadIdx.x;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -156,7 +158,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
     const uint64_t nhits = P.totals[0];
     const uint32_t b = P.todo[blockIdx.x];
-    const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * (2 * SLOTS);
+    const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * MSD_SNAP_WORDS;
+    const uint32_t snap_active = snap[2 * SLOTS] & 1u;
     const uint32_t mlen = P.valid[b];
     const uint64_t sys_ts = P.ts[2 * b + 1];
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     if (tid == 0) {
         sh_resume = base;
         sh_now = sys_ts; /* demod_2400.c:252-255 */
-        sh_nmsgs = sh_nadds = 0;
+        sh_nmsgs = sh_nadds = sh_nshort = 0;
     }
     __syncthreads();
     const uint64_t hb = sh_range[0], he = sh_range[1];
@@ -261,8 +264,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         for (uint32_t t = tid; t < seg_toff[n]; t += RT) { /* one try per thread: the loads of a round overlap */
             const uint32_t i = seg_thit[t];
             const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
-            const bool known = snap_known(snap, v.addr) || addset_has(addset, v.addr);
-            seg_try[t] = pack_try(v, known);
+            const uint32_t where = snap_probe(snap, v.addr);
+            seg_try[t] = pack_try(v, where != 0 || addset_has(addset, v.addr), (where >> snap_active) & 1u);
         }
         __syncthreads();
         const uint32_t ntries = seg_toff[n];
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             /* ---- phase S: the ordered walk over the hits that could be messages, on one lane ---- */
             if (tid == 0) {
                 uint64_t resume = sh_resume, now = sh_now;
-                uint32_t nmsgs = sh_nmsgs, nadds = sh_nadds, nacc = sh_nacc;
+                uint32_t nmsgs = sh_nmsgs, nadds = sh_nadds, nacc = sh_nacc, nshort = sh_nshort;
                 uint32_t c_unk = 0, c_acc0 = 0, c_acc1 = 0, next = n;
                 uint64_t c_bp = 0; /* best-phase counters, 11 bits each */
                 bool stop = false;
@@ -351,6 +354,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                                 if (nadds < MSD_RB_MSG_CAP)
                                     out_adds[nadds] = addr;
                                 nadds++;
+                                if (!((r >> 37) & 1u)) { /* not in the active table yet: the host filter changes */
+                                    if (nshort < MSD_RB_ADD_INLINE)
+                                        out_short[nshort] = addr;
+                                    nshort++;
+                                }
                                 fresh = !known; /* a new aircraft: the hits behind it must see it */
                             }
                         }
@@ -382,6 +390,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 sh_now = now;
                 sh_nmsgs = nmsgs;
                 sh_nadds = nadds;
+                sh_nshort = nshort;
                 sh_nacc = nacc;
                 sh_next = next;
                 sh_ctr[2] += c_unk;
@@ -459,18 +468,18 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
 
     { /* flush the lists, coalesced */
         const uint32_t na = sh_nadds < MSD_RB_MSG_CAP ? sh_nadds : MSD_RB_MSG_CAP;
-        for (uint32_t i = tid; i < na; i += RT) {
-            const uint32_t a = out_adds[i];
-            adds[i] = a;
-            if (i < MSD_RB_ADD_INLINE)
-                rb->adds[i] = a;
-        }
+        for (uint32_t i = tid; i < na; i += RT)
+            adds[i] = out_adds[i];
+        const uint32_t ns = sh_nshort < MSD_RB_ADD_INLINE ? sh_nshort : MSD_RB_ADD_INLINE;
+        for (uint32_t i = tid; i < ns; i += RT)
+            rb->adds[i] = out_short[i];
     }
     if (tid == 0) {
         for (int k = 0; k < 16; ++k)
             rb->ctr[k] = sh_ctr[k];
         rb->nmsgs = sh_nmsgs;
         rb->nadds = sh_nadds;
+        rb->nshort = sh_nshort;
         rb->version_used = P.snap_idx[b];
         rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP) ? 1u : 0u;
         rb->end_now = sh_now;
