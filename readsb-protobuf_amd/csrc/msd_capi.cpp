@@ -256,8 +256,12 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         HIPCHK(c, hipMemcpyAsync(s.d_ragged, s.d_iq + (s.nsamples & ~7ull) * bps, (s.nsamples & 7u) * bps,
                                  hipMemcpyDeviceToDevice, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(s.d_sums, 0, sizeof(uint64_t) * 2 * (s.nbuffers ? s.nbuffers : 1), c->stream));
-    HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
+    /* d_sums is zero: whoever published the slot's previous batch left it so.  The offsets kernel
+     * overwrites the totals. */
+    const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11;
+    const bool lean = nwg && !c->cfg.mode_ac && !fm; /* totals and sums are published by the offsets kernel */
+    if (!nwg)
+        HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
     if (c->cfg.mode_ac)
         HIPCHK(c, hipMemsetAsync(s.d_ac_totals, 0, sizeof(uint64_t) * 4, c->stream));
     HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
@@ -289,7 +293,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
         rc = msd_launch_gather(c->d_counts, nwg, c->d_offsets, s.d_totals, c->d_region_hits,
                                c->d_region_tries, p.hcap, p.tcap, s.d_hits, c->hit_arena, s.d_tries,
-                               c->try_arena, c->stream);
+                               c->try_arena, s.d_sums, s.nbuffers, lean ? s.h_totals : nullptr,
+                               lean ? s.h_sums : nullptr, c->stream);
         if (rc)
             return fail(c, rc, "gather kernel launch failed");
     } else {
@@ -316,8 +321,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
 
     /* totals and per-buffer sums go to pinned host memory from this stream, right behind the kernels */
-    {
-        const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11;
+    if (!lean) {
         int rc = msd_launch_publish(s.d_totals, c->cfg.mode_ac ? s.d_ac_totals : nullptr, s.d_sums,
                                     fm ? s.d_fmeans : nullptr, s.nbuffers, s.h_totals, s.h_ac_totals, s.h_sums,
                                     s.h_fmeans, c->stream);
@@ -1183,6 +1187,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_ragged), 64));
         CK(hipMemset(s.d_ragged, 0, 64));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));
+        CK(hipMemset(s.d_sums, 0, 2 * sizeof(uint64_t) * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_fmeans), 2 * sizeof(float) * c->max_buffers));
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
         if (cfg->mode_ac) {

@@ -805,7 +805,8 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
 /* exclusive offsets of the per-workgroup regions in the dense lists; single workgroup */
 __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *counts, uint32_t nwg,
                                                           uint64_t *offsets /* [nwg][2] */,
-                                                          uint64_t *totals /* [4] */)
+                                                          uint64_t *totals /* [4] */, uint64_t *sums,
+                                                          uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums)
 {
     __shared__ unsigned long long sh[256], st[256];
     __shared__ uint32_t ovf;
@@ -837,7 +838,17 @@ __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *c
         totals[0] = ah;
         totals[1] = at;
         totals[2] = ovf;
+        if (h_totals) { /* what the host waits for goes straight to pinned memory (see msd_publish_kernel) */
+            h_totals[0] = ah;
+            h_totals[1] = at;
+            h_totals[2] = ovf;
+        }
     }
+    if (h_sums)
+        for (uint32_t i = tid; i < 2 * nbuffers; i += 256) {
+            h_sums[i] = sums[i];
+            sums[i] = 0; /* ready for the slot's next batch */
+        }
     __syncthreads();
     h = sh[tid];
     t = st[tid];
@@ -1270,9 +1281,11 @@ extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint
                                  uint64_t *totals, const msd_hit *hits, const msd_try *tries,
                                  uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
                                  uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap,
+                                 uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums,
                                  hipStream_t stream)
 {
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, counts, nwg, offsets, totals);
+    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, counts, nwg, offsets, totals, sums, nbuffers,
+                       h_totals, h_sums);
     hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, offsets, hits, tries,
                        hcap, tcap, dense_hits, dense_hcap, dense_tries, dense_tcap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
@@ -1374,7 +1387,8 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     default:
         return -22;
     }
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, d_counts, nwg, d_offsets, d_totals);
+    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, d_counts, nwg, d_offsets, d_totals,
+                       (uint64_t *)nullptr, 0u, (uint64_t *)nullptr, (uint64_t *)nullptr);
     hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nwg), dim3(256), 0, stream, d_counts, d_offsets, d_regions,
                        (uint32_t)cap, d_dense, dense_cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;

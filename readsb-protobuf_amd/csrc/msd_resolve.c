@@ -349,6 +349,7 @@ typedef struct buf_result {
 
 struct msd_batch_state {
     struct msd_pool *pool;
+    int pool_tried;
     buf_result *res;
     uint32_t res_cap;
     msd_filter *snaps; /* membership versions of the filter within the current batch */
@@ -613,8 +614,6 @@ static struct msd_batch_state *batch_state(msd_resolver *r, uint32_t nbuffers)
         bs = calloc(1, sizeof *bs);
         if (!bs)
             return NULL;
-        const int n = r->threads > 0 ? r->threads : default_threads();
-        bs->pool = pool_create(n - 1);
         r->batch = bs;
     }
     if (nbuffers > bs->res_cap) {
@@ -709,6 +708,11 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         }
     }
 
+    if (!bs->pool && !bs->pool_tried && nbuffers >= 4) { /* the worker threads exist only once the host path is used */
+        const int n = r->threads > 0 ? r->threads : default_threads();
+        bs->pool = pool_create(n - 1);
+        bs->pool_tried = 1;
+    }
     const int serial = !bs->pool || bs->pool->nthreads == 0 || nbuffers < 4;
     msd_filter work;
     const int trace = getenv("MSD_RESOLVE_TRACE") != NULL;

@@ -489,42 +489,31 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     }
 }
 
-/* offsets[b] = number of accepted messages in front of buffer b (one workgroup) */
-__global__ void __launch_bounds__(256) msd_msg_offsets_kernel(const uint32_t *nmsgs, uint32_t nbuffers, uint32_t *offsets)
-{
-    __shared__ uint32_t part[256];
-    const uint32_t tid = threadIdx.x, per = (nbuffers + 255) / 256;
-    uint32_t sum = 0;
-    for (uint32_t i = tid * per; i < (tid + 1) * per && i < nbuffers; ++i)
-        sum += nmsgs[i];
-    part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t a = 0;
-        for (int i = 0; i < 256; ++i) {
-            const uint32_t x = part[i];
-            part[i] = a;
-            a += x;
-        }
-        offsets[nbuffers] = a;
-    }
-    __syncthreads();
-    uint32_t o = part[tid];
-    for (uint32_t i = tid * per; i < (tid + 1) * per && i < nbuffers; ++i) {
-        offsets[i] = o;
-        o += nmsgs[i];
-    }
-}
-
 /* The accepted messages of buffer b as msd_message records at dense[offsets[b]..), plus the request
  * list of the signal power kernel. */
-__global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const uint32_t *offsets,
+__global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, uint32_t *offsets,
                                                        msd_message *dense, uint64_t *dense_req, uint32_t cap)
 {
     if (P.totals[2])
         return;
     const uint32_t b = blockIdx.x;
-    const uint32_t o = offsets[b], nm = offsets[b + 1] - o;
+    /* o = messages in front of this buffer (also left in offsets[] for the power kernel) */
+    __shared__ uint32_t part[4];
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < b; i += 256)
+        mine += P.nmsgs[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    const uint32_t o = part[0] + part[1] + part[2] + part[3], nm = P.nmsgs[b];
+    if (threadIdx.x == 0) {
+        offsets[b] = o;
+        if (b + 1 == gridDim.x)
+            offsets[b + 1] = o + nm;
+    }
     const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
     const uint32_t base = b * MSD_CHUNK_SAMPLES;
     const msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
@@ -567,7 +556,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
  * written straight into pinned host memory at the end of the batch's kernels: a copy on another
  * stream would queue behind the persistent scan kernels of the following batches. */
 __global__ void __launch_bounds__(256) msd_publish_kernel(const uint64_t *totals, const uint64_t *ac_totals,
-                                                          const uint64_t *sums, const float *fmeans, uint32_t nbuffers,
+                                                          uint64_t *sums, const float *fmeans, uint32_t nbuffers,
                                                           uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums,
                                                           float *h_fmeans)
 {
@@ -579,6 +568,7 @@ __global__ void __launch_bounds__(256) msd_publish_kernel(const uint64_t *totals
     }
     for (uint32_t i = tid; i < 2 * nbuffers; i += blockDim.x) {
         h_sums[i] = sums[i];
+        sums[i] = 0; /* ready for the slot's next batch */
         if (fmeans)
             h_fmeans[i] = fmeans[i];
     }
@@ -586,7 +576,7 @@ __global__ void __launch_bounds__(256) msd_publish_kernel(const uint64_t *totals
 
 } /* namespace */
 
-extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, const uint64_t *sums,
+extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, uint64_t *sums,
                                   const float *fmeans, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals,
                                   uint64_t *h_sums, float *h_fmeans, hipStream_t stream)
 {
@@ -608,7 +598,6 @@ extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, uin
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_msg_offsets_kernel, dim3(1), dim3(256), 0, stream, p->nmsgs, nbuffers, d_offsets);
     hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, d_offsets, dense, dense_req, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
