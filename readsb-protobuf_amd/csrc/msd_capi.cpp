@@ -114,7 +114,7 @@ struct msd_ctx {
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
-    hipEvent_t ev_aux = nullptr;
+    hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
     uint32_t est_msgs = 0; /* messages of the last batch: sizes the speculative download of the next */
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
@@ -563,7 +563,9 @@ uint32_t slot_valid(const Slot &s, uint32_t b)
     return (uint32_t)(n > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : n);
 }
 
-/* one resolve pass over the s.resolve_ntodo buffers of the to-do list, on `ks` */
+/* one resolve pass over the s.resolve_ntodo buffers of the to-do list, on `ks`.  Its inputs (new
+ * filter snapshots, control arrays) go up on the aux stream right away -- `ks` is usually still busy
+ * with a scan -- and the kernel waits for them through an event. */
 int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
 {
     const GpuCtl g = gpu_ctl(c, s);
@@ -574,10 +576,14 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
         memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i, &active), sizeof(uint32_t) * 16384);
         stage[16384] = active;
         HIPCHK(c, hipMemcpyAsync(c->d_snaps + (size_t)i * MSD_SNAP_WORDS, stage, sizeof(uint32_t) * MSD_SNAP_WORDS,
-                                 hipMemcpyHostToDevice, ks));
+                                 hipMemcpyHostToDevice, c->aux_stream));
     }
     c->snaps_uploaded = nsn;
-    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, ks));
+    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
+    if (ks != c->aux_stream) {
+        HIPCHK(c, hipEventRecord(c->ev_inputs, c->aux_stream));
+        HIPCHK(c, hipStreamWaitEvent(ks, c->ev_inputs, 0));
+    }
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
     int rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
@@ -1057,6 +1063,7 @@ void destroy(msd_ctx *c)
     if (c->h_adds) (void)hipHostFree(c->h_adds);
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
+    if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
     for (uint8_t *t : c->d_tail)
         (void)hipFree(t);
     (void)hipFree(c->d_stage);
@@ -1226,6 +1233,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming));
     } else {
         c->gpu_resolve = false;
     }

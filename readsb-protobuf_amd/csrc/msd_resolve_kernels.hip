@@ -142,13 +142,16 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t out_adds[ADDSET / 2]; /* this buffer's adds, flushed at the end */
     __shared__ uint32_t out_short[MSD_RB_ADD_INLINE]; /* those the host must apply: not in the active table yet */
     __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
-    __shared__ uint32_t cand[SEG / 32]; /* hits whose best phase scores >= 0 */
+    __shared__ uint32_t okb[SEG / 32];  /* hits that would be accepted if nothing hides them */
+    __shared__ uint16_t ok_idx[SEG], ok_next[SEG], acc_k[SEG], add_first[SEG];
+    __shared__ uint32_t add_rank[ADDSET]; /* per address-set slot: rank of the first message of the round that adds it */
+    __shared__ uint32_t ok_pos[SEG];
     __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
     __shared__ uint32_t sh_ctr[16];
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ uint64_t sh_range[2];
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
-    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_newaddr, sh_nfit;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_newaddr, sh_nfit, sh_nok, sh_na, sh_last;
 
     const int tid = threadIdx.x;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -274,12 +277,17 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         uint32_t start = 0;
         while (start < n) {
             if (tid < (int)(SEG / 32))
-                cand[tid] = 0;
+                okb[tid] = 0;
+            if (tid == 0)
+                sh_last = 0;
             __syncthreads();
             /* best phase of every remaining hit: strict '>' so the first-tried phase wins ties
-             * (demod_2400.c:218); a position without tries scores -2 */
+             * (demod_2400.c:218); a position without tries scores -2.  Then the acceptance part of
+             * decodeModesMessage (mode_s.c:424-555), which only needs what the score used.
+             * seg_res bit 38: would be accepted if no earlier message hides it. */
             for (uint32_t i = start + tid; i < n; i += RT) {
-                const uint32_t nlive = MSD_HIT_NLIVE(seg_hits[i]), o = seg_toff[i];
+                const msd_hit h = seg_hits[i];
+                const uint32_t nlive = MSD_HIT_NLIVE(h), o = seg_toff[i];
                 int bestscore = -2;
                 uint64_t best = 0;
                 for (uint32_t q = 0; q < nlive; ++q) {
@@ -290,121 +298,184 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                         best = t | ((uint64_t)q << 16);
                     }
                 }
-                seg_res[i] = best | ((uint64_t)bestscore & 0xffffu);
-                if (bestscore >= 0)
-                    atomicOr(&cand[i >> 5], 1u << (i & 31));
+                uint64_t r = best | ((uint64_t)bestscore & 0xffffu);
+                if (bestscore >= 0 && MSD_HIT_POS(h) < end) {
+                    const uint32_t known = (uint32_t)(r >> 19) & 1u, df = (uint32_t)(r >> 20) & 31u;
+                    const uint32_t errbit = (uint32_t)(r >> 28) & 0xffu;
+                    const bool nerr = errbit != 0xffu;
+                    bool reject;
+                    if (df == 11)
+                        reject = nerr && !known; /* mode_s.c:492-498 */
+                    else if (df == 17 || df == 18)
+                        reject = nerr && errbit >= 8 && errbit <= 31 && !known; /* mode_s.c:522-526 */
+                    else
+                        reject = !known;
+                    if (!reject) {
+                        r |= 1ull << 38;
+                        atomicOr(&okb[i >> 5], 1u << (i & 31));
+                    }
+                }
+                seg_res[i] = r;
             }
             __syncthreads();
             PHASE(2)
-            /* ---- phase S: the ordered walk over the hits that could be messages, on one lane ---- */
-            if (tid == 0) {
-                uint64_t resume = sh_resume, now = sh_now;
-                uint32_t nmsgs = sh_nmsgs, nadds = sh_nadds, nacc = sh_nacc, nshort = sh_nshort;
-                uint32_t c_unk = 0, c_acc0 = 0, c_acc1 = 0, next = n;
-                uint64_t c_bp = 0; /* best-phase counters, 11 bits each */
-                bool stop = false;
-                for (uint32_t w = start >> 5; w < (n + 31) / 32 && !stop; ++w) {
-                    uint32_t m = cand[w];
-                    if (w == (start >> 5))
-                        m &= ~0u << (start & 31);
-                    while (m) {
-                        const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(m);
-                        m &= m - 1;
-                        const msd_hit h = seg_hits[i];
-                        const uint64_t a = MSD_HIT_POS(h);
-                        if (a >= end) {
-                            stop = true;
-                            break;
-                        }
-                        if (a < resume)
-                            continue; /* inside the previous message (demod_2400.c:416) */
-                        const uint64_t r = seg_res[i];
-                        const uint32_t known = (uint32_t)(r >> 19) & 1u, df = (uint32_t)(r >> 20) & 31u;
-                        const uint32_t tp = 4 + ((uint32_t)(r >> 25) & 7u), errbit = (uint32_t)(r >> 28) & 0xffu;
-                        const uint32_t addr = (uint32_t)(r >> 40);
-                        /* demod_2400.c:358-366, before decode: (timestampMsg - sampleTimestamp) / 12000 ms,
-                         * a 32-bit quotient (at most 131072 * 5 + 776) */
-                        now = sys_ts + ((uint32_t)(a - base) * 5u + (8 + 56) * 12 + tp) / 12000u;
-                        /* acceptance part of decodeModesMessage (mode_s.c:424-555) */
-                        const bool nerr = errbit != 0xffu;
-                        bool reject;
-                        if (df == 11)
-                            reject = nerr && !known; /* mode_s.c:492-498 */
-                        else if (df == 17 || df == 18)
-                            reject = nerr && errbit >= 8 && errbit <= 31 && !known; /* mode_s.c:522-526 */
-                        else
-                            reject = !known;
-                        if (reject) {
-                            c_unk++;
-                            continue;
-                        }
-                        bool fresh = false;
-                        if (!nerr && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) { /* mode_s.c:717-726 */
-                            uint32_t hs = (addr * 2654435761u) >> 21;
-                            bool seen = false;
-                            while (addset[hs] != VACANT) {
-                                if (addset[hs] == addr) {
-                                    seen = true;
-                                    break;
-                                }
-                                hs = (hs + 1) & (ADDSET - 1);
-                            }
-                            if (!seen) {
-                                addset[hs] = addr;
-                                if (nadds < MSD_RB_MSG_CAP)
-                                    out_adds[nadds] = addr;
-                                nadds++;
-                                if (!((r >> 37) & 1u)) { /* not in the active table yet: the host filter changes */
-                                    if (nshort < MSD_RB_ADD_INLINE)
-                                        out_short[nshort] = addr;
-                                    nshort++;
-                                }
-                                fresh = !known; /* a new aircraft: the hits behind it must see it */
-                            }
-                        }
-                        if (nerr)
-                            c_acc1++;
-                        else
-                            c_acc0++;
-                        c_bp += 1ull << (11 * (tp - 4));
-                        if (nmsgs < MSD_RB_MSG_CAP) {
-                            msd_acc rec;
-                            rec.pos = (uint32_t)a;
-                            rec.try_index = (uint32_t)(MSD_HIT_TRY(h) + ((uint32_t)(r >> 16) & 7u));
-                            rec.score = (int32_t)(int16_t)(r & 0xffffu);
-                            rec.pad = 0;
-                            acc[nmsgs] = rec;
-                        }
-                        nmsgs++;
-                        accidx[nacc++] = (uint16_t)i;
-                        resume = a + res_len(r) + 1; /* j += len, then the loop's ++ */
-                        if (fresh) {
-                            sh_newaddr = addr;
-                            next = i + 1;
-                            stop = true;
-                            break;
-                        }
-                    }
+            /* ---- phase S: which of the acceptable hits are not hidden by an earlier accepted one ----
+             * ordered list of the acceptable hits ... */
+            if (tid < 64) {
+                const uint32_t w = tid < (int)(SEG / 32) ? tid : 0;
+                uint32_t m = tid < (int)(SEG / 32) ? okb[w] : 0u;
+                if (w == (start >> 5))
+                    m &= ~0u << (start & 31);
+                else if (w < (start >> 5))
+                    m = 0;
+                uint32_t incl = (uint32_t)__popc(m);
+                const uint32_t cnt = incl;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d, 64);
+                    if (tid >= d)
+                        incl += up;
                 }
-                sh_resume = resume;
-                sh_now = now;
-                sh_nmsgs = nmsgs;
-                sh_nadds = nadds;
-                sh_nshort = nshort;
-                sh_nacc = nacc;
+                uint32_t k = incl - cnt;
+                while (m) {
+                    const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    ok_idx[k] = (uint16_t)i;
+                    ok_pos[k] = (uint32_t)(MSD_HIT_POS(seg_hits[i]) - base);
+                    ++k;
+                }
+                if (tid == 63)
+                    sh_nok = incl;
+            }
+            __syncthreads();
+            const uint32_t nok = sh_nok;
+            /* ... for each, the first acceptable hit behind its message (bit 15: it adds an address the
+             * filter does not know yet, so the hits behind it have to be looked at again) ... */
+            for (uint32_t k = tid; k < nok; k += RT) {
+                const uint64_t r = seg_res[ok_idx[k]];
+                const uint32_t resume = ok_pos[k] + res_len(r) + 1; /* j += len, then the loop's ++ */
+                uint32_t lo = k + 1, hi = nok;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ok_pos[mid] < resume)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                const uint32_t df = (uint32_t)(r >> 20) & 31u, errbit = (uint32_t)(r >> 28) & 0xffu;
+                const bool adds_addr = errbit == 0xffu && (df == 17 || (df == 11 && ((r >> 36) & 1u))); /* mode_s.c:717-726 */
+                const bool fresh = adds_addr && !((r >> 19) & 1u);
+                ok_next[k] = (uint16_t)(lo | (fresh ? 0x8000u : 0u));
+            }
+            __syncthreads();
+            /* ... and the chain of accepted ones, the only sequential bit */
+            if (tid == 0) {
+                const uint32_t from = (uint32_t)(sh_resume - base);
+                uint32_t lo = 0, hi = nok;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ok_pos[mid] < from)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                uint32_t k = lo, na = 0, next = n, lastk = 0xffffffffu;
+                while (k < nok) {
+                    const uint32_t nx = ok_next[k];
+                    acc_k[na++] = (uint16_t)k;
+                    lastk = k;
+                    if (nx & 0x8000u) {
+                        next = (uint32_t)ok_idx[k] + 1;
+                        break;
+                    }
+                    k = nx;
+                }
+                if (lastk != 0xffffffffu)
+                    sh_resume = base + ok_pos[lastk] + res_len(seg_res[ok_idx[lastk]]) + 1;
+                sh_na = na;
                 sh_next = next;
-                sh_ctr[2] += c_unk;
-                sh_ctr[3] += c_acc0;
-                sh_ctr[4] += c_acc1;
-                for (int k = 0; k < 5; ++k)
-                    sh_ctr[11 + k] += (uint32_t)(c_bp >> (11 * k)) & 2047u;
             }
             __syncthreads();
             PHASE(3)
+            /* the accepted messages of this round, in parallel: records, counters, addresses to add */
+            const uint32_t na = sh_na, nacc0 = sh_nacc, nmsgs0 = sh_nmsgs;
+            for (uint32_t j = tid; j < na; j += RT) {
+                const uint32_t i = ok_idx[acc_k[j]];
+                const msd_hit h = seg_hits[i];
+                const uint64_t r = seg_res[i];
+                const uint32_t df = (uint32_t)(r >> 20) & 31u, errbit = (uint32_t)(r >> 28) & 0xffu;
+                const uint32_t addr = (uint32_t)(r >> 40);
+                accidx[nacc0 + j] = (uint16_t)i;
+                if (nmsgs0 + j < MSD_RB_MSG_CAP) {
+                    msd_acc rec;
+                    rec.pos = (uint32_t)MSD_HIT_POS(h);
+                    rec.try_index = (uint32_t)(MSD_HIT_TRY(h) + ((uint32_t)(r >> 16) & 7u));
+                    rec.score = (int32_t)(int16_t)(r & 0xffffu);
+                    rec.pad = 0;
+                    acc[nmsgs0 + j] = rec;
+                }
+                atomicAdd(&sh_ctr[errbit != 0xffu ? 4 : 3], 1u);
+                atomicAdd(&sh_ctr[11 + ((uint32_t)(r >> 25) & 7u)], 1u);
+                add_first[j] = 0;
+                if (errbit == 0xffu && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) { /* mode_s.c:717-726 */
+                    uint32_t hs = (addr * 2654435761u) >> 21;
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&addset[hs], VACANT, addr);
+                        if (old == VACANT) { /* new in this buffer; several lanes may hold the same address: */
+                            add_rank[hs] = 0xffffffffu;
+                            break;
+                        }
+                        if (old == addr)
+                            break;
+                        hs = (hs + 1) & (ADDSET - 1);
+                    }
+                    add_first[j] = (uint16_t)(hs | 0x8000u); /* slot of the address; resolved below */
+                }
+            }
+            __syncthreads();
+            /* the first message of the round with a given new address is the one that adds it */
+            for (uint32_t j = tid; j < na; j += RT) {
+                const uint32_t f = add_first[j];
+                if (f & 0x8000u) {
+                    const uint32_t hs = f & 0x7fffu;
+                    if (add_rank[hs] != 0xfffffffeu) /* added in an earlier round or segment */
+                        atomicMin(&add_rank[hs], j);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { /* append them in message order (the host applies them in this order) */
+                uint32_t nadds = sh_nadds, nshort = sh_nshort;
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t f = add_first[j];
+                    if (!(f & 0x8000u))
+                        continue;
+                    const uint32_t hs = f & 0x7fffu;
+                    if (add_rank[hs] != j)
+                        continue;
+                    add_rank[hs] = 0xfffffffeu;
+                    const uint64_t r = seg_res[ok_idx[acc_k[j]]];
+                    const uint32_t addr = (uint32_t)(r >> 40);
+                    if (nadds < MSD_RB_MSG_CAP)
+                        out_adds[nadds] = addr;
+                    nadds++;
+                    if (!((r >> 37) & 1u)) { /* not in the active table yet: the host filter changes */
+                        if (nshort < MSD_RB_ADD_INLINE)
+                            out_short[nshort] = addr;
+                        nshort++;
+                    }
+                    if (!((r >> 19) & 1u))
+                        sh_newaddr = addr; /* at most one per round: the chain stops behind it */
+                }
+                sh_nadds = nadds;
+                sh_nshort = nshort;
+                sh_nacc = nacc0 + na;
+                sh_nmsgs = nmsgs0 + na;
+            }
+            __syncthreads();
             /* ---- phase C: the counters of every hit that no accepted message hides, in parallel ---- */
             const uint32_t stop_at = sh_next, nacc = sh_nacc;
             const uint64_t seg_resume = sh_seg_resume;
-            uint32_t c_pre = 0, c_bad = 0, c_unk = 0, c_p01 = 0, c_p23 = 0, c_p4 = 0;
+            uint32_t c_pre = 0, c_bad = 0, c_unk = 0, c_p01 = 0, c_p23 = 0, c_p4 = 0, last = 0;
             for (uint32_t i = start + tid; i < stop_at; i += RT) {
                 const msd_hit h = seg_hits[i];
                 const uint64_t a = MSD_HIT_POS(h);
@@ -430,16 +501,23 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 c_p01 += mask & 1u;
                 c_p23 += (mask >> 1) & 1u;
                 c_p4 += (mask >> 2) & 1u;
-                const uint32_t sc = (uint32_t)seg_res[i] & 0xffffu;
+                const uint64_t r = seg_res[i];
+                const uint32_t sc = (uint32_t)r & 0xffffu;
                 c_bad += sc == 0xfffeu;
-                c_unk += sc == 0xffffu;
+                /* unknown: scored -1, or scored >= 0 and then failed the acceptance rules */
+                c_unk += (sc == 0xffffu) || (!(sc & 0x8000u) && !((r >> 38) & 1u));
+                if (!(sc & 0x8000u))
+                    last = i + 1; /* reached decodeModesMessage: it set Modes.ifile_now first */
             }
             { /* six counters of at most 4 per lane, packed ten bits apart, summed over the wavefront */
                 uint64_t pk = (uint64_t)c_pre | ((uint64_t)c_bad << 10) | ((uint64_t)c_unk << 20) | ((uint64_t)c_p01 << 30) |
                               ((uint64_t)c_p23 << 40) | ((uint64_t)c_p4 << 50);
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
+                for (int o = 32; o > 0; o >>= 1) {
                     pk += __shfl_down(pk, o, 64);
+                    const uint32_t l2 = __shfl_down(last, o, 64);
+                    last = l2 > last ? l2 : last;
+                }
                 if ((tid & 63) == 0 && pk) {
                     atomicAdd(&sh_ctr[0], (uint32_t)pk & 1023u);
                     atomicAdd(&sh_ctr[1], (uint32_t)(pk >> 10) & 1023u);
@@ -450,10 +528,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     atomicAdd(&sh_ctr[8], p23);
                     atomicAdd(&sh_ctr[9], p23);
                     atomicAdd(&sh_ctr[10], (uint32_t)(pk >> 50) & 1023u);
+                    atomicMax(&sh_last, last);
                 }
             }
             start = stop_at;
-            if (start < n) { /* the walk stopped at a new aircraft: its later tries are known now */
+            if (start < n) { /* the chain stopped at a new aircraft: its later tries are known now */
                 const uint32_t x = sh_newaddr;
                 for (uint32_t t = tid; t < ntries; t += RT) {
                     const uint64_t v = seg_try[t];
@@ -462,6 +541,12 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 }
             }
             __syncthreads();
+            if (tid == 0 && sh_last) { /* demod_2400.c:358-366: (timestampMsg - sampleTimestamp) / 12000 ms */
+                const uint32_t i = sh_last - 1;
+                const uint64_t r = seg_res[i];
+                const uint32_t tp = 4 + ((uint32_t)(r >> 25) & 7u);
+                sh_now = sys_ts + ((uint32_t)(MSD_HIT_POS(seg_hits[i]) - base) * 5u + (8 + 56) * 12 + tp) / 12000u;
+            }
             PHASE(4)
         }
     }
