@@ -43,10 +43,10 @@ struct Slot {
     uint32_t resolve_ntodo = 0;
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
-    uint32_t *d_adds = nullptr, *d_nmsgs = nullptr, *d_off = nullptr;
+    uint32_t *d_adds = nullptr, *d_nmsgs = nullptr;
+    uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
-    msd_message *d_msgs = nullptr, *h_msgs = nullptr; /* message records of the emit kernel and their pinned copy */
-    uint32_t copied_msgs = 0;      /* how many of them the queued download covers */
+    msd_message *h_msgs = nullptr; /* pinned: the emit kernel writes the message records into it */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
     /* batch description */
     const uint8_t *d_iq = nullptr;
@@ -115,7 +115,6 @@ struct msd_ctx {
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
     hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
-    uint32_t est_msgs = 0; /* messages of the last batch: sizes the speculative download of the next */
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -177,18 +176,15 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     if (s.h_req) (void)hipHostFree(s.h_req);
     if (s.h_pow) (void)hipHostFree(s.h_pow);
     if (s.h_msgs) (void)hipHostFree(s.h_msgs);
-    (void)hipFree(s.d_msgs);
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
-    s.h_msgs = s.d_msgs = nullptr;
+    s.h_msgs = nullptr;
     s.req_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_pow), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_pow), cap * sizeof(uint64_t)));
-    if (c->gpu_resolve) {
+    if (c->gpu_resolve)
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_msgs), cap * sizeof(msd_message)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_msgs), cap * sizeof(msd_message)));
-    }
     s.req_cap = cap;
     return 0;
 }
@@ -592,48 +588,24 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
     return 0;
 }
 
-/* message records and signal power of every buffer on `ks`, then the download of the first `expect`
- * of them on the aux stream (the count is not known on the host yet); ev_resolve marks the end of both */
-int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks, size_t expect)
+/* message records and signal power of every buffer on `ks`: both kernels write straight into pinned
+ * host memory (a copy on another stream would contend with the next scan and arrive late);
+ * ev_records marks their end */
+int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
 {
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
-    int rc = msd_launch_emit(&rp, s.nbuffers, s.d_off, s.d_msgs, s.d_req, (uint32_t)s.req_cap, ks);
-    if (rc)
-        return fail(c, rc, "emit kernel launch failed");
     MsdScanParams p{};
     fill_params(c, s, p);
-    rc = msd_launch_power_buffers(&p, format, s.d_req, s.d_off, s.nbuffers, s.d_totals,
-                                  reinterpret_cast<unsigned long long *>(s.d_pow), (uint32_t)s.req_cap, ks);
+    int rc = msd_launch_power_buffers(&p, format, s.d_acc, s.d_tries, s.d_nmsgs, s.nbuffers, s.d_totals,
+                                      reinterpret_cast<unsigned long long *>(s.d_powr), ks);
     if (rc)
         return fail(c, rc, "power kernel launch failed");
-    if (expect > s.req_cap)
-        expect = s.req_cap;
-    hipStream_t cs = ks;
-    if (ks != c->aux_stream) {
-        HIPCHK(c, hipEventRecord(s.ev_records, ks));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, s.ev_records, 0));
-        cs = c->aux_stream;
-    }
-    if (expect) {
-        HIPCHK(c, hipMemcpyAsync(s.h_msgs, s.d_msgs, expect * sizeof(msd_message), hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, expect * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
-    }
-    s.copied_msgs = (uint32_t)expect;
-    HIPCHK(c, hipEventRecord(s.ev_resolve, cs));
-    return 0;
-}
-
-/* the records beyond the speculative download, if the batch held more messages than expected */
-int gpu_fetch_rest(msd_ctx *c, Slot &s, uint32_t total)
-{
-    if (total <= s.copied_msgs)
-        return 0;
-    const size_t o = s.copied_msgs, k = total - s.copied_msgs;
-    HIPCHK(c, hipMemcpyAsync(s.h_msgs + o, s.d_msgs + o, k * sizeof(msd_message), hipMemcpyDeviceToHost, c->aux_stream));
-    HIPCHK(c, hipMemcpyAsync(s.h_pow + o, s.d_pow + o, k * sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux_stream));
-    HIPCHK(c, hipStreamSynchronize(c->aux_stream));
-    s.copied_msgs = total;
+    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.h_msgs,
+                         reinterpret_cast<unsigned long long *>(s.h_pow), (uint32_t)s.req_cap, ks);
+    if (rc)
+        return fail(c, rc, "emit kernel launch failed");
+    HIPCHK(c, hipEventRecord(s.ev_records, ks));
     return 0;
 }
 
@@ -650,8 +622,10 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (!rc)
         rc = gpu_queue_pass(c, s, c->stream);
-    if (!rc)
-        rc = gpu_queue_emit(c, s, format, c->stream, c->est_msgs ? (size_t)c->est_msgs + c->est_msgs / 4 + 2048 : s.req_cap);
+    if (!rc) {
+        HIPCHK(c, hipEventRecord(s.ev_resolve, c->stream));
+        rc = gpu_queue_emit(c, s, format, c->stream);
+    }
     if (rc)
         return rc;
     s.resolve_inflight = true;
@@ -722,7 +696,8 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         total += s.h_rbuf[b].nmsgs;
         c->out_buf.insert(c->out_buf.end(), s.h_rbuf[b].nmsgs, b);
     }
-    if (total > s.req_cap) {
+    if (total > s.req_cap) { /* more messages than the arrays of the speculative records hold */
+        HIPCHK(c, hipEventSynchronize(s.ev_records));
         int rc = ensure_req(c, s, total);
         if (rc)
             return rc;
@@ -730,11 +705,10 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     }
     hipStream_t rs = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
     if (!records_current && total) {
-        int rc = gpu_queue_emit(c, s, format, rs, total);
+        int rc = gpu_queue_emit(c, s, format, rs);
         if (rc)
             return rc;
     }
-    c->est_msgs = total;
     /* the filter is final for this batch: its successor can start */
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
@@ -744,13 +718,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
                 return rc;
         }
     }
-    if (!records_current && total)
-        HIPCHK(c, hipEventSynchronize(s.ev_resolve));
-    {
-        int rc = gpu_fetch_rest(c, s, total);
-        if (rc)
-            return rc;
-    }
+    HIPCHK(c, hipEventSynchronize(s.ev_records));
     auto e1 = tnow();
     msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), s.h_msgs, nullptr, c->out_buf.data(), s.h_pow,
                       total);
@@ -1041,13 +1009,12 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_off);
+        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_msgs) (void)hipHostFree(s.h_msgs);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
-        (void)hipFree(s.d_msgs);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
@@ -1222,7 +1189,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_nmsgs), sizeof(uint32_t) * c->max_buffers));
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_off), sizeof(uint32_t) * (c->max_buffers + 1)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
             memset(s.h_ctl, 0, ctl_bytes);

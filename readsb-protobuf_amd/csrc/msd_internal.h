@@ -97,7 +97,7 @@ typedef struct msd_acc {
     uint32_t pos; /* batch-relative scan position */
     uint32_t try_index;
     int32_t score;
-    uint32_t pad;
+    uint32_t len; /* samples its signal power is summed over: msgbits * 12 / 5 */
 } msd_acc;
 
 /* ---- host tables (msd_tables.c) ---- */

@@ -57,14 +57,14 @@ int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, uint64
                        uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums, float *h_fmeans,
                        hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
-/* offsets (device scratch, nbuffers + 1) from the buffers' message counts, then the message records
- * and the request list of the power kernel; entries beyond cap are dropped (the host notices) */
-int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, uint32_t *d_offsets, msd_message *dense,
-                    uint64_t *dense_req, uint32_t cap, hipStream_t stream);
-/* signal power of the emitted messages, four workgroups per buffer: out[i] for i < cap */
-int msd_launch_power_buffers(const MsdScanParams *p, int format, const uint64_t *d_req, const uint32_t *d_offsets,
-                             uint32_t nbuffers, const uint64_t *totals, unsigned long long *out, uint32_t cap,
+/* signal power of the accepted messages of every buffer: out[buffer][MSD_RB_MSG_CAP] (device) */
+int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
+                             const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals, unsigned long long *out,
                              hipStream_t stream);
+/* the accepted messages as dense msd_message records plus their signal power, both into pinned host
+ * arrays of cap entries (what does not fit is dropped; the host notices from the counts) */
+int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_message *h_msgs,
+                    unsigned long long *h_pow, uint32_t cap, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 /* h_totals / h_sums, if not NULL, are pinned host addresses that receive the list totals and the

@@ -943,30 +943,37 @@ __global__ void __launch_bounds__(256) msd_power_kernel(const MsdScanParams P, c
 }
 
 /* The same for the GPU resolve stage, which does not know the number of messages on the host when
- * it queues the kernel: four workgroups per buffer walk that buffer's slice of the request list. */
+ * it queues the kernel: eight workgroups per buffer walk the accepted-message records the resolve
+ * kernel left for that buffer, one wavefront per message; out[buffer][MSD_RB_MSG_CAP]. */
 template <int FMT>
-__global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const uint64_t *req,
-                                                                const uint32_t *offsets, const uint64_t *totals,
-                                                                unsigned long long *out, uint32_t cap)
+__global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const msd_acc *acc,
+                                                                const msd_try *tries, const uint32_t *nmsgs,
+                                                                const uint64_t *totals, unsigned long long *out)
 {
     if (totals[2])
         return;
-    const uint32_t b = blockIdx.x >> 2, end = offsets[b + 1] < cap ? offsets[b + 1] : cap;
+    const uint32_t b = blockIdx.x >> 3, nm = nmsgs[b];
     const int lane = threadIdx.x & 63;
-    for (uint32_t i = offsets[b] + (blockIdx.x & 3u) * 4 + (threadIdx.x >> 6); i < end; i += 16) {
-        const uint64_t rq = req[i];
-        const int len = (int)(rq & 0xffffu);
-        const int64_t n0 = (int64_t)P.batch_first + (int64_t)(rq >> 16) - (int64_t)MSD_OVERLAP + 19;
-        unsigned long long acc = 0;
-        for (int k = lane; k < len; k += 64) {
-            const uint32_t x = stream_mag<FMT>(P, n0 + k, P.lut);
-            acc += (unsigned long long)(x * x);
+    for (uint32_t m = (blockIdx.x & 7u) * 4 + (threadIdx.x >> 6); m < nm; m += 32) {
+        const msd_acc rec = acc[(size_t)b * MSD_RB_MSG_CAP + m];
+        const int len = (int)rec.len;
+        const int64_t n0 = (int64_t)P.batch_first + (int64_t)rec.pos - (int64_t)MSD_OVERLAP + 19;
+        /* len is 134 or 268: five independent loads per lane instead of a data-dependent loop */
+        uint32_t x[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = lane + 64 * u;
+            x[u] = k < len ? stream_mag<FMT>(P, n0 + k, P.lut) : 0u;
         }
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            sum += (unsigned long long)(x[u] * x[u]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
-            acc += __shfl_down(acc, o);
+            sum += __shfl_down(sum, o);
         if (lane == 0)
-            out[i] = acc;
+            out[(size_t)b * MSD_RB_MSG_CAP + m] = sum;
     }
 }
 
@@ -1316,25 +1323,25 @@ extern "C" int msd_launch_power(const MsdScanParams *p, int format, const uint64
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, const uint64_t *d_req,
-                                        const uint32_t *d_offsets, uint32_t nbuffers, const uint64_t *totals,
-                                        unsigned long long *out, uint32_t cap, hipStream_t stream)
+extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
+                                        const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals,
+                                        unsigned long long *out, hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
-    const dim3 grid(nbuffers * 4), block(256);
+    const dim3 grid(nbuffers * 8), block(256);
     switch (format) {
     case MSD_FMT_UC8:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
         break;
     case MSD_FMT_SC16:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
         break;
     case MSD_FMT_SC16Q11:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
         break;
     case MSD_FMT_MAG16:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, d_req, d_offsets, totals, out, cap);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
         break;
     default:
         return -22;

@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     rec.pos = (uint32_t)MSD_HIT_POS(h);
                     rec.try_index = (uint32_t)(MSD_HIT_TRY(h) + ((uint32_t)(r >> 16) & 7u));
                     rec.score = (int32_t)(int16_t)(r & 0xffffu);
-                    rec.pad = 0;
+                    rec.len = res_len(r);
                     acc[nmsgs0 + j] = rec;
                 }
                 atomicAdd(&sh_ctr[errbit != 0xffu ? 4 : 3], 1u);
@@ -574,15 +574,16 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     }
 }
 
-/* The accepted messages of buffer b as msd_message records at dense[offsets[b]..), plus the request
- * list of the signal power kernel. */
-__global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, uint32_t *offsets,
-                                                       msd_message *dense, uint64_t *dense_req, uint32_t cap)
+/* The accepted messages of buffer b as msd_message records, dense over the batch, with the signal
+ * power the power kernel left per buffer; both arrays live in pinned host memory and consecutive
+ * lanes write consecutive records, so the stores leave as full PCIe bursts. */
+__global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
+                                                       msd_message *dense, unsigned long long *dense_pow, uint32_t cap)
 {
     if (P.totals[2])
         return;
     const uint32_t b = blockIdx.x;
-    /* o = messages in front of this buffer (also left in offsets[] for the power kernel) */
+    /* o = messages in front of this buffer */
     __shared__ uint32_t part[4];
     uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < b; i += 256)
@@ -594,11 +595,6 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         part[threadIdx.x >> 6] = mine;
     __syncthreads();
     const uint32_t o = part[0] + part[1] + part[2] + part[3], nm = P.nmsgs[b];
-    if (threadIdx.x == 0) {
-        offsets[b] = o;
-        if (b + 1 == gridDim.x)
-            offsets[b + 1] = o + nm;
-    }
     const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
     const uint32_t base = b * MSD_CHUNK_SAMPLES;
     const msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
@@ -631,9 +627,8 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         mm.pad = 0;
         if (o + m >= cap)
             break; /* the host notices (total > cap), grows the arrays and emits again */
-        const uint64_t rq = ((uint64_t)rec.pos << 16) | (uint64_t)(msgbits * 12 / 5);
         dense[o + m] = mm;
-        dense_req[o + m] = rq;
+        dense_pow[o + m] = power[(size_t)b * MSD_RB_MSG_CAP + m];
     }
 }
 
@@ -678,11 +673,11 @@ extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hip
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, uint32_t *d_offsets, msd_message *dense,
-                               uint64_t *dense_req, uint32_t cap, hipStream_t stream)
+extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power,
+                               msd_message *h_msgs, unsigned long long *h_pow, uint32_t cap, hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, d_offsets, dense, dense_req, cap);
+    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, h_msgs, h_pow, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
