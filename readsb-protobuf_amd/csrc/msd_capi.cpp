@@ -115,6 +115,11 @@ struct msd_ctx {
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
     hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
+    uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST] */
+    msd_pred_entry *h_pred = nullptr;
+    uint32_t *h_pred_count = nullptr;
+    msd_pred_patch *h_patches = nullptr;
+    uint32_t npatches = 0;
     /* the last MSD_HALO_FRONT samples of the previous batch, one buffer per pipeline stage + 1 */
     uint8_t *d_tail[MSD_PIPELINE_DEPTH + 1] = {};
     int tail_cur = 0;
@@ -550,6 +555,8 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     rp.nmsgs = s.d_nmsgs;
     rp.acc = s.d_acc;
     rp.adds = s.d_adds;
+    rp.pred_key = c->d_pred;
+    rp.pred_first = c->d_pred + MSD_PRED_SLOTS;
 }
 
 uint32_t slot_valid(const Slot &s, uint32_t b)
@@ -562,7 +569,7 @@ uint32_t slot_valid(const Slot &s, uint32_t b)
 /* one resolve pass over the s.resolve_ntodo buffers of the to-do list, on `ks`.  Its inputs (new
  * filter snapshots, control arrays) go up on the aux stream right away -- `ks` is usually still busy
  * with a scan -- and the kernel waits for them through an event. */
-int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
+int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
 {
     const GpuCtl g = gpu_ctl(c, s);
     const uint32_t nsn = msd_gpu_resolve_nsnaps(&c->resolver);
@@ -582,7 +589,14 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks)
     }
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
-    int rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
+    int rc = 0;
+    if (first_pass) /* which new addresses will this batch add, and where first */
+        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, c->d_pred, c->h_pred, c->h_pred_count, ks);
+    else
+        rc = msd_launch_pred_patch(c->d_pred + MSD_PRED_SLOTS, c->h_patches, c->npatches, ks);
+    if (rc)
+        return fail(c, rc, "prediction kernel launch failed");
+    rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
     if (rc)
         return fail(c, rc, "resolve kernel launch failed");
     return 0;
@@ -621,7 +635,7 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     c->snaps_uploaded = 0;
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (!rc)
-        rc = gpu_queue_pass(c, s, c->stream);
+        rc = gpu_queue_pass(c, s, c->stream, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, c->stream));
         rc = gpu_queue_emit(c, s, format, c->stream);
@@ -661,15 +675,17 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         ++npass;
         HIPCHK(c, hipEventSynchronize(wait_for));
         auto k1 = tnow();
-        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, g.h_snap,
-                                        g.h_todo, &s.resolve_ntodo);
+        int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
+                                        *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
+                                        &s.resolve_ntodo);
         if (rc == -2) { /* a flip, or very many new addresses in one buffer: the complete add lists are needed */
             c->timing.resolve_long_lists++;
             HIPCHK(c, hipMemcpyAsync(c->h_adds, s.d_adds, sizeof(uint32_t) * MSD_RB_MSG_CAP * n, hipMemcpyDeviceToHost,
                                      c->aux_stream));
             HIPCHK(c, hipStreamSynchronize(c->aux_stream));
-            rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, g.h_snap,
-                                        g.h_todo, &s.resolve_ntodo);
+            rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, c->h_pred,
+                                        *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
+                                        &s.resolve_ntodo);
         }
         t_wait += tms(k0, k1);
         t_replay += tms(k1, tnow());
@@ -679,7 +695,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
         hipStream_t ps = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
-        rc = gpu_queue_pass(c, s, ps);
+        rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
         HIPCHK(c, hipEventRecord(c->ev_aux, ps));
@@ -1031,6 +1047,10 @@ void destroy(msd_ctx *c)
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
+    (void)hipFree(c->d_pred);
+    if (c->h_pred) (void)hipHostFree(c->h_pred);
+    if (c->h_pred_count) (void)hipHostFree(c->h_pred_count);
+    if (c->h_patches) (void)hipHostFree(c->h_patches);
     for (uint8_t *t : c->d_tail)
         (void)hipFree(t);
     (void)hipFree(c->d_stage);
@@ -1201,6 +1221,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming));
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 1 + MSD_PRED_LIST)));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pred), sizeof(msd_pred_entry) * MSD_PRED_LIST));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pred_count), 64));
+        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_patches), sizeof(msd_pred_patch) * 2 * MSD_PRED_LIST));
+        *c->h_pred_count = 0;
     } else {
         c->gpu_resolve = false;
     }

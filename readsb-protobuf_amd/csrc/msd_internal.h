@@ -79,6 +79,24 @@ typedef struct msd_wg_counts {
 #define MSD_RB_ADD_INLINE 224u /* icaoFilterAdd addresses of one buffer reported inline: those that are not in the
                                   snapshot's active table already (the others cannot change the filter) */
 #define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[2][8192], then the index of the active table */
+/* Predicted adds of a batch: every address that is not in the filter when the batch starts but has
+ * a CRC-clean DF17 / DF11(II=0) try somewhere in it, with the first buffer holding such a try.  The
+ * resolve kernel treats the address as known in all later buffers, so a batch in which new aircraft
+ * show up still converges in one pass; the host checks every prediction against the adds that
+ * really happened (a predicted message can be hidden behind another one) and corrects the table. */
+#define MSD_PRED_SLOTS 16384u
+#define MSD_PRED_LIST 8192u /* at most this many predicted addresses; more: the host resolver takes the batch */
+#define MSD_PRED_NEVER 0xFFFFFFFFu
+typedef struct msd_pred_entry {
+    uint32_t addr;
+    uint32_t first; /* buffer of the first clean squitter */
+    uint32_t slot;  /* position in the device table, for corrections */
+    uint32_t pad;
+} msd_pred_entry;
+typedef struct msd_pred_patch {
+    uint32_t slot, first;
+} msd_pred_patch;
+
 /* what the resolve kernel reports per buffer; 1 KiB */
 typedef struct msd_rbuf {
     uint32_t ctr[16]; /* 0 preambles, 1 bad, 2 unknown, 3/4 accepted with 0/1 fixes, 6-10 preamble phases,
@@ -167,13 +185,17 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
  * needed.  Returns 0 when every buffer saw the right version, 1 when `todo` (and maybe new snapshots)
  * need another pass, -2 when all_adds is NULL but needed (fetch the lists and call again), -1 when the
  * batch must go through msd_resolve_batch instead (nothing has been committed in that case).
+ * pred[0..npred) is the batch's prediction list (its `first` fields are kept up to date); the
+ * corrections the device table needs before the next pass come back in patches[0..*npatches).
  * commit: counters, clocks and the filter, once replay returned 0. */
 void msd_gpu_resolve_begin(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, uint64_t *ts,
                            uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
 uint32_t msd_gpu_resolve_nsnaps(const msd_resolver *r);
 const uint32_t *msd_gpu_resolve_snapshot(const msd_resolver *r, uint32_t index, uint32_t *active);
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
-                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo, uint32_t *ntodo);
+                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, msd_pred_entry *pred, uint32_t npred,
+                           msd_pred_patch *patches, uint32_t *npatches, uint32_t *snap_idx, uint32_t *todo,
+                           uint32_t *ntodo);
 void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
 
 #ifdef __cplusplus

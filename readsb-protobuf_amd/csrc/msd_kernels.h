@@ -47,6 +47,8 @@ typedef struct MsdResolveParams {
     uint32_t *nmsgs;          /* [buffer] accepted messages, for the offsets of the emit kernel */
     msd_acc *acc;             /* [buffer][MSD_RB_MSG_CAP] */
     uint32_t *adds;           /* [buffer][MSD_RB_MSG_CAP]: the complete add lists (msd_rbuf holds the first ones) */
+    const uint32_t *pred_key; /* [MSD_PRED_SLOTS] predicted adds: address ... */
+    const uint32_t *pred_first; /* ... and the first buffer with a clean squitter of it */
 } MsdResolveParams;
 
 #ifdef __cplusplus
@@ -56,6 +58,13 @@ extern "C" {
 int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, uint64_t *sums, const float *fmeans,
                        uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums, float *h_fmeans,
                        hipStream_t stream);
+/* Builds the prediction table of a batch from its try list (against snapshot 0) and publishes the
+ * list of entries: h_list[0..*h_count) in pinned host memory, *h_count = MSD_PRED_LIST + 1 on overflow.
+ * pred (device): key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | counter | slot list[MSD_PRED_LIST]. */
+int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
+                       msd_pred_entry *h_list, uint32_t *h_count, hipStream_t stream);
+/* pred_first[patches[i].slot] = patches[i].first; patches is pinned host memory */
+int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
 /* signal power of the accepted messages of every buffer: out[buffer][MSD_RB_MSG_CAP] (device) */
 int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,

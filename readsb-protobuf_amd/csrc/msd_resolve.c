@@ -368,6 +368,10 @@ struct msd_batch_state {
     uint32_t ntodo;
     msd_filter work; /* GPU resolve: the filter behind the last replayed buffer */
     uint32_t *short_ok, cap_short;
+    uint32_t *pmap, pmap_cap, pmap_alloc; /* address -> 1 + index in the prediction list */
+    uint8_t *pconf, *stale;
+    uint32_t pconf_cap, stale_cap;
+    uint32_t undo_idx[2 * MSD_PRED_LIST], undo_first[2 * MSD_PRED_LIST]; /* to take back corrections on -2 */
 };
 
 static void push_msg(buf_result *br, const msd_message *mm, uint64_t req)
@@ -603,6 +607,9 @@ void msd_resolver_free(msd_resolver *r)
     free(bs->ts);
     free(bs->todo);
     free(bs->short_ok);
+    free(bs->pmap);
+    free(bs->pconf);
+    free(bs->stale);
     free(bs);
     r->batch = NULL;
 }
@@ -857,13 +864,31 @@ static int active_subset(const msd_filter *x, const msd_filter *y)
     return 1;
 }
 
+/* index of addr in the batch's prediction list, -1 if it is not there */
+static int pred_find(const struct msd_batch_state *bs, const msd_pred_entry *pred, uint32_t addr)
+{
+    if (!bs->pmap_cap)
+        return -1;
+    uint32_t h = (uint32_t)mix_addr(addr) & (bs->pmap_cap - 1);
+    while (bs->pmap[h]) {
+        if (pred[bs->pmap[h] - 1].addr == addr)
+            return (int)bs->pmap[h] - 1;
+        h = (h + 1) & (bs->pmap_cap - 1);
+    }
+    return -1;
+}
+
 int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *rb, const uint32_t *all_adds,
-                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, uint32_t *snap_idx, uint32_t *todo,
+                           uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, msd_pred_entry *pred, uint32_t npred,
+                           msd_pred_patch *patches, uint32_t *npatches, uint32_t *snap_idx, uint32_t *todo,
                            uint32_t *ntodo)
 {
     struct msd_batch_state *bs = r->batch;
+    *npatches = 0;
+    if (npred > MSD_PRED_LIST)
+        return -1; /* thousands of new aircraft in one batch: the table overflowed */
     bs->work = r->filter;
-    uint32_t version = 0, n = 0;
+    uint32_t version = 0, n = 0, np = 0;
     /* short_ok[v]: 1 + the flip count at which "snapshot v's active table is a subset of the live
      * one" was last verified; it stays true until the next flip (active tables only grow) */
     uint32_t flips = 0;
@@ -872,13 +897,41 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
         bs->cap_short = bs->cap_snaps;
     }
     memset(bs->short_ok, 0, (size_t)bs->cap_short * sizeof bs->short_ok[0]);
+    { /* addr -> prediction, confirmation flags, stale marks */
+        uint32_t cap = 64;
+        while (cap < 2 * npred + 2)
+            cap *= 2;
+        if (cap > bs->pmap_alloc) {
+            bs->pmap = realloc(bs->pmap, (size_t)cap * sizeof bs->pmap[0]);
+            bs->pmap_alloc = cap;
+        }
+        bs->pmap_cap = cap;
+        memset(bs->pmap, 0, (size_t)cap * sizeof bs->pmap[0]);
+        if (npred > bs->pconf_cap) {
+            bs->pconf = realloc(bs->pconf, npred);
+            bs->pconf_cap = npred;
+        }
+        if (npred)
+            memset(bs->pconf, 0, npred);
+        for (uint32_t i = 0; i < npred; ++i) {
+            uint32_t h = (uint32_t)mix_addr(pred[i].addr) & (cap - 1);
+            while (bs->pmap[h])
+                h = (h + 1) & (cap - 1);
+            bs->pmap[h] = i + 1;
+        }
+        if (nbuffers > bs->stale_cap) {
+            bs->stale = realloc(bs->stale, nbuffers);
+            bs->stale_cap = nbuffers;
+        }
+        memset(bs->stale, 0, nbuffers);
+    }
     for (uint32_t b = 0; b < nbuffers; ++b) {
         const msd_rbuf *br = &rb[b];
         if (br->fallback)
             return -1;
         snap_idx[b] = version;
         if (br->version_used != version)
-            todo[n++] = b;
+            bs->stale[b] = 1;
         const uint32_t v = br->version_used;
         int use_short = br->nshort <= inline_adds && v < bs->nsnaps;
         if (use_short && bs->short_ok[v] != flips + 1) {
@@ -887,17 +940,51 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
             else
                 use_short = 0;
         }
-        if (!use_short && !all_adds && br->nadds)
+        if (!use_short && !all_adds && br->nadds) {
+            while (np) { /* nothing may stick: the caller comes back with the complete lists */
+                --np;
+                pred[bs->undo_idx[np]].first = bs->undo_first[np];
+            }
             return -2;
+        }
         const uint32_t *adds = use_short ? br->adds : all_adds + (size_t)b * MSD_RB_MSG_CAP;
         const uint32_t nadds = use_short ? br->nshort : br->nadds;
-        int changed = 0;
-        for (uint32_t i = 0; i < nadds; ++i)
-            changed |= filter_add(&bs->work, adds[i]);
+        int regime_change = 0; /* the membership changed in a way the prediction table does not cover */
+        for (uint32_t i = 0; i < nadds; ++i) {
+            if (!filter_add(&bs->work, adds[i]))
+                continue;
+            /* a new member, known from buffer b + 1 on: was that predicted? */
+            const int e = pred_find(bs, pred, adds[i]);
+            if (e >= 0 && !bs->pconf[e] && pred[e].first <= b) {
+                if (pred[e].first < b) { /* the predicted message was hidden: the buffers in between assumed too much */
+                    for (uint32_t q = pred[e].first + 1; q <= b; ++q)
+                        bs->stale[q] = 1;
+                    bs->undo_idx[np] = (uint32_t)e;
+                    bs->undo_first[np] = pred[e].first;
+                    pred[e].first = b;
+                    patches[np].slot = pred[e].slot;
+                    patches[np++].first = b;
+                }
+                bs->pconf[e] = 1;
+            } else {
+                regime_change = 1;
+            }
+        }
         const int active_before = bs->work.active;
-        changed |= filter_expire(&bs->work, br->end_now); /* readsb.c:331, after the buffer */
+        if (filter_expire(&bs->work, br->end_now)) { /* readsb.c:331, after the buffer; members were dropped */
+            regime_change = 1;
+            for (uint32_t e = 0; e < npred; ++e) /* one of this batch's own additions? (needs a >60 s batch) */
+                if (bs->pconf[e] && !filter_test(&bs->work, pred[e].addr)) {
+                    bs->pconf[e] = 0;
+                    bs->undo_idx[np] = e;
+                    bs->undo_first[np] = pred[e].first;
+                    pred[e].first = MSD_PRED_NEVER;
+                    patches[np].slot = pred[e].slot;
+                    patches[np++].first = MSD_PRED_NEVER;
+                }
+        }
         flips += bs->work.active != active_before;
-        if (changed && b + 1 < nbuffers) {
+        if (regime_change && b + 1 < nbuffers) {
             version = push_snapshot(bs, &bs->work);
             if (bs->nsnaps > max_snaps)
                 return -1;
@@ -908,7 +995,19 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
             }
         }
     }
+    for (uint32_t e = 0; e < npred; ++e) /* predictions that never came true */
+        if (!bs->pconf[e] && pred[e].first != MSD_PRED_NEVER) {
+            for (uint32_t q = pred[e].first + 1; q < nbuffers; ++q)
+                bs->stale[q] = 1;
+            pred[e].first = MSD_PRED_NEVER;
+            patches[np].slot = pred[e].slot;
+            patches[np++].first = MSD_PRED_NEVER;
+        }
+    for (uint32_t b = 0; b < nbuffers; ++b)
+        if (bs->stale[b])
+            todo[n++] = b;
     *ntodo = n;
+    *npatches = np;
     if (n == 0)
         return 0;
     return pass >= MAX_SPECULATIVE_PASSES ? -1 : 1;

@@ -116,6 +116,20 @@ __device__ __forceinline__ uint32_t res_len(uint64_t r) /* samples hidden by the
     return (((uint32_t)(r >> 20) & 0x10u) ? 112u : 56u) * 12u / 5u;
 }
 
+/* predicted adds (msd_internal.h): the first buffer with a clean squitter of addr, or NEVER */
+__device__ __forceinline__ uint32_t pred_lookup(const uint32_t *key, const uint32_t *first, uint32_t addr)
+{
+    uint32_t h = (addr * 2654435761u) >> 18; /* 16384 slots */
+    for (;;) {
+        const uint32_t k = key[h];
+        if (k == addr)
+            return first[h];
+        if (k == VACANT)
+            return MSD_PRED_NEVER;
+        h = (h + 1) & (MSD_PRED_SLOTS - 1);
+    }
+}
+
 constexpr uint32_t TCAP = 2048;   /* tries staged per segment; a segment is cut short where they would not fit */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
 
@@ -268,7 +282,10 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             const uint32_t i = seg_thit[t];
             const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
             const uint32_t where = snap_probe(snap, v.addr);
-            seg_try[t] = pack_try(v, where != 0 || addset_has(addset, v.addr), (where >> snap_active) & 1u);
+            bool known = where != 0 || addset_has(addset, v.addr);
+            if (!known) /* added by an earlier buffer of this batch (predicted; the host verifies) */
+                known = pred_lookup(P.pred_key, P.pred_first, v.addr) < b;
+            seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
         }
         __syncthreads();
         const uint32_t ntries = seg_toff[n];
@@ -632,6 +649,64 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
     }
 }
 
+/* Prediction table of a batch: one thread per try; a clean DF17 / DF11(II=0) try whose address the
+ * filter does not hold yet claims a slot and lowers its first-buffer value. */
+__global__ void __launch_bounds__(256) msd_predict_kernel(const msd_try *tries, const uint64_t *totals,
+                                                          const uint32_t *snap0, uint32_t *pred_key,
+                                                          uint32_t *pred_first, uint32_t *count, uint32_t *list)
+{
+    if (totals[2])
+        return;
+    const uint64_t ntries = totals[1];
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntries; t += (uint64_t)gridDim.x * blockDim.x) {
+        const TryView v = load_try(tries + t);
+        const uint32_t df = (v.w0 & 0xffu) >> 3;
+        if ((v.w3 >> 24) != 0xffu || !(df == 17 || (df == 11 && (v.crc & 0x7fu) == 0)))
+            continue; /* mode_s.c:717-726: only these reach icaoFilterAdd */
+        if (snap_probe(snap0, v.addr))
+            continue;
+        const uint32_t buffer = tries[t].pos / MSD_CHUNK_SAMPLES;
+        uint32_t h = (v.addr * 2654435761u) >> 18;
+        for (;;) {
+            const uint32_t old = atomicCAS(&pred_key[h], VACANT, v.addr);
+            if (old == VACANT) {
+                const uint32_t k = atomicAdd(count, 1u) + 1u; /* the counter starts at 0xffffffff (one memset for all) */
+                if (k < MSD_PRED_LIST)
+                    list[k] = h;
+            }
+            if (old == VACANT || old == v.addr) {
+                atomicMin(&pred_first[h], buffer);
+                break;
+            }
+            h = (h + 1) & (MSD_PRED_SLOTS - 1);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) msd_pred_publish_kernel(const uint32_t *pred_key, const uint32_t *pred_first,
+                                                               const uint32_t *count, const uint32_t *list,
+                                                               msd_pred_entry *h_list, uint32_t *h_count)
+{
+    const uint32_t n = *count + 1u;
+    if (threadIdx.x == 0)
+        *h_count = n <= MSD_PRED_LIST ? n : MSD_PRED_LIST + 1;
+    for (uint32_t i = threadIdx.x; i < n && i < MSD_PRED_LIST; i += blockDim.x) {
+        const uint32_t h = list[i];
+        msd_pred_entry e;
+        e.addr = pred_key[h];
+        e.first = pred_first[h];
+        e.slot = h;
+        e.pad = 0;
+        h_list[i] = e;
+    }
+}
+
+__global__ void __launch_bounds__(64) msd_pred_patch_kernel(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        pred_first[patches[i].slot] = patches[i].first;
+}
+
 /* The small per-batch results the host waits for -- list totals and per-buffer level/power sums --
  * written straight into pinned host memory at the end of the batch's kernels: a copy on another
  * stream would queue behind the persistent scan kernels of the following batches. */
@@ -662,6 +737,27 @@ extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_tot
 {
     hipLaunchKernelGGL(msd_publish_kernel, dim3(1), dim3(256), 0, stream, totals, ac_totals, sums, fmeans, nbuffers,
                        h_totals, h_ac_totals, h_sums, h_fmeans);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
+                                  msd_pred_entry *h_list, uint32_t *h_count, hipStream_t stream)
+{
+    /* pred: key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | count - 1 | slot list[MSD_PRED_LIST] */
+    uint32_t *key = pred, *first = pred + MSD_PRED_SLOTS, *count = pred + 2 * MSD_PRED_SLOTS;
+    (void)hipMemsetAsync(pred, 0xff, sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 1), stream);
+    hipLaunchKernelGGL(msd_predict_kernel, dim3(1024), dim3(256), 0, stream, tries, totals, snap0, key, first, count,
+                       count + 1);
+    hipLaunchKernelGGL(msd_pred_publish_kernel, dim3(1), dim3(256), 0, stream, key, first, count, count + 1, h_list,
+                       h_count);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(msd_pred_patch_kernel, dim3(1), dim3(64), 0, stream, pred_first, patches, n);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
