@@ -44,6 +44,7 @@ struct Slot {
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
     uint32_t *d_adds = nullptr, *d_nmsgs = nullptr;
+    uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST]; wiped by the gather kernel */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_message *h_msgs = nullptr; /* pinned: the emit kernel writes the message records into it */
@@ -115,7 +116,6 @@ struct msd_ctx {
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
     hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
-    uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST] */
     msd_pred_entry *h_pred = nullptr;
     uint32_t *h_pred_count = nullptr;
     msd_pred_patch *h_patches = nullptr;
@@ -295,7 +295,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         rc = msd_launch_gather(c->d_counts, nwg, c->d_offsets, s.d_totals, c->d_region_hits,
                                c->d_region_tries, p.hcap, p.tcap, s.d_hits, c->hit_arena, s.d_tries,
                                c->try_arena, s.d_sums, s.nbuffers, lean ? s.h_totals : nullptr,
-                               lean ? s.h_sums : nullptr, c->stream);
+                               lean ? s.h_sums : nullptr, s.d_pred, s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0, c->stream);
         if (rc)
             return fail(c, rc, "gather kernel launch failed");
     } else {
@@ -555,8 +555,8 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     rp.nmsgs = s.d_nmsgs;
     rp.acc = s.d_acc;
     rp.adds = s.d_adds;
-    rp.pred_key = c->d_pred;
-    rp.pred_first = c->d_pred + MSD_PRED_SLOTS;
+    rp.pred_key = s.d_pred;
+    rp.pred_first = s.d_pred + MSD_PRED_SLOTS;
 }
 
 uint32_t slot_valid(const Slot &s, uint32_t b)
@@ -591,9 +591,9 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     gpu_params(c, s, rp);
     int rc = 0;
     if (first_pass) /* which new addresses will this batch add, and where first */
-        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, c->d_pred, c->h_pred, c->h_pred_count, ks);
+        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, s.d_pred, c->h_pred, c->h_pred_count, ks);
     else
-        rc = msd_launch_pred_patch(c->d_pred + MSD_PRED_SLOTS, c->h_patches, c->npatches, ks);
+        rc = msd_launch_pred_patch(s.d_pred + MSD_PRED_SLOTS, c->h_patches, c->npatches, ks);
     if (rc)
         return fail(c, rc, "prediction kernel launch failed");
     rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
@@ -1025,7 +1025,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr);
+        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_msgs) (void)hipHostFree(s.h_msgs);
@@ -1047,7 +1047,6 @@ void destroy(msd_ctx *c)
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
-    (void)hipFree(c->d_pred);
     if (c->h_pred) (void)hipHostFree(c->h_pred);
     if (c->h_pred_count) (void)hipHostFree(c->h_pred_count);
     if (c->h_patches) (void)hipHostFree(c->h_patches);
@@ -1209,6 +1208,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_nmsgs), sizeof(uint32_t) * c->max_buffers));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 4 + MSD_PRED_LIST)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
@@ -1221,7 +1221,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming));
-        CK(hipMalloc(reinterpret_cast<void **>(&c->d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 1 + MSD_PRED_LIST)));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pred), sizeof(msd_pred_entry) * MSD_PRED_LIST));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_pred_count), 64));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_patches), sizeof(msd_pred_patch) * 2 * MSD_PRED_LIST));

@@ -867,9 +867,12 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *co
                                                          const msd_try *tries, uint32_t hcap,
                                                          uint32_t tcap, msd_hit *dense_hits,
                                                          uint64_t dense_hcap, msd_try *dense_tries,
-                                                         uint64_t dense_tcap)
+                                                         uint64_t dense_tcap, uint4 *wipe, uint32_t wipe_n)
 {
     const uint32_t w = blockIdx.x;
+    /* all-ones into a scratch table of the slot's resolve stage (the prediction table), spread over the grid */
+    for (uint32_t i = w * blockDim.x + threadIdx.x; i < wipe_n; i += gridDim.x * blockDim.x)
+        wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     const uint32_t nh = counts[w].nhits < hcap ? counts[w].nhits : hcap;
     const uint32_t nt = counts[w].ntries < tcap ? counts[w].ntries : tcap;
     const uint64_t ho = offsets[2 * w], to = offsets[2 * w + 1];
@@ -1289,12 +1292,13 @@ extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint
                                  uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
                                  uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap,
                                  uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums,
-                                 hipStream_t stream)
+                                 void *wipe, uint32_t wipe_bytes, hipStream_t stream)
 {
     hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, counts, nwg, offsets, totals, sums, nbuffers,
                        h_totals, h_sums);
     hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, offsets, hits, tries,
-                       hcap, tcap, dense_hits, dense_hcap, dense_tries, dense_tcap);
+                       hcap, tcap, dense_hits, dense_hcap, dense_tries, dense_tcap, static_cast<uint4 *>(wipe),
+                       wipe_bytes / 16);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -745,7 +745,7 @@ extern "C" int msd_launch_predict(const msd_try *tries, const uint64_t *totals, 
 {
     /* pred: key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | count - 1 | slot list[MSD_PRED_LIST] */
     uint32_t *key = pred, *first = pred + MSD_PRED_SLOTS, *count = pred + 2 * MSD_PRED_SLOTS;
-    (void)hipMemsetAsync(pred, 0xff, sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 1), stream);
+    /* key, first and the counter are all-ones here: the slot's gather kernel wiped them */
     hipLaunchKernelGGL(msd_predict_kernel, dim3(1024), dim3(256), 0, stream, tries, totals, snap0, key, first, count,
                        count + 1);
     hipLaunchKernelGGL(msd_pred_publish_kernel, dim3(1), dim3(256), 0, stream, key, first, count, count + 1, h_list,
