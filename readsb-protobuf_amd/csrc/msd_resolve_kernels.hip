@@ -131,6 +131,7 @@ __device__ __forceinline__ uint32_t pred_lookup(const uint32_t *key, const uint3
 }
 
 constexpr uint32_t TCAP = 2048;   /* tries staged per segment; a segment is cut short where they would not fit */
+constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
 
 __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr)
@@ -165,7 +166,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ uint64_t sh_range[2];
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
-    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_newaddr, sh_nfit, sh_nok, sh_na, sh_last;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_nfit, sh_nok, sh_na, sh_last, sh_nf;
+    __shared__ uint32_t f_addr[FCAP], f_resume[FCAP], f_idx[FCAP]; /* new aircraft of the round: address, end and hit of the adding message */
 
     const int tid = threadIdx.x;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -385,7 +387,9 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 ok_next[k] = (uint16_t)(lo | (fresh ? 0x8000u : 0u));
             }
             __syncthreads();
-            /* ... and the chain of accepted ones, the only sequential bit */
+            /* ... and the chain of accepted ones, the only sequential bit.  A message that adds an
+             * address the filter does not know yet (a new aircraft) may change how later hits score;
+             * the chain runs on and the check below finds the first hit that really is affected. */
             if (tid == 0) {
                 const uint32_t from = (uint32_t)(sh_resume - base);
                 uint32_t lo = 0, hi = nok;
@@ -396,21 +400,75 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     else
                         hi = mid;
                 }
-                uint32_t k = lo, na = 0, next = n, lastk = 0xffffffffu;
+                uint32_t k = lo, na = 0, next = n, nf = 0;
                 while (k < nok) {
                     const uint32_t nx = ok_next[k];
                     acc_k[na++] = (uint16_t)k;
-                    lastk = k;
                     if (nx & 0x8000u) {
-                        next = (uint32_t)ok_idx[k] + 1;
-                        break;
+                        const uint32_t i = ok_idx[k];
+                        if (nf == FCAP) { /* more new aircraft than the check handles at once: stop behind this one */
+                            next = i;
+                            --na;
+                            break;
+                        }
+                        const uint64_t r = seg_res[i];
+                        f_addr[nf] = (uint32_t)(r >> 40);
+                        f_resume[nf] = ok_pos[k] + res_len(r) + 1;
+                        f_idx[nf] = i;
+                        ++nf;
                     }
-                    k = nx;
+                    k = nx & 0x7fffu;
                 }
-                if (lastk != 0xffffffffu)
-                    sh_resume = base + ok_pos[lastk] + res_len(seg_res[ok_idx[lastk]]) + 1;
                 sh_na = na;
                 sh_next = next;
+                sh_nf = nf;
+            }
+            __syncthreads();
+            if (sh_nf) { /* uniform */
+                /* first hit with a not yet known try of one of the new addresses behind the message that adds it */
+                const uint32_t nf = sh_nf;
+                uint32_t first = sh_next;
+                for (uint32_t t = tid; t < ntries; t += RT) {
+                    const uint64_t v = seg_try[t];
+                    if ((v >> 19) & 1u)
+                        continue;
+                    const uint32_t i = seg_thit[t];
+                    if (i < start || i >= first)
+                        continue;
+                    const uint32_t addr = (uint32_t)(v >> 40), pos = (uint32_t)(MSD_HIT_POS(seg_hits[i]) - base);
+                    for (uint32_t f = 0; f < nf; ++f)
+                        if (f_addr[f] == addr && pos >= f_resume[f]) {
+                            first = i;
+                            break;
+                        }
+                }
+                if (first < sh_next)
+                    atomicMin(&sh_next, first);
+                __syncthreads();
+                const uint32_t cut = sh_next;
+                /* the new addresses whose messages stay accepted are known from here on */
+                for (uint32_t t = tid; t < ntries; t += RT) {
+                    const uint64_t v = seg_try[t];
+                    if ((v >> 19) & 1u)
+                        continue;
+                    const uint32_t addr = (uint32_t)(v >> 40);
+                    for (uint32_t f = 0; f < nf; ++f)
+                        if (f_addr[f] == addr && f_idx[f] < cut) {
+                            seg_try[t] = v | (1ull << 19);
+                            break;
+                        }
+                }
+                if (tid == 0) { /* drop the accepted messages at or behind the cut */
+                    uint32_t na = sh_na;
+                    while (na && ok_idx[acc_k[na - 1]] >= cut)
+                        --na;
+                    sh_na = na;
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && sh_na) {
+                const uint32_t lastk = acc_k[sh_na - 1];
+                sh_resume = base + ok_pos[lastk] + res_len(seg_res[ok_idx[lastk]]) + 1;
             }
             __syncthreads();
             PHASE(3)
@@ -480,8 +538,6 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                             out_short[nshort] = addr;
                         nshort++;
                     }
-                    if (!((r >> 19) & 1u))
-                        sh_newaddr = addr; /* at most one per round: the chain stops behind it */
                 }
                 sh_nadds = nadds;
                 sh_nshort = nshort;
@@ -549,14 +605,6 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 }
             }
             start = stop_at;
-            if (start < n) { /* the chain stopped at a new aircraft: its later tries are known now */
-                const uint32_t x = sh_newaddr;
-                for (uint32_t t = tid; t < ntries; t += RT) {
-                    const uint64_t v = seg_try[t];
-                    if ((uint32_t)(v >> 40) == x)
-                        seg_try[t] = v | (1ull << 19);
-                }
-            }
             __syncthreads();
             if (tid == 0 && sh_last) { /* demod_2400.c:358-366: (timestampMsg - sampleTimestamp) / 12000 ms */
                 const uint32_t i = sh_last - 1;
@@ -668,14 +716,18 @@ __global__ void __launch_bounds__(256) msd_predict_kernel(const msd_try *tries, 
         const uint32_t buffer = tries[t].pos / MSD_CHUNK_SAMPLES;
         uint32_t h = (v.addr * 2654435761u) >> 18;
         for (;;) {
-            const uint32_t old = atomicCAS(&pred_key[h], VACANT, v.addr);
+            uint32_t old = __atomic_load_n(&pred_key[h], __ATOMIC_RELAXED); /* most tries find their aircraft's slot */
             if (old == VACANT) {
-                const uint32_t k = atomicAdd(count, 1u) + 1u; /* the counter starts at 0xffffffff (one memset for all) */
-                if (k < MSD_PRED_LIST)
-                    list[k] = h;
+                old = atomicCAS(&pred_key[h], VACANT, v.addr);
+                if (old == VACANT) {
+                    const uint32_t k = atomicAdd(count, 1u) + 1u; /* the counter starts at 0xffffffff */
+                    if (k < MSD_PRED_LIST)
+                        list[k] = h;
+                }
             }
             if (old == VACANT || old == v.addr) {
-                atomicMin(&pred_first[h], buffer);
+                if (__atomic_load_n(&pred_first[h], __ATOMIC_RELAXED) > buffer)
+                    atomicMin(&pred_first[h], buffer);
                 break;
             }
             h = (h + 1) & (MSD_PRED_SLOTS - 1);
