@@ -137,6 +137,7 @@ typedef struct msd_filter {
     uint64_t next_flip;
     uint64_t set_hash;  /* xor of a mix of every known address (identity of the membership) */
     uint32_t set_count; /* number of known addresses */
+    uint32_t active_used; /* occupied slots of the active table: icaoFilterAdd gives up when it is full */
 } msd_filter;
 
 /* ---- resolve stage (msd_resolve.c) ---- */

@@ -57,6 +57,7 @@ static void filter_init(msd_filter *f) /* icao_filter.c:67-71 */
     f->next_flip = 0;
     f->set_hash = 0;
     f->set_count = 0;
+    f->active_used = 0;
 }
 
 /* exact comparison of two filters' membership (used to confirm a set-hash match) */
@@ -139,8 +140,10 @@ static int filter_add_raw(msd_filter *f, uint32_t addr)
         if (h == start)
             return 0; /* table full: the reference gives up on both inserts */
     }
-    if (t[h] == VACANT)
+    if (t[h] == VACANT) {
         t[h] = addr;
+        f->active_used++;
+    }
 
     /* second copy keyed by the low 16 bits (icao_filter.c:89-97) */
     const uint32_t low = addr & 0xffffu;
@@ -150,8 +153,10 @@ static int filter_add_raw(msd_filter *f, uint32_t addr)
         if (h == start)
             return 0;
     }
-    if (t[h] == VACANT)
+    if (t[h] == VACANT) {
         t[h] = addr;
+        f->active_used++;
+    }
     return 1;
 }
 
@@ -174,6 +179,7 @@ static int filter_expire(msd_filter *f, uint64_t now)
     }
     memset(f->slot[other], 0xFF, sizeof f->slot[other]);
     f->active = other;
+    f->active_used = 0;
     f->next_flip = now + 60000u;
     return dropped;
 }
@@ -418,8 +424,15 @@ static int score_try(const msd_try *t, int known)
 
 /* demodulate2400 (demod_2400.c:236-428) for buffer b, everything except the signal-power
  * bookkeeping (msd_resolve_power), then the skip-ahead part of demodulate2400AC (:522-708). */
+/* While the active table has room, "the filter as it was when the buffer started, plus the
+ * addresses this buffer added" is exactly what the reference's filter answers inside the buffer.
+ * icaoFilterAdd silently gives up on a full table (icao_filter.c:82-86), though, so when the table
+ * could fill up within a buffer -- thousands of aircraft in one minute -- the buffer is replayed
+ * with `live`: adds go to the filter at once and only the filter is asked. */
+#define FULL_GUARD 6000u /* occupied slots; a buffer adds at most 970 addresses, two slots each */
+
 static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const msd_filter *snap,
-                           uint32_t version, buf_result *br)
+                           uint32_t version, buf_result *br, msd_filter *live)
 {
     local_set local;
     local_init(&local);
@@ -458,7 +471,8 @@ static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const m
         int bestscore = -2, known_best = 0;
         const msd_try *best = 0;
         for (unsigned k = 0; k < nlive; ++k) {
-            const int known = filter_test(snap, t[k].addr) || local_has(&local, t[k].addr);
+            const int known = live ? filter_test(live, t[k].addr)
+                                   : filter_test(snap, t[k].addr) || local_has(&local, t[k].addr);
             const int s = score_try(&t[k], known);
             if (s > bestscore) {
                 bestscore = s;
@@ -515,9 +529,12 @@ static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const m
             mm.msg[best->errbit >> 3] ^= (uint8_t)(0x80u >> (best->errbit & 7)); /* crc.c:417-425 */
         }
         mm.addr = best->addr; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
-        if (!nerr && (df == 17 || (df == 11 && mm.iid == 0))) /* mode_s.c:717-726 */
-            if (local_add(&local, mm.addr))
+        if (!nerr && (df == 17 || (df == 11 && mm.iid == 0))) { /* mode_s.c:717-726 */
+            if (live)
+                filter_add(live, mm.addr); /* the caller must not apply br->adds again (there are none) */
+            else if (local_add(&local, mm.addr))
                 push_add(br, mm.addr);
+        }
 
         br->ctr[C_ACC0 + mm.correctedbits]++;
         br->ctr[C_BPHASE0 + best->tp - 4]++;
@@ -557,7 +574,7 @@ static void job_resolve(void *arg, uint32_t index)
     struct msd_batch_state *bs = arg;
     const uint32_t b = bs->todo[index];
     const uint32_t v = bs->want[b];
-    resolve_buffer(bs, b, &bs->snaps[v], v, &bs->res[b]);
+    resolve_buffer(bs, b, &bs->snaps[v], v, &bs->res[b], NULL);
 }
 
 /* ---------------------------------------------------------------------------------------- */
@@ -732,7 +749,7 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         work = r->filter;
         for (uint32_t b = 0; b < nbuffers; ++b) {
             buf_result *br = &bs->res[b];
-            resolve_buffer(bs, b, &work, 0, br);
+            resolve_buffer(bs, b, &work, 0, br, work.active_used > FULL_GUARD ? &work : NULL);
             for (uint32_t i = 0; i < br->nadds; ++i)
                 filter_add(&work, br->adds[i]);
             filter_expire(&work, br->end_now); /* readsb.c:331, after the buffer */
@@ -746,6 +763,7 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
         }
         bs->ntodo = nbuffers;
         for (uint32_t pass = 0;; ++pass) {
+            int force_tail = 0;
             double ta = trace ? now_ms() : 0;
             pool_run(bs->pool, job_resolve, bs, bs->ntodo);
             double tb = trace ? now_ms() : 0;
@@ -763,6 +781,14 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
                         first_stale = b;
                     bs->todo[bs->ntodo++] = b;
                 }
+                if (first_stale == nbuffers && work.active_used > FULL_GUARD) {
+                    /* the active table may fill up: from here on only the exact sequential replay will do */
+                    first_stale = b;
+                    if (bs->ntodo == 0 || bs->todo[bs->ntodo - 1] != b)
+                        bs->todo[bs->ntodo++] = b;
+                    force_tail = 1;
+                    break;
+                }
                 if (pass >= MAX_SPECULATIVE_PASSES && first_stale != nbuffers)
                     break; /* `work` is now the exact state in front of the first stale buffer */
                 int changed = 0;
@@ -774,13 +800,13 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
             }
             if (bs->ntodo == 0)
                 break;
-            if (pass >= MAX_SPECULATIVE_PASSES) {
+            if (pass >= MAX_SPECULATIVE_PASSES || force_tail) {
                 /* membership keeps changing (every pass is exact up to its first stale buffer, but
                  * an input whose adds shift from pass to pass would need one pass per buffer):
                  * finish the tail with the plain sequential replay */
                 for (uint32_t b = first_stale; b < nbuffers; ++b) {
                     buf_result *br = &bs->res[b];
-                    resolve_buffer(bs, b, &work, 0, br);
+                    resolve_buffer(bs, b, &work, 0, br, work.active_used > FULL_GUARD ? &work : NULL);
                     for (uint32_t i = 0; i < br->nadds; ++i)
                         filter_add(&work, br->adds[i]);
                     filter_expire(&work, br->end_now);
@@ -927,8 +953,8 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
     }
     for (uint32_t b = 0; b < nbuffers; ++b) {
         const msd_rbuf *br = &rb[b];
-        if (br->fallback)
-            return -1;
+        if (br->fallback || bs->work.active_used > FULL_GUARD)
+            return -1; /* a nearly full active table needs the exact sequential replay (resolve_buffer) */
         snap_idx[b] = version;
         if (br->version_used != version)
             bs->stale[b] = 1;

@@ -124,6 +124,16 @@ def test_gpu_resolve_runs_and_converges(pkg, oracle, torch_cuda, resolve_stage):
     assert t["resolve_passes"] >= 1 and t["resolve_fallback"] == 0, t
 
 
+@pytest.mark.parametrize("seed,overlap,aircraft", [(21, 300, 2000), (22, 600, 150), (23, 50, 20000)])
+def test_gpu_resolve_overlaps_and_new_aircraft(pkg, oracle, torch_cuda, resolve_stage, seed, overlap, aircraft):
+    """Garbled/overlapping frames (hidden messages, wrong add predictions) together with aircraft that
+    keep appearing: the acceptance chain, the prediction table and its corrections, several batches.
+    The 20000-aircraft case also fills the ICAO filter's active table (icaoFilterAdd then gives up,
+    icao_filter.c:82-86), which only the exact sequential replay of the host resolver reproduces."""
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 48 * 131072 + 1234, seed=seed, nfix=1, batch=16 * 131072,
+                        n_aircraft=aircraft, msgs_per_sec=6000, overlap_permille=overlap, flip_permille=50)
+
+
 def test_gpu_resolve_long_add_lists(pkg, oracle, torch_cuda, resolve_stage, monkeypatch):
     """More unique addresses in one buffer than a per-buffer report holds inline (232; 40 here, the
     synthetic traffic peaks near 150): the complete add lists are fetched instead."""
