@@ -1,0 +1,50 @@
+"""Randomised parity sweep (not collected by pytest): python tests/fuzz_parity.py [cases] [first_seed]
+Each case draws a traffic model, a format, a batch size and the resolve path at random and compares the
+HIP path with the oracle message for message and counter for counter."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+from tests.test_gpu_parity import assert_same  # noqa: E402
+
+pkg = g.load_package()
+orc = g.load_oracle()
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+for case in range(first, first + ncases):
+    rng = np.random.default_rng(case)
+    fmt_name = rng.choice(["uc8", "uc8", "uc8", "sc16", "sc16q11"])
+    fmt, ofmt = {"uc8": (pkg.FMT_UC8, orc.FMT_UC8), "sc16": (pkg.FMT_SC16, orc.FMT_SC16),
+                 "sc16q11": (pkg.FMT_SC16Q11, orc.FMT_SC16Q11)}[fmt_name]
+    nbuf = int(rng.integers(1, 40))
+    n = nbuf * 131072 + int(rng.choice([0, 1, 7, 8, 1234, 65536, 131071]))
+    batch = int(rng.choice([1, 2, 4, 8, 16, 64])) * 131072
+    kw = dict(msgs_per_sec=int(rng.choice([200, 2000, 6000, 12000])), n_aircraft=int(rng.choice([3, 50, 800, 5000, 30000])),
+              overlap_permille=int(rng.choice([0, 10, 200, 700])), flip_permille=int(rng.choice([0, 20, 200])),
+              noise_fs=float(rng.choice([0.005, 0.02, 0.06])), ac_per_sec=int(rng.choice([0, 0, 500, 4000])))
+    nfix = int(rng.integers(0, 2))
+    mode_ac = int(kw["ac_per_sec"] > 0 and rng.integers(0, 2))
+    gpu_resolve = int(rng.integers(0, 2))
+    os.environ["MSD_GPU_RESOLVE"] = str(gpu_resolve)
+    os.environ["MSD_RESOLVE_THREADS"] = str(int(rng.choice([1, 4, 16])))
+    cfg = pkg.siggen.make_cfg(seed=case, fmt=fmt, **kw)
+    iq = pkg.siggen.generate(cfg, n)
+    d = torch.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19)
+    got = pkg.replay_device(dem, d.data_ptr(), n, batch)
+    want, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac).replay(iq, cap=1 << 19)
+    desc = f"case {case}: {fmt_name} n={n} batch={batch // 131072} nfix={nfix} ac={mode_ac} gpu_resolve={gpu_resolve} {kw}"
+    try:
+        assert_same(got, dem.stats(), want, wstats)
+        print("ok  ", desc, "msgs", len(want), "passes", dem.timing()["resolve_passes"], "fallback", dem.timing()["resolve_fallback"])
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", desc, str(e)[:200])
+    del dem
+print("failures:", bad)
+sys.exit(1 if bad else 0)
