@@ -174,7 +174,11 @@ def main():
         "roofline": roofline,
         "pipeline_ms": {k: round(float(np.mean([t[k] for t in timings])), 4) for k in
                         ("scan_kernel_ms", "other_kernels_ms", "d2h_ms", "resolve_ms", "hits", "tries")} if timings else None,
-        "capture_generation_s": round(gen_s, 2), "resolve_threads": int(os.environ["MSD_RESOLVE_THREADS"]),
+        "capture_generation_s": round(gen_s, 2),
+        "resolve_stage": ("gpu, %.2f passes per batch, %d batches handed to the host resolver"
+                          % (float(np.mean([t["resolve_passes"] for t in timings])), int(timings[-1]["resolve_fallback"]))
+                          if timings and any(t["resolve_passes"] for t in timings)
+                          else "host threads (%s)" % os.environ["MSD_RESOLVE_THREADS"]),
     }
 
     # ---- CPU baseline: the oracle on this host, one core, bounded sample (rank 0, N=1 only) ----
