@@ -546,11 +546,13 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     rp.hits = s.d_hits;
     rp.tries = s.d_tries;
     rp.totals = s.d_totals;
-    rp.valid = g.d_valid;
-    rp.ts = g.d_ts;
+    /* the control arrays are read where they are, in pinned host memory: a few words per workgroup,
+     * and an upload of 14 KiB would run as a blit kernel that fights the scan for compute units */
+    rp.valid = g.h_valid;
+    rp.ts = g.h_ts;
     rp.snaps = c->d_snaps;
-    rp.snap_idx = g.d_snap;
-    rp.todo = g.d_todo;
+    rp.snap_idx = g.h_snap;
+    rp.todo = g.h_todo;
     rp.rbuf = s.h_rbuf;
     rp.nmsgs = s.d_nmsgs;
     rp.acc = s.d_acc;
@@ -582,7 +584,6 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
                                  hipMemcpyHostToDevice, c->aux_stream));
     }
     c->snaps_uploaded = nsn;
-    HIPCHK(c, hipMemcpyAsync(s.d_ctl, s.h_ctl, g.bytes, hipMemcpyHostToDevice, c->aux_stream));
     if (ks != c->aux_stream) {
         HIPCHK(c, hipEventRecord(c->ev_inputs, c->aux_stream));
         HIPCHK(c, hipStreamWaitEvent(ks, c->ev_inputs, 0));

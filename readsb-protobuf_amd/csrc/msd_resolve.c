@@ -910,6 +910,7 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
                            uint32_t *ntodo)
 {
     struct msd_batch_state *bs = r->batch;
+    const int trace_replay = getenv("MSD_RESOLVE_TRACE") != NULL;
     *npatches = 0;
     if (npred > MSD_PRED_LIST)
         return -1; /* thousands of new aircraft in one batch: the table overflowed */
@@ -956,8 +957,11 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
         if (br->fallback || bs->work.active_used > FULL_GUARD)
             return -1; /* a nearly full active table needs the exact sequential replay (resolve_buffer) */
         snap_idx[b] = version;
-        if (br->version_used != version)
+        if (br->version_used != version) {
             bs->stale[b] = 1;
+            if (trace_replay)
+                fprintf(stderr, "replay: pass %u buffer %u used snapshot %u, needs %u\n", pass, b, br->version_used, version);
+        }
         const uint32_t v = br->version_used;
         int use_short = br->nshort <= inline_adds && v < bs->nsnaps;
         if (use_short && bs->short_ok[v] != flips + 1) {
@@ -981,6 +985,9 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
                 continue;
             /* a new member, known from buffer b + 1 on: was that predicted? */
             const int e = pred_find(bs, pred, adds[i]);
+            if (trace_replay && !(e >= 0 && !bs->pconf[e] && pred[e].first == b))
+                fprintf(stderr, "replay: pass %u buffer %u: new member %06x, prediction %s (first %d, confirmed %d)\n", pass, b,
+                        adds[i], e < 0 ? "missing" : "off", e < 0 ? -1 : (int)pred[e].first, e < 0 ? 0 : bs->pconf[e]);
             if (e >= 0 && !bs->pconf[e] && pred[e].first <= b) {
                 if (pred[e].first < b) { /* the predicted message was hidden: the buffers in between assumed too much */
                     for (uint32_t q = pred[e].first + 1; q <= b; ++q)
@@ -1023,6 +1030,8 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
     }
     for (uint32_t e = 0; e < npred; ++e) /* predictions that never came true */
         if (!bs->pconf[e] && pred[e].first != MSD_PRED_NEVER) {
+            if (trace_replay)
+                fprintf(stderr, "replay: pass %u: %06x predicted for buffer %u was never added\n", pass, pred[e].addr, pred[e].first);
             for (uint32_t q = pred[e].first + 1; q < nbuffers; ++q)
                 bs->stale[q] = 1;
             pred[e].first = MSD_PRED_NEVER;
