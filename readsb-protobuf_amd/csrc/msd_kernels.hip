@@ -1027,36 +1027,98 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
 }
 
 /* mean_level / mean_power of the float converters are *sequential* float sums
- * (convert.c:228-252): not associative, so one thread replays each buffer in order. */
+ * (convert.c:228-252): float addition is not associative, so the 131072 additions of a buffer are a
+ * dependent chain.  One workgroup per buffer: two wavefronts turn samples into level and power values
+ * in LDS, chunk by chunk and one chunk ahead; one lane of a third wavefront adds the levels up in
+ * order, one lane of a fourth the powers (a lone wavefront issues a dependent v_add_f32 about every
+ * 11 cycles, so each chain gets its own SIMD; ~0.7 ms per buffer, all buffers of a batch at once). */
+constexpr int FM_THREADS = 256, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 12, FM_CHUNK = FM_PRODUCERS * FM_PER;
+
 template <int FMT>
-__global__ void __launch_bounds__(64) msd_float_means_kernel(const uint8_t *iq, uint64_t nsamples,
-                                                             uint64_t buffer_len, uint32_t nbuffers,
-                                                             float *out /* [nbuffers][2] */)
+__global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8_t *iq, uint64_t nsamples,
+                                                                     uint64_t buffer_len, uint32_t nbuffers,
+                                                                     float *out /* [nbuffers][2] */)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float vals[2][2][FM_CHUNK]; /* [chunk parity][level, power][sample] */
+    const uint32_t b = blockIdx.x;
     if (b >= nbuffers)
         return;
     const uint64_t first = (uint64_t)b * buffer_len;
-    uint64_t n = nsamples > first ? nsamples - first : 0;
-    if (n > buffer_len)
-        n = buffer_len;
+    uint64_t n64 = nsamples > first ? nsamples - first : 0;
+    if (n64 > buffer_len)
+        n64 = buffer_len;
+    const uint32_t n = (uint32_t)n64;
     const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + first;
-    float sum_level = 0.0f, sum_power = 0.0f;
-    for (uint64_t k = 0; k < n; ++k) {
-        const uint32_t w = src[k];
-        const int I = (int)(int16_t)(w & 0xffffu), Q = (int)(int16_t)(w >> 16);
-        const float fi = (float)I * inv, fq = (float)Q * inv;
-        const float sq_i = fi * fi, sq_q = fq * fq;
-        float magsq = sq_i + sq_q;
-        if (magsq > 1.0f)
-            magsq = 1.0f;
-        const float m = __builtin_sqrtf(magsq);
-        sum_power = sum_power + magsq;
-        sum_level = sum_level + m;
+    const int tid = threadIdx.x;
+    const uint32_t nchunks = (n + FM_CHUNK - 1) / FM_CHUNK;
+    float sum = 0.0f; /* thread 0: level, thread 64: power */
+    for (uint32_t c = 0; c <= nchunks; ++c) {
+        if (tid >= 128) { /* producers: chunk c */
+            if (c < nchunks) {
+                const uint32_t p = (uint32_t)(tid - 128);
+#pragma unroll
+                for (int k = 0; k < FM_PER; ++k) { /* consecutive lanes read consecutive samples */
+                    const uint32_t i = (uint32_t)k * FM_PRODUCERS + p, g = c * FM_CHUNK + i;
+                    float m = 0.0f, magsq = 0.0f;
+                    if (g < n) {
+                        const uint32_t w = src[g];
+                        const int I = (int)(int16_t)(w & 0xffffu), Q = (int)(int16_t)(w >> 16);
+                        const float fi = (float)I * inv, fq = (float)Q * inv;
+                        const float sq_i = fi * fi, sq_q = fq * fq;
+                        magsq = sq_i + sq_q;
+                        if (magsq > 1.0f)
+                            magsq = 1.0f;
+                        m = __builtin_sqrtf(magsq);
+                    }
+                    vals[c & 1][0][i] = m;
+                    vals[c & 1][1][i] = magsq;
+                }
+            }
+        } else if ((tid & 63) == 0 && c > 0) { /* the two adders: chunk c - 1, strictly in order */
+            const uint32_t base = (c - 1) * FM_CHUNK;
+            const uint32_t cnt = n - base < (uint32_t)FM_CHUNK ? n - base : (uint32_t)FM_CHUNK;
+            const float *v = vals[(c - 1) & 1][tid >> 6];
+            const float4 *v4 = reinterpret_cast<const float4 *>(v);
+            uint32_t i = 0;
+            /* plain v_add_f32, one after the other (nothing for the compiler to re-associate or pack) */
+#define FM_ADD(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(x))
+#define FM_ADD4(X) FM_ADD((X).x); FM_ADD((X).y); FM_ADD((X).z); FM_ADD((X).w);
+            if (cnt >= 32) { /* the loads of the next 32 values are in flight while these are added */
+                float4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[u] = v4[u];
+                for (; i + 64 <= cnt; i += 32) {
+                    float4 nx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        nx[u] = v4[(i >> 2) + 8 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        FM_ADD4(x[u])
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        x[u] = nx[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    FM_ADD4(x[u])
+                }
+                i += 32;
+            }
+            for (; i < cnt; ++i) {
+                const float t = v[i];
+                FM_ADD(t);
+            }
+#undef FM_ADD4
+#undef FM_ADD
+        }
+        __syncthreads();
     }
-    out[2 * b] = sum_level;
-    out[2 * b + 1] = sum_power;
+    if ((tid & 63) == 0 && tid < 128)
+        out[2 * b + (tid >> 6)] = sum;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1438,12 +1500,12 @@ extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsa
                                       uint32_t nbuffers, float *d_out, hipStream_t stream)
 {
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
-    const uint32_t grid = (nbuffers + 63) / 64;
+    const uint32_t grid = nbuffers; /* one workgroup per buffer */
     if (format == MSD_FMT_SC16)
-        hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16>, dim3(grid), dim3(64), 0, stream, iq,
+        hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
                            nsamples, buffer_len, nbuffers, d_out);
     else if (format == MSD_FMT_SC16Q11)
-        hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(64), 0, stream, iq,
+        hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
                            nsamples, buffer_len, nbuffers, d_out);
     else
         return -22;
