@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1 << 29, help="samples the CPU baseline replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also diff the GPU message list against the oracle")
+    ap.add_argument("--mode-ac", action="store_true", help="BASELINE configs[4]: Mode A/C demodulator on, 500 replies/s")
     ap.add_argument("--overlap-captures", action="store_true",
                     help="two contexts on one stream: the next capture starts while the previous one drains")
     return ap.parse_args()
@@ -78,7 +79,7 @@ def main():
 
     # ---- synthetic capture, generated on the host from a seed, then made resident in HBM ----
     seed = pkg.sharding.capture_seed(rank)
-    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec)
+    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec, ac_per_sec=500 if args.mode_ac else 0)
     t0 = time.time()
     iq = pkg.siggen.generate(cfg, n)
     gen_s = time.time() - t0
@@ -92,7 +93,7 @@ def main():
     # Measured: no gain as long as everything stays in order on one stream (the scans then sit in front of
     # the draining capture's resolve passes), so it is not the default.
     nctx = 2 if args.overlap_captures else 1
-    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=0, device=local_rank,
+    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21)
             for _ in range(nctx)]
     dem = dems[0]
@@ -198,8 +199,9 @@ def main():
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32 (u8 IQ -> u16 magnitude -> int32 correlators, 24-bit CRC)", "data": "synthetic",
-        "config": {"workload": "%.3f GiB synthetic 2.4 MSPS %s capture per GPU, Mode S only, %s, preamble threshold 58, "
+        "config": {"workload": "%.3f GiB synthetic 2.4 MSPS %s capture per GPU, %s, %s, preamble threshold 58, "
                                "%d frames/s, seeds 10901+rank" % (n * bps / 2**30, args.format.upper(),
+                                                                  "Mode S + Mode A/C" if args.mode_ac else "Mode S only",
                                                                   "--no-fix" if args.fix == 0 else "--fix", args.msgs_per_sec),
                    "samples_per_gpu": n, "batch_samples": batch, "parallelism": "independent capture per GPU, no collective",
                    "captures": ("one context per GPU, captures strictly one after the other" if nctx == 1 else
@@ -222,7 +224,7 @@ def main():
         O = graft.load_oracle()
         ns = min(n, args.cpu_sample)
         ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-        orc = O.Oracle(ofmt, 58, args.fix, 0)
+        orc = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac))
         t0 = time.perf_counter()
         want, _ = orc.replay(iq[: ns * bps], cap=1 << 21)
         cpu_s = time.perf_counter() - t0
@@ -234,7 +236,7 @@ def main():
     if rank == 0 and world == 1 and args.check: # the whole capture, message for message
         O = graft.load_oracle()
         ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-        want, wstats = O.Oracle(ofmt, 58, args.fix, 0).replay(iq, cap=1 << 21)
+        want, wstats = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac)).replay(iq, cap=1 << 21)
         dem.reset()
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
         same = len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in

@@ -43,7 +43,7 @@ struct Slot {
     uint32_t resolve_ntodo = 0;
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
-    uint32_t *d_adds = nullptr, *d_nmsgs = nullptr;
+    uint32_t *d_adds = nullptr, *d_nmsgs = nullptr, *d_acc_ac = nullptr, *d_nac = nullptr;
     uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST]; wiped by the gather kernel */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
@@ -557,6 +557,12 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     rp.nmsgs = s.d_nmsgs;
     rp.acc = s.d_acc;
     rp.adds = s.d_adds;
+    if (c->cfg.mode_ac) {
+        rp.ac = s.d_ac;
+        rp.ac_totals = s.d_ac_totals;
+        rp.acc_ac = s.d_acc_ac;
+        rp.nac = s.d_nac;
+    }
     rp.pred_key = s.d_pred;
     rp.pred_first = s.d_pred + MSD_PRED_SLOTS;
 }
@@ -649,7 +655,7 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
 
 bool gpu_eligible(const msd_ctx *c, const Slot &s)
 {
-    return c->gpu_resolve && !c->cfg.mode_ac && s.nbuffers >= 4;
+    return c->gpu_resolve && s.nbuffers >= 4;
 }
 
 /* Returns 1 when the batch has to go through the host resolver instead (nothing committed). */
@@ -710,8 +716,9 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     uint32_t total = 0;
     c->out_buf.clear();
     for (uint32_t b = 0; b < n; ++b) {
-        total += s.h_rbuf[b].nmsgs;
-        c->out_buf.insert(c->out_buf.end(), s.h_rbuf[b].nmsgs, b);
+        const uint32_t k = s.h_rbuf[b].nmsgs + (c->cfg.mode_ac ? s.h_rbuf[b].nac : 0u);
+        total += k;
+        c->out_buf.insert(c->out_buf.end(), k, b);
     }
     if (total > s.req_cap) { /* more messages than the arrays of the speculative records hold */
         HIPCHK(c, hipEventSynchronize(s.ev_records));
@@ -846,6 +853,14 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->aux_stream));
         if (Tn)
             HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->aux_stream));
+        if (c->cfg.mode_ac) {
+            const uint64_t nac = s.h_ac_totals[0];
+            rc = ensure_ac_host(c, s, nac);
+            if (rc)
+                return rc;
+            if (nac)
+                HIPCHK(c, hipMemcpyAsync(s.h_ac, s.d_ac, nac * sizeof(msd_ac_hit), hipMemcpyDeviceToHost, c->aux_stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
         c->timing.resolve_fallback++;
     }
@@ -1026,7 +1041,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred);
+        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_msgs) (void)hipHostFree(s.h_msgs);
@@ -1202,13 +1217,17 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         if (ia && atoi(ia) >= 0 && (uint32_t)atoi(ia) < MSD_RB_ADD_INLINE)
             c->inline_adds = (uint32_t)atoi(ia);
     }
-    if (c->gpu_resolve && !cfg->mode_ac) {
+    if (c->gpu_resolve) {
         const size_t ctl_bytes = (size_t)28 * c->max_buffers;
         for (Slot &s : c->slots) {
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_rbuf), sizeof(msd_rbuf) * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_nmsgs), sizeof(uint32_t) * c->max_buffers));
+            if (cfg->mode_ac) {
+                CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc_ac), sizeof(uint32_t) * MSD_RB_AC_CAP * c->max_buffers));
+                CK(hipMalloc(reinterpret_cast<void **>(&s.d_nac), sizeof(uint32_t) * c->max_buffers));
+            }
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 4 + MSD_PRED_LIST)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));

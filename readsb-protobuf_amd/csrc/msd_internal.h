@@ -76,6 +76,7 @@ typedef struct msd_wg_counts {
 
 /* ---- GPU resolve stage (msd_resolve_kernels.hip) ---- */
 #define MSD_RB_MSG_CAP 1024u   /* accepted Mode S messages of one buffer: at most 131072/135 = 970 */
+#define MSD_RB_AC_CAP 2048u    /* accepted Mode A/C replies of one buffer: at most 131072/70 = 1872 */
 #define MSD_RB_ADD_INLINE 224u /* icaoFilterAdd addresses of one buffer reported inline: those that are not in the
                                   snapshot's active table already (the others cannot change the filter) */
 #define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[2][8192], then the index of the active table */
@@ -106,7 +107,7 @@ typedef struct msd_rbuf {
     uint32_t fallback;     /* the buffer needs the host path (cannot happen with valid candidate lists) */
     uint64_t end_now;      /* Modes.ifile_now when the buffer is done */
     uint32_t nshort;       /* entries of adds[] below, if <= MSD_RB_ADD_INLINE; else use the complete list */
-    uint32_t pad;
+    uint32_t nac;          /* accepted Mode A/C replies (they follow the Mode S messages of the buffer) */
     uint32_t cyc[8]; /* wall-clock ticks (100 MHz) lane 0 spent per phase: setup, stage, eval, walk, count, rest */
     uint32_t adds[MSD_RB_ADD_INLINE]; /* first occurrence order */
 } msd_rbuf;

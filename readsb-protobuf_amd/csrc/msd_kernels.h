@@ -47,6 +47,10 @@ typedef struct MsdResolveParams {
     uint32_t *nmsgs;          /* [buffer] accepted messages, for the offsets of the emit kernel */
     msd_acc *acc;             /* [buffer][MSD_RB_MSG_CAP] */
     uint32_t *adds;           /* [buffer][MSD_RB_MSG_CAP]: the complete add lists (msd_rbuf holds the first ones) */
+    const msd_ac_hit *ac;     /* Mode A/C candidates of the batch, ordered; NULL: Mode A/C off */
+    const uint64_t *ac_totals; /* [0] their number, [2] arena overflow flag */
+    uint32_t *acc_ac;         /* [buffer][MSD_RB_AC_CAP] indices of the accepted ones */
+    uint32_t *nac;            /* [buffer] how many */
     const uint32_t *pred_key; /* [MSD_PRED_SLOTS] predicted adds: address ... */
     const uint32_t *pred_first; /* ... and the first buffer with a clean squitter of it */
 } MsdResolveParams;

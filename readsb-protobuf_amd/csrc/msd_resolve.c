@@ -1062,6 +1062,7 @@ void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *
             st->demod_preamblePhase[k] += br->ctr[C_PPHASE0 + k];
             st->demod_bestPhase[k] += br->ctr[C_BPHASE0 + k];
         }
+        st->demod_modeac += br->nac;
         st->samples_processed += (uint64_t)valid[b] + MSD_OVERLAP; /* readsb.c:835 */
         st->buffers++;
         r->sample_counter += valid[b];
@@ -1079,7 +1080,7 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
     for (uint32_t b = 0; b < nbuffers; ++b) {
         uint64_t sum_scaled_signal_power = 0;
         for (; i < nmsgs && buffer[i] == b; ++i) {
-            if (power_req && !power_req[i])
+            if (power_req ? !power_req[i] : msgs[i].msgtype == 32)
                 continue; /* Mode A/C */
             const int signal_len = power_req ? (int)(power_req[i] & 0xffffu) : msgs[i].msgbits * 12 / 5;
             const uint64_t scaled = power[i];

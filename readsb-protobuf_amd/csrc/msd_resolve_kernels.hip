@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = wall_clock64();
 #define PHASE(k) { const uint64_t n_ = wall_clock64(); cyc[k] += (uint32_t)(n_ - tlast); tlast = n_; }
-    if (P.totals[2])
+    if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
     const uint64_t nhits = P.totals[0];
     const uint32_t b = P.todo[blockIdx.x];
@@ -616,6 +616,85 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         }
     }
 
+    /* ---- Mode A/C (demod_2400.c:522-708): every test is done, only the 69-sample skip-ahead of an
+     * accepted reply is left (:705); no filter, independent of the Mode S messages ---- */
+    uint32_t nac_total = 0;
+    if (P.ac) {
+        const uint64_t nac_all = P.ac_totals[0];
+        if (tid < 128) { /* the buffer's range in the ordered candidate list, as above */
+            const int lane = tid & 63;
+            const uint64_t want = base + ((tid >> 6) ? MSD_CHUNK_SAMPLES : 0);
+            uint64_t lo = 0, hi = nac_all;
+            while (lo < hi) {
+                const uint64_t step = (hi - lo + 63) / 64;
+                const uint64_t p = lo + (uint64_t)lane * step;
+                const bool below = p < hi && P.ac[p].pos < want;
+                const int k = __popcll(__ballot(below));
+                if (k == 0) {
+                    hi = lo;
+                } else {
+                    const uint64_t nhi = lo + (uint64_t)k * step;
+                    lo = lo + (uint64_t)(k - 1) * step + 1;
+                    if (nhi < hi)
+                        hi = nhi;
+                }
+            }
+            if (lane == 0)
+                sh_range[tid >> 6] = lo;
+        }
+        if (tid == 0)
+            sh_next = 0; /* first sample not hidden by an accepted reply, relative to the buffer */
+        __syncthreads();
+        const uint64_t ab = sh_range[0], ae = sh_range[1];
+        uint32_t *acc_ac = P.acc_ac + (size_t)b * MSD_RB_AC_CAP;
+        uint32_t m = 0;
+        for (uint64_t s0 = ab; s0 < ae; s0 += m) {
+            m = (ae - s0 < (uint64_t)SEG) ? (uint32_t)(ae - s0) : (uint32_t)SEG;
+            for (uint32_t i = tid; i < m; i += RT)
+                ok_pos[i] = (uint32_t)(P.ac[s0 + i].pos - base);
+            __syncthreads();
+            for (uint32_t k = tid; k < m; k += RT) { /* first candidate behind reply k: f1_sample += 20*87/25, then ++ */
+                const uint32_t resume = ok_pos[k] + 69u + 1u;
+                uint32_t lo = k + 1, hi = m;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ok_pos[mid] < resume)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                ok_next[k] = (uint16_t)lo;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t from = sh_next;
+                uint32_t lo = 0, hi = m;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ok_pos[mid] < from)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                uint32_t k = lo, na = 0, resume = from;
+                while (k < m && ok_pos[k] < mlen) {
+                    acc_k[na++] = (uint16_t)k;
+                    resume = ok_pos[k] + 70u;
+                    k = ok_next[k];
+                }
+                sh_na = na;
+                sh_next = resume;
+            }
+            __syncthreads();
+            const uint32_t na = sh_na;
+            for (uint32_t j = tid; j < na; j += RT)
+                if (nac_total + j < MSD_RB_AC_CAP)
+                    acc_ac[nac_total + j] = (uint32_t)(s0 + acc_k[j]);
+            nac_total += na;
+            __syncthreads();
+        }
+    }
+
     { /* flush the lists, coalesced */
         const uint32_t na = sh_nadds < MSD_RB_MSG_CAP ? sh_nadds : MSD_RB_MSG_CAP;
         for (uint32_t i = tid; i < na; i += RT)
@@ -630,12 +709,15 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         rb->nmsgs = sh_nmsgs;
         rb->nadds = sh_nadds;
         rb->nshort = sh_nshort;
+        rb->nac = nac_total;
         rb->version_used = P.snap_idx[b];
-        rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP) ? 1u : 0u;
+        rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP || nac_total > MSD_RB_AC_CAP) ? 1u : 0u;
         rb->end_now = sh_now;
         for (int k = 0; k < 8; ++k)
             rb->cyc[k] = cyc[k];
         P.nmsgs[b] = sh_nmsgs < MSD_RB_MSG_CAP ? sh_nmsgs : MSD_RB_MSG_CAP;
+        if (P.ac)
+            P.nac[b] = nac_total < MSD_RB_AC_CAP ? nac_total : MSD_RB_AC_CAP;
     }
 }
 
@@ -645,14 +727,14 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
                                                        msd_message *dense, unsigned long long *dense_pow, uint32_t cap)
 {
-    if (P.totals[2])
+    if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return;
     const uint32_t b = blockIdx.x;
-    /* o = messages in front of this buffer */
+    /* o = messages (Mode S and Mode A/C) in front of this buffer */
     __shared__ uint32_t part[4];
     uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < b; i += 256)
-        mine += P.nmsgs[i];
+        mine += P.nmsgs[i] + (P.ac ? P.nac[i] : 0u);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1)
         mine += __shfl_down(mine, d, 64);
@@ -694,6 +776,35 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             break; /* the host notices (total > cap), grows the arrays and emits again */
         dense[o + m] = mm;
         dense_pow[o + m] = power[(size_t)b * MSD_RB_MSG_CAP + m];
+    }
+    if (P.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
+        const uint32_t na = P.nac[b];
+        const uint32_t *acc_ac = P.acc_ac + (size_t)b * MSD_RB_AC_CAP;
+        for (uint32_t m = threadIdx.x; m < na; m += blockDim.x) {
+            if (o + nm + m >= cap)
+                break;
+            const msd_ac_hit c = P.ac[acc_ac[m]];
+            msd_message mm;
+            mm.timestampMsg = sample_ts + c.f2_clock / 5; /* demod_2400.c:695 */
+            mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+            mm.signalLevel = 0.0;
+            mm.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24); /* mode_ac.c:168-202 */
+            mm.crc = 0;
+            mm.score = 0;
+            mm.msgtype = 32;
+            mm.msgbits = 16;
+            mm.correctedbits = 0;
+            mm.bestphase = 0;
+#pragma unroll
+            for (int k = 0; k < 14; ++k)
+                mm.msg[k] = 0;
+            mm.msg[0] = (uint8_t)(c.modeac >> 8);
+            mm.msg[1] = (uint8_t)c.modeac;
+            mm.iid = 0;
+            mm.pad = 0;
+            dense[o + nm + m] = mm;
+            dense_pow[o + nm + m] = 0;
+        }
     }
 }
 

@@ -66,7 +66,8 @@ def test_s16_formats(pkg, oracle, torch_cuda, fmt):
 
 @pytest.mark.parametrize("fmt", ["uc8", "sc16q11"])
 def test_mode_s_plus_mode_ac_fix(pkg, oracle, torch_cuda, fmt):
-    """BASELINE.json configs[4]: Mode S + Mode A/C combined (demodulate2400AC) with --fix."""
+    """BASELINE.json configs[4]: Mode S + Mode A/C combined (demodulate2400AC) with --fix; six buffers, so the
+    GPU resolve handles the Mode A/C skip-ahead too when it is on."""
     f = pkg.FMT_UC8 if fmt == "uc8" else pkg.FMT_SC16Q11
     got, dem = run_case(pkg, oracle, torch_cuda, f, 6 * 131072 + 31, seed=44, nfix=1, mode_ac=1, msgs_per_sec=200,
                         ac_per_sec=2000)
