@@ -47,7 +47,7 @@ struct Slot {
     uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST]; wiped by the gather kernel */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
-    msd_message *h_msgs = nullptr; /* pinned: the emit kernel writes the message records into it */
+    msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
     /* batch description */
     const uint8_t *d_iq = nullptr;
@@ -180,16 +180,19 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
     if (s.h_req) (void)hipHostFree(s.h_req);
     if (s.h_pow) (void)hipHostFree(s.h_pow);
-    if (s.h_msgs) (void)hipHostFree(s.h_msgs);
+    if (s.h_wire) (void)hipHostFree(s.h_wire);
+    (void)hipFree(s.d_wire);
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
-    s.h_msgs = nullptr;
+    s.h_wire = s.d_wire = nullptr;
     s.req_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_pow), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_pow), cap * sizeof(uint64_t)));
-    if (c->gpu_resolve)
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_msgs), cap * sizeof(msd_message)));
+    if (c->gpu_resolve) {
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_wire), cap * sizeof(msd_wire)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_wire), cap * sizeof(msd_wire)));
+    }
     s.req_cap = cap;
     return 0;
 }
@@ -609,9 +612,8 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     return 0;
 }
 
-/* message records and signal power of every buffer on `ks`: both kernels write straight into pinned
- * host memory (a copy on another stream would contend with the next scan and arrive late);
- * ev_records marks their end */
+/* message records and signal power of every buffer on `ks` (device memory); ev_records marks the
+ * end.  The host fetches them with one DMA once it knows how many there are (fetch_records). */
 int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
 {
     MsdResolveParams rp{};
@@ -622,11 +624,26 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
                                       reinterpret_cast<unsigned long long *>(s.d_powr), ks);
     if (rc)
         return fail(c, rc, "power kernel launch failed");
-    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.h_msgs,
-                         reinterpret_cast<unsigned long long *>(s.h_pow), (uint32_t)s.req_cap, ks);
+    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.d_wire,
+                         (uint32_t)s.req_cap, ks);
     if (rc)
         return fail(c, rc, "emit kernel launch failed");
     HIPCHK(c, hipEventRecord(s.ev_records, ks));
+    return 0;
+}
+
+/* The records to pinned memory.  Issued only when the emit kernel is known to be done and on a
+ * stream with nothing else queued: the runtime then takes a DMA engine (~50 GB/s, no compute unit
+ * involved); a copy that has to wait for an event tends to become a blit kernel, which fights the
+ * running scan for compute units and is three times slower. */
+int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
+{
+    HIPCHK(c, hipEventSynchronize(s.ev_records));
+    if (total) {
+        HIPCHK(c, hipMemcpyAsync(s.h_wire, s.d_wire, (size_t)total * sizeof(msd_wire), hipMemcpyDeviceToHost,
+                                 c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    }
     return 0;
 }
 
@@ -742,10 +759,14 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
                 return rc;
         }
     }
-    HIPCHK(c, hipEventSynchronize(s.ev_records));
+    {
+        int rc = fetch_records(c, s, total);
+        if (rc)
+            return rc;
+    }
     auto e1 = tnow();
-    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), s.h_msgs, nullptr, c->out_buf.data(), s.h_pow,
-                      total);
+    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), &s.h_wire[0].mm, sizeof(msd_wire), nullptr,
+                      c->out_buf.data(), &s.h_wire[0].power, sizeof(msd_wire), total);
     if (trace) {
         double cyc[8] = {0};
         for (uint32_t b = 0; b < n; ++b)
@@ -760,7 +781,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
                 tms(e1, tnow()));
     if (sink)
         for (uint32_t i = 0; i < total; ++i)
-            sink(&s.h_msgs[i], user);
+            sink(&s.h_wire[i].mm, user);
     return 0;
 }
 
@@ -900,8 +921,8 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, nm * sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux_stream));
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
     }
-    msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(),
-                      c->out_req.data(), c->out_buf.data(), s.h_pow, nm);
+    msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(), sizeof(msd_message),
+                      c->out_req.data(), c->out_buf.data(), s.h_pow, sizeof(uint64_t), nm);
     auto t2 = std::chrono::steady_clock::now();
     if (sink)
         for (size_t i = 0; i < nm; ++i)
@@ -1044,9 +1065,10 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
-        if (s.h_msgs) (void)hipHostFree(s.h_msgs);
+        if (s.h_wire) (void)hipHostFree(s.h_wire);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
+        (void)hipFree(s.d_wire);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};

@@ -17,6 +17,7 @@
 #ifndef MSD_INTERNAL_H
 #define MSD_INTERNAL_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -173,10 +174,11 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
                        msd_emit_fn emit, void *user);
 /* Second half of demodulate2400's bookkeeping, once the signal power sums are known
  * (demod_2400.c:386-408,422-427): fills signalLevel and the power statistics, in order.
- * power_req may be NULL when every message is Mode S (the length follows from msgbits). */
+ * msgs / power are arrays of msd_message / uint64_t with the given byte strides; power_req may be NULL
+ * (the length then follows from msgbits, Mode A/C from msgtype). */
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
-                       struct msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
-                       const uint64_t *power, uint64_t nmsgs);
+                       void *msgs, size_t msg_stride, const uint64_t *power_req, const uint32_t *buffer,
+                       const void *power, size_t power_stride, uint64_t nmsgs);
 
 /* ---- host half of the GPU resolve (msd_resolve.c): the cross-buffer replay ----
  * begin: clocks, snapshot 0 (= the live filter), every buffer on the to-do list.

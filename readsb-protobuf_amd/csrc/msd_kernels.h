@@ -74,10 +74,15 @@ int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t st
 int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
                              const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals, unsigned long long *out,
                              hipStream_t stream);
-/* the accepted messages as dense msd_message records plus their signal power, both into pinned host
- * arrays of cap entries (what does not fit is dropped; the host notices from the counts) */
-int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_message *h_msgs,
-                    unsigned long long *h_pow, uint32_t cap, hipStream_t stream);
+/* one accepted message as the emit kernel leaves it: the record and its signal power sum */
+typedef struct msd_wire {
+    msd_message mm;
+    uint64_t power;
+} msd_wire;
+/* the accepted messages as dense records, cap entries (what does not fit is dropped; the host notices
+ * from the counts) */
+int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_wire *dense,
+                    uint32_t cap, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 /* h_totals / h_sums, if not NULL, are pinned host addresses that receive the list totals and the

@@ -1072,27 +1072,28 @@ void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *
 }
 
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
-                       msd_message *msgs, const uint64_t *power_req, const uint32_t *buffer,
-                       const uint64_t *power, uint64_t nmsgs)
+                       void *msgs_base, size_t msg_stride, const uint64_t *power_req, const uint32_t *buffer,
+                       const void *power_base, size_t power_stride, uint64_t nmsgs)
 {
     msd_stats *st = r->stats;
     uint64_t i = 0;
     for (uint32_t b = 0; b < nbuffers; ++b) {
         uint64_t sum_scaled_signal_power = 0;
         for (; i < nmsgs && buffer[i] == b; ++i) {
-            if (power_req ? !power_req[i] : msgs[i].msgtype == 32)
+            msd_message *mm = (msd_message *)((char *)msgs_base + i * msg_stride);
+            if (power_req ? !power_req[i] : mm->msgtype == 32)
                 continue; /* Mode A/C */
-            const int signal_len = power_req ? (int)(power_req[i] & 0xffffu) : msgs[i].msgbits * 12 / 5;
-            const uint64_t scaled = power[i];
+            const int signal_len = power_req ? (int)(power_req[i] & 0xffffu) : mm->msgbits * 12 / 5;
+            const uint64_t scaled = *(const uint64_t *)((const char *)power_base + i * power_stride);
             /* demod_2400.c:386-408 */
             const double signal_power = scaled / 65535.0 / 65535.0;
-            msgs[i].signalLevel = signal_power / signal_len;
+            mm->signalLevel = signal_power / signal_len;
             st->signal_power_sum += signal_power;
             st->signal_power_count += (uint64_t)signal_len;
             sum_scaled_signal_power += scaled;
-            if (msgs[i].signalLevel > st->peak_signal_power)
-                st->peak_signal_power = msgs[i].signalLevel;
-            if (msgs[i].signalLevel > 0.50119)
+            if (mm->signalLevel > st->peak_signal_power)
+                st->peak_signal_power = mm->signalLevel;
+            if (mm->signalLevel > 0.50119)
                 st->strong_signal_count++;
         }
         { /* demod_2400.c:422-427 */

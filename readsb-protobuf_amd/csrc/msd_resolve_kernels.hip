@@ -721,11 +721,10 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     }
 }
 
-/* The accepted messages of buffer b as msd_message records, dense over the batch, with the signal
- * power the power kernel left per buffer; both arrays live in pinned host memory and consecutive
- * lanes write consecutive records, so the stores leave as full PCIe bursts. */
+/* The accepted messages of buffer b as 64-byte records (msd_message + signal power sum), dense over
+ * the batch; one DMA then takes them to the host while the next scan runs. */
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
-                                                       msd_message *dense, unsigned long long *dense_pow, uint32_t cap)
+                                                       msd_wire *dense, uint32_t cap)
 {
     if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return;
@@ -774,8 +773,10 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         mm.pad = 0;
         if (o + m >= cap)
             break; /* the host notices (total > cap), grows the arrays and emits again */
-        dense[o + m] = mm;
-        dense_pow[o + m] = power[(size_t)b * MSD_RB_MSG_CAP + m];
+        msd_wire wr;
+        wr.mm = mm;
+        wr.power = power[(size_t)b * MSD_RB_MSG_CAP + m];
+        dense[o + m] = wr;
     }
     if (P.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
         const uint32_t na = P.nac[b];
@@ -802,8 +803,10 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             mm.msg[1] = (uint8_t)c.modeac;
             mm.iid = 0;
             mm.pad = 0;
-            dense[o + nm + m] = mm;
-            dense_pow[o + nm + m] = 0;
+            msd_wire wr;
+            wr.mm = mm;
+            wr.power = 0;
+            dense[o + nm + m] = wr;
         }
     }
 }
@@ -933,10 +936,10 @@ extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hip
 }
 
 extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power,
-                               msd_message *h_msgs, unsigned long long *h_pow, uint32_t cap, hipStream_t stream)
+                               msd_wire *dense, uint32_t cap, hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, h_msgs, h_pow, cap);
+    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
