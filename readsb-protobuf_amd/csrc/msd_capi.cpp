@@ -72,6 +72,7 @@ struct Slot {
     msd_try *h_tries = nullptr;
     size_t h_tries_cap = 0;
     uint8_t *d_ragged = nullptr; /* zero-padded copy of a partially filled last 8-sample group */
+    uint8_t *tail_dst = nullptr; /* where the gather kernel leaves the batch's last samples for its successor */
     /* Mode A/C candidates */
     msd_ac_hit *d_ac = nullptr;
     uint64_t *d_ac_totals = nullptr, *h_ac_totals = nullptr;
@@ -241,6 +242,11 @@ int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
     return 0;
 }
 
+size_t bps_of(int format)
+{
+    return (format == MSD_FMT_UC8 || format == MSD_FMT_MAG16) ? 2 : 4;
+}
+
 /* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
 int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
@@ -295,10 +301,17 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         if (rc)
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
-        rc = msd_launch_gather(c->d_counts, nwg, c->d_offsets, s.d_totals, c->d_region_hits,
-                               c->d_region_tries, p.hcap, p.tcap, s.d_hits, c->hit_arena, s.d_tries,
-                               c->try_arena, s.d_sums, s.nbuffers, lean ? s.h_totals : nullptr,
-                               lean ? s.h_sums : nullptr, s.d_pred, s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0, c->stream);
+        const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
+                               (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
+        rc = msd_launch_gather(c->d_counts, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
+                               s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers,
+                               lean ? s.h_totals : nullptr, lean ? s.h_sums : nullptr, s.d_pred,
+                               s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0,
+                               tail_here ? s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format) : nullptr,
+                               tail_here ? s.tail_dst : nullptr, tail_here ? (uint32_t)(TAIL_SAMPLES * bps_of(format)) : 0,
+                               c->stream);
+        if (tail_here)
+            s.tail_dst = nullptr; /* done */
         if (rc)
             return fail(c, rc, "gather kernel launch failed");
     } else {
@@ -982,6 +995,8 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
     s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
+    const int tail_nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
+    s.tail_dst = nsamples >= (uint64_t)TAIL_SAMPLES ? c->d_tail[tail_nxt] : nullptr;
     auto tl0 = std::chrono::steady_clock::now();
     rc = enqueue(c, s, c->cfg.format, nullptr);
     if (rc) {
@@ -1004,10 +1019,11 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         }
     }
     if (nsamples >= (uint64_t)TAIL_SAMPLES) {
-        const int nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
-        HIPCHK(c, hipMemcpyAsync(c->d_tail[nxt], s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
-                                 (size_t)TAIL_SAMPLES * c->bps, hipMemcpyDeviceToDevice, c->stream));
-        c->tail_cur = nxt;
+        if (s.tail_dst) /* no gather kernel ran (cannot happen with that many samples) */
+            HIPCHK(c, hipMemcpyAsync(s.tail_dst, s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
+                                     (size_t)TAIL_SAMPLES * c->bps, hipMemcpyDeviceToDevice, c->stream));
+        s.tail_dst = nullptr;
+        c->tail_cur = tail_nxt;
         c->have_prev = true;
     }
     c->next_sample += nsamples;

@@ -85,14 +85,16 @@ int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned
                     uint32_t cap, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
-/* h_totals / h_sums, if not NULL, are pinned host addresses that receive the list totals and the
- * per-buffer level/power sums; the device sums are zeroed for the next batch of the slot.
- * wipe[0..wipe_bytes) (a multiple of 16) is set to all-ones on the way. */
-int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets, uint64_t *totals,
-                      const msd_hit *hits, const msd_try *tries, uint32_t hcap, uint32_t tcap,
-                      msd_hit *dense_hits, uint64_t dense_hcap, msd_try *dense_tries,
-                      uint64_t dense_tcap, uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums,
-                      void *wipe, uint32_t wipe_bytes, hipStream_t stream);
+/* Regions -> dense ordered lists (every workgroup sums the counts in front of it); the last
+ * workgroup leaves the totals in `totals` and, if h_totals / h_sums are not NULL, writes them and the
+ * per-buffer level/power sums to those pinned host addresses and zeroes the device sums for the slot's
+ * next batch.  wipe[0..wipe_bytes) (a multiple of 16) is set to all-ones, tail_bytes (a multiple of
+ * 4) are copied from tail_src to tail_dst on the way. */
+int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *totals, const msd_hit *hits,
+                      const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,
+                      msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
+                      uint64_t *h_sums, void *wipe, uint32_t wipe_bytes, const void *tail_src, void *tail_dst,
+                      uint32_t tail_bytes, hipStream_t stream);
 int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
                      unsigned long long *d_out, hipStream_t stream);
 /* Mode A/C candidate stage: noise levels (unless noise_ready), candidate kernel, ordered gather.

@@ -862,31 +862,83 @@ __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *c
 
 /* dense[offset[w] + i] = region[w][i]; the try index inside a hit record is made dense too.
  * grid = nwg workgroups */
-__global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *counts,
-                                                         const uint64_t *offsets, const msd_hit *hits,
-                                                         const msd_try *tries, uint32_t hcap,
-                                                         uint32_t tcap, msd_hit *dense_hits,
-                                                         uint64_t dense_hcap, msd_try *dense_tries,
-                                                         uint64_t dense_tcap, uint4 *wipe, uint32_t wipe_n)
+__global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *counts, const msd_hit *hits,
+                                                         const msd_try *tries, uint32_t hcap, uint32_t tcap,
+                                                         msd_hit *dense_hits, uint64_t dense_hcap,
+                                                         msd_try *dense_tries, uint64_t dense_tcap, uint64_t *totals,
+                                                         uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
+                                                         uint64_t *h_sums, uint4 *wipe, uint32_t wipe_n,
+                                                         const uint32_t *tail_src, uint32_t *tail_dst,
+                                                         uint32_t tail_words)
 {
-    const uint32_t w = blockIdx.x;
-    /* all-ones into a scratch table of the slot's resolve stage (the prediction table), spread over the grid */
-    for (uint32_t i = w * blockDim.x + threadIdx.x; i < wipe_n; i += gridDim.x * blockDim.x)
-        wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __shared__ unsigned long long ph[4], pt[4];
+    __shared__ uint32_t povf[4];
+    const uint32_t w = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x;
+    /* this workgroup's offsets in the dense lists: the counts of all workgroups in front of it */
+    unsigned long long h = 0, t = 0;
+    uint32_t ovf = 0;
+    const bool last = w + 1 == nwg;
+    for (uint32_t i = tid; i < (last ? nwg : w); i += 256) { /* the last workgroup also owes the totals */
+        const msd_wg_counts c = counts[i];
+        if (i < w) {
+            h += c.nhits;
+            t += c.ntries;
+        }
+        ovf |= c.overflow;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        h += __shfl_down(h, d, 64);
+        t += __shfl_down(t, d, 64);
+        ovf |= __shfl_down(ovf, d, 64);
+    }
+    if ((tid & 63) == 0) {
+        ph[tid >> 6] = h;
+        pt[tid >> 6] = t;
+        povf[tid >> 6] = ovf;
+    }
+    __syncthreads();
+    const uint64_t ho = ph[0] + ph[1] + ph[2] + ph[3], to = pt[0] + pt[1] + pt[2] + pt[3];
     const uint32_t nh = counts[w].nhits < hcap ? counts[w].nhits : hcap;
     const uint32_t nt = counts[w].ntries < tcap ? counts[w].ntries : tcap;
-    const uint64_t ho = offsets[2 * w], to = offsets[2 * w + 1];
+    if (last) {
+        /* list totals and per-buffer level/power sums straight to pinned host memory (a copy on another
+         * stream would queue behind the following scans); the device sums are zeroed for the slot's next batch */
+        if (tid == 0) {
+            const uint64_t ah = ho + counts[w].nhits, at = to + counts[w].ntries;
+            const uint64_t o = (povf[0] | povf[1] | povf[2] | povf[3] | counts[w].overflow) ? 1 : 0;
+            totals[0] = ah;
+            totals[1] = at;
+            totals[2] = o;
+            if (h_totals) {
+                h_totals[0] = ah;
+                h_totals[1] = at;
+                h_totals[2] = o;
+            }
+        }
+        if (h_sums)
+            for (uint32_t i = tid; i < 2 * nbuffers; i += 256) {
+                h_sums[i] = sums[i];
+                sums[i] = 0;
+            }
+    }
+    if (w == 0) /* the last samples of the batch, kept for the look-behind of the next one */
+        for (uint32_t i = tid; i < tail_words; i += 256)
+            tail_dst[i] = tail_src[i];
+    /* all-ones into a scratch table of the slot's resolve stage (the prediction table), spread over the grid */
+    for (uint32_t i = w * blockDim.x + tid; i < wipe_n; i += nwg * blockDim.x)
+        wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     const msd_hit *hs = hits + (size_t)w * hcap;
-    for (uint32_t i = threadIdx.x; i < nh; i += blockDim.x) {
-        msd_hit h = hs[i];
-        if (MSD_HIT_NLIVE(h))
-            h += (msd_hit)to << 34;
+    for (uint32_t i = tid; i < nh; i += blockDim.x) {
+        msd_hit hr = hs[i];
+        if (MSD_HIT_NLIVE(hr))
+            hr += (msd_hit)to << 34;
         if (ho + i < dense_hcap)
-            dense_hits[ho + i] = h;
+            dense_hits[ho + i] = hr;
     }
     const uint4 *ts = reinterpret_cast<const uint4 *>(tries + (size_t)w * tcap);
     uint4 *td = reinterpret_cast<uint4 *>(dense_tries);
-    for (uint32_t i = threadIdx.x; i < 2 * nt; i += blockDim.x)
+    for (uint32_t i = tid; i < 2 * nt; i += blockDim.x)
         if (to + (i >> 1) < dense_tcap)
             td[2 * to + i] = ts[i];
 }
@@ -946,8 +998,10 @@ __global__ void __launch_bounds__(256) msd_power_kernel(const MsdScanParams P, c
 }
 
 /* The same for the GPU resolve stage, which does not know the number of messages on the host when
- * it queues the kernel: eight workgroups per buffer walk the accepted-message records the resolve
+ * it queues the kernel: PB_WGS workgroups per buffer walk the accepted-message records the resolve
  * kernel left for that buffer, one wavefront per message; out[buffer][MSD_RB_MSG_CAP]. */
+constexpr uint32_t PB_WGS = 8;  /* workgroups per buffer: a buffer rarely holds more than 96 messages */
+
 template <int FMT>
 __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const msd_acc *acc,
                                                                 const msd_try *tries, const uint32_t *nmsgs,
@@ -955,9 +1009,9 @@ __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanPar
 {
     if (totals[2])
         return;
-    const uint32_t b = blockIdx.x >> 3, nm = nmsgs[b];
+    const uint32_t b = blockIdx.x / PB_WGS, nm = nmsgs[b];
     const int lane = threadIdx.x & 63;
-    for (uint32_t m = (blockIdx.x & 7u) * 4 + (threadIdx.x >> 6); m < nm; m += 32) {
+    for (uint32_t m = (blockIdx.x % PB_WGS) * 4 + (threadIdx.x >> 6); m < nm; m += 4 * PB_WGS) {
         const msd_acc rec = acc[(size_t)b * MSD_RB_MSG_CAP + m];
         const int len = (int)rec.len;
         const int64_t n0 = (int64_t)P.batch_first + (int64_t)rec.pos - (int64_t)MSD_OVERLAP + 19;
@@ -1349,18 +1403,16 @@ extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg,
     }
 }
 
-extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *offsets,
-                                 uint64_t *totals, const msd_hit *hits, const msd_try *tries,
-                                 uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
-                                 uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap,
-                                 uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums,
-                                 void *wipe, uint32_t wipe_bytes, hipStream_t stream)
+extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *totals, const msd_hit *hits,
+                                 const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
+                                 uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums,
+                                 uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums, void *wipe, uint32_t wipe_bytes,
+                                 const void *tail_src, void *tail_dst, uint32_t tail_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, counts, nwg, offsets, totals, sums, nbuffers,
-                       h_totals, h_sums);
-    hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, offsets, hits, tries,
-                       hcap, tcap, dense_hits, dense_hcap, dense_tries, dense_tcap, static_cast<uint4 *>(wipe),
-                       wipe_bytes / 16);
+    hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, hits, tries, hcap, tcap, dense_hits,
+                       dense_hcap, dense_tries, dense_tcap, totals, sums, nbuffers, h_totals, h_sums,
+                       static_cast<uint4 *>(wipe), wipe_bytes / 16, static_cast<const uint32_t *>(tail_src),
+                       static_cast<uint32_t *>(tail_dst), tail_bytes / 4);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
@@ -1395,7 +1447,7 @@ extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, cons
 {
     if (nbuffers == 0)
         return 0;
-    const dim3 grid(nbuffers * 8), block(256);
+    const dim3 grid(nbuffers * PB_WGS), block(256);
     switch (format) {
     case MSD_FMT_UC8:
         hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
