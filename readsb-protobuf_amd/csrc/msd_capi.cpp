@@ -613,10 +613,14 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
     int rc = 0;
-    if (first_pass) /* which new addresses will this batch add, and where first */
-        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, s.d_pred, c->h_pred, c->h_pred_count, ks);
-    else
+    if (first_pass) { /* which new addresses will this batch add, and where first */
+        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, s.d_pred, ks);
+        rp.pred_list = s.d_pred + 2 * MSD_PRED_SLOTS;
+        rp.h_pred = c->h_pred;
+        rp.h_pred_count = c->h_pred_count;
+    } else {
         rc = msd_launch_pred_patch(s.d_pred + MSD_PRED_SLOTS, c->h_patches, c->npatches, ks);
+    }
     if (rc)
         return fail(c, rc, "prediction kernel launch failed");
     rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);

@@ -51,6 +51,10 @@ typedef struct MsdResolveParams {
     const uint64_t *ac_totals; /* [0] their number, [2] arena overflow flag */
     uint32_t *acc_ac;         /* [buffer][MSD_RB_AC_CAP] indices of the accepted ones */
     uint32_t *nac;            /* [buffer] how many */
+    /* first pass only: its first workgroup publishes the prediction list the predict kernel built */
+    const uint32_t *pred_list; /* counter - 1, then the used slots; NULL on later passes */
+    msd_pred_entry *h_pred;    /* pinned host memory */
+    uint32_t *h_pred_count;
     const uint32_t *pred_key; /* [MSD_PRED_SLOTS] predicted adds: address ... */
     const uint32_t *pred_first; /* ... and the first buffer with a clean squitter of it */
 } MsdResolveParams;
@@ -62,11 +66,12 @@ extern "C" {
 int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, uint64_t *sums, const float *fmeans,
                        uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums, float *h_fmeans,
                        hipStream_t stream);
-/* Builds the prediction table of a batch from its try list (against snapshot 0) and publishes the
- * list of entries: h_list[0..*h_count) in pinned host memory, *h_count = MSD_PRED_LIST + 1 on overflow.
- * pred (device): key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | counter | slot list[MSD_PRED_LIST]. */
+/* Builds the prediction table of a batch from its try list (against snapshot 0).
+ * pred (device): key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | counter | slot list[MSD_PRED_LIST], wiped to
+ * all-ones beforehand.  The list of entries is published by the first resolve pass: h_pred[0..*h_pred_count)
+ * in pinned host memory, *h_pred_count = MSD_PRED_LIST + 1 on overflow. */
 int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
-                       msd_pred_entry *h_list, uint32_t *h_count, hipStream_t stream);
+                       hipStream_t stream);
 /* pred_first[patches[i].slot] = patches[i].first; patches is pinned host memory */
 int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);

@@ -175,6 +175,20 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
 #define PHASE(k) { const uint64_t n_ = wall_clock64(); cyc[k] += (uint32_t)(n_ - tlast); tlast = n_; }
     if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
+    if (blockIdx.x == 0 && P.pred_list) { /* the prediction list of the batch, for the host's replay */
+        const uint32_t n = P.pred_list[0] + 1u; /* the counter started at 0xffffffff */
+        if (tid == 0)
+            *P.h_pred_count = n <= MSD_PRED_LIST ? n : MSD_PRED_LIST + 1;
+        for (uint32_t i = tid; i < n && i < MSD_PRED_LIST; i += RT) {
+            const uint32_t h = P.pred_list[1 + i];
+            msd_pred_entry e;
+            e.addr = P.pred_key[h];
+            e.first = P.pred_first[h];
+            e.slot = h;
+            e.pad = 0;
+            P.h_pred[i] = e;
+        }
+    }
     const uint64_t nhits = P.totals[0];
     const uint32_t b = P.todo[blockIdx.x];
     const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * MSD_SNAP_WORDS;
@@ -849,24 +863,6 @@ __global__ void __launch_bounds__(256) msd_predict_kernel(const msd_try *tries, 
     }
 }
 
-__global__ void __launch_bounds__(256) msd_pred_publish_kernel(const uint32_t *pred_key, const uint32_t *pred_first,
-                                                               const uint32_t *count, const uint32_t *list,
-                                                               msd_pred_entry *h_list, uint32_t *h_count)
-{
-    const uint32_t n = *count + 1u;
-    if (threadIdx.x == 0)
-        *h_count = n <= MSD_PRED_LIST ? n : MSD_PRED_LIST + 1;
-    for (uint32_t i = threadIdx.x; i < n && i < MSD_PRED_LIST; i += blockDim.x) {
-        const uint32_t h = list[i];
-        msd_pred_entry e;
-        e.addr = pred_key[h];
-        e.first = pred_first[h];
-        e.slot = h;
-        e.pad = 0;
-        h_list[i] = e;
-    }
-}
-
 __global__ void __launch_bounds__(64) msd_pred_patch_kernel(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n)
 {
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
@@ -907,15 +903,13 @@ extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_tot
 }
 
 extern "C" int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
-                                  msd_pred_entry *h_list, uint32_t *h_count, hipStream_t stream)
+                                  hipStream_t stream)
 {
-    /* pred: key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | count - 1 | slot list[MSD_PRED_LIST] */
+    /* pred: key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | count - 1 | slot list[MSD_PRED_LIST];
+     * key, first and the counter are all-ones here: the slot's gather kernel wiped them */
     uint32_t *key = pred, *first = pred + MSD_PRED_SLOTS, *count = pred + 2 * MSD_PRED_SLOTS;
-    /* key, first and the counter are all-ones here: the slot's gather kernel wiped them */
     hipLaunchKernelGGL(msd_predict_kernel, dim3(1024), dim3(256), 0, stream, tries, totals, snap0, key, first, count,
                        count + 1);
-    hipLaunchKernelGGL(msd_pred_publish_kernel, dim3(1), dim3(256), 0, stream, key, first, count, count + 1, h_list,
-                       h_count);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
