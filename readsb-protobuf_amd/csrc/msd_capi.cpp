@@ -116,6 +116,7 @@ struct msd_ctx {
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
+    bool records_dma = false; /* MSD_RECORDS_DMA=1: fetch the message records with a DMA instead of kernel stores */
     hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
     msd_pred_entry *h_pred = nullptr;
     uint32_t *h_pred_count = nullptr;
@@ -641,22 +642,24 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
                                       reinterpret_cast<unsigned long long *>(s.d_powr), ks);
     if (rc)
         return fail(c, rc, "power kernel launch failed");
-    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.d_wire,
-                         (uint32_t)s.req_cap, ks);
+    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr),
+                         c->records_dma ? s.d_wire : s.h_wire, (uint32_t)s.req_cap, ks);
     if (rc)
         return fail(c, rc, "emit kernel launch failed");
     HIPCHK(c, hipEventRecord(s.ev_records, ks));
     return 0;
 }
 
-/* The records to pinned memory.  Issued only when the emit kernel is known to be done and on a
- * stream with nothing else queued: the runtime then takes a DMA engine (~50 GB/s, no compute unit
- * involved); a copy that has to wait for an event tends to become a blit kernel, which fights the
- * running scan for compute units and is three times slower. */
+/* The records in pinned memory.  Default: the emit kernel wrote them there itself (PCIe-bound, ~45 us
+ * per 35 000 messages, in order behind the batch's other kernels, nothing else shares the GPU with a
+ * scan).  MSD_RECORDS_DMA=1: the emit kernel wrote to HBM and one hipMemcpyAsync fetches the records
+ * while the next scan runs -- faster when the runtime gives the copy a DMA engine (it does when the
+ * copy is issued on an idle stream with no event to wait for), but under rocprofv3, and whenever the
+ * runtime picks a blit kernel instead, that copy takes compute units from the scan. */
 int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
 {
     HIPCHK(c, hipEventSynchronize(s.ev_records));
-    if (total) {
+    if (total && c->records_dma) {
         HIPCHK(c, hipMemcpyAsync(s.h_wire, s.d_wire, (size_t)total * sizeof(msd_wire), hipMemcpyDeviceToHost,
                                  c->copy_stream));
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
@@ -1255,6 +1258,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     {
         const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
         c->gpu_resolve = g ? atoi(g) != 0 : true;
+        if (const char *rd = getenv("MSD_RECORDS_DMA"))
+            c->records_dma = atoi(rd) != 0;
         const char *ia = getenv("MSD_RESOLVE_INLINE_ADDS");
         if (ia && atoi(ia) >= 0 && (uint32_t)atoi(ia) < MSD_RB_ADD_INLINE)
             c->inline_adds = (uint32_t)atoi(ia);
