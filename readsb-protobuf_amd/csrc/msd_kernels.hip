@@ -1215,6 +1215,69 @@ static_assert(AC_LOAD % 8 == 0 && MSD_CHUNK_SAMPLES % ACT == 0, "whole groups, t
 /* Every F1 position that passes all tests of demod_2400.c:581-668; the 69-sample skip-ahead after
  * a decode (:705) is left to the resolve stage.  One thread per position, magnitudes staged in
  * LDS like in the Mode S scan; output appended in position order to a workgroup-private region. */
+/* All tests of demodulate2400AC (demod_2400.c:581-668) for the F1 position p of a tile whose first
+ * position is sample j0 of its buffer; mags[p + 2 + d] = m[f1_sample + d]. */
+template <bool f1_only>
+__device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0, uint32_t mlen, uint32_t noise_level,
+                                        uint32_t &f2_clock, uint32_t &modeac)
+{
+    const uint32_t f1_sample = j0 + (uint32_t)p;
+#define ACM(x) ((uint32_t)mags[p + 2 + (int)((x) - f1_sample)])
+    if (!(f1_sample >= 1 && f1_sample < mlen))
+        return false;
+    const uint32_t m0 = ACM(f1_sample), m1 = ACM(f1_sample + 1), m2 = ACM(f1_sample + 2);
+    const uint32_t f1_level = (m0 + m1) / 2;
+    if (!(ACM(f1_sample - 1) < m0 && !(m2 > m0 || m2 > m1) && !(noise_level * 2 > f1_level)))
+        return false;
+    if (f1_only)
+        return true; /* every pulse edge of a Mode S frame gets this far: the rest runs on a compacted list */
+    const float f1a_power = (float)m0 * (float)m0;
+    const float f1b_power = (float)m1 * (float)m1;
+    const float fsum = f1a_power + f1b_power;
+    const float fraction = f1b_power / fsum;
+    const float frac2 = fraction * fraction;
+    const float fpos = (float)f1_sample + frac2;
+    const float fclk = 25.0f * fpos;
+    const uint32_t f1_clock = (uint32_t)((double)fclk + 0.5);
+    f2_clock = f1_clock + (87 * 14);
+    const uint32_t f2_sample = f2_clock / 25;
+    const uint32_t n0 = ACM(f2_sample), n1 = ACM(f2_sample + 1), n2 = ACM(f2_sample + 2);
+    const uint32_t f2_level = (n0 + n1) / 2;
+    if (!(ACM(f2_sample - 1) < n0 && !(n2 > n0 || n2 > n1) && !(noise_level * 2 > f2_level)))
+        return false;
+    const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
+    const float midpoint = __builtin_sqrtf((float)(noise_level * f1f2_level)); /* u32 product */
+    const double up = (double)midpoint * 1.41421356237309504880;
+    const double down = (double)midpoint / 1.41421356237309504880;
+    const uint32_t signal_threshold = (uint32_t)(up + 0.5);
+    const uint32_t noise_threshold = (uint32_t)(down + 0.5);
+    uint32_t bits = 0, bad = 0;
+    uint32_t clock = f1_clock;
+    for (int bit = 0; bit < 20; ++bit, clock += 87) {
+        const uint32_t s = clock / 25;
+        const uint32_t x0 = ACM(s), x1 = ACM(s + 1), x2 = ACM(s + 2);
+        bits <<= 1;
+        if (x2 >= signal_threshold)
+            bad = 1; /* noisy quiet period */
+        if (x0 >= signal_threshold || x1 >= signal_threshold)
+            bits |= 1;
+        else if (x0 > noise_threshold && x1 > noise_threshold)
+            bad = 1; /* uncertain bit */
+    }
+#undef ACM
+    if (!((bits & 0x80020u) == 0x80020u && (bits & 0x0101Bu) == 0 && !bad))
+        return false;
+    /* demod_2400.c:672-685: 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 */
+    modeac = ((bits & 0x40000u) ? 0x0010u : 0) | ((bits & 0x20000u) ? 0x1000u : 0) |
+             ((bits & 0x10000u) ? 0x0020u : 0) | ((bits & 0x08000u) ? 0x2000u : 0) |
+             ((bits & 0x04000u) ? 0x0040u : 0) | ((bits & 0x02000u) ? 0x4000u : 0) |
+             ((bits & 0x00800u) ? 0x0100u : 0) | ((bits & 0x00400u) ? 0x0001u : 0) |
+             ((bits & 0x00200u) ? 0x0200u : 0) | ((bits & 0x00100u) ? 0x0002u : 0) |
+             ((bits & 0x00080u) ? 0x0400u : 0) | ((bits & 0x00040u) ? 0x0004u : 0) |
+             ((bits & 0x00004u) ? 0x0080u : 0);
+    return true;
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
                                                       const uint32_t *noise_levels, msd_ac_hit *out,
@@ -1222,7 +1285,8 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
 {
     __shared__ __attribute__((aligned(16))) uint16_t mags[AC_LOAD + 8];
     __shared__ __attribute__((aligned(16))) uint16_t lut[(FMT == MSD_FMT_UC8) ? 128 * LUT_STRIDE : 8];
-    __shared__ uint32_t wcount[ACNT / 64];
+    __shared__ uint8_t kcount[ACT / ACNT][ACNT / 64];
+    __shared__ uint16_t surv[ACT]; /* positions that pass the F1 test, in order */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wg = blockIdx.x;
     if (FMT == MSD_FMT_UC8) {
@@ -1240,17 +1304,34 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
     uint32_t cur = 0; /* workgroup-uniform output cursor */
     msd_ac_hit *const mine = out + (size_t)wg * cap;
 
+    /* the raw samples of a tile are fetched into registers one tile ahead */
+    constexpr int GPT_AC = (AC_LOAD / 8 + ACNT - 1) / ACNT;
+    RawGroup<FMT> rg[GPT_AC];
+    uint32_t vg[GPT_AC];
+#define AC_FETCH(TILE)                                                                               \
+    {                                                                                                \
+        const int64_t n0_ = (int64_t)(P.batch_first + (uint64_t)(TILE) * ACT) - FRONT;               \
+        _Pragma("unroll") for (int i_ = 0; i_ < GPT_AC; ++i_) {                                      \
+            const int g_ = tid + i_ * ACNT;                                                          \
+            vg[i_] = fetch_group<FMT>(P, n0_ + 8 * (g_ < AC_LOAD / 8 ? g_ : 0), rg[i_]);             \
+        }                                                                                            \
+    }
+    if (tile_lo < tile_hi)
+        AC_FETCH(tile_lo)
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         const uint64_t pos0 = (uint64_t)tile * ACT; /* batch-relative */
-        const uint64_t a0 = P.batch_first + pos0;
-        for (int g = tid; g < AC_LOAD / 8; g += ACNT) {
-            RawGroup<FMT> r;
-            const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * g, r);
-            uint32_t mg[8];
-            convert_group<FMT>(r, valid, lut, mg);
-            *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
+#pragma unroll
+        for (int i = 0; i < GPT_AC; ++i) {
+            const int g = tid + i * ACNT;
+            if (g < AC_LOAD / 8) {
+                uint32_t mg[8];
+                convert_group<FMT>(rg[i], vg[i], lut, mg);
+                *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
+            }
         }
         __syncthreads();
+        if (tile + 1 < tile_hi)
+            AC_FETCH(tile + 1)
 
         const uint32_t b = (uint32_t)(pos0 / MSD_CHUNK_SAMPLES);
         const uint32_t j0 = (uint32_t)(pos0 % MSD_CHUNK_SAMPLES);
@@ -1259,91 +1340,89 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
         const uint32_t mlen = mlen64 > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : (uint32_t)mlen64;
         const uint32_t noise_level = noise_levels[b];
 
-        for (int sub = 0; sub < ACT; sub += ACNT) {
-            const int p = sub + tid;
-            const uint32_t f1_sample = j0 + (uint32_t)p;
-            /* m[x] = mags[p + 2 + (x - f1_sample)]: the tile stages 328 = 326 + 2 samples behind */
-#define ACM(x) ((uint32_t)mags[p + 2 + (int)((x) - f1_sample)])
-            bool found = false;
-            uint32_t f2_clock = 0, modeac = 0;
-            if (f1_sample >= 1 && f1_sample < mlen) {
-                const uint32_t m0 = ACM(f1_sample), m1 = ACM(f1_sample + 1), m2 = ACM(f1_sample + 2);
-                const uint32_t f1_level = (m0 + m1) / 2;
-                if (ACM(f1_sample - 1) < m0 && !(m2 > m0 || m2 > m1) && !(noise_level * 2 > f1_level)) {
-                    const float f1a_power = (float)m0 * (float)m0;
-                    const float f1b_power = (float)m1 * (float)m1;
-                    const float fsum = f1a_power + f1b_power;
-                    const float fraction = f1b_power / fsum;
-                    const float frac2 = fraction * fraction;
-                    const float fpos = (float)f1_sample + frac2;
-                    const float fclk = 25.0f * fpos;
-                    const uint32_t f1_clock = (uint32_t)((double)fclk + 0.5);
-                    f2_clock = f1_clock + (87 * 14);
-                    const uint32_t f2_sample = f2_clock / 25;
-                    const uint32_t n0 = ACM(f2_sample), n1 = ACM(f2_sample + 1), n2 = ACM(f2_sample + 2);
-                    const uint32_t f2_level = (n0 + n1) / 2;
-                    if (ACM(f2_sample - 1) < n0 && !(n2 > n0 || n2 > n1) && !(noise_level * 2 > f2_level)) {
-                        const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
-                        const float midpoint = __builtin_sqrtf((float)(noise_level * f1f2_level)); /* u32 product */
-                        const double up = (double)midpoint * 1.41421356237309504880;
-                        const double down = (double)midpoint / 1.41421356237309504880;
-                        const uint32_t signal_threshold = (uint32_t)(up + 0.5);
-                        const uint32_t noise_threshold = (uint32_t)(down + 0.5);
-                        uint32_t bits = 0, bad = 0;
-                        uint32_t clock = f1_clock;
-                        for (int bit = 0; bit < 20; ++bit, clock += 87) {
-                            const uint32_t s = clock / 25;
-                            const uint32_t x0 = ACM(s), x1 = ACM(s + 1), x2 = ACM(s + 2);
-                            bits <<= 1;
-                            if (x2 >= signal_threshold)
-                                bad = 1; /* noisy quiet period */
-                            if (x0 >= signal_threshold || x1 >= signal_threshold)
-                                bits |= 1;
-                            else if (x0 > noise_threshold && x1 > noise_threshold)
-                                bad = 1; /* uncertain bit */
-                        }
-                        if ((bits & 0x80020u) == 0x80020u && (bits & 0x0101Bu) == 0 && !bad) {
-                            /* demod_2400.c:672-685: 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 */
-                            modeac = ((bits & 0x40000u) ? 0x0010u : 0) | ((bits & 0x20000u) ? 0x1000u : 0) |
-                                     ((bits & 0x10000u) ? 0x0020u : 0) | ((bits & 0x08000u) ? 0x2000u : 0) |
-                                     ((bits & 0x04000u) ? 0x0040u : 0) | ((bits & 0x02000u) ? 0x4000u : 0) |
-                                     ((bits & 0x00800u) ? 0x0100u : 0) | ((bits & 0x00400u) ? 0x0001u : 0) |
-                                     ((bits & 0x00200u) ? 0x0200u : 0) | ((bits & 0x00100u) ? 0x0002u : 0) |
-                                     ((bits & 0x00080u) ? 0x0400u : 0) | ((bits & 0x00040u) ? 0x0004u : 0) |
-                                     ((bits & 0x00004u) ? 0x0080u : 0);
-                            found = true;
-                        }
-                    }
-                }
-            }
-#undef ACM
-            /* ordered append */
-            const unsigned long long bal = __ballot(found);
+        /* Pass 1, position p = k * ACNT + tid (consecutive lanes read consecutive samples): the F1
+         * pulse test.  Survivors -- a few percent, every strong pulse edge -- go to an ordered list ... */
+        constexpr int PER = ACT / ACNT;
+        uint32_t mask = 0;
+#pragma unroll 1
+        for (int k = 0; k < PER; ++k) {
+            uint32_t f2c, code;
+            const bool pass = ac_eval<true>(mags, k * ACNT + tid, j0, mlen, noise_level, f2c, code);
+            const unsigned long long bal = __ballot(pass);
+            if (pass)
+                mask |= 1u << k;
             if (lane == 0)
-                wcount[wave] = (uint32_t)__popcll(bal);
-            __syncthreads();
+                kcount[k][wave] = (uint8_t)__popcll(bal);
+        }
+        __syncthreads();
+        uint32_t nsurv = 0;
+#pragma unroll 1
+        for (int k = 0; k < PER; ++k) {
             uint32_t before = 0, total = 0;
 #pragma unroll
             for (int i = 0; i < ACNT / 64; ++i) {
-                const uint32_t s = wcount[i];
+                const uint32_t sct = kcount[k][i];
                 if (i < wave)
-                    before += s;
-                total += s;
+                    before += sct;
+                total += sct;
             }
-            if (found) {
-                const uint32_t idx = cur + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                if (idx < cap) {
-                    msd_ac_hit h;
-                    h.pos = pos0 + (uint64_t)p;
-                    h.f2_clock = f2_clock;
-                    h.modeac = modeac;
-                    mine[idx] = h;
-                }
+            if (total) { /* workgroup-uniform */
+                const bool pass = (mask >> k) & 1u;
+                const unsigned long long bal = __ballot(pass);
+                if (pass)
+                    surv[nsurv + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(k * ACNT + tid);
+                nsurv += total;
             }
-            cur += total;
-            __syncthreads();
         }
+        __syncthreads();
+        /* ... pass 2, one lane per survivor: F2, thresholds, the 20 bit windows.  The few that decode are
+         * counted per (round, wavefront), ranked, and decoded once more for the record. */
+        const uint32_t rounds = (nsurv + ACNT - 1) / ACNT; /* <= PER */
+        mask = 0;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t i = r * ACNT + (uint32_t)tid;
+            uint32_t f2c, code;
+            const bool found = i < nsurv && ac_eval<false>(mags, surv[i], j0, mlen, noise_level, f2c, code);
+            const unsigned long long bal = __ballot(found);
+            if (found)
+                mask |= 1u << r;
+            if (lane == 0)
+                kcount[r][wave] = (uint8_t)__popcll(bal);
+        }
+        __syncthreads();
+        uint32_t base = cur;
+        for (uint32_t r = 0; r < rounds; ++r) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < ACNT / 64; ++i) {
+                const uint32_t sct = kcount[r][i];
+                if (i < wave)
+                    before += sct;
+                total += sct;
+            }
+            if (total) { /* workgroup-uniform */
+                const bool found = (mask >> r) & 1u;
+                const unsigned long long bal = __ballot(found);
+                if (found) {
+                    const uint32_t idx = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    const int p = surv[r * ACNT + (uint32_t)tid];
+                    uint32_t f2c = 0, code = 0;
+                    (void)ac_eval<false>(mags, p, j0, mlen, noise_level, f2c, code);
+                    if (idx < cap) {
+                        msd_ac_hit h;
+                        h.pos = pos0 + (uint64_t)p;
+                        h.f2_clock = f2c;
+                        h.modeac = code;
+                        mine[idx] = h;
+                    }
+                }
+                base += total;
+            }
+        }
+        cur = base;
+        __syncthreads();
     }
+#undef AC_FETCH
     if (tid == 0) {
         msd_wg_counts c;
         c.nhits = cur;
