@@ -129,6 +129,13 @@ int msd_reset(msd_ctx *ctx);
 #define MSD_PIPELINE_DEPTH 3
 int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
 int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
+/* The same for samples in host memory -- the streaming ingest behind the reference's reader thread
+ * (sdr_ifile.c:192-216, the SDR callbacks of sdr_rtlsdr.c:261-326): the upload of batch k+1 runs on a
+ * copy stream while batch k is scanned.  h_iq must stay valid and unchanged until the batch has been
+ * collected; for the upload to be a DMA at PCIe rate it should be page-locked (msd_host_alloc). */
+int msd_launch_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last);
+int msd_host_alloc(msd_ctx *ctx, size_t bytes, void **out); /* page-locked host memory */
+void msd_host_free(msd_ctx *ctx, void *p);
 
 int msd_get_stats(const msd_ctx *ctx, msd_stats *st);
 int msd_get_timing(const msd_ctx *ctx, msd_timing *t);

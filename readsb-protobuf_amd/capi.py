@@ -104,8 +104,8 @@ class _SinkState(C.Structure):
 
 EXPORTS = [
     "msd_create", "msd_destroy", "msd_last_error", "msd_submit_device", "msd_submit_host", "msd_reset",
-    "msd_launch_device", "msd_collect", "msd_get_stats", "msd_get_timing", "msd_get_buffer_means",
-    "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
+    "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
+    "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
 ]
 
 _lib = None
@@ -130,8 +130,14 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.msd_reset.restype = C.c_int
         L.msd_reset.argtypes = [C.c_void_p]
-        L.msd_launch_device.restype = C.c_int
-        L.msd_launch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        for name in ("msd_launch_device", "msd_launch_host"):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        L.msd_host_alloc.restype = C.c_int
+        L.msd_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.msd_host_free.restype = None
+        L.msd_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.msd_collect.restype = C.c_int
         L.msd_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.msd_get_stats.restype = C.c_int
@@ -220,6 +226,25 @@ class Demodulator:
 
     def launch_device(self, dptr, nsamples, last=False):
         self._check(lib().msd_launch_device(self._h, C.c_void_p(dptr), nsamples, int(last)))
+
+    def launch_host(self, iq, nsamples=None, last=False):
+        """Asynchronous ingest of host samples; `iq` (uint8 view) must stay alive and unchanged until collected.
+        Use host_buffer() for page-locked memory (the upload is then a DMA at PCIe rate)."""
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        if nsamples is None:
+            nsamples = iq.size // self.bytes_per_sample
+        self._check(lib().msd_launch_host(self._h, iq.ctypes.data, nsamples, int(last)))
+
+    def host_buffer(self, nbytes):
+        """A page-locked uint8 numpy array (msd_host_alloc); freed when the array is garbage collected."""
+        p = C.c_void_p()
+        self._check(lib().msd_host_alloc(self._h, nbytes, C.byref(p)))
+        raw = (C.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(raw, dtype=np.uint8)
+        import weakref
+        h, L = self._h, lib()
+        weakref.finalize(raw, lambda: L.msd_host_free(h, p))
+        return arr
 
     def collect(self, copy=True):
         return self._run(lambda fn, st: lib().msd_collect(self._h, fn, st), copy=copy)

@@ -207,20 +207,52 @@ static void run_magbuf(void)
     msd_fifo_destroy();
 }
 
+/* The reader thread's loop of sdr_ifile.c:164-237 with the GPU behind it: blocks of `batch_buffers`
+ * buffers are read into a ring of page-locked buffers and handed over asynchronously, so the read of
+ * the next block, the upload of the previous one and the kernels of the one before overlap. */
 static void run_fused(void)
 {
-    bool eof = false;
-    while (!eof) {
-        const size_t got = read_fully(F.readbuf, F.readbuf_bytes);
-        if (got < F.readbuf_bytes)
-            eof = true;
-        const uint64_t samples = got / F.bytes_per_sample;
-        int rc = msd_submit_host(F.ctx, F.readbuf, samples, eof ? 1 : 0, F.rx.sink, F.rx.sink_user);
-        if (rc) {
-            snprintf(F.err, sizeof F.err, "submit: %s", msd_last_error(F.ctx));
-            return;
+    enum { RING = MSD_PIPELINE_DEPTH + 1 };
+    char *ring[RING];
+    memset(ring, 0, sizeof ring);
+    for (int i = 0; i < RING; ++i)
+        if (msd_host_alloc(F.ctx, F.readbuf_bytes, (void **)&ring[i])) {
+            snprintf(F.err, sizeof F.err, "ifile: %s", msd_last_error(F.ctx));
+            goto out;
         }
+    {
+        bool eof = false;
+        int in_flight = 0;
+        unsigned k = 0;
+        while (!eof) {
+            char *buf = ring[k++ % RING]; /* the batch that used it RING turns ago has been collected */
+            const size_t got = read_fully(buf, F.readbuf_bytes);
+            if (got < F.readbuf_bytes)
+                eof = true;
+            const uint64_t samples = got / F.bytes_per_sample;
+            int rc = 0;
+            if (in_flight == MSD_PIPELINE_DEPTH) {
+                rc = msd_collect(F.ctx, F.rx.sink, F.rx.sink_user);
+                in_flight--;
+            }
+            if (!rc) {
+                rc = msd_launch_host(F.ctx, buf, samples, eof ? 1 : 0);
+                in_flight++;
+            }
+            if (rc) {
+                snprintf(F.err, sizeof F.err, "submit: %s", msd_last_error(F.ctx));
+                goto out;
+            }
+        }
+        while (in_flight-- > 0)
+            if (msd_collect(F.ctx, F.rx.sink, F.rx.sink_user)) {
+                snprintf(F.err, sizeof F.err, "collect: %s", msd_last_error(F.ctx));
+                break;
+            }
     }
+out:
+    for (int i = 0; i < RING; ++i)
+        msd_host_free(F.ctx, ring[i]);
 }
 
 void msd_ifileRun(void)

@@ -73,6 +73,8 @@ struct Slot {
     size_t h_tries_cap = 0;
     uint8_t *d_ragged = nullptr; /* zero-padded copy of a partially filled last 8-sample group */
     uint8_t *tail_dst = nullptr; /* where the gather kernel leaves the batch's last samples for its successor */
+    uint8_t *d_upload = nullptr; /* msd_launch_host: this slot's copy of the batch in HBM */
+    hipEvent_t ev_upload = nullptr;
     /* Mode A/C candidates */
     msd_ac_hit *d_ac = nullptr;
     uint64_t *d_ac_totals = nullptr, *h_ac_totals = nullptr;
@@ -1091,6 +1093,8 @@ void destroy(msd_ctx *c)
         if (s.h_wire) (void)hipHostFree(s.h_wire);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
+        if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
+        (void)hipFree(s.d_upload);
         (void)hipFree(s.d_wire);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
@@ -1363,6 +1367,49 @@ int msd_submit_device(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last,
     if (rc)
         return rc;
     return collect(c, sink, user);
+}
+
+int msd_launch_host(msd_ctx *c, const void *h_iq, uint64_t nsamples, int last)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (nsamples > c->cfg.max_batch_samples)
+        return fail(c, -E2BIG, "batch exceeds max_batch_samples");
+    if (c->outstanding >= MSD_PIPELINE_DEPTH)
+        return fail(c, -EBUSY, "pipeline full: call msd_collect() first");
+    if (nsamples && !h_iq)
+        return fail(c, -EINVAL, "IQ pointer must be non-null");
+    Slot &s = c->slots[(c->head + c->outstanding) % MSD_PIPELINE_DEPTH];
+    if (!s.d_upload) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_upload), c->cfg.max_batch_samples * c->bps + 64));
+        HIPCHK(c, hipEventCreateWithFlags(&s.ev_upload, hipEventDisableTiming));
+    }
+    /* upload on the copy stream (it runs ahead of the kernels of the batches in front), the batch's
+     * kernels wait for it through an event */
+    if (nsamples)
+        HIPCHK(c, hipMemcpyAsync(s.d_upload, h_iq, nsamples * c->bps, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(s.ev_upload, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_upload, 0));
+    return launch(c, s.d_upload, nsamples, last);
+}
+
+int msd_host_alloc(msd_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    *out = nullptr;
+    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1));
+    return 0;
+}
+
+void msd_host_free(msd_ctx *c, void *p)
+{
+    if (c && p) {
+        (void)hipSetDevice(c->cfg.device);
+        (void)hipHostFree(p);
+    }
 }
 
 int msd_submit_host(msd_ctx *c, const void *h_iq, uint64_t nsamples, int last, msd_message_fn sink,

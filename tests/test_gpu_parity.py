@@ -58,6 +58,34 @@ def test_uc8_pipelined_batches(pkg, oracle, torch_cuda):
     run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 20 * 131072 + 999, seed=5, nfix=1, batch=4 * 131072)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_streaming_host_ingest(pkg, oracle, torch_cuda, pinned):
+    """msd_launch_host / msd_collect: uploads run ahead of the kernels, three batches in flight, from
+    page-locked buffers (msd_host_alloc) or ordinary host memory; same messages as the oracle."""
+    n, batch = 22 * 131072 + 4321, 4 * 131072
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=31, msgs_per_sec=3000), n)
+    dem = pkg.Demodulator(fmt=pkg.FMT_UC8, nfix_crc=1, max_batch_samples=batch, message_capacity=1 << 18)
+    bufs = [dem.host_buffer(batch * 2) if pinned else np.empty(batch * 2, dtype=np.uint8) for _ in range(pkg.capi.PIPELINE_DEPTH)]
+    parts, inflight, off, k = [], 0, 0, 0
+    while off < n:
+        m = min(batch, n - off)
+        if inflight == pkg.capi.PIPELINE_DEPTH:
+            parts.append(dem.collect())
+            inflight -= 1
+        b = bufs[k % len(bufs)]  # its previous batch has been collected by now
+        b[: m * 2] = iq[off * 2:(off + m) * 2]
+        dem.launch_host(b, m, last=off + m >= n)
+        inflight += 1
+        off += m
+        k += 1
+    while inflight:
+        parts.append(dem.collect())
+        inflight -= 1
+    got = np.concatenate(parts)
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 18)
+    assert_same(got, dem.stats(), want, wstats)
+
+
 @pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
 def test_s16_formats(pkg, oracle, torch_cuda, fmt):
     f = pkg.FMT_SC16 if fmt == "sc16" else pkg.FMT_SC16Q11
