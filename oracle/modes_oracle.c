@@ -13,6 +13,7 @@
 #include "modes_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -833,4 +834,63 @@ void orc_destroy(orc_ctx *ctx)
 void orc_get_stats(const orc_ctx *ctx, orc_stats *st)
 {
     *st = ctx->st;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* wire formats (net_io.c:769-835, 870-896)                                                 */
+/* ---------------------------------------------------------------------------------------- */
+
+size_t orc_avr_line(const orc_message *mm, int mlat, char *out)
+{
+    /* net_io.c:877-893: "@%012" PRIX64 when --mlat and a timestamp exists, else '*'; two upper-case
+     * hex digits per byte (printHexDigit, :856-860); ";\n" */
+    int n = 0;
+    if (mlat && mm->timestampMsg)
+        n += sprintf(out + n, "@%012llX", (unsigned long long)mm->timestampMsg);
+    else
+        out[n++] = '*';
+    for (int j = 0; j < mm->msgbits / 8; ++j)
+        n += sprintf(out + n, "%02X", mm->msg[j]);
+    out[n++] = ';';
+    out[n++] = '\n';
+    out[n] = 0;
+    return (size_t)n;
+}
+
+static uint8_t *beast_put(uint8_t *p, uint8_t ch) /* net_io.c:794-797: a data byte 0x1A is sent twice */
+{
+    *p++ = ch;
+    if (ch == 0x1A)
+        *p++ = ch;
+    return p;
+}
+
+size_t orc_beast_frame(const orc_message *mm, uint8_t *out)
+{
+    const int msgLen = mm->msgbits / 8;
+    uint8_t *p = out;
+    *p++ = 0x1a;
+    if (msgLen == 7)
+        *p++ = '2';
+    else if (msgLen == 14)
+        *p++ = '3';
+    else if (msgLen == 2)
+        *p++ = '1';
+    else
+        return 0;
+    p = beast_put(p, (uint8_t)(mm->timestampMsg >> 40));
+    p = beast_put(p, (uint8_t)(mm->timestampMsg >> 32));
+    p = beast_put(p, (uint8_t)(mm->timestampMsg >> 24));
+    p = beast_put(p, (uint8_t)(mm->timestampMsg >> 16));
+    p = beast_put(p, (uint8_t)(mm->timestampMsg >> 8));
+    p = beast_put(p, (uint8_t)(mm->timestampMsg));
+    int sig = (int)round(sqrt(mm->signalLevel) * 255); /* net_io.c:819 */
+    if (mm->signalLevel > 0 && sig < 1)
+        sig = 1;
+    if (sig > 255)
+        sig = 255;
+    p = beast_put(p, (uint8_t)sig);
+    for (int j = 0; j < msgLen; ++j)
+        p = beast_put(p, mm->msg[j]);
+    return (size_t)(p - out);
 }

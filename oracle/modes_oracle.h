@@ -105,6 +105,11 @@ int orc_filter_test(const orc_ctx *ctx, uint32_t addr);
 void orc_slice(const uint16_t *m, uint32_t j, int try_phase, int nbytes, uint8_t *out);
 /* one buffer through demodulate2400 [+ demodulate2400AC] + icaoFilterExpire; data must hold
  * valid_length samples (overlap first). */
+/* Wire formats of accepted messages, restated from modesSendRawOutput (net_io.c:870-896) and
+ * modesSendBeastOutput (net_io.c:769-835); return the number of bytes written. */
+size_t orc_avr_line(const orc_message *mm, int mlat, char *out /* >= 48 */);
+size_t orc_beast_frame(const orc_message *mm, uint8_t *out /* >= 44 */);
+
 void orc_demod_buffer(orc_ctx *ctx, const uint16_t *data, unsigned valid_length,
                       uint64_t sample_timestamp, uint64_t sys_timestamp, double mean_level,
                       double mean_power, orc_message *out, size_t cap, size_t *nout);

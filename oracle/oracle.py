@@ -106,8 +106,28 @@ def lib():
         L.orc_demod_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64,
                                        C.c_double, C.c_double, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t)]
+        L.orc_avr_line.restype = C.c_size_t
+        L.orc_avr_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.orc_beast_frame.restype = C.c_size_t
+        L.orc_beast_frame.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def avr_line(message, mlat=False):
+    """AVR raw line of one message record (numpy void of MESSAGE_DTYPE), net_io.c:870-896."""
+    rec = np.ascontiguousarray(message).reshape(1)
+    buf = C.create_string_buffer(64)
+    n = lib().orc_avr_line(rec.ctypes.data, int(mlat), buf)
+    return buf.raw[:n]
+
+
+def beast_frame(message):
+    """Beast binary frame of one message record, net_io.c:769-835."""
+    rec = np.ascontiguousarray(message).reshape(1)
+    buf = (C.c_uint8 * 64)()
+    n = lib().orc_beast_frame(rec.ctypes.data, buf)
+    return bytes(buf[:n])
 
 
 class Oracle:

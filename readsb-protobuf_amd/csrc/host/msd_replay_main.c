@@ -3,7 +3,9 @@
  * [--preamble-threshold N] [--modeac] --raw --quiet-ish` for the part of readsb this repository
  * implements: replays a capture through the GPU receive path and prints one `*hex;` line per
  * accepted message like displayModesMessage does in --raw mode (mode_s.c:1786-1798), or
- * `@<12 hex digit timestamp>hex;` with --mlat.  Counters go to stderr with --stats.
+ * `@<12 hex digit timestamp>hex;` with --mlat.  --net-raw prints the lines of the raw TCP output
+ * instead (net_io.c:870-896, upper-case hex), --beast writes Beast binary frames (net_io.c:769-835).
+ * Counters go to stderr with --stats.
  */
 #define _GNU_SOURCE
 #include <inttypes.h>
@@ -12,6 +14,7 @@
 #include <string.h>
 
 #include "msd_sdr_ifile.h"
+#include "msd_wire.h"
 
 static int g_mlat;
 static uint64_t g_count;
@@ -26,6 +29,20 @@ static void print_raw(const msd_message *mm, void *user)
     for (int j = 0; j < mm->msgbits / 8; j++)
         fprintf(out, "%02x", mm->msg[j]);
     fputs(";\n", out);
+    g_count++;
+}
+
+static void print_net_raw(const msd_message *mm, void *user)
+{
+    char line[MSD_AVR_MAX];
+    fwrite(line, 1, msd_avr_line(mm, g_mlat, line), (FILE *)user);
+    g_count++;
+}
+
+static void write_beast(const msd_message *mm, void *user)
+{
+    uint8_t frame[MSD_BEAST_MAX];
+    fwrite(frame, 1, msd_beast_frame(mm, frame), (FILE *)user);
     g_count++;
 }
 
@@ -56,6 +73,8 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--modeac")) rx.mode_ac = 1;
         else if (!strcmp(a, "--mlat")) g_mlat = 1;
         else if (!strcmp(a, "--stats")) want_stats = 1;
+        else if (!strcmp(a, "--net-raw")) rx.sink = print_net_raw;
+        else if (!strcmp(a, "--beast")) rx.sink = write_beast;
         else if (!strcmp(a, "--raw") || !strcmp(a, "--quiet")) { /* this tool only has the raw dump */ }
         else if (!strcmp(a, "--device-type") && next) { ++i; /* always ifile */ }
         else if (!strcmp(a, "--device") && next) { rx.device = atoi(next); ++i; }
@@ -66,7 +85,8 @@ int main(int argc, char **argv)
             ++i;
         } else {
             fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix] "
-                            "[--preamble-threshold N] [--modeac] [--mlat] [--stats] [--path fused|magbuf] [--device N]\n");
+                            "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast] [--stats] [--path fused|magbuf] "
+                            "[--device N]\n");
             return 2;
         }
     }

@@ -127,6 +127,25 @@ def test_replay_cli_matches_oracle(pkg, oracle, torch_cuda, tmp_path, path):
         assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())
 
 
+def test_replay_cli_wire_formats(pkg, oracle, torch_cuda, tmp_path):
+    """the replay tool's --net-raw (AVR) and --beast outputs equal the oracle's
+    restatement of net_io.c:769-835,870-896 applied to the oracle's messages."""
+    import os
+    import subprocess
+    n = 9 * 131072 + 777
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=1091, msgs_per_sec=3000, ac_per_sec=800), n)
+    f = tmp_path / "capture.uc8"
+    iq.tofile(f)
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "msd_replay")
+    base = [exe, "--ifile", str(f), "--iformat", "uc8", "--fix", "--modeac", "--mlat", "--batch-buffers", "4"]
+    want, _ = oracle.Oracle(oracle.FMT_UC8, 58, 1, 1).replay(iq, cap=1 << 17)
+    assert (want["msgtype"] == 32).sum() > 20
+    raw = subprocess.run(base + ["--net-raw"], capture_output=True, check=True).stdout
+    assert raw == b"".join(oracle.avr_line(m, True) for m in want)
+    beast = subprocess.run(base + ["--beast"], capture_output=True, check=True).stdout
+    assert beast == b"".join(oracle.beast_frame(m) for m in want)
+
+
 @pytest.mark.parametrize("threads", ["1", "3", "16"])
 def test_resolve_threads_and_membership_churn(pkg, oracle, torch_cuda, monkeypatch, threads, resolve_stage):
     """The speculative buffer-parallel resolve must equal the sequential one for any thread count,
