@@ -464,6 +464,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             tbase = atomicAdd(try_cursor, wave_total);
         tbase = __shfl(tbase, 0);
     }
+    TMARKF(9); /* step D: counts, scan, reservation */
     if ((uint32_t)tid < nh) {
         uint32_t idx = tbase + incl - nl;
         if (hits_fit) {
