@@ -332,6 +332,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
                                      c->stream));
         MsdScanParams p{};
         fill_params(c, s, p);
+        {
+            const char *dbg = getenv("MSD_DEBUG_FLAGS");
+            p.debug_flags = dbg ? atoi(dbg) : 0;
+        }
         int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise, host_noise != nullptr,
                                c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
                                c->ac_arena, c->ac_max_wg, c->stream);
@@ -1228,7 +1232,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_offsets), c->max_wg * 2 * sizeof(uint64_t)));
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
-        c->ac_max_wg = (uint32_t)c->cu_count * 4u;
+        c->ac_max_wg = (uint32_t)c->cu_count * 8u;
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_regions), c->ac_arena * sizeof(msd_ac_hit)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_counts), c->ac_max_wg * sizeof(msd_wg_counts)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_offsets), c->ac_max_wg * 2 * sizeof(uint64_t)));

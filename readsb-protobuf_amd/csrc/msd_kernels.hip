@@ -1218,7 +1218,7 @@ static_assert(AC_LOAD % 8 == 0 && MSD_CHUNK_SAMPLES % ACT == 0, "whole groups, t
  * LDS like in the Mode S scan; output appended in position order to a workgroup-private region. */
 /* All tests of demodulate2400AC (demod_2400.c:581-668) for the F1 position p of a tile whose first
  * position is sample j0 of its buffer; mags[p + 2 + d] = m[f1_sample + d]. */
-template <bool f1_only>
+template <int STAGE> /* 0: the F1 pulse test only; 1: through the F2 pulse test; 2: everything */
 __device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0, uint32_t mlen, uint32_t noise_level,
                                         uint32_t &f2_clock, uint32_t &modeac)
 {
@@ -1230,8 +1230,8 @@ __device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0
     const uint32_t f1_level = (m0 + m1) / 2;
     if (!(ACM(f1_sample - 1) < m0 && !(m2 > m0 || m2 > m1) && !(noise_level * 2 > f1_level)))
         return false;
-    if (f1_only)
-        return true; /* every pulse edge of a Mode S frame gets this far: the rest runs on a compacted list */
+    if (STAGE == 0)
+        return true; /* every pulse edge of a Mode S frame, and a tenth of pure noise, gets this far */
     const float f1a_power = (float)m0 * (float)m0;
     const float f1b_power = (float)m1 * (float)m1;
     const float fsum = f1a_power + f1b_power;
@@ -1246,6 +1246,8 @@ __device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0
     const uint32_t f2_level = (n0 + n1) / 2;
     if (!(ACM(f2_sample - 1) < n0 && !(n2 > n0 || n2 > n1) && !(noise_level * 2 > f2_level)))
         return false;
+    if (STAGE == 1)
+        return true;
     const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
     const float midpoint = __builtin_sqrtf((float)(noise_level * f1f2_level)); /* u32 product */
     const double up = (double)midpoint * 1.41421356237309504880;
@@ -1279,24 +1281,64 @@ __device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0
     return true;
 }
 
+/* Ordered compaction inside a workgroup: dst[] = the entries i of [0, n) (or src[i]) for which pred(i)
+ * holds, in order; returns how many.  Entry i = r * ACNT + tid is looked at by thread tid in round r. */
+template <typename Pred>
+__device__ __forceinline__ uint32_t ac_compact(uint32_t n, const uint16_t *src, uint16_t *dst,
+                                               uint8_t (*kcount)[ACNT / 64], int tid, Pred pred)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t rounds = (n + ACNT - 1) / ACNT; /* <= ACT / ACNT */
+    uint32_t mask = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * ACNT + (uint32_t)tid;
+        const bool keep = i < n && pred(src ? (uint32_t)src[i] : i);
+        const unsigned long long bal = __ballot(keep);
+        if (keep)
+            mask |= 1u << r;
+        if (lane == 0)
+            kcount[r][wave] = (uint8_t)__popcll(bal);
+    }
+    __syncthreads();
+    uint32_t total_all = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < ACNT / 64; ++w) {
+            const uint32_t c = kcount[r][w];
+            if (w < wave)
+                before += c;
+            total += c;
+        }
+        if (total) { /* workgroup-uniform */
+            const bool keep = (mask >> r) & 1u;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const uint32_t i = r * ACNT + (uint32_t)tid;
+                dst[total_all + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] =
+                    src ? src[i] : (uint16_t)i;
+            }
+            total_all += total;
+        }
+    }
+    __syncthreads();
+    return total_all;
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
                                                       const uint32_t *noise_levels, msd_ac_hit *out,
                                                       uint32_t cap, msd_wg_counts *counts)
 {
     __shared__ __attribute__((aligned(16))) uint16_t mags[AC_LOAD + 8];
-    __shared__ __attribute__((aligned(16))) uint16_t lut[(FMT == MSD_FMT_UC8) ? 128 * LUT_STRIDE : 8];
+    /* the UC8 table stays in global memory here (L1/L2 hits): 35 KB of LDS per workgroup would halve the
+     * number of resident wavefronts, and this kernel lives on latency hiding */
+    const uint16_t *lut = P.lut;
     __shared__ uint8_t kcount[ACT / ACNT][ACNT / 64];
-    __shared__ uint16_t surv[ACT]; /* positions that pass the F1 test, in order */
+    __shared__ uint32_t kcount32[ACNT / 64];
+    __shared__ uint16_t surv[ACT], surv2[ACT]; /* positions that pass the F1 test / the F2 test too, in order */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wg = blockIdx.x;
-    if (FMT == MSD_FMT_UC8) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
-        uint4 *l = reinterpret_cast<uint4 *>(lut);
-        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += ACNT)
-            l[i] = g[i];
-    }
-    __syncthreads();
 
     const uint32_t tile_lo = wg * tiles_per_wg;
     uint32_t tile_hi = tile_lo + tiles_per_wg;
@@ -1341,86 +1383,83 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
         const uint32_t mlen = mlen64 > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : (uint32_t)mlen64;
         const uint32_t noise_level = noise_levels[b];
 
-        /* Pass 1, position p = k * ACNT + tid (consecutive lanes read consecutive samples): the F1
-         * pulse test.  Survivors -- a few percent, every strong pulse edge -- go to an ordered list ... */
-        constexpr int PER = ACT / ACNT;
-        uint32_t mask = 0;
-#pragma unroll 1
-        for (int k = 0; k < PER; ++k) {
-            uint32_t f2c, code;
-            const bool pass = ac_eval<true>(mags, k * ACNT + tid, j0, mlen, noise_level, f2c, code);
-            const unsigned long long bal = __ballot(pass);
-            if (pass)
-                mask |= 1u << k;
-            if (lane == 0)
-                kcount[k][wave] = (uint8_t)__popcll(bal);
+        /* Three ordered compactions: positions that pass the F1 pulse test (a few percent: every strong
+         * pulse edge, a tenth of pure noise) -> those that also pass the F2 test 20.3 us later -> those
+         * whose 20 bit windows decode.  Position p = r * ACNT + tid: consecutive lanes, consecutive samples. */
+        if (P.debug_flags & 32) { /* perf experiment: conversion only */
+            __syncthreads();
+            continue;
         }
-        __syncthreads();
-        uint32_t nsurv = 0;
-#pragma unroll 1
-        for (int k = 0; k < PER; ++k) {
-            uint32_t before = 0, total = 0;
+        /* Three ordered compactions: positions that pass the F1 pulse test (a few percent: every strong
+         * pulse edge, a tenth of pure noise) -> those that also pass the F2 test 20.3 us later -> those
+         * whose 20 bit windows decode.
+         * F1 test: a thread looks at ACT / ACNT = 16 consecutive positions out of a register window of
+         * 24 samples (three 16-byte LDS reads); m[f1_sample + d] = mags[p + 2 + d]. */
+        uint32_t n1;
+        {
+            constexpr int PER = ACT / ACNT;
+            static_assert(PER == 16, "three uint4 cover positions 16t .. 16t+15 and their neighbours");
+            const uint4 *w4 = reinterpret_cast<const uint4 *>(mags + PER * tid);
+            const uint4 wa = w4[0], wb = w4[1], wc = w4[2];
+            const uint32_t ww[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
+            uint32_t r[24];
 #pragma unroll
-            for (int i = 0; i < ACNT / 64; ++i) {
-                const uint32_t sct = kcount[k][i];
-                if (i < wave)
-                    before += sct;
-                total += sct;
+            for (int i = 0; i < 12; ++i) {
+                r[2 * i] = ww[i] & 0xffffu;
+                r[2 * i + 1] = ww[i] >> 16;
             }
-            if (total) { /* workgroup-uniform */
-                const bool pass = (mask >> k) & 1u;
-                const unsigned long long bal = __ballot(pass);
-                if (pass)
-                    surv[nsurv + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(k * ACNT + tid);
-                nsurv += total;
-            }
-        }
-        __syncthreads();
-        /* ... pass 2, one lane per survivor: F2, thresholds, the 20 bit windows.  The few that decode are
-         * counted per (round, wavefront), ranked, and decoded once more for the record. */
-        const uint32_t rounds = (nsurv + ACNT - 1) / ACNT; /* <= PER */
-        mask = 0;
-        for (uint32_t r = 0; r < rounds; ++r) {
-            const uint32_t i = r * ACNT + (uint32_t)tid;
-            uint32_t f2c, code;
-            const bool found = i < nsurv && ac_eval<false>(mags, surv[i], j0, mlen, noise_level, f2c, code);
-            const unsigned long long bal = __ballot(found);
-            if (found)
-                mask |= 1u << r;
-            if (lane == 0)
-                kcount[r][wave] = (uint8_t)__popcll(bal);
-        }
-        __syncthreads();
-        uint32_t base = cur;
-        for (uint32_t r = 0; r < rounds; ++r) {
-            uint32_t before = 0, total = 0;
+            uint32_t mask = 0;
 #pragma unroll
-            for (int i = 0; i < ACNT / 64; ++i) {
-                const uint32_t sct = kcount[r][i];
-                if (i < wave)
-                    before += sct;
-                total += sct;
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t f1_sample = j0 + (uint32_t)(PER * tid + k);
+                const uint32_t m0 = r[k + 2], m1 = r[k + 3], m2 = r[k + 4];
+                const bool pass = f1_sample >= 1 && f1_sample < mlen && r[k + 1] < m0 && !(m2 > m0 || m2 > m1) &&
+                                  !(noise_level * 2 > (m0 + m1) / 2); /* demod_2400.c:581-589 */
+                mask |= (pass ? 1u : 0u) << k;
             }
-            if (total) { /* workgroup-uniform */
-                const bool found = (mask >> r) & 1u;
-                const unsigned long long bal = __ballot(found);
-                if (found) {
-                    const uint32_t idx = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    const int p = surv[r * ACNT + (uint32_t)tid];
-                    uint32_t f2c = 0, code = 0;
-                    (void)ac_eval<false>(mags, p, j0, mlen, noise_level, f2c, code);
-                    if (idx < cap) {
-                        msd_ac_hit h;
-                        h.pos = pos0 + (uint64_t)p;
-                        h.f2_clock = f2c;
-                        h.modeac = code;
-                        mine[idx] = h;
-                    }
-                }
-                base += total;
+            const uint32_t mine_n = (uint32_t)__builtin_popcount(mask);
+            const uint32_t incl = wave_incl_scan(mine_n, lane);
+            if (lane == 63)
+                kcount32[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            n1 = 0;
+#pragma unroll
+            for (int w = 0; w < ACNT / 64; ++w) {
+                const uint32_t c = kcount32[w];
+                if (w < wave)
+                    before += c;
+                n1 += c;
+            }
+            uint32_t idx = before + incl - mine_n;
+            while (mask) {
+                const int k = __builtin_ctz(mask);
+                mask &= mask - 1;
+                surv[idx++] = (uint16_t)(PER * tid + k);
+            }
+            __syncthreads();
+        }
+        const uint32_t n2 = ac_compact(n1, surv, surv2, kcount, tid, [&](uint32_t p) {
+            uint32_t a, c;
+            return ac_eval<1>(mags, (int)p, j0, mlen, noise_level, a, c);
+        });
+        const uint32_t n3 = ac_compact(n2, surv2, surv, kcount, tid, [&](uint32_t p) {
+            uint32_t a, c;
+            return ac_eval<2>(mags, (int)p, j0, mlen, noise_level, a, c);
+        });
+        for (uint32_t i = (uint32_t)tid; i < n3; i += ACNT) { /* the records, decoded once more */
+            const int p = surv[i];
+            uint32_t f2c = 0, code = 0;
+            (void)ac_eval<2>(mags, p, j0, mlen, noise_level, f2c, code);
+            if (cur + i < cap) {
+                msd_ac_hit h;
+                h.pos = pos0 + (uint64_t)p;
+                h.f2_clock = f2c;
+                h.modeac = code;
+                mine[cur + i] = h;
             }
         }
-        cur = base;
+        cur += n3;
         __syncthreads();
     }
 #undef AC_FETCH
