@@ -35,7 +35,7 @@ typedef struct msd_config {
     int32_t preamble_threshold; /* --preamble-threshold, readsb.c:503-505 (default 58) */
     int32_t nfix_crc;           /* --no-fix = 0, --fix = 1 (readsb.c:491-496); 2 unsupported */
     int32_t mode_ac;            /* --modeac, readsb.c:509-512 */
-    int32_t reserved0;
+    int32_t flags;              /* MSD_CFG_* */
     uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk */
     void *stream;               /* hipStream_t to launch on; NULL = the context creates one */
 } msd_config;
@@ -57,6 +57,27 @@ typedef struct msd_message {
     uint8_t iid;
     uint8_t pad;
 } msd_message;
+
+/* msd_config.flags */
+#define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
+
+/* Header fields of an accepted message: what decodeModesMessage assigns after its CRC switch without
+ * looking into the ME / MB payloads (mode_s.c:557-715, decodeAC13Field / decodeID13Field :101-183), and
+ * decodeModeAMessage for Mode A/C replies (mode_ac.c:168-202).  Unset fields are 0. */
+#define MSD_INVALID_ALTITUDE (-9999) /* readsb.h:130 */
+typedef struct msd_fields {
+    int32_t altitude_baro;       /* feet; meaningful with altitude_baro_valid */
+    uint16_t AC;                 /* 13-bit altitude code (DF0/4/16/20) */
+    uint16_t ID;                 /* 13-bit identity code (DF5/21) */
+    uint16_t squawk;             /* four octal digits, hex-coded (DF5/21, Mode A/C) */
+    uint8_t altitude_baro_valid;
+    uint8_t altitude_baro_unit;  /* 0 feet, 1 metres (never decoded, mode_s.c:178-182) */
+    uint8_t squawk_valid;
+    uint8_t airground;           /* readsb.pb-c.h:32-35: 0 not set, 1 ground, 2 airborne, 3 uncertain */
+    uint8_t alert, alert_valid, spi, spi_valid;
+    uint8_t CA, CC, CF, DR, FS, KE, ND, RI, SL, UM, VS;
+    uint8_t pad[3];
+} msd_fields;
 
 /* struct stats demodulator counters, stats.h:61-80 */
 typedef struct msd_stats {
@@ -103,6 +124,13 @@ typedef struct msd_array_sink_state {
     size_t count;
 } msd_array_sink_state;
 void msd_array_sink(const msd_message *mm, void *state /* msd_array_sink_state* */);
+typedef struct msd_array_fields_sink_state {
+    msd_message *out;
+    msd_fields *fields;
+    size_t cap;
+    size_t count;
+} msd_array_fields_sink_state;
+void msd_array_fields_sink(const msd_message *mm, const msd_fields *fields, void *state);
 
 /* ---- life cycle: replaces modesInit's modesChecksumInit/icaoFilterInit (readsb.c:241-243) and
  *      init_converter (convert.h:40-43) ---- */
@@ -129,6 +157,14 @@ int msd_reset(msd_ctx *ctx);
 #define MSD_PIPELINE_DEPTH 3
 int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
 int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
+/* msd_collect with the header fields next to every message; the context must have been created with
+ * MSD_CFG_DECODE_FIELDS (the fields then come out of the same kernel that builds the message records). */
+typedef void (*msd_fields_fn)(const msd_message *mm, const msd_fields *fields, void *user);
+int msd_collect_fields(msd_ctx *ctx, msd_fields_fn sink, void *user);
+/* The same decode for one message on the host.  `carry`: for a Mode A/C reply, the fields of the
+ * previous Mode A/C reply of the same buffer (the reference reuses one message record per buffer, so a
+ * reply without altitude inherits the last one's, demod_2400.c:523-528); NULL otherwise. */
+void msd_decode_fields(const msd_message *mm, const msd_fields *carry, msd_fields *out);
 /* The same for samples in host memory -- the streaming ingest behind the reference's reader thread
  * (sdr_ifile.c:192-216, the SDR callbacks of sdr_rtlsdr.c:261-326): the upload of batch k+1 runs on a
  * copy stream while batch k is scanned.  h_iq must stay valid and unchanged until the batch has been

@@ -46,6 +46,10 @@ struct orc_ctx {
     /* fifo.c:43-44 */
     uint16_t carry[ORC_OVERLAP];
     uint16_t *buf; /* one mag_buf's data, ORC_CHUNK_SAMPLES + ORC_OVERLAP samples */
+    /* optional field decode next to the message list */
+    orc_fields *fields_out;
+    size_t fields_cap;
+    orc_fields ac_mm; /* what demodulate2400AC's one message record keeps between replies (demod_2400.c:523-528) */
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -530,10 +534,185 @@ static void try_phase(orc_ctx *ctx, const uint16_t *m, uint32_t j, int tp, struc
     }
 }
 
-static void emit(orc_message *out, size_t cap, size_t *nout, const orc_message *mm)
+/* ---------------------------------------------------------------------------------------- */
+/* header fields (mode_s.c:101-183,557-715; mode_ac.c:59-202)                                */
+/* ---------------------------------------------------------------------------------------- */
+
+static unsigned getbits(const uint8_t *data, unsigned firstbit, unsigned lastbit) /* mode_s.h:57-102 */
+{
+    unsigned v = 0;
+    for (unsigned b = firstbit; b <= lastbit; ++b) /* bit 1 = MSB of byte 0 */
+        v = (v << 1) | ((data[(b - 1) >> 3] >> (7 - ((b - 1) & 7))) & 1u);
+    return v;
+}
+
+unsigned orc_decode_id13(unsigned id13) /* mode_s.c:101-143 */
+{
+    static const struct { unsigned from, to; } map[12] = {
+        {0x1000, 0x0010}, {0x0800, 0x1000}, {0x0400, 0x0020}, {0x0200, 0x2000}, {0x0100, 0x0040}, {0x0080, 0x4000},
+        {0x0020, 0x0100}, {0x0010, 0x0001}, {0x0008, 0x0200}, {0x0004, 0x0002}, {0x0002, 0x0400}, {0x0001, 0x0004},
+    };
+    unsigned hex = 0;
+    for (int i = 0; i < 12; ++i)
+        if (id13 & map[i].from)
+            hex |= map[i].to;
+    return hex;
+}
+
+/* mode_ac.c:101-163 */
+static int gillham_to_mode_c(unsigned ModeA)
+{
+    unsigned FiveHundreds = 0, OneHundreds = 0;
+    if ((ModeA & 0xFFFF8889u) != 0 || (ModeA & 0x000000F0u) == 0)
+        return ORC_INVALID_ALTITUDE;
+    if (ModeA & 0x0010) OneHundreds ^= 0x007;
+    if (ModeA & 0x0020) OneHundreds ^= 0x003;
+    if (ModeA & 0x0040) OneHundreds ^= 0x001;
+    if ((OneHundreds & 5) == 5)
+        OneHundreds ^= 2;
+    if (OneHundreds > 5)
+        return ORC_INVALID_ALTITUDE;
+    if (ModeA & 0x0002) FiveHundreds ^= 0x0FF;
+    if (ModeA & 0x0004) FiveHundreds ^= 0x07F;
+    if (ModeA & 0x1000) FiveHundreds ^= 0x03F;
+    if (ModeA & 0x2000) FiveHundreds ^= 0x01F;
+    if (ModeA & 0x4000) FiveHundreds ^= 0x00F;
+    if (ModeA & 0x0100) FiveHundreds ^= 0x007;
+    if (ModeA & 0x0200) FiveHundreds ^= 0x003;
+    if (ModeA & 0x0400) FiveHundreds ^= 0x001;
+    if (FiveHundreds & 1)
+        OneHundreds = 6 - OneHundreds;
+    return (int)(FiveHundreds * 5 + OneHundreds) - 13;
+}
+
+/* modeACInit + modeAToModeC (mode_ac.c:63-87) with the index packing of track.h:246-256: a table over
+ * the 4096 twelve-bit codes, looked up through the packed index (so stray bits are ignored) */
+static int g_mode_a_to_c[4096];
+static int g_mode_a_ready;
+
+int orc_mode_a_to_mode_c(unsigned modeA)
+{
+    if (!g_mode_a_ready) {
+        for (unsigned i = 0; i < 4096; ++i) {
+            const unsigned a = (i & 0007) | ((i & 0070) << 1) | ((i & 0700) << 2) | ((i & 07000) << 3);
+            g_mode_a_to_c[i] = gillham_to_mode_c(a);
+        }
+        g_mode_a_ready = 1;
+    }
+    const unsigned i = (modeA & 0x0007) | ((modeA & 0x0070) >> 1) | ((modeA & 0x0700) >> 2) | ((modeA & 0x7000) >> 3);
+    return g_mode_a_to_c[i];
+}
+
+int orc_decode_ac13(unsigned AC13Field, int *unit) /* mode_s.c:152-183 */
+{
+    const unsigned m_bit = AC13Field & 0x0040, q_bit = AC13Field & 0x0010;
+    if (m_bit) {
+        *unit = 1;
+        return ORC_INVALID_ALTITUDE;
+    }
+    *unit = 0;
+    if (q_bit) {
+        const int n = (int)(((AC13Field & 0x1F80) >> 2) | ((AC13Field & 0x0020) >> 1) | (AC13Field & 0x000F));
+        return n * 25 - 1000;
+    }
+    const int n = orc_mode_a_to_mode_c(orc_decode_id13(AC13Field));
+    return n < -12 ? ORC_INVALID_ALTITUDE : 100 * n;
+}
+
+static void fields_mode_s(const orc_message *mm, orc_fields *f) /* mode_s.c:557-715 */
+{
+    const uint8_t *msg = mm->msg;
+    const int t = mm->msgtype;
+    memset(f, 0, sizeof *f);
+    if (t == 0 || t == 4 || t == 16 || t == 20) {
+        f->AC = (uint16_t)getbits(msg, 20, 32);
+        if (f->AC) {
+            int unit = 0;
+            f->altitude_baro = orc_decode_ac13(f->AC, &unit);
+            f->altitude_baro_unit = (uint8_t)unit;
+            if (f->altitude_baro != ORC_INVALID_ALTITUDE)
+                f->altitude_baro_valid = 1;
+        }
+    }
+    if (t == 11 || t == 17) {
+        static const uint8_t ag[8] = {3, 0, 0, 0, 1, 2, 3, 3}; /* CA 0,4,5,6,7 set it; 1-3 leave it alone */
+        f->CA = (uint8_t)getbits(msg, 6, 8);
+        f->airground = ag[f->CA];
+    }
+    if (t == 0)
+        f->CC = (uint8_t)getbits(msg, 7, 7);
+    if (t == 18)
+        f->CF = (uint8_t)getbits(msg, 6, 8);
+    if (t == 4 || t == 5 || t == 20 || t == 21) {
+        f->DR = (uint8_t)getbits(msg, 9, 13);
+        f->FS = (uint8_t)getbits(msg, 6, 8);
+        f->alert_valid = 1;
+        f->spi_valid = 1;
+        switch (f->FS) {
+        case 0: f->airground = 3; break;
+        case 1: f->airground = 1; break;
+        case 2: f->airground = 3; f->alert = 1; break;
+        case 3: f->airground = 1; f->alert = 1; break;
+        case 4: f->airground = 3; f->alert = 1; f->spi = 1; break;
+        case 5: f->airground = 3; f->spi = 1; break;
+        default: f->spi_valid = 0; f->alert_valid = 0; break;
+        }
+        f->UM = (uint8_t)getbits(msg, 14, 19);
+    }
+    if (t == 5 || t == 21) {
+        f->ID = (uint16_t)getbits(msg, 20, 32);
+        if (f->ID) {
+            f->squawk = (uint16_t)orc_decode_id13(f->ID);
+            f->squawk_valid = 1;
+        }
+    }
+    if (t >= 24 && t <= 31) {
+        f->KE = (uint8_t)getbits(msg, 4, 4);
+        f->ND = (uint8_t)getbits(msg, 5, 8);
+    }
+    if (t == 0 || t == 16) {
+        f->RI = (uint8_t)getbits(msg, 14, 17);
+        f->SL = (uint8_t)getbits(msg, 9, 11);
+        f->VS = (uint8_t)getbits(msg, 6, 6);
+        f->airground = f->VS ? 1 : 3;
+    }
+}
+
+/* decodeModeAMessage (mode_ac.c:168-202) on the record demodulate2400AC reuses within a buffer */
+static void fields_mode_ac(orc_fields *mm, unsigned ModeA)
+{
+    mm->squawk = (uint16_t)(ModeA & 0x7777);
+    mm->squawk_valid = 1;
+    mm->spi = (ModeA & 0x0080) ? 1 : 0;
+    mm->spi_valid = 1;
+    if (!mm->spi) {
+        const int modeC = orc_mode_a_to_mode_c(ModeA);
+        if (modeC != ORC_INVALID_ALTITUDE) {
+            mm->altitude_baro = modeC * 100;
+            mm->altitude_baro_unit = 0;
+            mm->altitude_baro_valid = 1;
+        }
+    }
+}
+
+void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap)
+{
+    ctx->fields_out = fields;
+    ctx->fields_cap = cap;
+}
+
+static void emit(orc_ctx *ctx, orc_message *out, size_t cap, size_t *nout, const orc_message *mm)
 {
     if (*nout < cap)
         out[*nout] = *mm;
+    if (ctx->fields_out && *nout < ctx->fields_cap) {
+        if (mm->msgtype == 32) {
+            fields_mode_ac(&ctx->ac_mm, ((unsigned)mm->msg[0] << 8) | mm->msg[1]);
+            ctx->fields_out[*nout] = ctx->ac_mm;
+        } else {
+            fields_mode_s(mm, &ctx->fields_out[*nout]);
+        }
+    }
     ++*nout;
 }
 
@@ -633,7 +812,7 @@ static void demod_mode_s(orc_ctx *ctx, const uint16_t *m, unsigned valid_length,
         }
 
         j += (uint32_t)(msglen * 12 / 5); /* demod_2400.c:416 */
-        emit(out, cap, nout, &mm);         /* useModesMessage, demod_2400.c:419 */
+        emit(ctx, out, cap, nout, &mm);    /* useModesMessage, demod_2400.c:419 */
     }
 
     { /* demod_2400.c:422-427 */
@@ -654,6 +833,7 @@ static void demod_mode_ac(orc_ctx *ctx, const uint16_t *m, unsigned valid_length
     uint32_t mlen = valid_length - ORC_OVERLAP;
     double noise_stddev = sqrt(mean_power - mean_level * mean_level);
     unsigned noise_level = (unsigned)((mean_power + noise_stddev) * 65535 + 0.5);
+    memset(&ctx->ac_mm, 0, sizeof ctx->ac_mm); /* demod_2400.c:523-528: cleared once per buffer */
 
     for (unsigned f1_sample = 1; f1_sample < mlen; ++f1_sample) {
         if (!(m[f1_sample - 1] < m[f1_sample + 0]))
@@ -729,7 +909,7 @@ static void demod_mode_ac(orc_ctx *ctx, const uint16_t *m, unsigned valid_length
         mm.msg[0] = (uint8_t)(modeac >> 8);
         mm.msg[1] = (uint8_t)modeac;
         mm.addr = (modeac & 0x0000FF7Fu) | 0x01000000u; /* MODES_NON_ICAO_ADDRESS, readsb.h */
-        emit(out, cap, nout, &mm);
+        emit(ctx, out, cap, nout, &mm);
 
         f1_sample += (20 * 87 / 25);
         ctx->st.demod_modeac++;

@@ -105,6 +105,27 @@ int orc_filter_test(const orc_ctx *ctx, uint32_t addr);
 void orc_slice(const uint16_t *m, uint32_t j, int try_phase, int nbytes, uint8_t *out);
 /* one buffer through demodulate2400 [+ demodulate2400AC] + icaoFilterExpire; data must hold
  * valid_length samples (overlap first). */
+/* Header fields of an accepted message (first stage): the field assignments
+ * of decodeModesMessage after its CRC switch (mode_s.c:557-715) except the ME / MB payload decoders,
+ * and decodeModeAMessage (mode_ac.c:168-202).  Same layout as msd_fields (include/modes_hip.h). */
+#define ORC_INVALID_ALTITUDE (-9999) /* readsb.h:130 */
+typedef struct orc_fields {
+    int32_t altitude_baro;
+    uint16_t AC, ID, squawk;
+    uint8_t altitude_baro_valid, altitude_baro_unit;
+    uint8_t squawk_valid;
+    uint8_t airground; /* readsb.pb-c.h:32-35: 0 invalid, 1 ground, 2 airborne, 3 uncertain */
+    uint8_t alert, alert_valid, spi, spi_valid;
+    uint8_t CA, CC, CF, DR, FS, KE, ND, RI, SL, UM, VS;
+    uint8_t pad[3];
+} orc_fields;
+/* From now on orc_replay / orc_demod_buffer also write the fields of message i to fields[i] (i < cap). */
+void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap);
+/* single pieces, for known-answer tests */
+int orc_decode_ac13(unsigned ac13, int *unit);
+unsigned orc_decode_id13(unsigned id13);
+int orc_mode_a_to_mode_c(unsigned mode_a);
+
 /* Wire formats of accepted messages, restated from modesSendRawOutput (net_io.c:870-896) and
  * modesSendBeastOutput (net_io.c:769-835); return the number of bytes written. */
 size_t orc_avr_line(const orc_message *mm, int mlat, char *out /* >= 48 */);

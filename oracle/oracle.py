@@ -37,6 +37,16 @@ MESSAGE_DTYPE = np.dtype(
 )
 assert MESSAGE_DTYPE.itemsize == 56
 
+# numpy mirror of orc_fields
+FIELDS_DTYPE = np.dtype(
+    [("altitude_baro", "<i4"), ("AC", "<u2"), ("ID", "<u2"), ("squawk", "<u2"), ("altitude_baro_valid", "u1"),
+     ("altitude_baro_unit", "u1"), ("squawk_valid", "u1"), ("airground", "u1"), ("alert", "u1"), ("alert_valid", "u1"),
+     ("spi", "u1"), ("spi_valid", "u1"), ("CA", "u1"), ("CC", "u1"), ("CF", "u1"), ("DR", "u1"), ("FS", "u1"),
+     ("KE", "u1"), ("ND", "u1"), ("RI", "u1"), ("SL", "u1"), ("UM", "u1"), ("VS", "u1"), ("pad", "u1", (3,))],
+    align=True,
+)
+assert FIELDS_DTYPE.itemsize == 32
+
 
 class Stats(C.Structure):
     _fields_ = [
@@ -106,6 +116,14 @@ def lib():
         L.orc_demod_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64,
                                        C.c_double, C.c_double, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t)]
+        L.orc_set_fields_out.restype = None
+        L.orc_set_fields_out.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_decode_ac13.restype = C.c_int
+        L.orc_decode_ac13.argtypes = [C.c_uint, C.POINTER(C.c_int)]
+        L.orc_decode_id13.restype = C.c_uint
+        L.orc_decode_id13.argtypes = [C.c_uint]
+        L.orc_mode_a_to_mode_c.restype = C.c_int
+        L.orc_mode_a_to_mode_c.argtypes = [C.c_uint]
         L.orc_avr_line.restype = C.c_size_t
         L.orc_avr_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         L.orc_beast_frame.restype = C.c_size_t
@@ -150,6 +168,14 @@ class Oracle:
     @property
     def bytes_per_sample(self):
         return 2 if self.fmt == FMT_UC8 else 4
+
+    def replay_fields(self, iq, cap):
+        """replay() that also decodes the header fields: returns (messages, fields, stats)."""
+        self._fields = np.zeros(cap, dtype=FIELDS_DTYPE)
+        lib().orc_set_fields_out(self._h, self._fields.ctypes.data, cap)
+        msgs, st = self.replay(iq, cap=cap)
+        lib().orc_set_fields_out(self._h, None, 0)
+        return msgs, self._fields[: len(msgs)].copy(), st
 
     def replay(self, iq, cap=None, want_means=False):
         """Run a whole capture (bytes-like / uint8 array).  Returns (messages, stats[, means])."""

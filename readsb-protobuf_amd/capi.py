@@ -39,6 +39,17 @@ MESSAGE_DTYPE = np.dtype(
 )
 assert MESSAGE_DTYPE.itemsize == 56
 
+FIELDS_DTYPE = np.dtype(
+    [("altitude_baro", "<i4"), ("AC", "<u2"), ("ID", "<u2"), ("squawk", "<u2"), ("altitude_baro_valid", "u1"),
+     ("altitude_baro_unit", "u1"), ("squawk_valid", "u1"), ("airground", "u1"), ("alert", "u1"), ("alert_valid", "u1"),
+     ("spi", "u1"), ("spi_valid", "u1"), ("CA", "u1"), ("CC", "u1"), ("CF", "u1"), ("DR", "u1"), ("FS", "u1"),
+     ("KE", "u1"), ("ND", "u1"), ("RI", "u1"), ("SL", "u1"), ("UM", "u1"), ("VS", "u1"), ("pad", "u1", (3,))],
+    align=True,
+)
+assert FIELDS_DTYPE.itemsize == 32
+CFG_DECODE_FIELDS = 1
+INVALID_ALTITUDE = -9999
+
 
 class Config(C.Structure):
     _fields_ = [
@@ -47,7 +58,7 @@ class Config(C.Structure):
         ("preamble_threshold", C.c_int32),
         ("nfix_crc", C.c_int32),
         ("mode_ac", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("flags", C.c_int32),
         ("max_batch_samples", C.c_uint64),
         ("stream", C.c_void_p),
     ]
@@ -102,10 +113,15 @@ class _SinkState(C.Structure):
     _fields_ = [("out", C.c_void_p), ("cap", C.c_size_t), ("count", C.c_size_t)]
 
 
+class _FieldsSinkState(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("fields", C.c_void_p), ("cap", C.c_size_t), ("count", C.c_size_t)]
+
+
 EXPORTS = [
     "msd_create", "msd_destroy", "msd_last_error", "msd_submit_device", "msd_submit_host", "msd_reset",
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
+    "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
 ]
 
 _lib = None
@@ -136,6 +152,10 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.msd_host_alloc.restype = C.c_int
         L.msd_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.msd_collect_fields.restype = C.c_int
+        L.msd_collect_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.msd_decode_fields.restype = None
+        L.msd_decode_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.msd_host_free.restype = None
         L.msd_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.msd_collect.restype = C.c_int
@@ -164,11 +184,11 @@ class Demodulator:
     """One receiver context on one GPU (its own ICAO filter, clock, counters and HIP streams)."""
 
     def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, device=0,
-                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16):
+                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16, decode_fields=False):
         self._h = C.c_void_p()
         self.fmt = fmt
         cfg = Config(device=device, format=fmt, preamble_threshold=preamble_threshold, nfix_crc=nfix_crc,
-                     mode_ac=mode_ac, reserved0=0, max_batch_samples=max_batch_samples,
+                     mode_ac=mode_ac, flags=CFG_DECODE_FIELDS if decode_fields else 0, max_batch_samples=max_batch_samples,
                      stream=C.c_void_p(stream) if stream else None)
         rc = lib().msd_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
@@ -209,6 +229,16 @@ class Demodulator:
             # a context is stateful, so a too-small array cannot simply be retried: grow ahead of time
             raise MsdError(f"message array too small ({st.count} > {self._buf.size}); "
                            "construct the Demodulator with a larger message_capacity")
+
+    def collect_fields(self):
+        """msd_collect_fields: (messages, header fields) of the oldest outstanding batch (copies)."""
+        if not hasattr(self, "_fbuf") or self._fbuf.size != self._buf.size:
+            self._fbuf = np.zeros(self._buf.size, dtype=FIELDS_DTYPE)
+        st = _FieldsSinkState(self._buf.ctypes.data, self._fbuf.ctypes.data, self._buf.size, 0)
+        self._check(lib().msd_collect_fields(self._h, C.cast(lib().msd_array_fields_sink, C.c_void_p), C.byref(st)))
+        if st.count > self._buf.size:
+            raise MsdError(f"message array too small ({st.count} > {self._buf.size})")
+        return self._buf[: st.count].copy(), self._fbuf[: st.count].copy()
 
     def reserve_messages(self, n):
         if n > self._buf.size:
@@ -309,3 +339,12 @@ def replay_device(demod, dptr, nsamples, batch_samples):
         out.append(demod.collect())
         inflight -= 1
     return np.concatenate(out) if out else np.zeros(0, dtype=MESSAGE_DTYPE)
+
+
+def decode_fields(message, carry=None):
+    """msd_decode_fields on one message record; carry = fields of the previous Mode A/C reply of the buffer."""
+    rec = np.ascontiguousarray(message).reshape(1)
+    out = np.zeros(1, dtype=FIELDS_DTYPE)
+    cp = np.ascontiguousarray(carry).reshape(1).ctypes.data if carry is not None else None
+    lib().msd_decode_fields(rec.ctypes.data, cp, out.ctypes.data)
+    return out[0]

@@ -48,6 +48,7 @@ struct Slot {
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
+    msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
     /* batch description */
     const uint8_t *d_iq = nullptr;
@@ -118,6 +119,10 @@ struct msd_ctx {
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
+    bool want_fields = false;       /* MSD_CFG_DECODE_FIELDS */
+    msd_fields_fn fsink = nullptr;  /* set while msd_collect_fields runs: messages go here with their fields */
+    void *fuser = nullptr;
+    std::vector<msd_fields> out_fields; /* host-resolve path */
     bool records_dma = false; /* MSD_RECORDS_DMA=1: fetch the message records with a DMA instead of kernel stores */
     hipEvent_t ev_aux = nullptr, ev_inputs = nullptr;
     msd_pred_entry *h_pred = nullptr;
@@ -185,9 +190,11 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     if (s.h_req) (void)hipHostFree(s.h_req);
     if (s.h_pow) (void)hipHostFree(s.h_pow);
     if (s.h_wire) (void)hipHostFree(s.h_wire);
+    if (s.h_fields) (void)hipHostFree(s.h_fields);
     (void)hipFree(s.d_wire);
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
     s.h_wire = s.d_wire = nullptr;
+    s.h_fields = nullptr;
     s.req_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_pow), cap * sizeof(uint64_t)));
@@ -196,6 +203,8 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     if (c->gpu_resolve) {
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_wire), cap * sizeof(msd_wire)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_wire), cap * sizeof(msd_wire)));
+        if (c->want_fields)
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_fields), cap * sizeof(msd_fields)));
     }
     s.req_cap = cap;
     return 0;
@@ -649,7 +658,8 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
     if (rc)
         return fail(c, rc, "power kernel launch failed");
     rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr),
-                         c->records_dma ? s.d_wire : s.h_wire, (uint32_t)s.req_cap, ks);
+                         c->records_dma ? s.d_wire : s.h_wire, c->want_fields ? s.h_fields : nullptr,
+                         (uint32_t)s.req_cap, ks);
     if (rc)
         return fail(c, rc, "emit kernel launch failed");
     HIPCHK(c, hipEventRecord(s.ev_records, ks));
@@ -805,7 +815,10 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
                 "power stats %.3f ms\n", npass, early ? " (first one queued early)" : "", t_wait, t_replay, tms(e0, e1),
                 tms(e1, tnow()));
-    if (sink)
+    if (c->fsink)
+        for (uint32_t i = 0; i < total; ++i)
+            c->fsink(&s.h_wire[i].mm, &s.h_fields[i], c->fuser);
+    else if (sink)
         for (uint32_t i = 0; i < total; ++i)
             sink(&s.h_wire[i].mm, user);
     return 0;
@@ -950,7 +963,12 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(), sizeof(msd_message),
                       c->out_req.data(), c->out_buf.data(), s.h_pow, sizeof(uint64_t), nm);
     auto t2 = std::chrono::steady_clock::now();
-    if (sink)
+    if (c->fsink) { /* header fields on the host for the batches resolved here */
+        c->out_fields.resize(nm ? nm : 1);
+        msd_fields_batch(c->out_msgs.data(), sizeof(msd_message), c->out_buf.data(), nm, c->out_fields.data());
+        for (size_t i = 0; i < nm; ++i)
+            c->fsink(&c->out_msgs[i], &c->out_fields[i], c->fuser);
+    } else if (sink)
         for (size_t i = 0; i < nm; ++i)
             sink(&c->out_msgs[i], user);
     if (getenv("MSD_RESOLVE_TRACE")) {
@@ -1095,6 +1113,7 @@ void destroy(msd_ctx *c)
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_wire) (void)hipHostFree(s.h_wire);
+        if (s.h_fields) (void)hipHostFree(s.h_fields);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
         if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
@@ -1266,6 +1285,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     {
         const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
         c->gpu_resolve = g ? atoi(g) != 0 : true;
+        c->want_fields = (cfg->flags & MSD_CFG_DECODE_FIELDS) != 0;
         if (const char *rd = getenv("MSD_RECORDS_DMA"))
             c->records_dma = atoi(rd) != 0;
         const char *ia = getenv("MSD_RESOLVE_INLINE_ADDS");
@@ -1354,6 +1374,31 @@ int msd_collect(msd_ctx *c, msd_message_fn sink, void *user)
         return -EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return collect(c, sink, user);
+}
+
+int msd_collect_fields(msd_ctx *c, msd_fields_fn sink, void *user)
+{
+    if (!c)
+        return -EINVAL;
+    if (!c->want_fields)
+        return fail(c, -EINVAL, "the context was created without MSD_CFG_DECODE_FIELDS");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->fsink = sink;
+    c->fuser = user;
+    const int rc = collect(c, nullptr, nullptr);
+    c->fsink = nullptr;
+    c->fuser = nullptr;
+    return rc;
+}
+
+void msd_array_fields_sink(const msd_message *mm, const msd_fields *fields, void *state)
+{
+    msd_array_fields_sink_state *st = static_cast<msd_array_fields_sink_state *>(state);
+    if (st->count < st->cap) {
+        st->out[st->count] = *mm;
+        st->fields[st->count] = *fields;
+    }
+    st->count++;
 }
 
 int msd_submit_device(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last, msd_message_fn sink,

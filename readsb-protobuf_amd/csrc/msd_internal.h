@@ -180,6 +180,10 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
                        void *msgs, size_t msg_stride, const uint64_t *power_req, const uint32_t *buffer,
                        const void *power, size_t power_stride, uint64_t nmsgs);
 
+/* header fields of a whole batch on the host (msd_fields.c); msgs[i] belongs to buffer[i] */
+struct msd_fields;
+void msd_fields_batch(const void *msgs, size_t msg_stride, const uint32_t *buffer, uint64_t n, struct msd_fields *out);
+
 /* ---- host half of the GPU resolve (msd_resolve.c): the cross-buffer replay ----
  * begin: clocks, snapshot 0 (= the live filter), every buffer on the to-do list.
  * replay: after a kernel pass, walks the buffers' add lists and flip times in order and decides which

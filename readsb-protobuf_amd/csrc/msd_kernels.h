@@ -87,7 +87,7 @@ typedef struct msd_wire {
 /* the accepted messages as dense records, cap entries (what does not fit is dropped; the host notices
  * from the counts) */
 int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_wire *dense,
-                    uint32_t cap, hipStream_t stream);
+                    msd_fields *fields /* NULL: no field decode */, uint32_t cap, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 /* Regions -> dense ordered lists (every workgroup sums the counts in front of it); the last

@@ -19,6 +19,7 @@
 #include "modes_hip.h"
 #include "msd_internal.h"
 #include "msd_kernels.h"
+#include "msd_fields_impl.h"
 
 namespace {
 
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
 /* The accepted messages of buffer b as 64-byte records (msd_message + signal power sum), dense over
  * the batch; one DMA then takes them to the host while the next scan runs. */
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
-                                                       msd_wire *dense, uint32_t cap)
+                                                       msd_wire *dense, msd_fields *fields, uint32_t cap)
 {
     if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return;
@@ -791,10 +792,27 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         wr.mm = mm;
         wr.power = power[(size_t)b * MSD_RB_MSG_CAP + m];
         dense[o + m] = wr;
+        if (fields) { /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
+            msd_fields f;
+            msd_fields_mode_s(mm.msg, df, &f);
+            fields[o + m] = f;
+        }
     }
     if (P.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
         const uint32_t na = P.nac[b];
         const uint32_t *acc_ac = P.acc_ac + (size_t)b * MSD_RB_AC_CAP;
+        __shared__ uint32_t has_alt[MSD_RB_AC_CAP / 32]; /* replies that carry an altitude of their own */
+        if (fields) {
+            for (uint32_t i = threadIdx.x; i < MSD_RB_AC_CAP / 32; i += blockDim.x)
+                has_alt[i] = 0;
+            __syncthreads();
+            for (uint32_t m = threadIdx.x; m < na; m += blockDim.x) {
+                const uint32_t a = P.ac[acc_ac[m]].modeac;
+                if (!(a & 0x0080u) && msd_mode_a_to_c(a) != MSD_INVALID_ALTITUDE)
+                    atomicOr(&has_alt[m >> 5], 1u << (m & 31));
+            }
+            __syncthreads();
+        }
         for (uint32_t m = threadIdx.x; m < na; m += blockDim.x) {
             if (o + nm + m >= cap)
                 break;
@@ -821,6 +839,23 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             wr.mm = mm;
             wr.power = 0;
             dense[o + nm + m] = wr;
+            if (fields) {
+                /* the reference's one message record per buffer keeps the last decoded altitude
+                 * (demod_2400.c:523-528): find the last earlier reply of this buffer that had one */
+                msd_fields carry, f;
+                const msd_fields *cp = nullptr;
+                int32_t w = (int32_t)(m >> 5);
+                uint32_t bits = m & 31 ? has_alt[w] & ((1u << (m & 31)) - 1u) : 0u;
+                while (!bits && --w >= 0)
+                    bits = has_alt[w];
+                if (bits) {
+                    const uint32_t prev = (uint32_t)w * 32 + (31u - (uint32_t)__builtin_clz(bits));
+                    msd_fields_mode_ac(P.ac[acc_ac[prev]].modeac, nullptr, &carry);
+                    cp = &carry;
+                }
+                msd_fields_mode_ac(c.modeac, cp, &f);
+                fields[o + nm + m] = f;
+            }
         }
     }
 }
@@ -930,10 +965,10 @@ extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hip
 }
 
 extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power,
-                               msd_wire *dense, uint32_t cap, hipStream_t stream)
+                               msd_wire *dense, msd_fields *fields, uint32_t cap, hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, cap);
+    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -1,0 +1,181 @@
+"""Header fields of accepted messages (first stage): the altitude / identity
+codes against an independent Python statement of the encodings (exhaustive over all 8192 codes) and
+published Gillham values, the per-format fields against hand-built messages, and the host entry
+point (the code the emit kernel shares) against the oracle on replayed captures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import load_golden
+
+FIELD_NAMES = ("altitude_baro", "AC", "ID", "squawk", "altitude_baro_valid", "altitude_baro_unit", "squawk_valid",
+               "airground", "alert", "alert_valid", "spi", "spi_valid", "CA", "CC", "CF", "DR", "FS", "KE", "ND", "RI",
+               "SL", "UM", "VS")
+
+
+def code_bits(code13):
+    b = lambda n: (code13 >> n) & 1  # noqa: E731
+    return dict(C1=b(12), A1=b(11), C2=b(10), A2=b(9), C4=b(8), A4=b(7), B1=b(5), D1=b(4), B2=b(3), D2=b(2), B4=b(1),
+                D4=b(0))
+
+
+def squawk_py(code13):
+    """identity / altitude code -> the four octal digits A B C D, one hex digit each"""
+    k = code_bits(code13)
+    digit = lambda x: k[x + "4"] * 4 + k[x + "2"] * 2 + k[x + "1"]  # noqa: E731
+    return (digit("A") << 12) | (digit("B") << 8) | (digit("C") << 4) | digit("D")
+
+
+def gray_to_bin(bits):
+    acc, n = 0, 0
+    for g in bits:
+        acc ^= g
+        n = (n << 1) | acc
+    return n
+
+
+def gillham_feet_py(code13):
+    """Altitude code without Q: D2 D4 A1 A2 A4 B1 B2 B4 is a Gray-coded count of 500 ft, C1 C2 C4 a Gray-coded
+    count of 100 ft (1..4 and 7 standing for 5) that runs backwards in odd 500 ft blocks; offset -1300 ft."""
+    k = code_bits(code13)
+    if k["D1"] or not (k["C1"] or k["C2"] or k["C4"]):
+        return None
+    n500 = gray_to_bin([k[x] for x in ("D2", "D4", "A1", "A2", "A4", "B1", "B2", "B4")])
+    n100 = gray_to_bin([k["C1"], k["C2"], k["C4"]])
+    if n100 == 7:
+        n100 = 5
+    elif n100 in (5, 6):
+        return None
+    if n500 & 1:
+        n100 = 6 - n100
+    return n500 * 500 + n100 * 100 - 1300
+
+
+def ac13_feet_py(ac13):
+    if ac13 & 0x40:  # M bit: metric, never decoded
+        return None
+    if ac13 & 0x10:  # Q bit: 25 ft steps
+        return ((((ac13 & 0x1F80) >> 2) | ((ac13 & 0x20) >> 1) | (ac13 & 0xF)) * 25) - 1000
+    return gillham_feet_py(ac13)
+
+
+def msg_record(pkg, df, payload27=0):
+    """A message record with DF and the 27 bits behind it (bits 6..32) set; the rest zero."""
+    rec = np.zeros(1, dtype=pkg.capi.MESSAGE_DTYPE)
+    word = (df << 27) | (payload27 & 0x7FFFFFF)
+    rec["msg"][0, :4] = np.frombuffer(int(word).to_bytes(4, "big"), dtype=np.uint8)
+    rec["msgtype"] = df
+    rec["msgbits"] = 112 if df >= 16 else 56
+    return rec[0]
+
+
+def test_identity_and_altitude_codes_exhaustive(pkg, oracle):
+    lib = oracle.lib()
+    for code in range(8192):
+        sq = squawk_py(code)
+        assert lib.orc_decode_id13(code) == sq
+        f = pkg.capi.decode_fields(msg_record(pkg, 5, code))
+        assert (f["ID"], f["squawk"], f["squawk_valid"]) == (code, sq if code else 0, 1 if code else 0)
+        want = ac13_feet_py(code)
+        unit = C.c_int(0)
+        got = lib.orc_decode_ac13(code, C.byref(unit))
+        assert got == (-9999 if want is None else want), code
+        assert unit.value == (1 if code & 0x40 else 0)
+        f = pkg.capi.decode_fields(msg_record(pkg, 20, code))
+        assert f["AC"] == code
+        if code == 0:
+            assert (f["altitude_baro"], f["altitude_baro_valid"], f["altitude_baro_unit"]) == (0, 0, 0)
+        else:
+            assert f["altitude_baro"] == (-9999 if want is None else want), code
+            assert f["altitude_baro_valid"] == (0 if want is None else 1)
+            assert f["altitude_baro_unit"] == (1 if code & 0x40 else 0)
+
+
+def test_gillham_table_properties_and_published_values(oracle):
+    lib = oracle.lib()
+    seen = {}
+    for i in range(4096):
+        a = (i & 0o7) | ((i & 0o70) << 1) | ((i & 0o700) << 2) | ((i & 0o7000) << 3)
+        c = lib.orc_mode_a_to_mode_c(a)
+        if c != -9999:
+            assert c not in seen
+            seen[c] = a
+    assert sorted(seen) == list(range(-12, 1268))  # 1280 codes: -1200 ft .. 126700 ft in 100 ft steps
+    for c in range(-12, 1267):  # neighbouring altitudes differ in exactly one pulse
+        assert bin(seen[c] ^ seen[c + 1]).count("1") == 1
+    for feet, octal in {-1200: 0o0040, -1000: 0o0020, 0: 0o0620, 100: 0o0630, 500: 0o0220}.items():  # ABCD
+        hexcoded = ((octal >> 9) & 7) << 12 | ((octal >> 6) & 7) << 8 | ((octal >> 3) & 7) << 4 | (octal & 7)
+        assert seen[feet // 100] == hexcoded, (feet, oct(octal))
+    assert lib.orc_mode_a_to_mode_c(0x8620 | 0x0808) == lib.orc_mode_a_to_mode_c(0x0620)  # stray bits are ignored
+
+
+def test_per_format_header_fields(pkg):
+    # FS 0..7 for DF4/5/20/21 (mode_s.c:613-650): (airground, alert, spi, valid)
+    fs_table = {0: (3, 0, 0, 1), 1: (1, 0, 0, 1), 2: (3, 1, 0, 1), 3: (1, 1, 0, 1), 4: (3, 1, 1, 1), 5: (3, 0, 1, 1),
+                6: (0, 0, 0, 0), 7: (0, 0, 0, 0)}
+    for df in (4, 5, 20, 21):
+        for fs, (ag, alert, spi, valid) in fs_table.items():
+            f = pkg.capi.decode_fields(msg_record(pkg, df, (fs << 24) | (0b10101 << 19) | (0b110011 << 13)))
+            assert (f["FS"], f["airground"], f["alert"], f["spi"], f["alert_valid"], f["spi_valid"]) == \
+                   (fs, ag, alert, spi, valid, valid)
+            assert (f["DR"], f["UM"]) == (0b10101, 0b110011)
+    for df in (11, 17):  # CA (mode_s.c:577-597): 1..3 leave airground alone
+        for ca, ag in {0: 3, 1: 0, 2: 0, 3: 0, 4: 1, 5: 2, 6: 3, 7: 3}.items():
+            f = pkg.capi.decode_fields(msg_record(pkg, df, ca << 24))
+            assert (f["CA"], f["airground"]) == (ca, ag)
+    for df in (0, 16):  # VS bit 6, CC bit 7 (DF0), SL bits 9-11, RI bits 14-17
+        for vs in (0, 1):
+            f = pkg.capi.decode_fields(msg_record(pkg, df, (vs << 26) | (1 << 25) | (0b101 << 21) | (0b1001 << 15)))
+            assert (f["VS"], f["airground"], f["SL"], f["RI"]) == (vs, 1 if vs else 3, 0b101, 0b1001)
+            assert f["CC"] == (1 if df == 0 else 0)
+    assert pkg.capi.decode_fields(msg_record(pkg, 18, 0b110 << 24))["CF"] == 0b110
+    for df in (24, 27, 31):  # KE is bit 4 (inside the 5-bit DF number), ND bits 5-8
+        f = pkg.capi.decode_fields(msg_record(pkg, df, 0b011 << 24))
+        assert (f["KE"], f["ND"]) == ((df >> 1) & 1, ((df & 1) << 3) | 0b011)
+    f = pkg.capi.decode_fields(msg_record(pkg, 11, 5 << 24))
+    assert all(f[x] == 0 for x in ("AC", "ID", "squawk", "FS", "DR", "UM", "RI", "SL", "VS", "altitude_baro_valid"))
+
+
+def test_mode_ac_reply_fields_and_altitude_carry(pkg):
+    def ac(code):
+        rec = np.zeros(1, dtype=pkg.capi.MESSAGE_DTYPE)
+        rec["msgtype"], rec["msgbits"] = 32, 16
+        rec["msg"][0, 0], rec["msg"][0, 1] = code >> 8, code & 0xFF
+        return rec[0]
+    a = pkg.capi.decode_fields(ac(0x0620))  # the Mode C code of 0 ft
+    assert (a["squawk"], a["squawk_valid"], a["spi"], a["spi_valid"]) == (0x0620, 1, 0, 1)
+    assert (a["altitude_baro"], a["altitude_baro_valid"]) == (0, 1)
+    hi = pkg.capi.decode_fields(ac(0x0630))
+    assert (hi["altitude_baro"], hi["altitude_baro_valid"]) == (100, 1)
+    b = pkg.capi.decode_fields(ac(0x7777), carry=hi)  # not a Mode C code: the buffer's record keeps the altitude
+    assert (b["squawk"], b["altitude_baro"], b["altitude_baro_valid"]) == (0x7777, 100, 1)
+    assert pkg.capi.decode_fields(ac(0x7777))["altitude_baro_valid"] == 0
+    d = pkg.capi.decode_fields(ac(0x06A0), carry=b)  # ident pulse: SPI, no altitude of its own (mode_ac.c:186-197)
+    assert (d["spi"], d["squawk"], d["altitude_baro"], d["altitude_baro_valid"]) == (1, 0x0620, 100, 1)
+
+
+@pytest.mark.parametrize("name", ["uc8_fix_modeac", "sc16q11_fix_modeac", "uc8_nofix"])
+def test_host_decode_matches_oracle_on_replayed_captures(pkg, oracle, name):
+    """msd_decode_fields (the code the emit kernel shares) against the oracle's independent restatement:
+    the golden capture is regenerated from its seed, the oracle decodes fields during its replay, the
+    host entry point decodes the same messages one by one (Mode A/C replies with the buffer's carry)."""
+    meta, z = load_golden(name)
+    fmt = {"uc8": pkg.FMT_UC8, "sc16": pkg.FMT_SC16, "sc16q11": pkg.FMT_SC16Q11}[meta["format"]]
+    ofmt = {"uc8": oracle.FMT_UC8, "sc16": oracle.FMT_SC16, "sc16q11": oracle.FMT_SC16Q11}[meta["format"]]
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=meta["seed"], fmt=fmt, **meta["gen"]), meta["nsamples"])
+    msgs, fields, _ = oracle.Oracle(ofmt, 58, meta["nfix_crc"], meta["mode_ac"]).replay_fields(iq, cap=1 << 17)
+    assert len(msgs) == len(z["timestampMsg"]) and np.array_equal(msgs["timestampMsg"], z["timestampMsg"])
+    # buffer of a Mode A/C reply: its F1 position is at most 131071, so f2_clock / 5 < 131072 * 5 + 244 ticks
+    carry, carry_buf, nac = None, None, 0
+    for m, want in zip(msgs, fields):
+        if m["msgtype"] == 32:
+            buf = (int(m["timestampMsg"]) - 244) // (131072 * 5)
+            got = pkg.capi.decode_fields(m, carry if carry_buf == buf else None)
+            carry, carry_buf = got, buf
+            nac += 1
+        else:
+            got = pkg.capi.decode_fields(m)
+        for f in FIELD_NAMES:
+            assert got[f] == want[f], (f, int(got[f]), int(want[f]), int(m["msgtype"]))
+    assert nac > 0 or not meta["mode_ac"]

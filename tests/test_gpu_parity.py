@@ -127,6 +127,39 @@ def test_replay_cli_matches_oracle(pkg, oracle, torch_cuda, tmp_path, path):
         assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())
 
 
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", 1), ("uc8", 0), ("sc16q11", 1)])
+def test_header_fields_from_the_emit_kernel(pkg, oracle, torch_cuda, fmt, mode_ac, resolve_stage):
+    """SURVEY.md 8(f) rank 1, first stage: MSD_CFG_DECODE_FIELDS / msd_collect_fields deliver the header
+    fields of every accepted message (from the emit kernel, or from the same code on the host when the
+    batch was resolved there), equal to the oracle's restatement -- including the altitude a Mode A/C
+    reply inherits from an earlier reply of its buffer."""
+    from test_fields import FIELD_NAMES
+    f, of = (pkg.FMT_UC8, oracle.FMT_UC8) if fmt == "uc8" else (pkg.FMT_SC16Q11, oracle.FMT_SC16Q11)
+    n, batch = 21 * 131072 + 999, 8 * 131072
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=61, fmt=f, msgs_per_sec=4000, ac_per_sec=3000 * mode_ac,
+                                                 n_aircraft=120), n)
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 18,
+                          decode_fields=True)
+    msgs, fields = [], []
+    bps = dem.bytes_per_sample
+    for off in range(0, n, batch):
+        m = min(batch, n - off)
+        dem.launch_device(d.data_ptr() + off * bps, m, off + m >= n)
+        mm, ff = dem.collect_fields()
+        msgs.append(mm)
+        fields.append(ff)
+    msgs, fields = np.concatenate(msgs), np.concatenate(fields)
+    want, wfields, wstats = oracle.Oracle(of, 58, 1, mode_ac).replay_fields(iq, cap=1 << 18)
+    assert_same(msgs, dem.stats(), want, wstats)
+    for name in FIELD_NAMES:
+        assert np.array_equal(fields[name], wfields[name]), name
+    assert (fields["altitude_baro_valid"] == 1).sum() > 50
+    if mode_ac:
+        ac = msgs["msgtype"] == 32
+        assert ac.sum() > 200 and (fields["altitude_baro_valid"][ac] == 1).sum() > 20
+
+
 def test_replay_cli_wire_formats(pkg, oracle, torch_cuda, tmp_path):
     """the replay tool's --net-raw (AVR) and --beast outputs equal the oracle's
     restatement of net_io.c:769-835,870-896 applied to the oracle's messages."""
