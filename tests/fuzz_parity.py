@@ -35,12 +35,29 @@ for case in range(first, first + ncases):
     cfg = pkg.siggen.make_cfg(seed=case, fmt=fmt, **kw)
     iq = pkg.siggen.generate(cfg, n)
     d = torch.from_numpy(iq).to("cuda:0")
-    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19)
-    got = pkg.replay_device(dem, d.data_ptr(), n, batch)
-    want, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac).replay(iq, cap=1 << 19)
-    desc = f"case {case}: {fmt_name} n={n} batch={batch // 131072} nfix={nfix} ac={mode_ac} gpu_resolve={gpu_resolve} {kw}"
+    with_fields = int(rng.integers(0, 2))
+    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19,
+                          decode_fields=bool(with_fields))
+    desc = (f"case {case}: {fmt_name} n={n} batch={batch // 131072} nfix={nfix} ac={mode_ac} gpu_resolve={gpu_resolve} "
+            f"fields={with_fields} {kw}")
+    if with_fields:
+        parts, fparts, bps = [], [], dem.bytes_per_sample
+        for off in list(range(0, n, batch)) or [0]:
+            m = min(batch, n - off)
+            dem.launch_device(d.data_ptr() + off * bps, m, off + m >= n)
+            mm, ff = dem.collect_fields()
+            parts.append(mm)
+            fparts.append(ff)
+        got, gfields = np.concatenate(parts), np.concatenate(fparts)
+        want, wfields, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac).replay_fields(iq, cap=1 << 19)
+    else:
+        got = pkg.replay_device(dem, d.data_ptr(), n, batch)
+        want, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac).replay(iq, cap=1 << 19)
     try:
         assert_same(got, dem.stats(), want, wstats)
+        if with_fields:
+            for name in gfields.dtype.names:
+                assert np.array_equal(gfields[name], wfields[name]), "field " + name
         print("ok  ", desc, "msgs", len(want), "passes", dem.timing()["resolve_passes"], "fallback", dem.timing()["resolve_fallback"])
     except AssertionError as e:
         bad += 1
