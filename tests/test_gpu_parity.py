@@ -47,11 +47,28 @@ def run_case(pkg, oracle, torch, fmt, n, seed, nfix, batch=None, mode_ac=0, **cf
 
 
 @pytest.mark.parametrize("nfix", [0, 1])
-@pytest.mark.parametrize("n", [3 * 131072 + 4567, 4 * 131072, 1000, 131072 + 1])
+@pytest.mark.parametrize("n", [3 * 131072 + 4567, 4 * 131072, 131072 + 1])
 def test_uc8_single_batch(pkg, oracle, torch_cuda, n, nfix):
-    if n == 1000:
-        pytest.skip("covered by test_short_captures")
     run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, n, seed=1090 + n % 7, nfix=nfix)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16"])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 325, 326, 327, 1000, 4095, 131071, 131073])
+def test_short_captures(pkg, oracle, torch_cuda, n, fmt):
+    """Captures shorter than a buffer, shorter than the 326-sample overlap, shorter than one 8-sample load
+    group, and empty: same messages (possibly none), counters and per-buffer means as the oracle."""
+    f, of = (pkg.FMT_UC8, oracle.FMT_UC8) if fmt == "uc8" else (pkg.FMT_SC16, oracle.FMT_SC16)
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=90 + n % 13, fmt=f, msgs_per_sec=8000, n_aircraft=4,
+                                                 overlap_permille=0), max(n, 4096))[: n * (2 if fmt == "uc8" else 4)]
+    d = torch_cuda.from_numpy(np.concatenate([iq, np.zeros(64, dtype=np.uint8)])).to("cuda:0")  # keep a valid pointer for n = 0
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=2 * 131072, message_capacity=1 << 12)
+    got = dem.submit_device(d.data_ptr(), n, last=True)
+    want, wstats, wmeans = oracle.Oracle(of, 58, 1, 0).replay(iq, cap=1 << 12, want_means=True)
+    assert_same(got, dem.stats(), want, wstats)
+    gmeans = dem.buffer_means()
+    assert np.array_equal(gmeans, wmeans[: len(gmeans)], equal_nan=True) and len(gmeans) == wstats["buffers"]
+    if n >= 131071:
+        assert len(want) > 0
 
 
 def test_uc8_pipelined_batches(pkg, oracle, torch_cuda):
