@@ -46,7 +46,7 @@ struct Slot {
     uint32_t *d_adds = nullptr, *d_nmsgs = nullptr, *d_acc_ac = nullptr, *d_nac = nullptr;
     uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST]; wiped by the gather kernel */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
-    uint8_t *d_ctl = nullptr, *h_ctl = nullptr; /* ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
+    uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
     msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
@@ -103,7 +103,6 @@ struct msd_ctx {
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
     msd_wg_counts *d_counts = nullptr;
-    uint64_t *d_offsets = nullptr;
     uint32_t max_wg = 0, max_buffers = 0;
     /* Mode A/C candidate regions */
     msd_ac_hit *d_ac_regions = nullptr;
@@ -551,24 +550,16 @@ constexpr uint32_t SNAP_CAP = 64; /* filter membership versions of one batch kep
 struct GpuCtl {
     uint64_t *h_ts;
     uint32_t *h_valid, *h_snap, *h_todo;
-    const uint64_t *d_ts;
-    const uint32_t *d_valid, *d_snap, *d_todo;
-    size_t bytes;
 };
 
 GpuCtl gpu_ctl(const msd_ctx *c, const Slot &s)
 {
     const size_t N = c->max_buffers;
     GpuCtl g;
-    g.bytes = 28 * N;
     g.h_ts = reinterpret_cast<uint64_t *>(s.h_ctl);
     g.h_valid = reinterpret_cast<uint32_t *>(s.h_ctl + 16 * N);
     g.h_snap = g.h_valid + N;
     g.h_todo = g.h_snap + N;
-    g.d_ts = reinterpret_cast<const uint64_t *>(s.d_ctl);
-    g.d_valid = reinterpret_cast<const uint32_t *>(s.d_ctl + 16 * N);
-    g.d_snap = g.d_valid + N;
-    g.d_todo = g.d_snap + N;
     return g;
 }
 
@@ -1109,7 +1100,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_ctl); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
+        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_wire) (void)hipHostFree(s.h_wire);
@@ -1127,7 +1118,7 @@ void destroy(msd_ctx *c)
                 (void)hipEventDestroy(*e);
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
-    (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_offsets);
+    (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
     (void)hipFree(c->d_snaps);
@@ -1248,7 +1239,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_wg_counts)));
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_offsets), c->max_wg * 2 * sizeof(uint64_t)));
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
         c->ac_max_wg = (uint32_t)c->cu_count * 8u;
@@ -1305,7 +1295,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             }
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 4 + MSD_PRED_LIST)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ctl), ctl_bytes));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
             memset(s.h_ctl, 0, ctl_bytes);
             CK(hipEventCreateWithFlags(&s.ev_resolve, hipEventDisableTiming));
