@@ -793,7 +793,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     }
     auto e1 = tnow();
     msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), &s.h_wire[0].mm, sizeof(msd_wire), nullptr,
-                      c->out_buf.data(), &s.h_wire[0].power, sizeof(msd_wire), total);
+                      c->out_buf.data(), &s.h_wire[0].mm.signalLevel, sizeof(msd_wire), total);
     if (trace) {
         double cyc[8] = {0};
         for (uint32_t b = 0; b < n; ++b)

@@ -79,10 +79,11 @@ int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t st
 int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
                              const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals, unsigned long long *out,
                              hipStream_t stream);
-/* one accepted message as the emit kernel leaves it: the record and its signal power sum */
+/* one accepted message as the emit kernel leaves it: the record, with the 64-bit signal power sum
+ * sitting in the bytes of signalLevel until the host has turned it into the level (it needs the sum
+ * itself for the power statistics, and 8 bytes less per message cross PCIe) */
 typedef struct msd_wire {
     msd_message mm;
-    uint64_t power;
 } msd_wire;
 /* the accepted messages as dense records, cap entries (what does not fit is dropped; the host notices
  * from the counts) */

@@ -1084,7 +1084,8 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
             if (power_req ? !power_req[i] : mm->msgtype == 32)
                 continue; /* Mode A/C */
             const int signal_len = power_req ? (int)(power_req[i] & 0xffffu) : mm->msgbits * 12 / 5;
-            const uint64_t scaled = *(const uint64_t *)((const char *)power_base + i * power_stride);
+            uint64_t scaled; /* may sit in the bytes of mm->signalLevel (GPU resolve): no typed access */
+            memcpy(&scaled, (const char *)power_base + i * power_stride, sizeof scaled);
             /* demod_2400.c:386-408 */
             const double signal_power = scaled / 65535.0 / 65535.0;
             mm->signalLevel = signal_power / signal_len;

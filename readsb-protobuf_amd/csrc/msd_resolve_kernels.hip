@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             break; /* the host notices (total > cap), grows the arrays and emits again */
         msd_wire wr;
         wr.mm = mm;
-        wr.power = power[(size_t)b * MSD_RB_MSG_CAP + m];
+        wr.mm.signalLevel = __longlong_as_double((long long)power[(size_t)b * MSD_RB_MSG_CAP + m]); /* bits, not a value */
         dense[o + m] = wr;
         if (fields) { /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
             msd_fields f;
@@ -837,7 +837,6 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             mm.pad = 0;
             msd_wire wr;
             wr.mm = mm;
-            wr.power = 0;
             dense[o + nm + m] = wr;
             if (fields) {
                 /* the reference's one message record per buffer keeps the last decoded altitude
