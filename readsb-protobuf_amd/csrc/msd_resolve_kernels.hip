@@ -40,27 +40,37 @@ __device__ __forceinline__ uint32_t hash24(uint32_t a) /* icao_filter.c:44-65 */
     return h & (SLOTS - 1);
 }
 
-__device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint32_t start)
+/* linear probing from slot h; `stop` is the slot the probe started at (a full circle ends it) */
+__device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint32_t h, uint32_t stop)
 {
-    uint32_t h = start;
-    for (;;) {
+    while (h != stop) {
         const uint32_t v = t[h];
         if (v == addr)
             return true;
         if (v == VACANT)
             return false;
         h = (h + 1) & (SLOTS - 1);
-        if (h == start)
-            return false;
     }
+    return false;
 }
 
 /* icaoFilterTest (icao_filter.c:99-119) against a snapshot: two tables of 8192 slots.
- * bit 0: in table 0, bit 1: in table 1 */
+ * bit 0: in table 0, bit 1: in table 1.  The first slot of both tables is fetched at once (at the
+ * usual load that already decides both probes); only a collision walks on. */
 __device__ __forceinline__ uint32_t snap_probe(const uint32_t *snap, uint32_t addr)
 {
     const uint32_t start = hash24(addr);
-    return (table_has(snap, addr, start) ? 1u : 0u) | (table_has(snap + SLOTS, addr, start) ? 2u : 0u);
+    const uint32_t a = snap[start], b = snap[SLOTS + start];
+    uint32_t where = 0;
+    if (a == addr)
+        where |= 1u;
+    else if (a != VACANT && table_has(snap, addr, (start + 1) & (SLOTS - 1), start))
+        where |= 1u;
+    if (b == addr)
+        where |= 2u;
+    else if (b != VACANT && table_has(snap + SLOTS, addr, (start + 1) & (SLOTS - 1), start))
+        where |= 2u;
+    return where;
 }
 
 struct TryView {
