@@ -65,17 +65,49 @@ typedef struct msd_message {
  * looking into the ME / MB payloads (mode_s.c:557-715, decodeAC13Field / decodeID13Field :101-183), and
  * decodeModeAMessage for Mode A/C replies (mode_ac.c:168-202).  Unset fields are 0. */
 #define MSD_INVALID_ALTITUDE (-9999) /* readsb.h:130 */
+#define MSD_NON_ICAO_ADDRESS (1u << 24) /* readsb.h:197 */
 typedef struct msd_fields {
     int32_t altitude_baro;       /* feet; meaningful with altitude_baro_valid */
     uint16_t AC;                 /* 13-bit altitude code (DF0/4/16/20) */
     uint16_t ID;                 /* 13-bit identity code (DF5/21) */
-    uint16_t squawk;             /* four octal digits, hex-coded (DF5/21, Mode A/C) */
+    uint16_t squawk;             /* four octal digits, hex-coded (DF5/21, Mode A/C, ES types 23 and 28) */
     uint8_t altitude_baro_valid;
     uint8_t altitude_baro_unit;  /* 0 feet, 1 metres (never decoded, mode_s.c:178-182) */
     uint8_t squawk_valid;
     uint8_t airground;           /* readsb.pb-c.h:32-35: 0 not set, 1 ground, 2 airborne, 3 uncertain */
     uint8_t alert, alert_valid, spi, spi_valid;
     uint8_t CA, CC, CF, DR, FS, KE, ND, RI, SL, UM, VS;
+    uint8_t source;              /* datasource_t, readsb.h:133-142: 1 Mode A/C, 3 Mode S, 4 Mode S checked, 5 TIS-B,
+                                    6 ADS-R, 7 ADS-B */
+    uint8_t addrtype;            /* AIRCRAFT_META__ADDR_TYPE, readsb.pb-c.h:45-81 */
+    uint8_t imf;                 /* setIMF was applied (mode_s.c:770-792) */
+    uint32_t addr;               /* msd_message.addr, with MSD_NON_ICAO_ADDRESS where DF18 / IMF / Mode A/C say so */
+    /* ---- extended squitter payload, DF17/18 (mode_s.c:736-1058,1373-1474): identification, positions,
+     * velocity, test and status messages; target state (29) and operational status (31) are not decoded.
+     * Speeds, headings and movement are delivered as the integers the message carries (the reference
+     * turns them into floats with sqrtf / atan2 / fixed tables). ---- */
+    uint8_t metype, mesub;
+    uint8_t cpr_valid, cpr_type, cpr_odd; /* cpr_type_t, readsb.h:155: 0 surface, 1 airborne */
+    uint8_t nic_b_valid, nic_b;
+    uint8_t callsign_valid;
+    char callsign[8];            /* not NUL-terminated */
+    uint32_t cpr_lat, cpr_lon;   /* 17 bits each */
+    int32_t altitude_geom;
+    uint8_t altitude_geom_valid, altitude_geom_unit;
+    uint8_t category, category_valid;
+    uint8_t nac_v_valid, nac_v;
+    uint8_t velocity_valid;      /* ew_vel / ns_vel hold the signed components (knots, x4 already applied for subtype 2) */
+    uint8_t heading_valid;       /* heading_raw / heading_type: type 19 subtypes 3,4 (x 360/1024) or surface (x 360/128) */
+    int16_t ew_vel, ns_vel;
+    uint16_t heading_raw;
+    uint8_t heading_type;        /* heading_type_t, readsb.h:158-165; ground track from ew/ns is not derived here */
+    uint8_t movement;            /* surface movement code 1..124, 0 = not available (mode_s.c:910-915) */
+    uint16_t ias, tas;
+    uint8_t ias_valid, tas_valid, baro_rate_valid, geom_rate_valid;
+    int16_t baro_rate, geom_rate; /* ft/min */
+    int16_t geom_delta;          /* ft */
+    uint8_t geom_delta_valid;
+    uint8_t emergency_valid, emergency; /* ES type 28 subtype 1 */
     uint8_t pad[3];
 } msd_fields;
 

@@ -619,11 +619,248 @@ int orc_decode_ac13(unsigned AC13Field, int *unit) /* mode_s.c:152-183 */
     return n < -12 ? ORC_INVALID_ALTITUDE : 100 * n;
 }
 
+static int decode_ac12(unsigned AC12Field) /* mode_s.c:187-208 */
+{
+    if (AC12Field & 0x10) {
+        const int n = (int)(((AC12Field & 0x0FE0) >> 1) | (AC12Field & 0x000F));
+        return n * 25 - 1000;
+    }
+    int n = (int)(((AC12Field & 0x0FC0) << 1) | (AC12Field & 0x003F));
+    n = orc_mode_a_to_mode_c(orc_decode_id13((unsigned)n));
+    return n < -12 ? ORC_INVALID_ALTITUDE : 100 * n;
+}
+
+enum { AT_ADSB_ICAO, AT_ADSB_ICAO_NT, AT_ADSR_ICAO, AT_TISB_ICAO, AT_ADSB_OTHER, AT_ADSR_OTHER, AT_TISB_TRACKFILE,
+       AT_TISB_OTHER, AT_MODE_A, AT_UNKNOWN };                   /* readsb.pb-c.h:45-81 */
+enum { SRC_MODE_AC = 1, SRC_MODE_S = 3, SRC_MODE_S_CHECKED = 4, SRC_TISB = 5, SRC_ADSR = 6, SRC_ADSB = 7 }; /* readsb.h:133-142 */
+#define NON_ICAO 0x01000000u /* readsb.h:197 */
+
+static void set_imf(orc_fields *f) /* mode_s.c:770-792 */
+{
+    f->addr |= NON_ICAO;
+    f->imf = 1;
+    switch (f->addrtype) {
+    case AT_ADSB_ICAO: case AT_ADSB_ICAO_NT: f->addrtype = AT_ADSB_OTHER; break;
+    case AT_TISB_ICAO: f->addrtype = AT_TISB_TRACKFILE; break;
+    case AT_ADSR_ICAO: f->addrtype = AT_ADSR_OTHER; break;
+    default: break;
+    }
+}
+
+static const char ais_charset[64] = "@ABCDEFGHIJKLMNOPQRSTUVWXYZ[\\]^_ !\"#$%&'()*+,-./0123456789:;<=>?"; /* ais_charset.c */
+
+static void es_ident(const uint8_t *me, orc_fields *f) /* mode_s.c:736-766 */
+{
+    f->mesub = (uint8_t)getbits(me, 6, 8);
+    for (unsigned i = 0; i < 8; ++i)
+        f->callsign[i] = ais_charset[getbits(me, 9 + 6 * i, 14 + 6 * i)];
+    f->callsign_valid = 1;
+    for (unsigned i = 0; i < 8; ++i) {
+        const char c = f->callsign[i];
+        if (!(c >= 'A' && c <= 'Z') && !(c >= '0' && c <= '9') && c != ' ') {
+            f->callsign_valid = 0;
+            break;
+        }
+    }
+    f->category = (uint8_t)(((0x0E - f->metype) << 4) | f->mesub);
+    f->category_valid = 1;
+}
+
+static void es_velocity(const uint8_t *me, orc_fields *f, int check_imf) /* mode_s.c:794-900 */
+{
+    f->mesub = (uint8_t)getbits(me, 6, 8);
+    if (f->mesub < 1 || f->mesub > 4)
+        return;
+    if (check_imf && getbits(me, 9, 9))
+        set_imf(f);
+    f->nac_v_valid = 1;
+    f->nac_v = (uint8_t)getbits(me, 11, 13);
+    switch (f->mesub) {
+    case 1: case 2: {
+        const unsigned ew_raw = getbits(me, 15, 24), ns_raw = getbits(me, 26, 35);
+        if (ew_raw && ns_raw) {
+            const int ew_vel = (int)(ew_raw - 1) * (getbits(me, 14, 14) ? -1 : 1) * ((f->mesub == 2) ? 4 : 1);
+            const int ns_vel = (int)(ns_raw - 1) * (getbits(me, 25, 25) ? -1 : 1) * ((f->mesub == 2) ? 4 : 1);
+            f->ew_vel = (int16_t)ew_vel; /* gs = sqrtf(ns^2 + ew^2 + 0.5), track = atan2(ew, ns): left to the caller */
+            f->ns_vel = (int16_t)ns_vel;
+            f->velocity_valid = 1;
+        }
+        break;
+    }
+    default: {
+        if (getbits(me, 14, 14)) {
+            f->heading_valid = 1;
+            f->heading_raw = (uint16_t)getbits(me, 15, 24); /* x 360 / 1024 */
+            f->heading_type = 4;
+        }
+        const unsigned airspeed = getbits(me, 26, 35);
+        if (airspeed) {
+            const unsigned speed = (airspeed - 1) * (f->mesub == 4 ? 4 : 1);
+            if (getbits(me, 25, 25)) {
+                f->tas_valid = 1;
+                f->tas = (uint16_t)speed;
+            } else {
+                f->ias_valid = 1;
+                f->ias = (uint16_t)speed;
+            }
+        }
+        break;
+    }
+    }
+    const unsigned vert_rate = getbits(me, 38, 46);
+    if (vert_rate) {
+        const int rate = (int)(vert_rate - 1) * (getbits(me, 37, 37) ? -64 : 64);
+        if (getbits(me, 36, 36)) {
+            f->baro_rate = (int16_t)rate;
+            f->baro_rate_valid = 1;
+        } else {
+            f->geom_rate = (int16_t)rate;
+            f->geom_rate_valid = 1;
+        }
+    }
+    const unsigned raw_delta = getbits(me, 50, 56);
+    if (raw_delta) {
+        f->geom_delta_valid = 1;
+        f->geom_delta = (int16_t)((int)(raw_delta - 1) * (getbits(me, 49, 49) ? -25 : 25));
+    }
+}
+
+static void es_surface(const uint8_t *me, orc_fields *f, int check_imf) /* mode_s.c:902-937 */
+{
+    f->airground = 1;
+    f->cpr_valid = 1;
+    f->cpr_type = 0; /* CPR_SURFACE */
+    const unsigned movement = getbits(me, 6, 12);
+    if (movement > 0 && movement < 125)
+        f->movement = (uint8_t)movement; /* gs via decodeMovementFieldV0/V2: left to the caller */
+    if (getbits(me, 13, 13)) {
+        f->heading_valid = 1;
+        f->heading_raw = (uint16_t)getbits(me, 14, 20); /* x 360 / 128 */
+        f->heading_type = 5;
+    }
+    if (check_imf && getbits(me, 21, 21))
+        set_imf(f);
+    f->cpr_odd = (uint8_t)getbits(me, 22, 22);
+    f->cpr_lat = getbits(me, 23, 39);
+    f->cpr_lon = getbits(me, 40, 56);
+}
+
+static void es_airborne(const uint8_t *me, orc_fields *f, int check_imf) /* mode_s.c:939-1022 */
+{
+    switch (getbits(me, 6, 7)) {
+    case 0:
+        f->alert_valid = f->spi_valid = 1;
+        f->alert = f->spi = 0;
+        break;
+    case 1: case 2:
+        f->alert_valid = 1;
+        f->alert = 1;
+        break;
+    case 3:
+        f->alert_valid = f->spi_valid = 1;
+        f->alert = 0;
+        f->spi = 1;
+        break;
+    }
+    if (check_imf) {
+        if (getbits(me, 8, 8))
+            set_imf(f);
+    } else {
+        f->nic_b_valid = 1;
+        f->nic_b = (uint8_t)getbits(me, 8, 8);
+    }
+    const unsigned AC12Field = getbits(me, 9, 20);
+    if (f->metype != 0) {
+        f->cpr_lat = getbits(me, 23, 39);
+        f->cpr_lon = getbits(me, 40, 56);
+        if (AC12Field == 0 && f->cpr_lon == 0 && (f->cpr_lat & 0x0fff) == 0 && f->metype == 15) {
+            /* stats cpr_filtered++ in the reference */
+        } else {
+            f->cpr_valid = 1;
+            f->cpr_type = 1; /* CPR_AIRBORNE */
+            f->cpr_odd = (uint8_t)getbits(me, 22, 22);
+        }
+    }
+    if (AC12Field && f->airground != 1) {
+        const int alt = decode_ac12(AC12Field);
+        if (alt != ORC_INVALID_ALTITUDE) {
+            if (f->metype == 20 || f->metype == 21 || f->metype == 22) {
+                f->altitude_geom = alt;
+                f->altitude_geom_unit = 0;
+                f->altitude_geom_valid = 1;
+            } else {
+                f->altitude_baro = alt;
+                f->altitude_baro_unit = 0;
+                f->altitude_baro_valid = 1;
+            }
+        }
+    }
+}
+
+static void extended_squitter(const orc_message *mm, orc_fields *f) /* mode_s.c:1373-1474 */
+{
+    const uint8_t *me = mm->msg + 4;
+    const unsigned metype = getbits(me, 1, 5);
+    int check_imf = 0;
+    f->metype = (uint8_t)metype;
+    if (mm->msgtype == 18) {
+        switch (f->CF) {
+        case 0: f->addrtype = AT_ADSB_ICAO_NT; break;
+        case 1: f->addrtype = AT_ADSB_OTHER; f->addr |= NON_ICAO; break;
+        case 2: f->source = SRC_TISB; f->addrtype = AT_TISB_ICAO; check_imf = 1; break;
+        case 3:
+            f->source = SRC_TISB;
+            f->addrtype = AT_TISB_ICAO;
+            if (getbits(me, 1, 1))
+                set_imf(f);
+            return;
+        case 5: f->addrtype = AT_TISB_OTHER; f->source = SRC_TISB; f->addr |= NON_ICAO; break;
+        case 6: f->addrtype = AT_ADSR_ICAO; f->source = SRC_ADSR; check_imf = 1; break;
+        default: f->addrtype = AT_UNKNOWN; f->addr |= NON_ICAO; return;
+        }
+    }
+    switch (metype) {
+    case 1: case 2: case 3: case 4: es_ident(me, f); break;
+    case 19: es_velocity(me, f, check_imf); break;
+    case 5: case 6: case 7: case 8: es_surface(me, f, check_imf); break;
+    case 0: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18:
+    case 20: case 21: case 22: es_airborne(me, f, check_imf); break;
+    case 23: /* test message, mode_s.c:1024-1036 */
+        f->mesub = (uint8_t)getbits(me, 6, 8);
+        if (f->mesub == 7) {
+            const unsigned ID13Field = getbits(me, 9, 21);
+            if (ID13Field) {
+                f->squawk_valid = 1;
+                f->squawk = (uint16_t)orc_decode_id13(ID13Field);
+            }
+        }
+        break;
+    case 28: /* aircraft status, mode_s.c:1038-1057 */
+        f->mesub = (uint8_t)getbits(me, 6, 8);
+        if (f->mesub == 1) {
+            f->emergency_valid = 1;
+            f->emergency = (uint8_t)getbits(me, 9, 11);
+            const unsigned ID13Field = getbits(me, 12, 24);
+            if (ID13Field) {
+                f->squawk_valid = 1;
+                f->squawk = (uint16_t)orc_decode_id13(ID13Field);
+            }
+            if (check_imf && getbits(me, 56, 56))
+                set_imf(f);
+        }
+        break;
+    default: /* 29 and 31 are not restated; 24, 30 and the rest carry nothing the reference decodes */
+        break;
+    }
+}
+
 static void fields_mode_s(const orc_message *mm, orc_fields *f) /* mode_s.c:557-715 */
 {
     const uint8_t *msg = mm->msg;
     const int t = mm->msgtype;
     memset(f, 0, sizeof *f);
+    f->addr = mm->addr;
+    f->source = (t == 11) ? SRC_MODE_S_CHECKED : ((t == 17 || t == 18) ? SRC_ADSB : SRC_MODE_S); /* mode_s.c:447-551 */
     if (t == 0 || t == 4 || t == 16 || t == 20) {
         f->AC = (uint16_t)getbits(msg, 20, 32);
         if (f->AC) {
@@ -676,11 +913,16 @@ static void fields_mode_s(const orc_message *mm, orc_fields *f) /* mode_s.c:557-
         f->VS = (uint8_t)getbits(msg, 6, 6);
         f->airground = f->VS ? 1 : 3;
     }
+    if (t == 17 || t == 18)
+        extended_squitter(mm, f);
 }
 
 /* decodeModeAMessage (mode_ac.c:168-202) on the record demodulate2400AC reuses within a buffer */
 static void fields_mode_ac(orc_fields *mm, unsigned ModeA)
 {
+    mm->source = 1;   /* SOURCE_MODE_AC */
+    mm->addrtype = 8; /* ADDR_MODE_A */
+    mm->addr = (ModeA & 0x0000FF7F) | 0x01000000u;
     mm->squawk = (uint16_t)(ModeA & 0x7777);
     mm->squawk_valid = 1;
     mm->spi = (ModeA & 0x0080) ? 1 : 0;

@@ -117,6 +117,32 @@ typedef struct orc_fields {
     uint8_t airground; /* readsb.pb-c.h:32-35: 0 invalid, 1 ground, 2 airborne, 3 uncertain */
     uint8_t alert, alert_valid, spi, spi_valid;
     uint8_t CA, CC, CF, DR, FS, KE, ND, RI, SL, UM, VS;
+    uint8_t source, addrtype, imf;
+    uint32_t addr;
+    /* extended squitter (decodeExtendedSquitter, mode_s.c:1373-1474, without types 29 and 31); speeds,
+     * headings and movement as the integers the message carries */
+    uint8_t metype, mesub;
+    uint8_t cpr_valid, cpr_type, cpr_odd;
+    uint8_t nic_b_valid, nic_b;
+    uint8_t callsign_valid;
+    char callsign[8];
+    uint32_t cpr_lat, cpr_lon;
+    int32_t altitude_geom;
+    uint8_t altitude_geom_valid, altitude_geom_unit;
+    uint8_t category, category_valid;
+    uint8_t nac_v_valid, nac_v;
+    uint8_t velocity_valid;
+    uint8_t heading_valid;
+    int16_t ew_vel, ns_vel;
+    uint16_t heading_raw;
+    uint8_t heading_type;
+    uint8_t movement;
+    uint16_t ias, tas;
+    uint8_t ias_valid, tas_valid, baro_rate_valid, geom_rate_valid;
+    int16_t baro_rate, geom_rate;
+    int16_t geom_delta;
+    uint8_t geom_delta_valid;
+    uint8_t emergency_valid, emergency;
     uint8_t pad[3];
 } orc_fields;
 /* From now on orc_replay / orc_demod_buffer also write the fields of message i to fields[i] (i < cap). */

@@ -43,10 +43,19 @@ FIELDS_DTYPE = np.dtype(
     [("altitude_baro", "<i4"), ("AC", "<u2"), ("ID", "<u2"), ("squawk", "<u2"), ("altitude_baro_valid", "u1"),
      ("altitude_baro_unit", "u1"), ("squawk_valid", "u1"), ("airground", "u1"), ("alert", "u1"), ("alert_valid", "u1"),
      ("spi", "u1"), ("spi_valid", "u1"), ("CA", "u1"), ("CC", "u1"), ("CF", "u1"), ("DR", "u1"), ("FS", "u1"),
-     ("KE", "u1"), ("ND", "u1"), ("RI", "u1"), ("SL", "u1"), ("UM", "u1"), ("VS", "u1"), ("pad", "u1", (3,))],
+     ("KE", "u1"), ("ND", "u1"), ("RI", "u1"), ("SL", "u1"), ("UM", "u1"), ("VS", "u1"), ("source", "u1"),
+     ("addrtype", "u1"), ("imf", "u1"), ("addr", "<u4"), ("metype", "u1"), ("mesub", "u1"), ("cpr_valid", "u1"),
+     ("cpr_type", "u1"), ("cpr_odd", "u1"), ("nic_b_valid", "u1"), ("nic_b", "u1"), ("callsign_valid", "u1"),
+     ("callsign", "S8"), ("cpr_lat", "<u4"), ("cpr_lon", "<u4"), ("altitude_geom", "<i4"),
+     ("altitude_geom_valid", "u1"), ("altitude_geom_unit", "u1"), ("category", "u1"), ("category_valid", "u1"),
+     ("nac_v_valid", "u1"), ("nac_v", "u1"), ("velocity_valid", "u1"), ("heading_valid", "u1"), ("ew_vel", "<i2"),
+     ("ns_vel", "<i2"), ("heading_raw", "<u2"), ("heading_type", "u1"), ("movement", "u1"), ("ias", "<u2"),
+     ("tas", "<u2"), ("ias_valid", "u1"), ("tas_valid", "u1"), ("baro_rate_valid", "u1"), ("geom_rate_valid", "u1"),
+     ("baro_rate", "<i2"), ("geom_rate", "<i2"), ("geom_delta", "<i2"), ("geom_delta_valid", "u1"),
+     ("emergency_valid", "u1"), ("emergency", "u1"), ("pad", "u1", (3,))],
     align=True,
 )
-assert FIELDS_DTYPE.itemsize == 32
+assert FIELDS_DTYPE.itemsize == 100
 CFG_DECODE_FIELDS = 1
 INVALID_ALTITUDE = -9999
 

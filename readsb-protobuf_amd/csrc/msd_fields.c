@@ -8,7 +8,7 @@ void msd_decode_fields(const msd_message *mm, const msd_fields *carry, msd_field
     if (mm->msgtype == 32)
         msd_fields_mode_ac(((uint32_t)mm->msg[0] << 8) | mm->msg[1], carry, out);
     else
-        msd_fields_mode_s(mm->msg, mm->msgtype, out);
+        msd_fields_mode_s(mm->msg, mm->msgtype, mm->addr, out);
 }
 
 /* a whole batch on the host (the paths that resolve on host threads): msgs[i] belongs to buffer[i] */

@@ -2,7 +2,9 @@
  * (device) and the host paths: what decodeModesMessage fills in after its CRC switch without looking
  * into the ME / MB payloads (mode_s.c:557-715), decodeAC13Field / decodeID13Field (mode_s.c:101-183),
  * the Gillham altitude of mode_ac.c:101-163, and decodeModeAMessage (mode_ac.c:168-202).
- * SURVEY.md 8(f) rank 1, first stage; extended squitter and Comm-B payloads are not decoded here. */
+ * Second stage: the extended squitter payload of DF17/18 (decodeExtendedSquitter, mode_s.c:736-1058,
+ * 1373-1474) except target state (type 29) and operational status (type 31); Comm-B is not decoded.
+ * SURVEY.md 8(f) rank 1. */
 #ifndef MSD_FIELDS_IMPL_H
 #define MSD_FIELDS_IMPL_H
 
@@ -94,12 +96,207 @@ MSD_HD int32_t msd_ac13_altitude(uint32_t ac13, uint8_t *unit)
     return 100 * n;
 }
 
-/* a Mode S message (msgtype 0..31, corrected bytes) */
-MSD_HD void msd_fields_mode_s(const uint8_t *msg, uint32_t df, msd_fields *f)
+/* 12-bit altitude code of the airborne position squitter (mode_s.c:187-208): always feet */
+MSD_HD int32_t msd_ac12_altitude(uint32_t ac12)
+{
+    if (ac12 & 0x10u) /* Q bit */
+        return (int32_t)(((ac12 & 0x0FE0u) >> 1) | (ac12 & 0x000Fu)) * 25 - 1000;
+    const int32_t n = msd_mode_a_to_c(msd_id13_to_squawk(((ac12 & 0x0FC0u) << 1) | (ac12 & 0x003Fu)));
+    return n < -12 ? MSD_INVALID_ALTITUDE : 100 * n;
+}
+
+/* setIMF (mode_s.c:770-792): the address is not an ICAO address after all */
+MSD_HD void msd_fields_set_imf(msd_fields *f)
+{
+    f->addr |= MSD_NON_ICAO_ADDRESS;
+    f->imf = 1;
+    if (f->addrtype == 0 || f->addrtype == 1)
+        f->addrtype = 4; /* ADSB_ICAO / ADSB_ICAO_NT -> ADSB_OTHER */
+    else if (f->addrtype == 3)
+        f->addrtype = 6; /* TISB_ICAO -> TISB_TRACKFILE */
+    else if (f->addrtype == 2)
+        f->addrtype = 5; /* ADSR_ICAO -> ADSR_OTHER */
+}
+
+/* decodeExtendedSquitter (mode_s.c:1373-1474) and the per-type decoders it calls; me = msg + 4.
+ * f already holds the header fields (CF for DF18, airground from CA for DF17). */
+MSD_HD void msd_fields_es(const uint8_t *me, uint32_t df, msd_fields *f)
+{
+    const uint32_t metype = msd_field_bits(me, 1, 5);
+    int check_imf = 0;
+    f->metype = (uint8_t)metype;
+    if (df == 18) {
+        switch (f->CF) {
+        case 0: f->addrtype = 1; break;                                   /* ADS-B, non-transponder device */
+        case 1: f->addrtype = 4; f->addr |= MSD_NON_ICAO_ADDRESS; break;  /* anonymous / vehicle / obstruction */
+        case 2: f->source = 5; f->addrtype = 3; check_imf = 1; break;     /* fine TIS-B */
+        case 3:                                                           /* coarse TIS-B: only the IMF bit */
+            f->source = 5;
+            f->addrtype = 3;
+            if (msd_field_bits(me, 1, 1))
+                msd_fields_set_imf(f);
+            return;
+        case 5: f->addrtype = 7; f->source = 5; f->addr |= MSD_NON_ICAO_ADDRESS; break; /* TIS-B, non-ICAO */
+        case 6: f->addrtype = 2; f->source = 6; check_imf = 1; break;     /* ADS-R */
+        default:
+            f->addrtype = 9;
+            f->addr |= MSD_NON_ICAO_ADDRESS;
+            return;
+        }
+    }
+    if (metype >= 1 && metype <= 4) { /* identification and category, mode_s.c:736-766 */
+        const char *ais = "@ABCDEFGHIJKLMNOPQRSTUVWXYZ[\\]^_ !\"#$%&'()*+,-./0123456789:;<=>?"; /* ais_charset.c */
+        f->mesub = (uint8_t)msd_field_bits(me, 6, 8);
+        f->callsign_valid = 1;
+        for (int i = 0; i < 8; ++i) {
+            const char c = ais[msd_field_bits(me, 9 + 6 * i, 14 + 6 * i)];
+            f->callsign[i] = c;
+            if (!((c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == ' '))
+                f->callsign_valid = 0;
+        }
+        f->category = (uint8_t)(((0x0Eu - metype) << 4) | f->mesub);
+        f->category_valid = 1;
+    } else if (metype == 19) { /* airborne velocity, mode_s.c:794-900 */
+        f->mesub = (uint8_t)msd_field_bits(me, 6, 8);
+        if (f->mesub < 1 || f->mesub > 4)
+            return;
+        if (check_imf && msd_field_bits(me, 9, 9))
+            msd_fields_set_imf(f);
+        f->nac_v_valid = 1;
+        f->nac_v = (uint8_t)msd_field_bits(me, 11, 13);
+        if (f->mesub <= 2) {
+            const int32_t ew_raw = (int32_t)msd_field_bits(me, 15, 24), ns_raw = (int32_t)msd_field_bits(me, 26, 35);
+            if (ew_raw && ns_raw) {
+                const int32_t scale = f->mesub == 2 ? 4 : 1;
+                f->ew_vel = (int16_t)((ew_raw - 1) * (msd_field_bits(me, 14, 14) ? -1 : 1) * scale);
+                f->ns_vel = (int16_t)((ns_raw - 1) * (msd_field_bits(me, 25, 25) ? -1 : 1) * scale);
+                f->velocity_valid = 1;
+            }
+        } else {
+            if (msd_field_bits(me, 14, 14)) {
+                f->heading_valid = 1;
+                f->heading_raw = (uint16_t)msd_field_bits(me, 15, 24);
+                f->heading_type = 4; /* HEADING_MAGNETIC_OR_TRUE */
+            }
+            const uint32_t airspeed = msd_field_bits(me, 26, 35);
+            if (airspeed) {
+                const uint32_t speed = (airspeed - 1) * (f->mesub == 4 ? 4u : 1u);
+                if (msd_field_bits(me, 25, 25)) {
+                    f->tas_valid = 1;
+                    f->tas = (uint16_t)speed;
+                } else {
+                    f->ias_valid = 1;
+                    f->ias = (uint16_t)speed;
+                }
+            }
+        }
+        const int32_t vert_rate = (int32_t)msd_field_bits(me, 38, 46);
+        if (vert_rate) {
+            const int32_t rate = (vert_rate - 1) * (msd_field_bits(me, 37, 37) ? -64 : 64);
+            if (msd_field_bits(me, 36, 36)) {
+                f->baro_rate = (int16_t)rate;
+                f->baro_rate_valid = 1;
+            } else {
+                f->geom_rate = (int16_t)rate;
+                f->geom_rate_valid = 1;
+            }
+        }
+        const int32_t raw_delta = (int32_t)msd_field_bits(me, 50, 56);
+        if (raw_delta) {
+            f->geom_delta_valid = 1;
+            f->geom_delta = (int16_t)((raw_delta - 1) * (msd_field_bits(me, 49, 49) ? -25 : 25));
+        }
+    } else if (metype >= 5 && metype <= 8) { /* surface position, mode_s.c:902-937 */
+        f->airground = 1;
+        f->cpr_valid = 1;
+        f->cpr_type = 0;
+        const uint32_t movement = msd_field_bits(me, 6, 12);
+        if (movement > 0 && movement < 125)
+            f->movement = (uint8_t)movement;
+        if (msd_field_bits(me, 13, 13)) {
+            f->heading_valid = 1;
+            f->heading_raw = (uint16_t)msd_field_bits(me, 14, 20);
+            f->heading_type = 5; /* HEADING_TRACK_OR_HEADING */
+        }
+        if (check_imf && msd_field_bits(me, 21, 21))
+            msd_fields_set_imf(f);
+        f->cpr_odd = (uint8_t)msd_field_bits(me, 22, 22);
+        f->cpr_lat = msd_field_bits(me, 23, 39);
+        f->cpr_lon = msd_field_bits(me, 40, 56);
+    } else if (metype == 0 || (metype >= 9 && metype <= 18) || (metype >= 20 && metype <= 22)) {
+        /* airborne position, mode_s.c:939-1022 */
+        switch (msd_field_bits(me, 6, 7)) { /* surveillance status */
+        case 0: f->alert_valid = f->spi_valid = 1; f->alert = f->spi = 0; break;
+        case 1: case 2: f->alert_valid = 1; f->alert = 1; break;
+        default: f->alert_valid = f->spi_valid = 1; f->alert = 0; f->spi = 1; break;
+        }
+        if (check_imf) {
+            if (msd_field_bits(me, 8, 8))
+                msd_fields_set_imf(f);
+        } else {
+            f->nic_b_valid = 1;
+            f->nic_b = (uint8_t)msd_field_bits(me, 8, 8);
+        }
+        const uint32_t ac12 = msd_field_bits(me, 9, 20);
+        if (metype != 0) {
+            f->cpr_lat = msd_field_bits(me, 23, 39);
+            f->cpr_lon = msd_field_bits(me, 40, 56);
+            /* a known transmitter fault: altitude 0, longitude 0, type 15, zeros in the latitude LSBs */
+            if (!(ac12 == 0 && f->cpr_lon == 0 && (f->cpr_lat & 0x0fffu) == 0 && metype == 15)) {
+                f->cpr_valid = 1;
+                f->cpr_type = 1;
+                f->cpr_odd = (uint8_t)msd_field_bits(me, 22, 22);
+            }
+        }
+        if (ac12 && f->airground != 1) {
+            const int32_t alt = msd_ac12_altitude(ac12);
+            if (alt != MSD_INVALID_ALTITUDE) {
+                if (metype >= 20) {
+                    f->altitude_geom = alt;
+                    f->altitude_geom_unit = 0;
+                    f->altitude_geom_valid = 1;
+                } else {
+                    f->altitude_baro = alt;
+                    f->altitude_baro_unit = 0;
+                    f->altitude_baro_valid = 1;
+                }
+            }
+        }
+    } else if (metype == 23) { /* test message, mode_s.c:1024-1036 */
+        f->mesub = (uint8_t)msd_field_bits(me, 6, 8);
+        if (f->mesub == 7) {
+            const uint32_t id13 = msd_field_bits(me, 9, 21);
+            if (id13) {
+                f->squawk_valid = 1;
+                f->squawk = (uint16_t)msd_id13_to_squawk(id13);
+            }
+        }
+    } else if (metype == 28) { /* aircraft status, mode_s.c:1038-1057 */
+        f->mesub = (uint8_t)msd_field_bits(me, 6, 8);
+        if (f->mesub == 1) {
+            f->emergency_valid = 1;
+            f->emergency = (uint8_t)msd_field_bits(me, 9, 11);
+            const uint32_t id13 = msd_field_bits(me, 12, 24);
+            if (id13) {
+                f->squawk_valid = 1;
+                f->squawk = (uint16_t)msd_id13_to_squawk(id13);
+            }
+            if (check_imf && msd_field_bits(me, 56, 56))
+                msd_fields_set_imf(f);
+        }
+    }
+    /* 29 (target state and status) and 31 (operational status) are not decoded; 24, 30 and the rest
+     * carry nothing the reference decodes either */
+}
+
+/* a Mode S message (msgtype 0..31, corrected bytes); addr = msd_message.addr */
+MSD_HD void msd_fields_mode_s(const uint8_t *msg, uint32_t df, uint32_t addr, msd_fields *f)
 {
     uint8_t *z = (uint8_t *)f;
     for (unsigned i = 0; i < sizeof *f; ++i)
         z[i] = 0;
+    f->addr = addr;
+    f->source = df == 11 ? 4 : ((df == 17 || df == 18) ? 7 : 3); /* the CRC switch, mode_s.c:447-551 */
     if (df == 0 || df == 4 || df == 16 || df == 20) { /* AC, mode_s.c:565-572 */
         f->AC = (uint16_t)msd_field_bits(msg, 20, 32);
         if (f->AC) {
@@ -147,6 +344,8 @@ MSD_HD void msd_fields_mode_s(const uint8_t *msg, uint32_t df, msd_fields *f)
         f->VS = (uint8_t)msd_field_bits(msg, 6, 6);
         f->airground = f->VS ? 1 : 3;
     }
+    if (df == 17 || df == 18) /* ME, mode_s.c:678-682 */
+        msd_fields_es(msg + 4, df, f);
 }
 
 /* a Mode A/C reply (mode_ac.c:168-202).  `carry` is the state demodulate2400AC's message record is in
@@ -158,6 +357,9 @@ MSD_HD void msd_fields_mode_ac(uint32_t mode_a, const msd_fields *carry, msd_fie
     uint8_t *z = (uint8_t *)f;
     for (unsigned i = 0; i < sizeof *f; ++i)
         z[i] = 0;
+    f->addr = (mode_a & 0x0000FF7Fu) | MSD_NON_ICAO_ADDRESS;
+    f->source = 1;   /* SOURCE_MODE_AC */
+    f->addrtype = 8; /* ADDR_MODE_A */
     if (carry) {
         f->altitude_baro = carry->altitude_baro;
         f->altitude_baro_valid = carry->altitude_baro_valid;

@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         dense[o + m] = wr;
         if (fields) { /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
             msd_fields f;
-            msd_fields_mode_s(mm.msg, df, &f);
+            msd_fields_mode_s(mm.msg, df, mm.addr, &f);
             fields[o + m] = f;
         }
     }

@@ -11,7 +11,12 @@ from helpers import load_golden
 
 FIELD_NAMES = ("altitude_baro", "AC", "ID", "squawk", "altitude_baro_valid", "altitude_baro_unit", "squawk_valid",
                "airground", "alert", "alert_valid", "spi", "spi_valid", "CA", "CC", "CF", "DR", "FS", "KE", "ND", "RI",
-               "SL", "UM", "VS")
+               "SL", "UM", "VS", "source", "addrtype", "imf", "addr", "metype", "mesub", "cpr_valid", "cpr_type",
+               "cpr_odd", "nic_b_valid", "nic_b", "callsign_valid", "callsign", "cpr_lat", "cpr_lon", "altitude_geom",
+               "altitude_geom_valid", "altitude_geom_unit", "category", "category_valid", "nac_v_valid", "nac_v",
+               "velocity_valid", "heading_valid", "ew_vel", "ns_vel", "heading_raw", "heading_type", "movement", "ias",
+               "tas", "ias_valid", "tas_valid", "baro_rate_valid", "geom_rate_valid", "baro_rate", "geom_rate",
+               "geom_delta", "geom_delta_valid", "emergency_valid", "emergency")
 
 
 def code_bits(code13):
@@ -153,6 +158,90 @@ def test_mode_ac_reply_fields_and_altitude_carry(pkg):
     assert pkg.capi.decode_fields(ac(0x7777))["altitude_baro_valid"] == 0
     d = pkg.capi.decode_fields(ac(0x06A0), carry=b)  # ident pulse: SPI, no altitude of its own (mode_ac.c:186-197)
     assert (d["spi"], d["squawk"], d["altitude_baro"], d["altitude_baro_valid"]) == (1, 0x0620, 100, 1)
+
+
+def es_record(pkg, hexmsg):
+    rec = np.zeros(1, dtype=pkg.capi.MESSAGE_DTYPE)
+    raw = bytes.fromhex(hexmsg)
+    rec["msg"][0, : len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    rec["msgtype"] = raw[0] >> 3
+    rec["msgbits"] = 8 * len(raw)
+    rec["addr"] = int.from_bytes(raw[1:4], "big")
+    return rec[0]
+
+
+def test_extended_squitter_published_examples(pkg):
+    """Messages and decoded values from the public ADS-B decoding literature (J. Sun, 'The 1090 MHz riddle')."""
+    f = pkg.capi.decode_fields(es_record(pkg, "8D4840D6202CC371C32CE0576098"))  # identification
+    assert (f["metype"], f["callsign_valid"], f["callsign"], f["category"], f["category_valid"]) == \
+           (4, 1, b"KLM1023 ", 0xA0, 1)
+    assert (f["source"], f["addrtype"], f["addr"], f["CA"], f["airground"]) == (7, 0, 0x4840D6, 5, 2)
+    even = pkg.capi.decode_fields(es_record(pkg, "8D40621D58C382D690C8AC2863A7"))  # airborne position, even frame
+    odd = pkg.capi.decode_fields(es_record(pkg, "8D40621D58C386435CC412692AD6"))   # odd frame of the pair
+    for f, is_odd, lat, lon in ((even, 0, 93000, 51372), (odd, 1, 74158, 50194)):
+        assert (f["metype"], f["cpr_valid"], f["cpr_type"], f["cpr_odd"], f["cpr_lat"], f["cpr_lon"]) == \
+               (11, 1, 1, is_odd, lat, lon)
+        assert (f["altitude_baro"], f["altitude_baro_valid"], f["altitude_geom_valid"]) == (38000, 1, 0)
+        assert (f["alert_valid"], f["alert"], f["spi_valid"], f["spi"], f["nic_b_valid"]) == (1, 0, 1, 0, 1)
+    v = pkg.capi.decode_fields(es_record(pkg, "8D485020994409940838175B284F"))  # velocity, subtype 1 (ground speed)
+    assert (v["metype"], v["mesub"], v["velocity_valid"], v["ew_vel"], v["ns_vel"]) == (19, 1, 1, -8, -159)
+    assert abs(np.hypot(-8.0, -159.0) - 159.20) < 0.01                       # 159.20 kt ...
+    assert abs(np.degrees(np.arctan2(-8.0, -159.0)) % 360 - 182.88) < 0.01   # ... on track 182.88 deg
+    assert (v["geom_rate_valid"], v["geom_rate"], v["baro_rate_valid"]) == (1, -832, 0)
+    assert (v["geom_delta_valid"], v["geom_delta"]) == (1, 550)
+    a = pkg.capi.decode_fields(es_record(pkg, "8DA05F219B06B6AF189400CBC33F"))  # velocity, subtype 3 (airspeed)
+    assert (a["metype"], a["mesub"], a["heading_valid"], a["heading_type"], a["velocity_valid"]) == (19, 3, 1, 4, 0)
+    assert abs(a["heading_raw"] * 360.0 / 1024.0 - 243.98) < 0.01
+    assert (a["tas_valid"], a["tas"], a["ias_valid"]) == (1, 375, 0)
+    assert (a["baro_rate_valid"], a["baro_rate"]) == (1, -2304)
+
+
+def test_extended_squitter_df18_address_qualifiers(pkg):
+    """DF18 control field and IMF bit (mode_s.c:1379-1426,770-792): where the address stops being an ICAO one."""
+    def df18(cf, me_hex):
+        return es_record(pkg, "%02X" % ((18 << 3) | cf) + "ABCDEF" + me_hex + "000000")
+    airborne_imf = "%014X" % ((11 << 51) | (1 << 48))  # type 11, bit 8 set
+    airborne = "%014X" % (11 << 51)
+    table = {  # cf: (me, source, addrtype, imf, non_icao)
+        0: (airborne_imf, 7, 1, 0, 0),  # ADS-B from a non-transponder device: bit 8 is NIC-B there
+        1: (airborne, 7, 4, 0, 1),
+        2: (airborne, 5, 3, 0, 0),
+        5: (airborne, 5, 7, 0, 1),
+        6: (airborne, 6, 2, 0, 0),
+        4: (airborne, 7, 9, 0, 1),
+    }
+    for cf, (me, source, addrtype, imf, non_icao) in table.items():
+        f = pkg.capi.decode_fields(df18(cf, me))
+        assert (f["CF"], f["source"], f["addrtype"], f["imf"], f["addr"]) == \
+               (cf, source, addrtype, imf, 0xABCDEF | (non_icao << 24)), cf
+    f = pkg.capi.decode_fields(df18(2, airborne_imf))  # fine TIS-B with IMF: track file number instead of an address
+    assert (f["source"], f["addrtype"], f["imf"], f["addr"], f["nic_b_valid"]) == (5, 6, 1, 0x1ABCDEF, 0)
+    f = pkg.capi.decode_fields(df18(6, airborne_imf))  # ADS-R with IMF
+    assert (f["source"], f["addrtype"], f["imf"], f["addr"]) == (6, 5, 1, 0x1ABCDEF)
+    f = pkg.capi.decode_fields(df18(3, "%014X" % (1 << 55)))  # coarse TIS-B: only the IMF bit (bit 1 of ME) is looked at
+    assert (f["source"], f["addrtype"], f["imf"], f["cpr_valid"], f["callsign_valid"]) == (5, 6, 1, 0, 0)
+    f = pkg.capi.decode_fields(df18(0, airborne_imf))
+    assert (f["nic_b_valid"], f["nic_b"]) == (1, 1)
+
+
+def test_extended_squitter_surface_status_and_fault_pattern(pkg):
+    me = (7 << 51) | (17 << 44) | (1 << 43) | (33 << 36) | (1 << 34) | (39195 << 17) | 110320  # type 7 surface position
+    f = pkg.capi.decode_fields(es_record(pkg, "8C484175" + "%014X" % me + "000000"))
+    assert (f["metype"], f["airground"], f["cpr_valid"], f["cpr_type"], f["cpr_odd"], f["cpr_lat"], f["cpr_lon"]) == \
+           (7, 1, 1, 0, 1, 39195, 110320)
+    assert (f["movement"], f["heading_valid"], f["heading_raw"], f["heading_type"]) == (17, 1, 33, 5)
+    me = (28 << 51) | (1 << 48) | (2 << 45) | (0b1010101010101 << 32)  # aircraft status: emergency 2 and a squawk
+    f = pkg.capi.decode_fields(es_record(pkg, "8D484175" + "%014X" % me + "000000"))
+    assert (f["metype"], f["mesub"], f["emergency_valid"], f["emergency"], f["squawk_valid"]) == (28, 1, 1, 2, 1)
+    assert f["squawk"] == squawk_py(0b1010101010101)
+    me = (15 << 51) | (0x1F000 << 17)  # type 15, altitude 0, longitude 0, zeros in the latitude LSBs: the known fault
+    f = pkg.capi.decode_fields(es_record(pkg, "8D484175" + "%014X" % me + "000000"))
+    assert (f["metype"], f["cpr_valid"], f["cpr_lat"], f["altitude_baro_valid"]) == (15, 0, 0x1F000, 0)
+    me = (21 << 51) | (0xC38 << 36) | (5 << 17) | 9  # type 21: geometric altitude
+    f = pkg.capi.decode_fields(es_record(pkg, "8D484175" + "%014X" % me + "000000"))
+    assert (f["altitude_geom_valid"], f["altitude_geom"], f["altitude_baro_valid"], f["cpr_valid"]) == (1, 38000, 0, 1)
+    on_ground = pkg.capi.decode_fields(es_record(pkg, "8C484175" + "%014X" % ((11 << 51) | (0xC38 << 36)) + "000000"))
+    assert (on_ground["CA"], on_ground["airground"], on_ground["altitude_baro_valid"]) == (4, 1, 0)  # CA 4: no altitude
 
 
 @pytest.mark.parametrize("name", ["uc8_fix_modeac", "sc16q11_fix_modeac", "uc8_nofix"])
