@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also diff the GPU message list against the oracle")
     ap.add_argument("--mode-ac", action="store_true", help="BASELINE configs[4]: Mode A/C demodulator on, 500 replies/s")
+    ap.add_argument("--fields", action="store_true",
+                    help="MSD_CFG_DECODE_FIELDS: also decode header and extended squitter fields of every message")
     ap.add_argument("--overlap-captures", action="store_true",
                     help="two contexts on one stream: the next capture starts while the previous one drains")
     return ap.parse_args()
@@ -94,7 +96,8 @@ def main():
     # the draining capture's resolve passes), so it is not the default.
     nctx = 2 if args.overlap_captures else 1
     dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank,
-                            max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21)
+                            max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
+                            decode_fields=args.fields)
             for _ in range(nctx)]
     dem = dems[0]
 
@@ -115,7 +118,7 @@ def main():
             self.off += m
 
         def collect_one(self):
-            self.nmsg += len(self.d.collect(copy=False))
+            self.nmsg += len(self.d.collect_fields(copy=False)[0]) if args.fields else len(self.d.collect(copy=False))
             if self.timing is not None:
                 self.timing.append(self.d.timing())
             self.inflight -= 1

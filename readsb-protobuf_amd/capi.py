@@ -189,6 +189,13 @@ class MsdError(RuntimeError):
     pass
 
 
+def _raw_copy(a):
+    """Copy of a contiguous record array as one memcpy (numpy copies structured arrays field by field)."""
+    out = np.empty(a.shape, dtype=a.dtype)
+    out.view(np.uint8)[:] = a.view(np.uint8)
+    return out
+
+
 class Demodulator:
     """One receiver context on one GPU (its own ICAO filter, clock, counters and HIP streams)."""
 
@@ -234,20 +241,23 @@ class Demodulator:
             rc = call(self._sink_fn, C.byref(st))
             self._check(rc)
             if st.count <= self._buf.size:
-                return self._buf[: st.count].copy() if copy else self._buf[: st.count]
+                return _raw_copy(self._buf[: st.count]) if copy else self._buf[: st.count]
             # a context is stateful, so a too-small array cannot simply be retried: grow ahead of time
             raise MsdError(f"message array too small ({st.count} > {self._buf.size}); "
                            "construct the Demodulator with a larger message_capacity")
 
-    def collect_fields(self):
-        """msd_collect_fields: (messages, header fields) of the oldest outstanding batch (copies)."""
+    def collect_fields(self, copy=True):
+        """msd_collect_fields: (messages, header fields) of the oldest outstanding batch.  copy=False
+        returns views of the context's arrays, valid until the next collect."""
         if not hasattr(self, "_fbuf") or self._fbuf.size != self._buf.size:
             self._fbuf = np.zeros(self._buf.size, dtype=FIELDS_DTYPE)
         st = _FieldsSinkState(self._buf.ctypes.data, self._fbuf.ctypes.data, self._buf.size, 0)
         self._check(lib().msd_collect_fields(self._h, C.cast(lib().msd_array_fields_sink, C.c_void_p), C.byref(st)))
         if st.count > self._buf.size:
             raise MsdError(f"message array too small ({st.count} > {self._buf.size})")
-        return self._buf[: st.count].copy(), self._fbuf[: st.count].copy()
+        if not copy:
+            return self._buf[: st.count], self._fbuf[: st.count]
+        return _raw_copy(self._buf[: st.count]), _raw_copy(self._fbuf[: st.count])
 
     def reserve_messages(self, n):
         if n > self._buf.size:

@@ -746,6 +746,26 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     }
 }
 
+/* rows [first, first + n) of the record arrays from their LDS images, clipped to cap */
+__device__ inline void emit_rows(msd_wire *dense, msd_fields *fields, const msd_wire *sh_rec, const msd_fields *sh_f,
+                                 uint32_t first, uint32_t n, uint32_t cap)
+{
+    if (first >= cap)
+        return;
+    n = min(n, cap - first);
+    static_assert(sizeof(msd_wire) % 8 == 0 && sizeof(msd_fields) % 4 == 0, "record sizes");
+    uint2 *d = reinterpret_cast<uint2 *>(dense + first);
+    const uint2 *r = reinterpret_cast<const uint2 *>(sh_rec);
+    for (uint32_t i = threadIdx.x; i < n * (uint32_t)(sizeof(msd_wire) / 8); i += blockDim.x)
+        d[i] = r[i];
+    if (fields) {
+        uint32_t *fd = reinterpret_cast<uint32_t *>(fields + first);
+        const uint32_t *fr = reinterpret_cast<const uint32_t *>(sh_f);
+        for (uint32_t i = threadIdx.x; i < n * (uint32_t)(sizeof(msd_fields) / 4); i += blockDim.x)
+            fd[i] = fr[i];
+    }
+}
+
 /* The accepted messages of buffer b as 64-byte records (msd_message + signal power sum), dense over
  * the batch; one DMA then takes them to the host while the next scan runs. */
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
@@ -769,44 +789,49 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
     const uint64_t sample_ts = P.ts[2 * b], sys_ts = P.ts[2 * b + 1];
     const uint32_t base = b * MSD_CHUNK_SAMPLES;
     const msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
-    for (uint32_t m = threadIdx.x; m < nm; m += blockDim.x) {
-        const msd_acc rec = acc[m];
-        const msd_try *t = P.tries + rec.try_index;
-        const uint4 lo = *reinterpret_cast<const uint4 *>(t);
-        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
-        const uint32_t df = (lo.x & 0xffu) >> 3, tp = (lo.w >> 16) & 0xffu, errbit = lo.w >> 24;
-        const uint32_t msgbits = (df & 0x10u) ? 112u : 56u;
-        const uint32_t j = rec.pos - base;
-        msd_message mm;
-        mm.timestampMsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
-        mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-        mm.signalLevel = 0.0;
-        mm.addr = hi.x; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
-        mm.crc = hi.y;
-        mm.score = rec.score;
-        mm.msgtype = (uint8_t)df;
-        mm.msgbits = (uint8_t)msgbits;
-        mm.correctedbits = errbit != 0xffu ? 1 : 0;
-        mm.bestphase = (uint8_t)tp;
-        uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w & 0xffffu};
-        if (errbit != 0xffu)
-            w[errbit >> 5] ^= (0x80u >> (errbit & 7u)) << (8 * ((errbit >> 3) & 3u)); /* crc.c:417-425 */
+    /* 256 records at a time are put together in LDS and leave as whole-wavefront runs of consecutive
+     * words: the destination is host memory, where a lane-strided struct store costs a PCIe write per
+     * piece */
+    __shared__ msd_wire sh_rec[256];
+    __shared__ msd_fields sh_f[256];
+    for (uint32_t m0 = 0; m0 < nm; m0 += 256) {
+        const uint32_t m = m0 + threadIdx.x;
+        if (m < nm) {
+            const msd_acc rec = acc[m];
+            const msd_try *t = P.tries + rec.try_index;
+            const uint4 lo = *reinterpret_cast<const uint4 *>(t);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
+            const uint32_t df = (lo.x & 0xffu) >> 3, tp = (lo.w >> 16) & 0xffu, errbit = lo.w >> 24;
+            const uint32_t msgbits = (df & 0x10u) ? 112u : 56u;
+            const uint32_t j = rec.pos - base;
+            msd_message mm;
+            mm.timestampMsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
+            mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+            /* the power sum's bits, not a value */
+            mm.signalLevel = __longlong_as_double((long long)power[(size_t)b * MSD_RB_MSG_CAP + m]);
+            mm.addr = hi.x; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
+            mm.crc = hi.y;
+            mm.score = rec.score;
+            mm.msgtype = (uint8_t)df;
+            mm.msgbits = (uint8_t)msgbits;
+            mm.correctedbits = errbit != 0xffu ? 1 : 0;
+            mm.bestphase = (uint8_t)tp;
+            uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w & 0xffffu};
+            if (errbit != 0xffu)
+                w[errbit >> 5] ^= (0x80u >> (errbit & 7u)) << (8 * ((errbit >> 3) & 3u)); /* crc.c:417-425 */
 #pragma unroll
-        for (int k = 0; k < 14; ++k)
-            mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-        mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
-        mm.pad = 0;
-        if (o + m >= cap)
-            break; /* the host notices (total > cap), grows the arrays and emits again */
-        msd_wire wr;
-        wr.mm = mm;
-        wr.mm.signalLevel = __longlong_as_double((long long)power[(size_t)b * MSD_RB_MSG_CAP + m]); /* bits, not a value */
-        dense[o + m] = wr;
-        if (fields) { /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
-            msd_fields f;
-            msd_fields_mode_s(mm.msg, df, mm.addr, &f);
-            fields[o + m] = f;
+            for (int k = 0; k < 14; ++k)
+                mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
+            mm.pad = 0;
+            sh_rec[threadIdx.x].mm = mm;
+            if (fields) /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
+                msd_fields_mode_s(mm.msg, df, mm.addr, &sh_f[threadIdx.x]);
         }
+        __syncthreads();
+        /* what does not fit is dropped: the host notices (total > cap), grows the arrays and emits again */
+        emit_rows(dense, fields, sh_rec, sh_f, o + m0, min(256u, nm - m0), cap);
+        __syncthreads();
     }
     if (P.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
         const uint32_t na = P.nac[b];
@@ -823,48 +848,49 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             }
             __syncthreads();
         }
-        for (uint32_t m = threadIdx.x; m < na; m += blockDim.x) {
-            if (o + nm + m >= cap)
-                break;
-            const msd_ac_hit c = P.ac[acc_ac[m]];
-            msd_message mm;
-            mm.timestampMsg = sample_ts + c.f2_clock / 5; /* demod_2400.c:695 */
-            mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-            mm.signalLevel = 0.0;
-            mm.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24); /* mode_ac.c:168-202 */
-            mm.crc = 0;
-            mm.score = 0;
-            mm.msgtype = 32;
-            mm.msgbits = 16;
-            mm.correctedbits = 0;
-            mm.bestphase = 0;
+        for (uint32_t m0 = 0; m0 < na; m0 += 256) {
+            const uint32_t m = m0 + threadIdx.x;
+            if (m < na) {
+                const msd_ac_hit c = P.ac[acc_ac[m]];
+                msd_message mm;
+                mm.timestampMsg = sample_ts + c.f2_clock / 5; /* demod_2400.c:695 */
+                mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
+                mm.signalLevel = 0.0;
+                mm.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24); /* mode_ac.c:168-202 */
+                mm.crc = 0;
+                mm.score = 0;
+                mm.msgtype = 32;
+                mm.msgbits = 16;
+                mm.correctedbits = 0;
+                mm.bestphase = 0;
 #pragma unroll
-            for (int k = 0; k < 14; ++k)
-                mm.msg[k] = 0;
-            mm.msg[0] = (uint8_t)(c.modeac >> 8);
-            mm.msg[1] = (uint8_t)c.modeac;
-            mm.iid = 0;
-            mm.pad = 0;
-            msd_wire wr;
-            wr.mm = mm;
-            dense[o + nm + m] = wr;
-            if (fields) {
-                /* the reference's one message record per buffer keeps the last decoded altitude
-                 * (demod_2400.c:523-528): find the last earlier reply of this buffer that had one */
-                msd_fields carry, f;
-                const msd_fields *cp = nullptr;
-                int32_t w = (int32_t)(m >> 5);
-                uint32_t bits = m & 31 ? has_alt[w] & ((1u << (m & 31)) - 1u) : 0u;
-                while (!bits && --w >= 0)
-                    bits = has_alt[w];
-                if (bits) {
-                    const uint32_t prev = (uint32_t)w * 32 + (31u - (uint32_t)__builtin_clz(bits));
-                    msd_fields_mode_ac(P.ac[acc_ac[prev]].modeac, nullptr, &carry);
-                    cp = &carry;
+                for (int k = 0; k < 14; ++k)
+                    mm.msg[k] = 0;
+                mm.msg[0] = (uint8_t)(c.modeac >> 8);
+                mm.msg[1] = (uint8_t)c.modeac;
+                mm.iid = 0;
+                mm.pad = 0;
+                sh_rec[threadIdx.x].mm = mm;
+                if (fields) {
+                    /* the reference's one message record per buffer keeps the last decoded altitude
+                     * (demod_2400.c:523-528): find the last earlier reply of this buffer that had one */
+                    msd_fields carry;
+                    const msd_fields *cp = nullptr;
+                    int32_t w = (int32_t)(m >> 5);
+                    uint32_t bits = m & 31 ? has_alt[w] & ((1u << (m & 31)) - 1u) : 0u;
+                    while (!bits && --w >= 0)
+                        bits = has_alt[w];
+                    if (bits) {
+                        const uint32_t prev = (uint32_t)w * 32 + (31u - (uint32_t)__builtin_clz(bits));
+                        msd_fields_mode_ac(P.ac[acc_ac[prev]].modeac, nullptr, &carry);
+                        cp = &carry;
+                    }
+                    msd_fields_mode_ac(c.modeac, cp, &sh_f[threadIdx.x]);
                 }
-                msd_fields_mode_ac(c.modeac, cp, &f);
-                fields[o + nm + m] = f;
             }
+            __syncthreads();
+            emit_rows(dense, fields, sh_rec, sh_f, o + nm + m0, min(256u, na - m0), cap);
+            __syncthreads();
         }
     }
 }
