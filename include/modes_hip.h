@@ -128,6 +128,7 @@ typedef struct msd_stats {
     double signal_power_sum;
     double peak_signal_power;
     uint64_t buffers;
+    uint64_t samples_dropped; /* stats.h:68; fed by msd_note_dropped() */
 } msd_stats;
 
 /* Timing of the most recent batch, measured with HIP events on the context's stream. */
@@ -182,6 +183,18 @@ int msd_submit_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last,
                     msd_message_fn sink, void *user);
 /* Forget the stream position, ICAO filter, clock and counters (a new capture). */
 int msd_reset(msd_ctx *ctx);
+/* A live receiver that could not hand `nsamples` samples over (rtlsdrCallback's FIFO-full branch,
+ * sdr_rtlsdr.c:281-296; bladeRF the same way, sdr_bladerf.c:317-341) says so before it launches the
+ * next batch.  That batch then starts with a MAGBUF_DISCONTINUOUS buffer: its 326-sample look-behind
+ * is zeros instead of the end of the previous batch (fifo.c:178-181), the sample clock has advanced
+ * by the dropped samples (sampleCounter, sdr_rtlsdr.c:284,299-300) and msd_stats.samples_dropped
+ * grows by them (readsb.c:836) when the batch is collected.  -EINVAL after the last batch. */
+int msd_note_dropped(msd_ctx *ctx, uint64_t nsamples);
+/* Modes.preambleThreshold for the batches launched from now on.  The reference raises it to
+ * max(PREAMBLE_THRESHOLD_PIZERO = 75, threshold) while its 15-minute statistics hold dropped samples
+ * (demod_2400.c:285-290); that statistics window belongs to the host program, which calls this when
+ * it opens and closes.  -EINVAL outside 1..255. */
+int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
 
 /* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the
  * oldest outstanding batch, runs the ordered resolve and delivers its messages.  At most

@@ -90,6 +90,7 @@ class Stats(C.Structure):
         ("signal_power_sum", C.c_double),
         ("peak_signal_power", C.c_double),
         ("buffers", C.c_uint64),
+        ("samples_dropped", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -131,6 +132,7 @@ EXPORTS = [
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
+    "msd_note_dropped", "msd_set_preamble_threshold",
 ]
 
 _lib = None
@@ -155,6 +157,10 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.msd_reset.restype = C.c_int
         L.msd_reset.argtypes = [C.c_void_p]
+        L.msd_note_dropped.restype = C.c_int
+        L.msd_note_dropped.argtypes = [C.c_void_p, C.c_uint64]
+        L.msd_set_preamble_threshold.restype = C.c_int
+        L.msd_set_preamble_threshold.argtypes = [C.c_void_p, C.c_int]
         for name in ("msd_launch_device", "msd_launch_host"):
             f = getattr(L, name)
             f.restype = C.c_int
@@ -300,6 +306,13 @@ class Demodulator:
 
     def reset(self):
         self._check(lib().msd_reset(self._h))
+
+    def note_dropped(self, nsamples):
+        """msd_note_dropped: the receiver lost nsamples in front of the next batch (MAGBUF_DISCONTINUOUS)."""
+        self._check(lib().msd_note_dropped(self._h, nsamples))
+
+    def set_preamble_threshold(self, threshold):
+        self._check(lib().msd_set_preamble_threshold(self._h, threshold))
 
     def stats(self):
         st = Stats()

@@ -40,6 +40,8 @@ struct Slot {
     bool download_started = false;
     bool gpu_resolve = false; /* the candidate lists stay in HBM: resolved there (msd_resolve_kernels.hip) */
     bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
+    int threshold = 0;             /* Modes.preambleThreshold when the batch was launched */
+    uint64_t dropped_before = 0;   /* msd_note_dropped(): samples missing in front of this batch, not yet on the clock */
     uint32_t resolve_ntodo = 0;
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
@@ -138,6 +140,7 @@ struct msd_ctx {
     int head = 0, outstanding = 0;
     uint64_t next_sample = 0;
     bool finished = false;
+    uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
     msd_resolver resolver{};
     msd_stats stats{};
     msd_timing timing{};
@@ -215,7 +218,7 @@ void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
     p.prev_tail = s.d_prev;
     p.ragged = s.d_ragged;
     p.have_prev = s.have_prev;
-    p.threshold = c->cfg.preamble_threshold;
+    p.threshold = s.threshold;
     p.batch_first = s.batch_first;
     p.nsamples = s.nsamples;
     p.lut = c->d_lut;
@@ -677,8 +680,18 @@ int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
 /* Clocks, snapshot 0 = the live filter, first pass over every buffer and the (speculative) message
  * records, all behind the batch's own kernels on the scan stream.  Every earlier batch must have
  * been committed: this is the earliest moment its successor can start. */
+/* the samples a live receiver dropped in front of this batch go onto the sample clock when the batch's
+ * turn comes (every earlier batch has been committed by then), sdr_rtlsdr.c:284,299 */
+void apply_dropped(msd_ctx *c, Slot &s)
+{
+    c->resolver.sample_counter += s.dropped_before;
+    c->stats.samples_dropped += s.dropped_before; /* readsb.c:836 */
+    s.dropped_before = 0;
+}
+
 int gpu_begin(msd_ctx *c, Slot &s, int format)
 {
+    apply_dropped(c, s);
     const GpuCtl g = gpu_ctl(c, s);
     for (uint32_t b = 0; b < s.nbuffers; ++b)
         g.h_valid[b] = slot_valid(s, b);
@@ -919,8 +932,9 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     c->out_msgs.clear();
     c->out_req.clear();
     c->out_buf.clear();
+    apply_dropped(c, s);
     if (!skip_resolve)
-    msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
+        msd_resolve_batch(&c->resolver, resolver_first_chunk, s.nbuffers, c->valid.data(), s.h_hits, H, s.h_tries, Tn,
                       c->cfg.mode_ac ? s.h_ac : nullptr, c->cfg.mode_ac ? s.h_ac_totals[0] : 0, ts_override,
                       emit_thunk, c);
     auto t1 = std::chrono::steady_clock::now();
@@ -1014,6 +1028,9 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.batch_first = c->next_sample;
     s.nsamples = nsamples;
     s.last = last;
+    s.dropped_before = c->pending_dropped;
+    c->pending_dropped = 0;
+    s.threshold = c->cfg.preamble_threshold;
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
     s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
@@ -1344,8 +1361,32 @@ int msd_reset(msd_ctx *c)
     c->next_sample = 0;
     c->have_prev = false;
     c->finished = false;
+    c->pending_dropped = 0;
     msd_resolver_reset(&c->resolver);
     memset(&c->timing, 0, sizeof c->timing);
+    return 0;
+}
+
+int msd_note_dropped(msd_ctx *c, uint64_t nsamples)
+{
+    if (!c)
+        return -EINVAL;
+    if (c->finished)
+        return fail(c, -EINVAL, "capture already finished; call msd_reset()");
+    if (nsamples) {
+        c->pending_dropped += nsamples;
+        c->have_prev = false; /* MAGBUF_DISCONTINUOUS: fifo.c:178-181 zeroes the overlap */
+    }
+    return 0;
+}
+
+int msd_set_preamble_threshold(msd_ctx *c, int threshold)
+{
+    if (!c)
+        return -EINVAL;
+    if (threshold < 1 || threshold > 255)
+        return fail(c, -EINVAL, "preamble threshold %d outside 1..255", threshold);
+    c->cfg.preamble_threshold = threshold;
     return 0;
 }
 
@@ -1573,6 +1614,8 @@ int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength
     s.d_iq = c->d_stage;
     s.d_prev = tail;
     s.have_prev = 1;
+    s.threshold = c->cfg.preamble_threshold;
+    s.dropped_before = 0;
     s.batch_first = 0;
     s.nsamples = mlen;
     s.nbuffers = 1;

@@ -260,3 +260,57 @@ def test_interference_storm_overflows_and_is_rerun_in_pieces(pkg, oracle, torch_
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)
     assert_same(got, dem.stats(), want, wstats)
     assert wstats["demod_preambles"] > 0.05 * n
+
+
+@pytest.mark.parametrize("drop", [1, 12345, 131072, 5 * 131072 + 17])
+def test_dropped_samples_between_batches(pkg, oracle, torch_cuda, drop):
+    """msd_note_dropped: the batch behind a gap starts with a MAGBUF_DISCONTINUOUS buffer (zero look-behind),
+    the sample clock runs on over the gap, msd_stats.samples_dropped counts it (sdr_rtlsdr.c:281-300,
+    fifo.c:176-184, readsb.c:836).  Two gaps, batches in flight together."""
+    from helpers import oracle_live_feed
+    C = pkg.CHUNK
+    n = 13 * C + 999
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=400 + drop % 9, msgs_per_sec=7000, n_aircraft=25), n)
+    cuts = [0, 4 * C, 9 * C, n]
+    drops = [0, drop, 3 * drop + 1]
+    segs = [iq[2 * a: 2 * b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want, wstats = oracle_live_feed(oracle.Oracle(oracle.FMT_UC8, 58, 1, 0), segs, drops)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=5 * C, message_capacity=1 << 16)
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if drops[i]:
+            dem.note_dropped(drops[i])
+        dem.launch_device(d_iq.data_ptr() + 2 * a, b - a, last=b == n)
+    got = np.concatenate([dem.collect() for _ in range(3)])
+    assert len(want) > 100
+    assert_same(got, dem.stats(), want, wstats)
+    assert dem.stats()["samples_dropped"] == sum(drops)
+    with pytest.raises(pkg.MsdError):
+        dem.note_dropped(1)  # the capture is over
+
+
+def test_preamble_threshold_change_applies_to_later_batches(pkg, oracle, torch_cuda):
+    """msd_set_preamble_threshold (demod_2400.c:285-290 raises the threshold to 75 while samples were
+    dropped recently): batches launched before the call keep the old value."""
+    from helpers import oracle_live_feed
+    C = pkg.CHUNK
+    n = 8 * C
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=31, msgs_per_sec=7000, n_aircraft=25), n)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, preamble_threshold=58, max_batch_samples=4 * C, message_capacity=1 << 16)
+    dem.launch_device(d_iq.data_ptr(), 4 * C, last=False)
+    dem.set_preamble_threshold(75)
+    dem.launch_device(d_iq.data_ptr() + 8 * C, 4 * C, last=True)
+    got = np.concatenate([dem.collect(), dem.collect()])
+    lo = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)[0]
+    hi = oracle.Oracle(oracle.FMT_UC8, 75, 1, 0).replay(iq, cap=1 << 16)[0]
+    border = 4 * C * 5
+    # away from the border (the skip-ahead / filter state of the first half can differ) the halves are
+    # those of the two thresholds
+    first = got[got["timestampMsg"] < border - 10000]
+    assert np.array_equal(first, lo[: len(first)])
+    assert len(lo) != len(hi)
+    st = dem.stats()
+    assert st["demod_preambles"] < oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)[1]["demod_preambles"]
+    with pytest.raises(pkg.MsdError):
+        dem.set_preamble_threshold(0)
