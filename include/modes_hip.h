@@ -33,7 +33,8 @@ typedef struct msd_config {
     int32_t device;             /* HIP device ordinal */
     int32_t format;             /* --iformat, sdr_ifile.c:88-101 */
     int32_t preamble_threshold; /* --preamble-threshold, readsb.c:503-505 (default 58) */
-    int32_t nfix_crc;           /* --no-fix = 0, --fix = 1 (readsb.c:491-496); 2 unsupported */
+    int32_t nfix_crc;           /* --no-fix = 0, --fix = 1 (readsb.c:491-496), --aggressive = 2 (readsb.c:542: two-bit
+                                   correction of DF17/18 against the (2, 4) tables of crc.c:374-379) */
     int32_t mode_ac;            /* --modeac, readsb.c:509-512 */
     int32_t flags;              /* MSD_CFG_* */
     uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk */

@@ -26,9 +26,10 @@
 #define FILTER_TTL_MS 60000u        /* icao_filter.c:30 */
 #define CRC_POLY 0xfff409u          /* crc.c:31 */
 
-struct syndrome_entry { /* crc.h:32-37, restricted to what nfix<=1 needs */
+struct syndrome_entry { /* struct errorinfo, crc.h:32-37 */
     uint32_t syndrome;
-    int bit;
+    int errors;  /* 1 or 2; -1 while flagged for removal */
+    int bit[2];
 };
 
 struct orc_ctx {
@@ -38,7 +39,7 @@ struct orc_ctx {
     int active;
     uint64_t next_flip; /* icao_filter.c:151 (function static there) */
     /* crc.c:84-88 */
-    struct syndrome_entry tab56[51], tab112[107];
+    const struct syndrome_entry *tab56, *tab112; /* shared between contexts with the same nfix */
     int ntab56, ntab112;
     /* readsb.h:288-289: startup_time is fixed to 0 here */
     uint64_t ifile_now;
@@ -188,19 +189,101 @@ static int by_syndrome(const void *a, const void *b)
     return (int)x->syndrome - (int)y->syndrome; /* crc.c:94-98 */
 }
 
-/* crc.c:184-354 for max_correct == max_detect == 1: one entry per single-bit error in bits
- * 5..bits-1 (the DF field is never "corrected"), syndromes taken at offset 112-bits, sorted.
- * Single-bit syndromes are pairwise distinct, so the collision passes remove nothing. */
-static int build_syndrome_table(struct syndrome_entry *t, int bits)
+/* prepareSubtable, crc.c:133-153: every error pattern of up to max_errors bits out of [startbit, endbit),
+ * extending the pattern of *base, in the order the reference's recursion visits them */
+static int fill_patterns(struct syndrome_entry *t, int n, int offset, int startbit, int endbit,
+                         const struct syndrome_entry *base, int have, int max_errors)
 {
-    int n = 0;
-    for (int i = 5; i < bits; ++i) {
-        t[n].syndrome = g_bit_syndrome[i + 112 - bits];
-        t[n].bit = i;
-        ++n;
+    if (have >= max_errors)
+        return n;
+    for (int i = startbit; i < endbit; ++i) {
+        t[n] = *base;
+        t[n].syndrome ^= g_bit_syndrome[i + offset];
+        t[n].errors = have + 1;
+        t[n].bit[have] = i;
+        const int mine = n++;
+        n = fill_patterns(t, n, offset, i + 1, endbit, &t[mine], have + 1, max_errors);
     }
-    qsort(t, (size_t)n, sizeof t[0], by_syndrome);
     return n;
+}
+
+/* flagCollisions, crc.c:155-178: every pattern of first..last error bits whose syndrome is in the
+ * table marks that entry (errors = -1) */
+static int flag_collisions(struct syndrome_entry *t, int n, int offset, int startbit, int endbit, uint32_t base,
+                           int nbits, int first, int last)
+{
+    if (nbits > last)
+        return 0;
+    int count = 0;
+    for (int i = startbit; i < endbit; ++i) {
+        struct syndrome_entry key;
+        key.syndrome = base ^ g_bit_syndrome[i + offset];
+        if (nbits >= first) {
+            struct syndrome_entry *hit = bsearch(&key, t, (size_t)n, sizeof t[0], by_syndrome);
+            if (hit && hit->errors != -1) {
+                hit->errors = -1;
+                ++count;
+            }
+        }
+        count += flag_collisions(t, n, offset, i + 1, endbit, key.syndrome, nbits + 1, first, last);
+    }
+    return count;
+}
+
+/* prepareErrorTable, crc.c:184-354: patterns of up to max_correct wrong bits in bits 5..bits-1 (the DF
+ * field is never "corrected"), syndromes taken at offset 112-bits, sorted; syndromes that more than one
+ * pattern produces are dropped altogether (:236-258), and so are those that a pattern of
+ * max_correct+1 .. max_detect bits produces as well (:266-287).  modesChecksumInit (crc.c:360-381) asks
+ * for (1, 1) with --fix and (2, 4) with --aggressive. */
+static struct syndrome_entry *build_syndrome_table(int bits, int max_correct, int max_detect, int *size_out)
+{
+    int maxsize = 0;
+    for (int k = 1, c = 1; k <= max_correct; ++k) {
+        c = c * (bits - 5 - (k - 1)) / k; /* (bits-5 choose k), crc.c:103-118 */
+        maxsize += c;
+    }
+    struct syndrome_entry *t = malloc((size_t)maxsize * sizeof t[0]);
+    struct syndrome_entry base = {0, 0, {-1, -1}};
+    int n = fill_patterns(t, 0, 112 - bits, 5, bits, &base, 0, max_correct);
+    qsort(t, (size_t)n, sizeof t[0], by_syndrome);
+    int j = 0;
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 < n && t[i + 1].syndrome == t[i].syndrome) {
+            while (i + 1 < n && t[i + 1].syndrome == t[i].syndrome)
+                ++i;
+            continue; /* t[i] was the last of the duplicates */
+        }
+        t[j++] = t[i];
+    }
+    n = j;
+    if (max_detect > max_correct &&
+        flag_collisions(t, n, 112 - bits, 5, bits, 0, 1, max_correct + 1, max_detect) > 0) {
+        j = 0;
+        for (int i = 0; i < n; ++i)
+            if (t[i].errors != -1)
+                t[j++] = t[i];
+        n = j;
+    }
+    *size_out = n;
+    return t;
+}
+
+/* the tables only depend on nfix: built once per process and shared (the --aggressive ones take a moment) */
+static const struct syndrome_entry *g_tab[3][2];
+static int g_ntab[3][2];
+
+static void syndrome_tables(int nfix, const struct syndrome_entry **t56, int *n56, const struct syndrome_entry **t112,
+                            int *n112)
+{
+    if (!g_tab[nfix][0]) {
+        const int detect = nfix == 1 ? 1 : 4; /* crc.c:367-379 */
+        g_tab[nfix][0] = build_syndrome_table(56, nfix, detect, &g_ntab[nfix][0]);
+        g_tab[nfix][1] = build_syndrome_table(112, nfix, detect, &g_ntab[nfix][1]);
+    }
+    *t56 = g_tab[nfix][0];
+    *n56 = g_ntab[nfix][0];
+    *t112 = g_tab[nfix][1];
+    *n112 = g_ntab[nfix][1];
 }
 
 /* crc.c:389-412 */
@@ -213,12 +296,13 @@ int orc_diagnose(const orc_ctx *ctx, uint32_t syndrome, int bitlen, int bit[2])
     int n = (bitlen == 56) ? ctx->ntab56 : ctx->ntab112;
     if (n == 0)
         return -1; /* nfix_crc == 0: no table (crc.c:362-365,408-409) */
-    struct syndrome_entry key = {syndrome, 0};
+    struct syndrome_entry key = {syndrome, 0, {-1, -1}};
     const struct syndrome_entry *hit = bsearch(&key, t, (size_t)n, sizeof t[0], by_syndrome);
     if (!hit)
         return -1;
-    bit[0] = hit->bit;
-    return 1;
+    bit[0] = hit->bit[0];
+    bit[1] = hit->bit[1];
+    return hit->errors;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1219,8 +1303,8 @@ uint64_t orc_replay(orc_ctx *ctx, const void *iq, uint64_t nsamples, orc_message
 
 orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_ac)
 {
-    if (format < ORC_FMT_UC8 || format > ORC_FMT_SC16Q11 || nfix_crc < 0 || nfix_crc > 1)
-        return NULL; /* nfix_crc == 2 (--aggressive) is outside the configs, SURVEY.md 8(f) */
+    if (format < ORC_FMT_UC8 || format > ORC_FMT_SC16Q11 || nfix_crc < 0 || nfix_crc > 2)
+        return NULL; /* MODES_MAX_BITERRORS, crc.h:30 */
     orc_ctx *ctx = calloc(1, sizeof *ctx);
     if (!ctx)
         return NULL;
@@ -1235,10 +1319,8 @@ orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_a
     ctx->mode_ac = mode_ac;
     build_uc8_table();
     build_crc_tables();
-    if (nfix_crc == 1) { /* crc.c:367-372 */
-        ctx->ntab56 = build_syndrome_table(ctx->tab56, 56);
-        ctx->ntab112 = build_syndrome_table(ctx->tab112, 112);
-    }
+    if (nfix_crc >= 1) /* crc.c:367-379 */
+        syndrome_tables(nfix_crc, &ctx->tab56, &ctx->ntab56, &ctx->tab112, &ctx->ntab112);
     memset(ctx->filt, 0xFF, sizeof ctx->filt); /* icao_filter.c:67-71 */
     ctx->active = 0;
     ctx->next_flip = 0;

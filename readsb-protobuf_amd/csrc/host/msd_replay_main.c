@@ -1,5 +1,5 @@
 /*
- * msd_replay -- `readsb --device-type ifile --ifile F --iformat X [--fix|--no-fix]
+ * msd_replay -- `readsb --device-type ifile --ifile F --iformat X [--fix|--no-fix|--aggressive]
  * [--preamble-threshold N] [--modeac] --raw --quiet-ish` for the part of readsb this repository
  * implements: replays a capture through the GPU receive path and prints one `*hex;` line per
  * accepted message like displayModesMessage does in --raw mode (mode_s.c:1786-1798), or
@@ -70,6 +70,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--path") && next) { msd_ifileHandleOption(MSD_OPT_IFILE_MODE, next); ++i; }
         else if (!strcmp(a, "--fix")) rx.nfix_crc = 1;
         else if (!strcmp(a, "--no-fix")) rx.nfix_crc = 0;
+        else if (!strcmp(a, "--aggressive")) rx.nfix_crc = 2; /* readsb.c:542 */
         else if (!strcmp(a, "--modeac")) rx.mode_ac = 1;
         else if (!strcmp(a, "--mlat")) g_mlat = 1;
         else if (!strcmp(a, "--stats")) want_stats = 1;
@@ -84,7 +85,7 @@ int main(int argc, char **argv)
             rx.preamble_threshold = (int)(v < 40 ? 40 : (v > 400 ? 400 : v));
             ++i;
         } else {
-            fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix] "
+            fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] "
                             "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast] [--stats] [--path fused|magbuf] "
                             "[--device N]\n");
             return 2;

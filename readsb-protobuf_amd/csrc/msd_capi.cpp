@@ -100,6 +100,8 @@ struct msd_ctx {
     msd_tables *tables = nullptr;
     uint16_t *d_lut = nullptr;
     uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr;
+    uint64_t *d_fix2[2] = {nullptr, nullptr}; /* two-bit correction tables for 56 / 112 bits (nfix_crc == 2) */
+    uint32_t fix2_lg[2] = {0, 0};
     /* per-workgroup candidate regions (shared by all batches: stream order serialises them) */
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
@@ -227,6 +229,10 @@ void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
     p.syn112 = c->d_syn112;
     p.nsyn56 = c->tables->nsyn56;
     p.nsyn112 = c->tables->nsyn112;
+    p.fix2_56 = c->d_fix2[0];
+    p.fix2_112 = c->d_fix2[1];
+    p.fix2_lg56 = c->fix2_lg[0];
+    p.fix2_lg112 = c->fix2_lg[1];
 }
 
 int ensure_host(msd_ctx *c, Slot &s, size_t nh, size_t nt)
@@ -1135,6 +1141,7 @@ void destroy(msd_ctx *c)
                 (void)hipEventDestroy(*e);
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
+    (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -1178,7 +1185,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     if (!cfg || !out)
         return -EINVAL;
     *out = nullptr;
-    if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 1 ||
+    if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
         cfg->preamble_threshold <= 0)
         return -EINVAL;
     int ndev = 0;
@@ -1239,6 +1246,21 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMemcpy(c->d_crc, c->tables->crc_byte, sizeof c->tables->crc_byte, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn56, c->tables->syn56, sizeof c->tables->syn56, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn112, c->tables->syn112, sizeof c->tables->syn112, hipMemcpyHostToDevice));
+    if (cfg->nfix_crc == 2) { /* --aggressive, crc.c:374-379 */
+        for (int k = 0; k < 2; ++k) {
+            uint64_t *tab = msd_fix2_table(c->tables, k ? 112 : 56, &c->fix2_lg[k]);
+            if (!tab) {
+                destroy(c);
+                return -ENOMEM;
+            }
+            const size_t bytes = sizeof(uint64_t) << c->fix2_lg[k];
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_fix2[k]), bytes);
+            if (e == hipSuccess)
+                e = hipMemcpy(c->d_fix2[k], tab, bytes, hipMemcpyHostToDevice);
+            free(tab);
+            CK(e);
+        }
+    }
 
     const uint64_t B = c->cfg.max_batch_samples;
     uint64_t hit_want = B / 8, try_want = B / 16;

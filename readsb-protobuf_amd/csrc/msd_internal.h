@@ -52,11 +52,12 @@ typedef uint64_t msd_hit;
 typedef struct msd_try {
     uint8_t msg[14]; /* sliced bytes, uncorrected (demod_2400.c:191-209) */
     uint8_t tp;      /* trial phase 4..8 */
-    uint8_t errbit;  /* single-bit error position from the syndrome table, 0xff = none */
+    uint8_t errbit;  /* (first) corrected bit from the syndrome table, 0xff = none */
     uint32_t addr;   /* address the score tests: CRC for AP formats, (corrected) AA otherwise */
     uint32_t crc;    /* modesChecksum of the uncorrected message */
     uint32_t pos;    /* batch-relative scan position (same as the owning hit's) */
-    uint32_t pad;
+    uint8_t errbit2; /* second corrected bit (--aggressive only), 0xff = none; errbit < errbit2 */
+    uint8_t pad[3];
 } msd_try;
 
 /* Mode A/C candidate: every f1_sample that passes all tests of demod_2400.c:581-668; only the
@@ -130,6 +131,10 @@ typedef struct msd_tables {
     uint32_t nsyn56, nsyn112;
 } msd_tables;
 void msd_tables_build(msd_tables *t, int nfix_crc);
+/* two-bit correction (msd_tables.c); the caller frees the table */
+#define MSD_FIX2_HASH(syndrome, log2_slots) (((uint32_t)(syndrome) * 0x9E3779B1u) >> (32u - (log2_slots)))
+uint64_t *msd_fix2_table(const msd_tables *t, int bits, uint32_t *log2_slots);
+int msd_fix2_diagnose(int bits, uint32_t syndrome, int bit[2]);
 uint32_t msd_crc24(const msd_tables *t, const uint8_t *msg, int nbits);
 
 /* ---- ICAO filter (msd_resolve.c), icao_filter.c semantics ---- */

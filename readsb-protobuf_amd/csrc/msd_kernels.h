@@ -24,6 +24,9 @@ typedef struct MsdScanParams {
     const uint32_t *syn56;
     const uint32_t *syn112;
     uint32_t nsyn56, nsyn112;
+    const uint64_t *fix2_56, *fix2_112; /* --aggressive: the two-bit correction hash tables (msd_fix2_table);
+                                           NULL otherwise */
+    uint32_t fix2_lg56, fix2_lg112;
     msd_hit *hits;
     msd_try *tries;
     uint32_t hcap, tcap; /* per-workgroup region capacities */

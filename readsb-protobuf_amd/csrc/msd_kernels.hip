@@ -288,6 +288,7 @@ __device__ __forceinline__ void wave_lds_sync()
  *   step C  CRC-24, syndrome lookup and the filter-independent part of scoreModesMessage, one lane
  *           per try (crc.c:67-82,389-412; mode_s.c:311-409).
  *   step D  records out: per hit, its live tries in phase order at consecutive indices. */
+template <bool FIX2>
 __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, const uint16_t *mags,
                                                     const uint32_t *crc_tab, const uint32_t *syn,
                                                     unsigned char *cs, int tid, uint32_t nh, uint64_t tile_pos0,
@@ -404,31 +405,54 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
         const uint32_t df = (w[0] & 0xffu) >> 3;
         const uint32_t aa = (((w[0] >> 8) & 0xffu) << 16) | (((w[0] >> 16) & 0xffu) << 8) | (w[0] >> 24);
         bool alive = (orall != 0); /* mode_s.c:325 */
-        uint32_t addr = crc, errbit = 0xffu;
+        uint32_t addr = crc, errbit = 0xffu, errbit2 = 0xffu;
         if (alive && (df == 11 || df == 17 || df == 18)) {
             addr = aa;
             const uint32_t syndrome = (df == 11) ? (crc & 0xffff80u) : crc;
             if (syndrome != 0) {
-                /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted single-bit
-                 * table, or give up */
-                const uint32_t *tab = (df == 11) ? syn : syn + 51;
-                int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
                 alive = false;
-                while (lo2 < hi2) {
-                    const int mid = (lo2 + hi2) >> 1;
-                    const uint32_t e = tab[mid];
-                    if ((e & 0xffffffu) == syndrome) {
-                        errbit = e >> 24;
-                        alive = true;
-                        break;
+                if (FIX2) {
+                    /* --aggressive: modesChecksumDiagnose against the (2, 4) tables, a hash probe in
+                     * global memory (they do not fit next to the rest in LDS; 10 / 82 KiB, L2-resident) */
+                    const uint64_t *tab = (df == 11) ? P.fix2_56 : P.fix2_112;
+                    const uint32_t lg = (df == 11) ? P.fix2_lg56 : P.fix2_lg112;
+                    uint32_t slot = MSD_FIX2_HASH(syndrome, lg);
+                    for (;;) {
+                        const uint64_t e = tab[slot];
+                        if (e == ~0ull)
+                            break;
+                        if (((uint32_t)e & 0xffffffu) == syndrome) {
+                            errbit = (uint32_t)(e >> 32) & 0xffu;
+                            errbit2 = (uint32_t)(e >> 40) & 0xffu;
+                            /* two wrong bits in a DF11 are ambiguous: never corrected (mode_s.c:352-356) */
+                            alive = !(df == 11 && errbit2 != 0xffu);
+                            break;
+                        }
+                        slot = (slot + 1) & ((1u << lg) - 1u);
                     }
-                    if ((e & 0xffffffu) < syndrome)
-                        lo2 = mid + 1;
-                    else
-                        hi2 = mid;
+                } else {
+                    /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted single-bit
+                     * table, or give up */
+                    const uint32_t *tab = (df == 11) ? syn : syn + 51;
+                    int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
+                    while (lo2 < hi2) {
+                        const int mid = (lo2 + hi2) >> 1;
+                        const uint32_t e = tab[mid];
+                        if ((e & 0xffffffu) == syndrome) {
+                            errbit = e >> 24;
+                            alive = true;
+                            break;
+                        }
+                        if ((e & 0xffffffu) < syndrome)
+                            lo2 = mid + 1;
+                        else
+                            hi2 = mid;
+                    }
                 }
                 if (alive && errbit >= 8 && errbit <= 31)
                     addr ^= 1u << (31 - errbit); /* correct_aa_field, mode_s.c:266-281 */
+                if (alive && errbit2 >= 8 && errbit2 <= 31)
+                    addr ^= 1u << (31 - errbit2);
             }
         }
         const uint32_t q = (me >> 13) & 7u, h = me >> 20;
@@ -436,7 +460,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             *reinterpret_cast<uint4 *>(smsg + 16 * u) =
                 make_uint4(w[0], w[1], w[2], (w[3] & 0xffffu) | ((4u + q) << 16) | (errbit << 24));
             sres[2 * u] = addr;
-            sres[2 * u + 1] = crc;
+            sres[2 * u + 1] = crc | (errbit2 << 24); /* the CRC has 24 bits */
         } else {
             survidx[h * 5 + q] = 0xffffu; /* scores -2 whatever the filter holds */
         }
@@ -480,7 +504,8 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
                 if (idx < P.tcap) {
                     uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
                     dst[0] = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
-                    dst[1] = make_uint4(sres[2 * u], sres[2 * u + 1], (uint32_t)(tile_pos0 + pos), 0u);
+                    const uint32_t cw = sres[2 * u + 1];
+                    dst[1] = make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos), cw >> 24);
                 }
                 ++idx;
             }
@@ -489,7 +514,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
     return 0;
 }
 
-template <int FMT>
+template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */>
 __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -736,7 +761,7 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                     lds_barrier();
                     TMARK(5); /* plist + barrier */
                     const uint32_t out0 = hcur + r0;
-                    const uint32_t got = candidate_round(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
+                    const uint32_t got = candidate_round<FIX2>(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
                                                          my_hits + out0, out0 + nh <= P.hcap, my_tries, try_cursor
 #ifdef MSD_KERNEL_TIMING
                                                          , tacc_, &tlast_
@@ -1499,16 +1524,22 @@ extern "C" size_t msd_scan_lds_bytes(int format)
     return format == MSD_FMT_UC8 ? (size_t)LDS_UC8 : (size_t)LDS_COMMON;
 }
 
-template <int FMT>
-static int launch_scan_fmt(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
+template <int FMT, bool FIX2>
+static int launch_scan_fix(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
 {
     const size_t lds = msd_scan_lds_bytes(FMT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT, FIX2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return -5;
-    hipLaunchKernelGGL(msd_scan_kernel<FMT>, dim3(nwg), dim3(NT), lds, stream, *p);
+    hipLaunchKernelGGL((msd_scan_kernel<FMT, FIX2>), dim3(nwg), dim3(NT), lds, stream, *p);
     return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+template <int FMT>
+static int launch_scan_fmt(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
+{
+    return p->fix2_112 ? launch_scan_fix<FMT, true>(p, nwg, stream) : launch_scan_fix<FMT, false>(p, nwg, stream);
 }
 
 extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream)

@@ -407,7 +407,7 @@ static void push_add(buf_result *br, uint32_t addr)
 static int score_try(const msd_try *t, int known)
 {
     const int df = t->msg[0] >> 3;
-    const int nerr = (t->errbit != 0xff);
+    const int nerr = (t->errbit != 0xff) + (t->errbit2 != 0xff);
     switch (df) {
     case 11:
         if ((t->crc & 0x7f) == 0)
@@ -503,7 +503,8 @@ static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const m
         mm.msgtype = (uint8_t)df;
         mm.msgbits = (uint8_t)msgbits;
         mm.crc = best->crc;
-        const int nerr = (best->errbit != 0xff);
+        const int nerr = (best->errbit != 0xff) + (best->errbit2 != 0xff);
+        const int fix_in_aa = (best->errbit >= 8 && best->errbit <= 31) || (best->errbit2 >= 8 && best->errbit2 <= 31);
         int verdict = 0;
         switch (df) {
         case 11:
@@ -512,7 +513,7 @@ static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const m
                 verdict = -1; /* mode_s.c:492-498 */
             break;
         case 17: case 18:
-            if (nerr && best->errbit >= 8 && best->errbit <= 31 && !known_best)
+            if (nerr && fix_in_aa && !known_best)
                 verdict = -1; /* mode_s.c:522-526: the fix changed AA */
             break;
         default:
@@ -525,8 +526,10 @@ static void resolve_buffer(const struct msd_batch_state *bs, uint32_t b, const m
             continue;
         }
         if (nerr) {
-            mm.correctedbits = 1;
+            mm.correctedbits = (uint8_t)nerr;
             mm.msg[best->errbit >> 3] ^= (uint8_t)(0x80u >> (best->errbit & 7)); /* crc.c:417-425 */
+            if (nerr > 1)
+                mm.msg[best->errbit2 >> 3] ^= (uint8_t)(0x80u >> (best->errbit2 & 7));
         }
         mm.addr = best->addr; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
         if (!nerr && (df == 17 || (df == 11 && mm.iid == 0))) { /* mode_s.c:717-726 */

@@ -76,29 +76,33 @@ __device__ __forceinline__ uint32_t snap_probe(const uint32_t *snap, uint32_t ad
 struct TryView {
     uint32_t w0, w3; /* message bytes 0..3 and 12..15 (tp, errbit in the top half) */
     uint32_t addr, crc;
+    uint32_t errbit2; /* 0xff: none */
 };
 
 __device__ __forceinline__ TryView load_try(const msd_try *t)
 {
     const uint4 lo = *reinterpret_cast<const uint4 *>(t);
-    const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
+    const uint4 hi = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(t) + 16);
     TryView v;
     v.w0 = lo.x;
     v.w3 = lo.w;
     v.addr = hi.x;
     v.crc = hi.y;
+    v.errbit2 = hi.w & 0xffu;
     return v;
 }
 
 /* A try as phase P keeps it in LDS (everything the score and the verdict need):
- *   19 address known   20-24 DF   25-27 phase-4   28-35 corrected bit (0xff none)
+ *   19 address known   20-24 DF   25-27 phase-4   28-29 corrected bits (0..2)   30 a corrected bit lies in AA
  *   36 DF11 with IID 0   37 address in the snapshot's active table   40-63 address
  * and the best phase of a hit: the same word plus  0-15 score (int16)   16-18 offset of the try. */
 __device__ __forceinline__ uint64_t pack_try(const TryView &v, bool known, bool in_active)
 {
     const uint32_t df = (v.w0 & 0xffu) >> 3, tp = (v.w3 >> 16) & 0xffu, errbit = v.w3 >> 24;
+    const uint32_t nerr = errbit == 0xffu ? 0u : (v.errbit2 == 0xffu ? 1u : 2u);
+    const bool in_aa = (errbit >= 8 && errbit <= 31) || (v.errbit2 >= 8 && v.errbit2 <= 31);
     return ((uint64_t)(known ? 1u : 0u) << 19) | ((uint64_t)df << 20) | ((uint64_t)(tp - 4) << 25) |
-           ((uint64_t)errbit << 28) | ((uint64_t)((v.crc & 0x7fu) == 0 ? 1u : 0u) << 36) |
+           ((uint64_t)(nerr | (in_aa ? 4u : 0u)) << 28) | ((uint64_t)((v.crc & 0x7fu) == 0 ? 1u : 0u) << 36) |
            ((uint64_t)(in_active ? 1u : 0u) << 37) | ((uint64_t)(v.addr & 0xffffffu) << 40);
 }
 
@@ -107,13 +111,15 @@ __device__ __forceinline__ int score_packed(uint64_t t)
 {
     const uint32_t df = (uint32_t)(t >> 20) & 31u;
     const bool known = (t >> 19) & 1u;
-    const int nerr = (((uint32_t)(t >> 28) & 0xffu) != 0xffu) ? 1 : 0;
+    const int nerr = (int)((uint32_t)(t >> 28) & 3u);
     switch (df) {
-    case 11: /* x / (nerr + 1) with nerr 0 or 1: a shift */
+    case 11: /* x / (nerr + 1) with nerr 0 or 1 (two wrong bits never get here): a shift */
         if ((t >> 36) & 1u)
             return (known ? 1600 : 750) >> nerr;
         return known ? 1000 >> nerr : -1;
     case 17: case 18:
+        if (nerr == 2)
+            return known ? 600 : 466; /* 1800 / 3, 1400 / 3 */
         return (known ? 1800 : 1400) >> nerr;
     case 20: case 21:
         return known ? 1000 : -2;
@@ -345,13 +351,12 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 uint64_t r = best | ((uint64_t)bestscore & 0xffffu);
                 if (bestscore >= 0 && MSD_HIT_POS(h) < end) {
                     const uint32_t known = (uint32_t)(r >> 19) & 1u, df = (uint32_t)(r >> 20) & 31u;
-                    const uint32_t errbit = (uint32_t)(r >> 28) & 0xffu;
-                    const bool nerr = errbit != 0xffu;
+                    const bool nerr = ((uint32_t)(r >> 28) & 3u) != 0, in_aa = (r >> 30) & 1u;
                     bool reject;
                     if (df == 11)
                         reject = nerr && !known; /* mode_s.c:492-498 */
                     else if (df == 17 || df == 18)
-                        reject = nerr && errbit >= 8 && errbit <= 31 && !known; /* mode_s.c:522-526 */
+                        reject = in_aa && !known; /* mode_s.c:522-526: the fix changed AA */
                     else
                         reject = !known;
                     if (!reject) {
@@ -406,8 +411,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     else
                         hi = mid;
                 }
-                const uint32_t df = (uint32_t)(r >> 20) & 31u, errbit = (uint32_t)(r >> 28) & 0xffu;
-                const bool adds_addr = errbit == 0xffu && (df == 17 || (df == 11 && ((r >> 36) & 1u))); /* mode_s.c:717-726 */
+                const uint32_t df = (uint32_t)(r >> 20) & 31u, nerr = (uint32_t)(r >> 28) & 3u;
+                const bool adds_addr = nerr == 0 && (df == 17 || (df == 11 && ((r >> 36) & 1u))); /* mode_s.c:717-726 */
                 const bool fresh = adds_addr && !((r >> 19) & 1u);
                 ok_next[k] = (uint16_t)(lo | (fresh ? 0x8000u : 0u));
             }
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 const uint32_t i = ok_idx[acc_k[j]];
                 const msd_hit h = seg_hits[i];
                 const uint64_t r = seg_res[i];
-                const uint32_t df = (uint32_t)(r >> 20) & 31u, errbit = (uint32_t)(r >> 28) & 0xffu;
+                const uint32_t df = (uint32_t)(r >> 20) & 31u, nerr = (uint32_t)(r >> 28) & 3u;
                 const uint32_t addr = (uint32_t)(r >> 40);
                 accidx[nacc0 + j] = (uint16_t)i;
                 if (nmsgs0 + j < MSD_RB_MSG_CAP) {
@@ -514,10 +519,10 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     rec.len = res_len(r);
                     acc[nmsgs0 + j] = rec;
                 }
-                atomicAdd(&sh_ctr[errbit != 0xffu ? 4 : 3], 1u);
+                atomicAdd(&sh_ctr[3 + nerr], 1u);
                 atomicAdd(&sh_ctr[11 + ((uint32_t)(r >> 25) & 7u)], 1u);
                 add_first[j] = 0;
-                if (errbit == 0xffu && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) { /* mode_s.c:717-726 */
+                if (nerr == 0 && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) { /* mode_s.c:717-726 */
                     uint32_t hs = (addr * 2654435761u) >> 21;
                     for (;;) {
                         const uint32_t old = atomicCAS(&addset[hs], VACANT, addr);
@@ -800,8 +805,9 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             const msd_acc rec = acc[m];
             const msd_try *t = P.tries + rec.try_index;
             const uint4 lo = *reinterpret_cast<const uint4 *>(t);
-            const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(t) + 16);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(t) + 16);
             const uint32_t df = (lo.x & 0xffu) >> 3, tp = (lo.w >> 16) & 0xffu, errbit = lo.w >> 24;
+            const uint32_t errbit2 = hi.w & 0xffu;
             const uint32_t msgbits = (df & 0x10u) ? 112u : 56u;
             const uint32_t j = rec.pos - base;
             msd_message mm;
@@ -814,11 +820,13 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             mm.score = rec.score;
             mm.msgtype = (uint8_t)df;
             mm.msgbits = (uint8_t)msgbits;
-            mm.correctedbits = errbit != 0xffu ? 1 : 0;
+            mm.correctedbits = errbit == 0xffu ? 0 : (errbit2 == 0xffu ? 1 : 2);
             mm.bestphase = (uint8_t)tp;
             uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w & 0xffffu};
             if (errbit != 0xffu)
                 w[errbit >> 5] ^= (0x80u >> (errbit & 7u)) << (8 * ((errbit >> 3) & 3u)); /* crc.c:417-425 */
+            if (errbit2 != 0xffu)
+                w[errbit2 >> 5] ^= (0x80u >> (errbit2 & 7u)) << (8 * ((errbit2 >> 3) & 3u));
 #pragma unroll
             for (int k = 0; k < 14; ++k)
                 mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));

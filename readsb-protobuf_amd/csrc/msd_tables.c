@@ -84,6 +84,100 @@ void msd_tables_build(msd_tables *t, int nfix_crc)
     }
 }
 
+/* --aggressive (Modes.nfix_crc == 2): prepareErrorTable(bits, 2, 4), crc.c:184-354,374-379, as an
+ * open-addressing hash table for the device.  An error pattern of one or two bits out of bits
+ * 5..bits-1 is correctable iff no other pattern of up to two bits (crc.c:236-258) and no pattern of three
+ * or four bits (flagCollisions, crc.c:155-178,266-287) has the same syndrome.  Instead of the
+ * reference's sorted table and one binary search per four-bit pattern, a 16 Mi-entry census over
+ * all 24-bit syndromes is taken (low bits: patterns of <= 2 bits seen, saturating; bit 7: a 3- or
+ * 4-bit pattern maps here), which makes the 5.4 M patterns of a 112-bit message a few milliseconds.
+ * Entry: syndrome | errors << 24 | bit[0] << 32 | bit[1] << 40 (0xff: none); vacant = all ones;
+ * slot = MSD_FIX2_HASH(syndrome, log2_slots), linear probing. */
+uint64_t *msd_fix2_table(const msd_tables *t, int bits, uint32_t *log2_slots)
+{
+    const int lo = 5, n = bits - lo;
+    uint32_t single[112];
+    uint8_t probe[14];
+    for (int i = lo; i < bits; ++i) {
+        memset(probe, 0, sizeof probe);
+        probe[i >> 3] = (uint8_t)(0x80u >> (i & 7));
+        single[i - lo] = msd_crc24(t, probe, bits);
+    }
+    uint8_t *census = calloc(1u << 24, 1);
+    if (!census)
+        return NULL;
+    for (int a = 0; a < n; ++a) {
+        const uint32_t sa = single[a];
+        if ((census[sa] & 3) < 2)
+            census[sa]++;
+        for (int b = a + 1; b < n; ++b) {
+            const uint32_t sb = sa ^ single[b];
+            if ((census[sb] & 3) < 2)
+                census[sb]++;
+            for (int c = b + 1; c < n; ++c) {
+                const uint32_t sc = sb ^ single[c];
+                census[sc] |= 0x80;
+                for (int d = c + 1; d < n; ++d)
+                    census[sc ^ single[d]] |= 0x80;
+            }
+        }
+    }
+    const uint32_t lg = bits == 56 ? 12 : 14; /* 1326 / 5778 patterns at most: load factor <= 0.36 */
+    uint64_t *tab = malloc(sizeof(uint64_t) << lg);
+    if (!tab) {
+        free(census);
+        return NULL;
+    }
+    memset(tab, 0xff, sizeof(uint64_t) << lg);
+    for (int a = 0; a < n; ++a)
+        for (int b = a; b < n; ++b) { /* b == a: the single-bit pattern */
+            const uint32_t syn = b == a ? single[a] : single[a] ^ single[b];
+            if (census[syn] != 1)
+                continue;
+            uint64_t e = syn | ((uint64_t)(b == a ? 1 : 2) << 24) | ((uint64_t)(a + lo) << 32) |
+                         ((uint64_t)(b == a ? 0xff : b + lo) << 40);
+            uint32_t h = MSD_FIX2_HASH(syn, lg);
+            while (tab[h] != ~0ull)
+                h = (h + 1) & ((1u << lg) - 1);
+            tab[h] = e;
+        }
+    free(census);
+    *log2_slots = lg;
+    return tab;
+}
+
+/* modesChecksumDiagnose against the --aggressive tables on the host (tests; the kernels do the same
+ * probe): number of wrong bits (0 for a zero syndrome), -1 if uncorrectable. */
+int msd_fix2_diagnose(int bits, uint32_t syndrome, int bit[2])
+{
+    static uint64_t *tab[2];
+    static uint32_t lg[2];
+    const int k = bits == 112;
+    bit[0] = bit[1] = -1;
+    if (syndrome == 0)
+        return 0;
+    if (!tab[k]) {
+        msd_tables *t = malloc(sizeof *t);
+        if (!t)
+            return -1;
+        msd_tables_build(t, 0);
+        tab[k] = msd_fix2_table(t, bits, &lg[k]);
+        free(t);
+        if (!tab[k])
+            return -1;
+    }
+    for (uint32_t h = MSD_FIX2_HASH(syndrome, lg[k]);; h = (h + 1) & ((1u << lg[k]) - 1)) {
+        const uint64_t e = tab[k][h];
+        if (e == ~0ull)
+            return -1;
+        if ((e & 0xffffffu) == syndrome) {
+            bit[0] = (int)((e >> 32) & 0xff);
+            bit[1] = ((e >> 40) & 0xff) == 0xff ? -1 : (int)((e >> 40) & 0xff);
+            return (int)((e >> 24) & 0xff);
+        }
+    }
+}
+
 /* Checks the folding identity the kernels rely on; returns the number of mismatching slots. */
 int msd_tables_selftest(const msd_tables *t)
 {

@@ -27,7 +27,7 @@ for case in range(first, first + ncases):
     kw = dict(msgs_per_sec=int(rng.choice([200, 2000, 6000, 12000])), n_aircraft=int(rng.choice([3, 50, 800, 5000, 30000])),
               overlap_permille=int(rng.choice([0, 10, 200, 700])), flip_permille=int(rng.choice([0, 20, 200])),
               noise_fs=float(rng.choice([0.005, 0.02, 0.06])), ac_per_sec=int(rng.choice([0, 0, 500, 4000])))
-    nfix = int(rng.integers(0, 2))
+    nfix = int(rng.integers(0, 3))
     mode_ac = int(kw["ac_per_sec"] > 0 and rng.integers(0, 2))
     gpu_resolve = int(rng.integers(0, 2))
     os.environ["MSD_GPU_RESOLVE"] = str(gpu_resolve)

@@ -46,7 +46,7 @@ def run_case(pkg, oracle, torch, fmt, n, seed, nfix, batch=None, mode_ac=0, **cf
     return got, dem
 
 
-@pytest.mark.parametrize("nfix", [0, 1])
+@pytest.mark.parametrize("nfix", [0, 1, 2])
 @pytest.mark.parametrize("n", [3 * 131072 + 4567, 4 * 131072, 131072 + 1])
 def test_uc8_single_batch(pkg, oracle, torch_cuda, n, nfix):
     run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, n, seed=1090 + n % 7, nfix=nfix)
@@ -314,3 +314,36 @@ def test_preamble_threshold_change_applies_to_later_batches(pkg, oracle, torch_c
     assert st["demod_preambles"] < oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)[1]["demod_preambles"]
     with pytest.raises(pkg.MsdError):
         dem.set_preamble_threshold(0)
+
+
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", 0), ("uc8", 1), ("sc16", 0)])
+def test_aggressive_two_bit_correction(pkg, oracle, torch_cuda, fmt, mode_ac):
+    """--aggressive (Modes.nfix_crc = 2, readsb.c:542): DF17/18 with two wrong bits are corrected against the
+    (2, 4) tables of crc.c:374-379, DF11 never with more than one (mode_s.c:352-356); several batches, header
+    fields from the corrected bytes."""
+    from helpers import fmt_ids
+    f, of = fmt_ids(pkg, oracle, fmt)
+    n = 24 * 131072 + 4321
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=2024, fmt=f, msgs_per_sec=9000, n_aircraft=60), n)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=f, nfix_crc=2, mode_ac=mode_ac, max_batch_samples=8 * 131072, message_capacity=1 << 17,
+                          decode_fields=True)
+    bps = 2 if fmt == "uc8" else 4
+    parts, off, inflight = [], 0, 0
+    while off < n:
+        if inflight == 3:
+            parts.append(dem.collect_fields())
+            inflight -= 1
+        m = min(8 * 131072, n - off)
+        dem.launch_device(d_iq.data_ptr() + off * bps, m, last=off + m >= n)
+        off += m
+        inflight += 1
+    for _ in range(inflight):
+        parts.append(dem.collect_fields())
+    got = np.concatenate([p[0] for p in parts])
+    gfields = np.concatenate([p[1] for p in parts])
+    want, wfields, wstats = oracle.Oracle(of, 58, 2, mode_ac).replay_fields(iq, cap=1 << 17)
+    assert_same(got, dem.stats(), want, wstats)
+    assert gfields.tobytes() == wfields.tobytes()
+    assert wstats["demod_accepted"][2] > 20 and (want["correctedbits"] == 2).sum() == wstats["demod_accepted"][2]
+    assert not ((want["correctedbits"] == 2) & (want["msgtype"] == 11)).any()

@@ -203,3 +203,60 @@ def test_timestamp_and_skip_ahead_on_a_constructed_frame(oracle):
     assert m["msgtype"] == 17 and m["addr"] == 0x4840D6 and m["score"] == 1400 and m["correctedbits"] == 0
     assert o.filter_test(0x4840D6)                # mode_s.c:717-726
     assert m["sysTimestampMsg"] == 77 + (int(m["timestampMsg"]) - 1_000_000) // 12000
+
+
+def test_two_bit_tables_cover_what_the_reference_says(oracle):
+    """crc.c:374-376: detecting out to four wrong bits 'reduces our 2-bit coverage to about 65%' for long
+    messages; every single wrong bit stays correctable; short messages keep every pair."""
+    import itertools
+    o = oracle.Oracle(oracle.FMT_UC8, 58, 2, 0)
+
+    def syndrome(bits, nbits):
+        msg = bytearray(nbits // 8)
+        for b in bits:
+            msg[b >> 3] ^= 0x80 >> (b & 7)
+        return oracle.checksum(bytes(msg))
+
+    for nbits, want_pairs in ((56, 1275), (112, None)):
+        assert all(o.diagnose(syndrome([i], nbits), nbits) == (1, [i, -1]) for i in range(5, nbits))
+        pairs = list(itertools.combinations(range(5, nbits), 2))
+        good = sum(1 for p in pairs if o.diagnose(syndrome(p, nbits), nbits) == (2, list(p)))
+        bad = sum(1 for p in pairs if o.diagnose(syndrome(p, nbits), nbits)[0] == -1)
+        assert good + bad == len(pairs)
+        if want_pairs:
+            assert good == want_pairs
+        else:
+            assert 0.63 < good / len(pairs) < 0.68
+    # the DF field is never corrected
+    assert o.diagnose(syndrome([2], 112), 112)[0] != 1 or o.diagnose(syndrome([2], 112), 112)[1][0] != 2
+
+
+def test_product_two_bit_tables_equal_the_oracles(oracle, pkg):
+    """msd_fix2_table (a census over all 24-bit syndromes + hash table) against the oracle's restatement of
+    prepareErrorTable(bits, 2, 4): every pattern of one, two and three wrong bits, and random syndromes."""
+    import ctypes as C
+    import itertools
+    lib = pkg.capi.lib()
+    lib.msd_fix2_diagnose.restype = C.c_int
+    lib.msd_fix2_diagnose.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_int * 2)]
+    o = oracle.Oracle(oracle.FMT_UC8, 58, 2, 0)
+    rng = np.random.default_rng(24)
+
+    def product(syn, nbits):
+        b = (C.c_int * 2)()
+        n = lib.msd_fix2_diagnose(nbits, syn, C.byref(b))
+        return n, list(b)
+
+    for nbits in (56, 112):
+        single = []
+        for i in range(nbits):
+            msg = bytearray(nbits // 8)
+            msg[i >> 3] ^= 0x80 >> (i & 7)
+            single.append(oracle.checksum(bytes(msg)))
+        syns = set(single)
+        syns.update(a ^ b for a, b in itertools.combinations(single, 2))
+        tri = list(itertools.combinations(single[5:], 3))
+        syns.update(a ^ b ^ c for a, b, c in (tri if nbits == 56 else [tri[i] for i in rng.integers(0, len(tri), 20000)]))
+        syns.update(int(x) for x in rng.integers(0, 1 << 24, 20000))
+        for s in syns:
+            assert product(s, nbits) == o.diagnose(s, nbits), (nbits, hex(s))
