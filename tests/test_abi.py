@@ -56,7 +56,7 @@ def test_no_cpu_fallback_without_a_gpu(pkg):
 def test_bad_configuration_is_rejected(pkg):
     lib = pkg.capi.lib()
     h = C.c_void_p()
-    for kw in (dict(format=9), dict(nfix_crc=2), dict(preamble_threshold=0)):
+    for kw in (dict(format=9), dict(nfix_crc=3), dict(preamble_threshold=0)):
         cfg = pkg.capi.Config(device=0, format=0, preamble_threshold=58, nfix_crc=1, mode_ac=0, reserved0=0,
                               max_batch_samples=131072, stream=None)
         for k, v in kw.items():
