@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--mode-ac", action="store_true", help="BASELINE configs[4]: Mode A/C demodulator on, 500 replies/s")
     ap.add_argument("--fields", action="store_true",
                     help="MSD_CFG_DECODE_FIELDS: also decode header and extended squitter fields of every message")
+    ap.add_argument("--dcfilter", action="store_true",
+                    help="MSD_CFG_DC_FILTER: the DC-blocking converters (sequential by nature, ~0.1 GS/s); use a small --samples")
     ap.add_argument("--overlap-captures", action="store_true",
                     help="two contexts on one stream: the next capture starts while the previous one drains")
     return ap.parse_args()
@@ -95,7 +97,7 @@ def main():
     # Measured: no gain as long as everything stays in order on one stream (the scans then sit in front of
     # the draining capture's resolve passes), so it is not the default.
     nctx = 2 if args.overlap_captures else 1
-    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank,
+    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank, dc_filter=args.dcfilter,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
                             decode_fields=args.fields)
             for _ in range(nctx)]
@@ -227,7 +229,7 @@ def main():
         O = graft.load_oracle()
         ns = min(n, args.cpu_sample)
         ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-        orc = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac))
+        orc = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac), dc_filter=args.dcfilter)
         t0 = time.perf_counter()
         want, _ = orc.replay(iq[: ns * bps], cap=1 << 21)
         cpu_s = time.perf_counter() - t0
@@ -239,7 +241,7 @@ def main():
     if rank == 0 and world == 1 and args.check: # the whole capture, message for message
         O = graft.load_oracle()
         ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-        want, wstats = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac)).replay(iq, cap=1 << 21)
+        want, wstats = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac), dc_filter=args.dcfilter).replay(iq, cap=1 << 21)
         dem.reset()
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
         same = len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in

@@ -61,6 +61,9 @@ typedef struct msd_message {
 
 /* msd_config.flags */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
+#define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
+                                   374-423).  Their state and float sums run through the stream strictly in order,
+                                   which bounds this mode at about 0.1 Gsamples/s; not with MSD_FMT_MAG16 */
 
 /* Header fields of an accepted message: what decodeModesMessage assigns after its CRC switch without
  * looking into the ME / MB payloads (mode_s.c:557-715, decodeAC13Field / decodeID13Field :101-183), and

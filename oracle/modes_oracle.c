@@ -34,6 +34,8 @@ struct syndrome_entry { /* struct errorinfo, crc.h:32-37 */
 
 struct orc_ctx {
     int format, threshold, nfix, mode_ac;
+    int dc_filter; /* struct converter_state, convert.c:28-33 */
+    float dc_z1_i, dc_z1_q, dc_a, dc_b;
     /* icao_filter.c:38-40 */
     uint32_t filt[2][FILTER_SLOTS];
     int active;
@@ -129,8 +131,62 @@ static void convert_s16(const uint8_t *iq, uint16_t *mag, unsigned n, float scal
         *mp = sum_power / n;
 }
 
+/* The "generic" converters the reference picks with --dcfilter (convert.c:113-163 UC8, :165-213 SC16,
+ * :374-423 SC16Q11; selection :425-451): a one-pole DC estimate per channel that runs on through the
+ * whole stream (struct converter_state survives the calls), subtracted before the magnitude. */
+static void convert_dc(orc_ctx *ctx, const uint8_t *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
+{
+    float z1_i = ctx->dc_z1_i, z1_q = ctx->dc_z1_q;
+    const float dc_a = ctx->dc_a, dc_b = ctx->dc_b;
+    float sum_level = 0, sum_power = 0;
+    for (unsigned k = 0; k < n; ++k) {
+        float fi, fq;
+        if (ctx->format == ORC_FMT_UC8) {
+            uint8_t I = iq[2 * k], Q = iq[2 * k + 1];
+            fi = (I - 127.5f) / 127.5f;
+            fq = (Q - 127.5f) / 127.5f;
+        } else {
+            const float scale = ctx->format == ORC_FMT_SC16 ? 32768.0f : 2048.0f;
+            int16_t I = (int16_t)((unsigned)iq[4 * k] | ((unsigned)iq[4 * k + 1] << 8));
+            int16_t Q = (int16_t)((unsigned)iq[4 * k + 2] | ((unsigned)iq[4 * k + 3] << 8));
+            fi = I / scale;
+            fq = Q / scale;
+        }
+        z1_i = fi * dc_a + z1_i * dc_b;
+        z1_q = fq * dc_a + z1_q * dc_b;
+        fi -= z1_i;
+        fq -= z1_q;
+        float magsq = fi * fi + fq * fq;
+        if (magsq > 1)
+            magsq = 1;
+        float m = sqrtf(magsq);
+        sum_power += magsq;
+        sum_level += m;
+        mag[k] = (uint16_t)(m * 65535.0f + 0.5f);
+    }
+    ctx->dc_z1_i = z1_i;
+    ctx->dc_z1_q = z1_q;
+    if (ml)
+        *ml = sum_level / n;
+    if (mp)
+        *mp = sum_power / n;
+}
+
+/* --dcfilter (readsb.c:486): init_converter's "DC block @ 1Hz" (convert.c:479-482) at 2.4 MHz */
+void orc_set_dc_filter(orc_ctx *ctx, int on)
+{
+    ctx->dc_filter = on;
+    ctx->dc_z1_i = ctx->dc_z1_q = 0;
+    ctx->dc_b = exp(-2.0 * M_PI * 1.0 / 2400000.0);
+    ctx->dc_a = 1.0 - ctx->dc_b;
+}
+
 void orc_convert(orc_ctx *ctx, const void *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
 {
+    if (ctx->dc_filter) {
+        convert_dc(ctx, iq, mag, n, ml, mp);
+        return;
+    }
     switch (ctx->format) { /* convert.c:425-444 selection, filter_dc == 0 */
     case ORC_FMT_UC8:
         convert_uc8(iq, mag, n, ml, mp);

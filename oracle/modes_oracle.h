@@ -74,6 +74,8 @@ typedef struct orc_stats {
 typedef struct orc_ctx orc_ctx;
 
 orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_ac);
+/* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,374-423); resets its state */
+void orc_set_dc_filter(orc_ctx *ctx, int on);
 void orc_destroy(orc_ctx *ctx);
 
 /* Replay a whole capture exactly as `readsb --device-type ifile --ifile F --iformat X --throttle`

@@ -104,6 +104,8 @@ def lib():
         L = C.CDLL(_LIB)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int] * 4
+        L.orc_set_dc_filter.restype = None
+        L.orc_set_dc_filter.argtypes = [C.c_void_p, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_replay.restype = C.c_uint64
         L.orc_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
@@ -160,10 +162,12 @@ def beast_frame(message):
 class Oracle:
     """One receiver context (its own ICAO filter, clock and counters)."""
 
-    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0):
+    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, dc_filter=False):
         self._h = lib().orc_create(fmt, preamble_threshold, nfix_crc, mode_ac)
         if not self._h:
             raise ValueError("orc_create rejected the configuration")
+        if dc_filter:
+            lib().orc_set_dc_filter(self._h, 1)
         self.fmt = fmt
 
     def close(self):

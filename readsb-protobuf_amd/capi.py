@@ -57,6 +57,7 @@ FIELDS_DTYPE = np.dtype(
 )
 assert FIELDS_DTYPE.itemsize == 100
 CFG_DECODE_FIELDS = 1
+CFG_DC_FILTER = 2
 INVALID_ALTITUDE = -9999
 
 
@@ -206,11 +207,11 @@ class Demodulator:
     """One receiver context on one GPU (its own ICAO filter, clock, counters and HIP streams)."""
 
     def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, device=0,
-                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16, decode_fields=False):
+                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16, decode_fields=False, dc_filter=False):
         self._h = C.c_void_p()
         self.fmt = fmt
         cfg = Config(device=device, format=fmt, preamble_threshold=preamble_threshold, nfix_crc=nfix_crc,
-                     mode_ac=mode_ac, flags=CFG_DECODE_FIELDS if decode_fields else 0, max_batch_samples=max_batch_samples,
+                     mode_ac=mode_ac, flags=(CFG_DECODE_FIELDS if decode_fields else 0) | (CFG_DC_FILTER if dc_filter else 0), max_batch_samples=max_batch_samples,
                      stream=C.c_void_p(stream) if stream else None)
         rc = lib().msd_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

@@ -72,6 +72,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--no-fix")) rx.nfix_crc = 0;
         else if (!strcmp(a, "--aggressive")) rx.nfix_crc = 2; /* readsb.c:542 */
         else if (!strcmp(a, "--modeac")) rx.mode_ac = 1;
+        else if (!strcmp(a, "--dcfilter")) rx.dc_filter = 1; /* readsb.c:486 */
         else if (!strcmp(a, "--mlat")) g_mlat = 1;
         else if (!strcmp(a, "--stats")) want_stats = 1;
         else if (!strcmp(a, "--net-raw")) rx.sink = print_net_raw;
@@ -85,7 +86,7 @@ int main(int argc, char **argv)
             rx.preamble_threshold = (int)(v < 40 ? 40 : (v > 400 ? 400 : v));
             ++i;
         } else {
-            fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] "
+            fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] [--dcfilter] "
                             "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast] [--stats] [--path fused|magbuf] "
                             "[--device N]\n");
             return 2;

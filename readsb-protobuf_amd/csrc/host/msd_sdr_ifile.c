@@ -111,6 +111,14 @@ bool msd_ifileOpen(void)
     cfg.preamble_threshold = F.rx.preamble_threshold;
     cfg.nfix_crc = F.rx.nfix_crc;
     cfg.mode_ac = F.rx.mode_ac;
+    if (F.rx.dc_filter) {
+        if (F.mode != MSD_IFILE_FUSED) { /* the stateful converters live inside msd_launch_* */
+            snprintf(F.err, sizeof F.err, "ifile: --dcfilter needs the fused path");
+            msd_ifileClose();
+            return false;
+        }
+        cfg.flags |= MSD_CFG_DC_FILTER; /* init_converter(..., Modes.dc_filter, ...), sdr_ifile.c:150-153 */
+    }
     cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * nbuf;
     int rc = msd_create(&cfg, &F.ctx);
     if (rc) {

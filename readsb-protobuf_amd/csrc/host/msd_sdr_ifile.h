@@ -34,6 +34,7 @@ typedef struct msd_receiver_options {
     unsigned batch_buffers; /* fused mode: buffers per GPU batch (default 64) */
     msd_message_fn sink;    /* useModesMessage */
     void *sink_user;
+    int dc_filter;          /* Modes.dc_filter (--dcfilter, readsb.c:486); fused mode only */
 } msd_receiver_options;
 
 void msd_ifileInitConfig(void);                    /* sdr_ifile.c:70-80 */

@@ -41,6 +41,9 @@ struct Slot {
     bool gpu_resolve = false; /* the candidate lists stay in HBM: resolved there (msd_resolve_kernels.hip) */
     bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
     int threshold = 0;             /* Modes.preambleThreshold when the batch was launched */
+    bool dc = false;               /* --dcfilter: d_iq points at d_dcmag, the float sums come from d_magsq */
+    uint16_t *d_dcmag = nullptr;   /* DC-blocked magnitudes of the batch (what the scan kernel reads) */
+    float *d_magsq = nullptr;      /* their clamped squares, for the per-buffer float sums */
     uint64_t dropped_before = 0;   /* msd_note_dropped(): samples missing in front of this batch, not yet on the clock */
     uint32_t resolve_ntodo = 0;
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
@@ -143,6 +146,11 @@ struct msd_ctx {
     uint64_t next_sample = 0;
     bool finished = false;
     uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
+    bool dc = false;              /* MSD_CFG_DC_FILTER */
+    float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
+    float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
+    int scan_format = 0;          /* what the scan and its follow-up kernels read: cfg.format, or MAG16 behind the DC filter */
+    size_t scan_bps = 2;
     msd_resolver resolver{};
     msd_stats stats{};
     msd_timing timing{};
@@ -288,7 +296,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     }
     /* d_sums is zero: whoever published the slot's previous batch left it so.  The offsets kernel
      * overwrites the totals. */
-    const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11;
+    const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || s.dc;
     const bool lean = nwg && !c->cfg.mode_ac && !fm; /* totals and sums are published by the offsets kernel */
     if (!nwg)
         HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
@@ -337,9 +345,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     } else {
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
-    if ((format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11) && s.nbuffers) {
-        int rc = msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers,
-                                        s.d_fmeans, c->stream);
+    if (fm && s.nbuffers) {
+        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, c->stream)
+                      : msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
+                                               c->stream);
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
     }
@@ -353,7 +362,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
             const char *dbg = getenv("MSD_DEBUG_FLAGS");
             p.debug_flags = dbg ? atoi(dbg) : 0;
         }
-        int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise, host_noise != nullptr,
+        int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
+                               host_noise != nullptr ? 1 : (s.dc ? 2 : 0),
                                c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
                                c->ac_arena, c->ac_max_wg, c->stream);
         if (rc)
@@ -414,9 +424,11 @@ int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
             const uint64_t n = s.nsamples - off < piece ? s.nsamples - off : piece;
             const bool is_last = off + n >= s.nsamples;
             const uint64_t b0 = off / MSD_CHUNK_SAMPLES;
-            t.d_iq = s.d_iq + off * c->bps;
+            t.d_iq = s.d_iq + off * bps_of(format);
+            if (s.d_magsq)
+                t.d_magsq = s.d_magsq + off;
             if (off) {
-                t.d_prev = s.d_iq + (off - TAIL_SAMPLES) * c->bps;
+                t.d_prev = s.d_iq + (off - TAIL_SAMPLES) * bps_of(format);
                 t.have_prev = 1;
             }
             t.batch_first = s.batch_first + off;
@@ -800,7 +812,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
         if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight) {
-            int rc = gpu_begin(c, nx, c->cfg.format);
+            int rc = gpu_begin(c, nx, c->scan_format);
             if (rc)
                 return rc;
         }
@@ -850,7 +862,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
         if (&nx != &s && nx.busy && hipEventQuery(nx.ev_totals) == hipSuccess) {
-            rc = start_download(c, nx, c->cfg.format); /* its kernels are done: does not block */
+            rc = start_download(c, nx, c->scan_format); /* its kernels are done: does not block */
             if (rc)
                 return rc;
         }
@@ -868,7 +880,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         if (means_override) {
             c->means[2 * b] = means_override[2 * b];
             c->means[2 * b + 1] = means_override[2 * b + 1];
-        } else if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11) {
+        } else if (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || s.dc) {
             /* convert.c:245-251: float sum / unsigned -> float division, widened to double */
             c->means[2 * b] = (double)(s.h_fmeans[2 * b] / (float)(unsigned)n);
             c->means[2 * b + 1] = (double)(s.h_fmeans[2 * b + 1] / (float)(unsigned)n);
@@ -892,7 +904,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             if (c->outstanding > 1) {
                 Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
                 if (&nx != &s && nx.busy && !nx.download_started) {
-                    rc = start_download(c, nx, c->cfg.format);
+                    rc = start_download(c, nx, c->scan_format);
                     if (rc)
                         return rc;
                 }
@@ -947,7 +959,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     if (c->outstanding > 1) { /* if the next batch was still running before the resolve, fetch it now */
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
         if (&nx != &s && nx.busy && !nx.download_started) {
-            rc = start_download(c, nx, c->cfg.format);
+            rc = start_download(c, nx, c->scan_format);
             if (rc)
                 return rc;
         }
@@ -1037,13 +1049,23 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.dropped_before = c->pending_dropped;
     c->pending_dropped = 0;
     s.threshold = c->cfg.preamble_threshold;
+    s.dc = c->dc;
+    if (c->dc) { /* the converter proper: IQ -> DC-blocked magnitudes, strictly in stream order */
+        rc = msd_launch_dcfilter(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, s.d_dcmag, s.d_magsq,
+                                 c->stream);
+        if (rc) {
+            s.busy = false;
+            return fail(c, rc, "DC filter kernel launch failed");
+        }
+        s.d_iq = reinterpret_cast<const uint8_t *>(s.d_dcmag);
+    }
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
     s.nbuffers = (uint32_t)(nsamples / MSD_CHUNK_SAMPLES) + (last ? 1u : 0u);
     const int tail_nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
     s.tail_dst = nsamples >= (uint64_t)TAIL_SAMPLES ? c->d_tail[tail_nxt] : nullptr;
     auto tl0 = std::chrono::steady_clock::now();
-    rc = enqueue(c, s, c->cfg.format, nullptr);
+    rc = enqueue(c, s, c->scan_format, nullptr);
     if (rc) {
         s.busy = false;
         return rc;
@@ -1057,7 +1079,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.gpu_resolve = gpu_eligible(c, s);
     s.resolve_inflight = false;
     if (s.gpu_resolve && c->outstanding == 0) { /* no earlier batch to wait for: resolve right behind the scan */
-        rc = gpu_begin(c, s, c->cfg.format);
+        rc = gpu_begin(c, s, c->scan_format);
         if (rc) {
             s.busy = false;
             return rc;
@@ -1065,8 +1087,8 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     }
     if (nsamples >= (uint64_t)TAIL_SAMPLES) {
         if (s.tail_dst) /* no gather kernel ran (cannot happen with that many samples) */
-            HIPCHK(c, hipMemcpyAsync(s.tail_dst, s.d_iq + (nsamples - TAIL_SAMPLES) * c->bps,
-                                     (size_t)TAIL_SAMPLES * c->bps, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(s.tail_dst, s.d_iq + (nsamples - TAIL_SAMPLES) * c->scan_bps,
+                                     (size_t)TAIL_SAMPLES * c->scan_bps, hipMemcpyDeviceToDevice, c->stream));
         s.tail_dst = nullptr;
         c->tail_cur = tail_nxt;
         c->have_prev = true;
@@ -1085,7 +1107,7 @@ int collect(msd_ctx *c, msd_message_fn sink, void *user)
     if (c->outstanding == 0)
         return fail(c, -ENODATA, "no batch outstanding");
     Slot &s = c->slots[c->head];
-    int rc = finish(c, s, c->cfg.format, sink, user, nullptr, nullptr, s.batch_first / MSD_CHUNK_SAMPLES);
+    int rc = finish(c, s, c->scan_format, sink, user, nullptr, nullptr, s.batch_first / MSD_CHUNK_SAMPLES);
     c->head = (c->head + 1) % MSD_PIPELINE_DEPTH;
     c->outstanding--;
     return rc;
@@ -1128,6 +1150,7 @@ void destroy(msd_ctx *c)
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_wire) (void)hipHostFree(s.h_wire);
         if (s.h_fields) (void)hipHostFree(s.h_fields);
+        (void)hipFree(s.d_dcmag); (void)hipFree(s.d_magsq);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
         if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
@@ -1142,6 +1165,7 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
+    (void)hipFree(c->d_dcstate);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -1186,7 +1210,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         return -EINVAL;
     *out = nullptr;
     if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
-        cfg->preamble_threshold <= 0)
+        cfg->preamble_threshold <= 0 || ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16))
         return -EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
@@ -1200,6 +1224,13 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     if (c->cfg.max_batch_samples > MSD_MAX_BATCH_SAMPLES)
         c->cfg.max_batch_samples = MSD_MAX_BATCH_SAMPLES;
     c->bps = (cfg->format == MSD_FMT_UC8 || cfg->format == MSD_FMT_MAG16) ? 2 : 4;
+    c->dc = (cfg->flags & MSD_CFG_DC_FILTER) != 0;
+    c->scan_format = c->dc ? (int)MSD_FMT_MAG16 : cfg->format;
+    c->scan_bps = bps_of(c->scan_format);
+    if (c->dc) { /* init_converter's "DC block @ 1Hz", convert.c:479-482, at Modes.sample_rate = 2.4 MHz */
+        c->dc_b = (float)exp(-2.0 * M_PI * 1.0 / 2400000.0);
+        c->dc_a = (float)(1.0 - c->dc_b);
+    }
 
 #define CK(call)                                                              \
     do {                                                                      \
@@ -1307,9 +1338,17 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         }
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_sums), 2 * sizeof(uint64_t) * c->max_buffers));
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_fmeans), 2 * sizeof(float) * c->max_buffers));
+        if (c->dc) {
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_dcmag), c->cfg.max_batch_samples * sizeof(uint16_t) + 64));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_magsq), c->cfg.max_batch_samples * sizeof(float) + 64));
+        }
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
         for (hipEvent_t *e : evs)
             CK(hipEventCreate(e));
+    }
+    if (c->dc) {
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_dcstate), 2 * sizeof(float)));
+        CK(hipMemset(c->d_dcstate, 0, 2 * sizeof(float))); /* convert.c:476-477 */
     }
     {
         const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
@@ -1384,6 +1423,8 @@ int msd_reset(msd_ctx *c)
     c->have_prev = false;
     c->finished = false;
     c->pending_dropped = 0;
+    if (c->d_dcstate)
+        HIPCHK(c, hipMemset(c->d_dcstate, 0, 2 * sizeof(float)));
     msd_resolver_reset(&c->resolver);
     memset(&c->timing, 0, sizeof c->timing);
     return 0;
@@ -1566,6 +1607,8 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
 {
     if (!c || c->cfg.format == MSD_FMT_MAG16)
         return -EINVAL;
+    if (c->dc) /* the DC-blocking converters keep state between calls; they run inside msd_launch_* */
+        return fail(c, -ENOTSUP, "msd_convert is the stateless converter; MSD_CFG_DC_FILTER contexts convert in msd_launch_*");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (nsamples > c->cfg.max_batch_samples)
         return fail(c, -E2BIG, "nsamples exceeds max_batch_samples");

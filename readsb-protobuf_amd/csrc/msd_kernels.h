@@ -114,6 +114,12 @@ int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, co
                   msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
+/* --dcfilter: IQ -> DC-blocked u16 magnitudes + f32 squares, the converter state (z1_I, z1_Q, device
+ * memory) carried from call to call; then the sequential per-buffer float sums of those squares */
+int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
+                        uint16_t *d_mag, float *d_magsq, hipStream_t stream);
+int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
+                       hipStream_t stream);
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
                            uint32_t nbuffers, float *d_out, hipStream_t stream);
 #ifdef __cplusplus

@@ -1112,6 +1112,7 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
  * in LDS, chunk by chunk and one chunk ahead; one lane of a third wavefront adds the levels up in
  * order, one lane of a fourth the powers (a lone wavefront issues a dependent v_add_f32 about every
  * 11 cycles, so each chain gets its own SIMD; ~0.7 ms per buffer, all buffers of a batch at once). */
+constexpr int MSD_FMT_MAGSQ = 100; /* internal source "format" of the float sums: f32 magnitude squares */
 constexpr int FM_THREADS = 256, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 12, FM_CHUNK = FM_PRODUCERS * FM_PER;
 
 template <int FMT>
@@ -1141,7 +1142,12 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
                 for (int k = 0; k < FM_PER; ++k) { /* consecutive lanes read consecutive samples */
                     const uint32_t i = (uint32_t)k * FM_PRODUCERS + p, g = c * FM_CHUNK + i;
                     float m = 0.0f, magsq = 0.0f;
-                    if (g < n) {
+                    if (FMT == MSD_FMT_MAGSQ) { /* --dcfilter: the clamped squares msd_dcfilter_kernel left */
+                        if (g < n) {
+                            magsq = __uint_as_float(src[g]);
+                            m = __builtin_sqrtf(magsq);
+                        }
+                    } else if (g < n) {
                         const uint32_t w = src[g];
                         const int I = (int)(int16_t)(w & 0xffffu), Q = (int)(int16_t)(w >> 16);
                         const float fi = (float)I * inv, fq = (float)Q * inv;
@@ -1199,6 +1205,118 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
     }
     if ((tid & 63) == 0 && tid < 128)
         out[2 * b + (tid >> 6)] = sum;
+}
+
+/* --dcfilter: the "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11).
+ * Per channel z = f * dc_a + z * dc_b runs through the WHOLE stream (the converter state survives
+ * the calls, convert.c:476-477), and a float recurrence cannot be re-associated bit-exactly, so this is
+ * one dependent chain per channel: ~2 x 12 cycles per sample on one lane, about 100 Msamples/s -- 40x
+ * real time for one receiver, and what this option costs.  One workgroup walks the batch in blocks:
+ *   wavefronts 1-3  block k+1: samples -> f * dc_a for both channels, into LDS
+ *   wavefront 0     block k:   lanes 0 (I) and 1 (Q) run the two chains in lock step, z into LDS
+ *   wavefronts 1-3  block k-1: f - z, clamp, sqrt -> u16 magnitudes (what the scan kernel then reads as
+ *                              MSD_FMT_MAG16) and the f32 squares for the per-buffer sums
+ * (sum_level / sum_power restart with every buffer: msd_float_means_kernel<MSD_FMT_MAGSQ>). */
+constexpr int DC_BLK = 1536, DC_THREADS = 256, DC_WORKERS = DC_THREADS - 64;
+
+template <int FMT>
+__device__ __forceinline__ void dc_sample(const uint8_t *iq, uint64_t g, float &fi, float &fq)
+{
+    if (FMT == MSD_FMT_UC8) {
+        const uint32_t pair = reinterpret_cast<const uint16_t *>(iq)[g];
+        fi = ((float)(pair & 0xffu) - 127.5f) / 127.5f; /* convert.c:133-134: a real division */
+        fq = ((float)(pair >> 8) - 127.5f) / 127.5f;
+    } else {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(iq)[g];
+        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f); /* exact: powers of two */
+        fi = (float)(int)(int16_t)(w & 0xffffu) * inv;
+        fq = (float)(int)(int16_t)(w >> 16) * inv;
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t *iq, uint64_t nsamples, float dc_a,
+                                                                  float dc_b, float *state /* z1_I, z1_Q */,
+                                                                  uint16_t *mag, float *magsq_out)
+{
+    __shared__ __attribute__((aligned(16))) float tv[2][2][DC_BLK]; /* [block parity][channel] f * dc_a */
+    __shared__ __attribute__((aligned(16))) float zv[2][2][DC_BLK]; /* [block parity][channel] z */
+    const int tid = threadIdx.x;
+    const uint64_t nblk = (nsamples + DC_BLK - 1) / DC_BLK;
+    float z = tid < 2 ? state[tid] : 0.0f;
+    for (uint64_t k = 0; k < nblk + 2; ++k) {
+        if (tid >= 64) {
+            const int p = tid - 64;
+            if (k < nblk) { /* block k */
+                const uint64_t base = k * DC_BLK;
+                for (int i = p; i < DC_BLK; i += DC_WORKERS) {
+                    float fi = 0.0f, fq = 0.0f;
+                    if (base + i < nsamples)
+                        dc_sample<FMT>(iq, base + i, fi, fq);
+                    tv[k & 1][0][i] = fi * dc_a;
+                    tv[k & 1][1][i] = fq * dc_a;
+                }
+            }
+            if (k >= 2) { /* block k - 2 */
+                const uint64_t base = (k - 2) * DC_BLK;
+                for (int i = p; i < DC_BLK && base + i < nsamples; i += DC_WORKERS) {
+                    float fi, fq;
+                    dc_sample<FMT>(iq, base + i, fi, fq);
+                    fi -= zv[k & 1][0][i];
+                    fq -= zv[k & 1][1][i];
+                    const float sq_i = fi * fi, sq_q = fq * fq;
+                    float magsq = sq_i + sq_q;
+                    if (magsq > 1.0f)
+                        magsq = 1.0f;
+                    const float m = __builtin_sqrtf(magsq);
+                    mag[base + i] = (uint16_t)(m * 65535.0f + 0.5f);
+                    magsq_out[base + i] = magsq;
+                }
+            }
+        } else if (tid < 2 && k >= 1 && k <= nblk) { /* block k - 1: the two chains */
+            const uint64_t base = (k - 1) * DC_BLK;
+            const uint32_t cnt = nsamples - base < (uint64_t)DC_BLK ? (uint32_t)(nsamples - base) : (uint32_t)DC_BLK;
+            const float4 *t4 = reinterpret_cast<const float4 *>(tv[(k - 1) & 1][tid]);
+            float4 *z4 = reinterpret_cast<float4 *>(zv[(k - 1) & 1][tid]);
+            /* z = t + z * dc_b as two plain instructions (separately rounded product and sum, like the
+             * reference's SSE2 build; nothing for the compiler to contract or reorder) */
+#define DC_STEP(T, OUT)                                                                                      \
+    asm volatile("v_mul_f32 %0, %1, %3\n\tv_add_f32 %0, %2, %0" : "=&v"(OUT) : "v"(z), "v"(T), "v"(dc_b)); \
+    z = OUT; /* a rename, not a move: the next step reads OUT's register */
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                x[u] = t4[u];
+            for (uint32_t i = 0; i < cnt; i += 16) { /* the next 16 values are on their way while these are used */
+                float4 nx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    nx[u] = t4[((i + 16) >> 2) + u < DC_BLK / 4 ? ((i + 16) >> 2) + u : 0];
+                if (i + 16 <= cnt) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float4 o;
+                        DC_STEP(x[u].x, o.x) DC_STEP(x[u].y, o.y) DC_STEP(x[u].z, o.z) DC_STEP(x[u].w, o.w)
+                        z4[(i >> 2) + u] = o;
+                    }
+                } else {
+                    const float *tt = tv[(k - 1) & 1][tid];
+                    float *zz = zv[(k - 1) & 1][tid];
+                    for (uint32_t j = i; j < cnt; ++j) {
+                        const float t = tt[j];
+                        DC_STEP(t, zz[j])
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    x[u] = nx[u];
+            }
+#undef DC_STEP
+        }
+        __syncthreads();
+    }
+    if (tid < 2)
+        state[tid] = z;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1625,8 +1743,8 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
 {
     if (nbuffers == 0)
         return 0;
-    if (!noise_ready) {
-        const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11);
+    if (noise_ready != 1) { /* 2: from the float sums whatever the format (magnitudes behind the DC filter) */
+        const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || noise_ready == 2);
         hipLaunchKernelGGL(msd_ac_noise_kernel, dim3((nbuffers + 63) / 64), dim3(64), 0, stream, d_sums, d_fmeans,
                            use_float, p->nsamples, nbuffers, d_noise);
     }
@@ -1698,6 +1816,37 @@ extern "C" int msd_launch_convert(int format, const void *d_iq, uint32_t nsample
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+extern "C" int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b,
+                                   float *d_state, uint16_t *d_mag, float *d_magsq, hipStream_t stream)
+{
+    const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
+    if (nsamples == 0)
+        return 0;
+    switch (format) {
+    case MSD_FMT_UC8:
+        hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_UC8>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples, dc_a,
+                           dc_b, d_state, d_mag, d_magsq);
+        break;
+    case MSD_FMT_SC16:
+        hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_SC16>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples, dc_a,
+                           dc_b, d_state, d_mag, d_magsq);
+        break;
+    case MSD_FMT_SC16Q11:
+        hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_SC16Q11>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples,
+                           dc_a, dc_b, d_state, d_mag, d_magsq);
+        break;
+    default:
+        return -22;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers,
+                                  float *d_out, hipStream_t stream)
+{
+    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, stream);
+}
+
 extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
                                       uint32_t nbuffers, float *d_out, hipStream_t stream)
 {
@@ -1708,6 +1857,9 @@ extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsa
                            nsamples, buffer_len, nbuffers, d_out);
     else if (format == MSD_FMT_SC16Q11)
         hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
+                           nsamples, buffer_len, nbuffers, d_out);
+    else if (format == MSD_FMT_MAGSQ) /* msd_launch_dc_sums */
+        hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_MAGSQ>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
                            nsamples, buffer_len, nbuffers, d_out);
     else
         return -22;

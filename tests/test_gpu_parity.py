@@ -347,3 +347,66 @@ def test_aggressive_two_bit_correction(pkg, oracle, torch_cuda, fmt, mode_ac):
     assert gfields.tobytes() == wfields.tobytes()
     assert wstats["demod_accepted"][2] > 20 and (want["correctedbits"] == 2).sum() == wstats["demod_accepted"][2]
     assert not ((want["correctedbits"] == 2) & (want["msgtype"] == 11)).any()
+
+
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", 0), ("sc16", 0), ("sc16q11", 1)])
+def test_dc_filter(pkg, oracle, torch_cuda, fmt, mode_ac):
+    """--dcfilter (MSD_CFG_DC_FILTER): the converters with the 1 Hz DC block (convert.c:113-213,374-423).  Their
+    filter state runs through the whole stream (two batches and a ragged end here), the level / power sums
+    restart with every buffer; a receiver with a DC offset on both channels."""
+    from helpers import fmt_ids
+    f, of = fmt_ids(pkg, oracle, fmt)
+    n = 6 * 131072 + 555
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=808, fmt=f, msgs_per_sec=6000, n_aircraft=15,
+                                                 ac_per_sec=400 if mode_ac else 0), n)
+    if fmt == "uc8":
+        v = iq.reshape(-1, 2).astype(np.int32) + np.array([9, -6])
+        iq = np.clip(v, 0, 255).astype(np.uint8).reshape(-1)
+    else:
+        full = 32768 if fmt == "sc16" else 2048
+        v = iq.view("<i2").reshape(-1, 2).astype(np.int32) + np.array([full // 25, -full // 40])
+        iq = np.clip(v, -full, full - 1).astype("<i2").reshape(-1).view(np.uint8)
+    bps = 2 if fmt == "uc8" else 4
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, mode_ac=mode_ac, max_batch_samples=4 * 131072, message_capacity=1 << 16,
+                          dc_filter=True)
+    dem.launch_device(d_iq.data_ptr(), 4 * 131072, last=False)
+    dem.launch_device(d_iq.data_ptr() + 4 * 131072 * bps, n - 4 * 131072, last=True)
+    got = dem.collect()
+    means = [dem.buffer_means()]
+    got = np.concatenate([got, dem.collect()])
+    means.append(dem.buffer_means())
+    want, wstats, wmeans = oracle.Oracle(of, 58, 1, mode_ac, dc_filter=True).replay(iq, cap=1 << 16, want_means=True)
+    plain = oracle.Oracle(of, 58, 1, mode_ac).replay(iq, cap=1 << 16)[0]
+    assert len(want) > 300 and want.tobytes() != plain.tobytes()  # the filter matters for this capture
+    assert_same(got, dem.stats(), want, wstats)
+    gm = np.concatenate(means)
+    assert np.array_equal(gm, wmeans[: len(gm)], equal_nan=True) and len(gm) == wstats["buffers"]
+    # a new capture starts from a zero filter state again
+    dem.reset()
+    again = dem.submit_device(d_iq.data_ptr(), 4 * 131072, last=True)
+    w2 = oracle.Oracle(of, 58, 1, mode_ac, dc_filter=True).replay(iq[: 4 * 131072 * bps], cap=1 << 16)[0]
+    assert again.tobytes() == w2.tobytes()
+
+
+def test_replay_cli_aggressive_dcfilter(pkg, oracle, torch_cuda, tmp_path):
+    """The option pair that completes the converter / CRC flags of the path (readsb.c:486,542) through the
+    --ifile handler: msd_replay --aggressive --dcfilter equals the oracle with nfix 2 and the DC block."""
+    import os
+    import subprocess
+    n = 9 * 131072 + 321
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=1092, msgs_per_sec=5000, flip_permille=200), n)
+    iq = np.clip(iq.reshape(-1, 2).astype(np.int32) + np.array([7, -4]), 0, 255).astype(np.uint8).reshape(-1)
+    f = tmp_path / "capture.uc8"
+    iq.tofile(f)
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "msd_replay")
+    out = subprocess.run([exe, "--ifile", str(f), "--iformat", "uc8", "--aggressive", "--dcfilter", "--mlat", "--raw",
+                          "--batch-buffers", "4"], capture_output=True, text=True, check=True)
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 2, 0, dc_filter=True).replay(iq, cap=1 << 16)
+    assert wstats["demod_accepted"][2] > 0
+    lines = out.stdout.split()
+    assert len(lines) == len(want) > 100
+    for line, m in zip(lines, want):
+        assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())
+    bad = subprocess.run([exe, "--ifile", str(f), "--dcfilter", "--path", "magbuf"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "fused" in bad.stderr
