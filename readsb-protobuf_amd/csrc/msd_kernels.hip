@@ -202,6 +202,29 @@ __device__ __forceinline__ int correlate(int m0, int m1, int m2, int m3)
     return 4 * m0 + 15 * m1 - 20 * m2 + m3;
 }
 
+/* the weights of correlator c (demod_2400.c:73-93) that fall on sample pair `pair` of a window whose first
+ * sample is the low (odd = 0) or the high (odd = 1) half of pair 0: positive ones or, negated, the
+ * negative ones, packed like the samples (low half = even sample) */
+__host__ __device__ constexpr uint32_t corr_pair(int c, int odd, int pair, bool positive)
+{
+    constexpr int W[5][4] = {{18, -15, -3, 0}, {14, -5, -9, 0}, {16, 5, -20, 0}, {7, 11, -18, 0}, {4, 15, -20, 1}};
+    uint32_t out = 0;
+    for (int e = 0; e < 4; ++e) {
+        const int w = W[c][e], s = odd + e; /* sample index within the pairs */
+        if ((s >> 1) != pair)
+            continue;
+        const int m = positive ? (w > 0 ? w : 0) : (w < 0 ? -w : 0);
+        out |= (uint32_t)m << (16 * (s & 1));
+    }
+    return out;
+}
+
+__device__ __forceinline__ uint32_t dot2u(uint32_t pair, uint32_t weights, uint32_t acc)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pair), __builtin_bit_cast(us2, weights), acc, false);
+}
+
 /* One message byte whose first bit sits at PPM phase PH (0..4) of sample mags[first]: bit k is
  * correlator (PH + 12k) % 5 at sample first + (PH + 12k) / 5  (demod_2400.c:98-177 in closed
  * form).  With PH uniform across the wavefront every tap is a compile-time offset.  The 21 samples
@@ -220,17 +243,26 @@ __device__ __forceinline__ uint32_t slice_byte_phase(const uint16_t *mags, uint3
     for (int k = 0; k < 10; ++k)
         a[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
     a[10] = d[10] >> sh;
-#define MSD_S(K) ((int)((a[(K) >> 1] >> (16 * ((K) & 1))) & 0xffffu))
+    /* a[k] holds samples 2k (low half) and 2k+1 of the byte's window.  A correlator is a weighted sum of
+     * three or four consecutive samples; its positive and its negative weights are summed separately
+     * with v_dot2_u32_u16 straight from the packed pairs (two samples per instruction, nothing to
+     * unpack) and the bit is pos > neg -- the same integers as demod_2400.c:73-93, just not subtracted. */
     uint32_t v = 0;
 #define MSD_BIT(K)                                                                                   \
     {                                                                                                \
         constexpr int t = PH + 12 * (K);                                                             \
-        constexpr int i = t / 5, c = t % 5;                                                          \
-        v = (v << 1) | (correlate<c>(MSD_S(i), MSD_S(i + 1), MSD_S(i + 2), MSD_S((i + 3 > 20) ? 20 : i + 3)) > 0 ? 1u : 0u); \
+        constexpr int i = t / 5, c = t % 5, j = i >> 1, odd = i & 1;                                 \
+        uint32_t pos = 0, neg = 0;                                                                   \
+        if (corr_pair(c, odd, 0, true)) pos = dot2u(a[j], corr_pair(c, odd, 0, true), pos);          \
+        if (corr_pair(c, odd, 1, true)) pos = dot2u(a[j + 1], corr_pair(c, odd, 1, true), pos);      \
+        if (corr_pair(c, odd, 2, true)) pos = dot2u(a[(j + 2 > 10) ? 10 : j + 2], corr_pair(c, odd, 2, true), pos); \
+        if (corr_pair(c, odd, 0, false)) neg = dot2u(a[j], corr_pair(c, odd, 0, false), neg);        \
+        if (corr_pair(c, odd, 1, false)) neg = dot2u(a[j + 1], corr_pair(c, odd, 1, false), neg);    \
+        if (corr_pair(c, odd, 2, false)) neg = dot2u(a[(j + 2 > 10) ? 10 : j + 2], corr_pair(c, odd, 2, false), neg); \
+        v = v + v + (pos > neg ? 1u : 0u);                                                           \
     }
     MSD_BIT(0) MSD_BIT(1) MSD_BIT(2) MSD_BIT(3) MSD_BIT(4) MSD_BIT(5) MSD_BIT(6) MSD_BIT(7)
 #undef MSD_BIT
-#undef MSD_S
     return v;
 }
 
