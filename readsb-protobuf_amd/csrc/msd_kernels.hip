@@ -157,9 +157,15 @@ __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t v
 {
     if (FMT == MSD_FMT_UC8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t pair = (r.w[k >> 1] >> (16 * (k & 1))) & 0xffffu; /* I | Q << 8 */
-            mg[k] = lut[fold8(pair >> 8) * LUT_STRIDE + fold8(pair & 0xffu)];
+        for (int k = 0; k < 4; ++k) {
+            /* fold8 of the four bytes I0 Q0 I1 Q1 at once: bytes with the top bit set keep their low
+             * seven bits, the others are complemented */
+            const uint32_t w = r.w[k];
+            const uint32_t top = w & 0x80808080u;
+            const uint32_t keep = top - (top >> 7); /* 0x7f in the bytes >= 128 */
+            const uint32_t f = (w ^ ~keep) & 0x7f7f7f7fu;
+            mg[2 * k] = lut[((f >> 8) & 0xffu) * LUT_STRIDE + (f & 0xffu)];
+            mg[2 * k + 1] = lut[(f >> 24) * LUT_STRIDE + ((f >> 16) & 0xffu)];
         }
     } else if (FMT == MSD_FMT_MAG16) {
 #pragma unroll
@@ -655,12 +661,15 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
         for (int k = 0; k < GPT; ++k) {
             uint32_t mg[8];
             convert_group<FMT>(cur[k], cur_valid[k], lut, mg);
-            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (tid + NT * k)) = pack8(mg);
+            const uint4 packed = pack8(mg);
+            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (tid + NT * k)) = packed;
+            sum_level = dot2u(packed.x, 0x00010001u, sum_level); /* two magnitudes per instruction */
+            sum_level = dot2u(packed.y, 0x00010001u, sum_level);
+            sum_level = dot2u(packed.z, 0x00010001u, sum_level);
+            sum_level = dot2u(packed.w, 0x00010001u, sum_level);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                sum_level += mg[i];
+            for (int i = 0; i < 8; ++i)
                 sum_power += (unsigned long long)(mg[i] * mg[i]);
-            }
         }
         if (tile + 1 < tile_hi) {
 #pragma unroll
@@ -688,48 +697,49 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                 sm[2 * k] = (int)(v[k] & 0xffffu);
                 sm[2 * k + 1] = (int)(v[k] >> 16);
             }
-            uint32_t nib_lo = 0, nib_hi = 0; /* 4 bits per position: which tests fired */
+            /* one bit plane per test, position q at bit 15 - q: every verdict is a lane mask in scalar
+             * registers (v_cmp + s_and), and `plane = 2 * plane + verdict` is one v_addc_co_u32 with that
+             * mask as the carry-in */
+            uint32_t pl0 = 0, pl1 = 0, pl2 = 0;
+#define MSD_PUSH(PLANE, MASK) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(PLANE) : "s"(MASK) : "vcc")
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 /* pa[d] = mags[p + 2 + d]: the tile stages 328 samples ahead, the reference's
                  * overlap is 326.  Branch-free on purpose: with 64 lanes some lane almost always
                  * passes the pre-check, so a branch only adds exec-mask bookkeeping. */
 #define PA(d) (sm[q + 2 + (d)])
-                const bool pre = (PA(1) > PA(7)) & (PA(12) > PA(14)) & (PA(12) > PA(15));
+                const uint64_t pre = __ballot(PA(1) > PA(7)) & __ballot(PA(12) > PA(14)) & __ballot(PA(12) > PA(15));
                 const uint32_t base_noise = (uint32_t)(PA(5) + PA(8) + PA(16) + PA(17) + PA(18));
                 const int ref_level = (int)(__umul24(base_noise, (uint32_t)P.threshold) >> 5); /* < 2^24 each */
                 const int diff_2_3 = PA(2) - PA(3);
                 const int sum_1_4 = PA(1) + PA(4);
                 const int diff_10_11 = PA(10) - PA(11);
                 const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
-                uint32_t m = 0;
-                m |= (pre & (common3456 - diff_10_11 >= ref_level)) ? 1u : 0u;
-                m |= (pre & (common3456 + diff_10_11 >= ref_level)) ? 2u : 0u;
-                m |= (pre & (sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level)) ? 4u : 0u;
+                const uint64_t f0 = pre & __ballot(common3456 - diff_10_11 >= ref_level);
+                const uint64_t f1 = pre & __ballot(common3456 + diff_10_11 >= ref_level);
+                const uint64_t f2 = pre & __ballot(sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level);
 #undef PA
-                if (q < 8)
-                    nib_lo |= m << (4 * q);
-                else
-                    nib_hi |= m << (4 * (q - 8));
+                MSD_PUSH(pl0, f0);
+                MSD_PUSH(pl1, f1);
+                MSD_PUSH(pl2, f2);
             }
-            uint64_t nib = (uint64_t)nib_lo | ((uint64_t)nib_hi << 32);
+#undef MSD_PUSH
             /* positions past the last one the reference scans */
             {
                 const uint64_t first = a0 + 16ull * tid;
                 if (first + 16 > batch_end) {
                     const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
-                    nib = keep ? (nib & ((1ull << (4 * keep)) - 1ull)) : 0ull;
+                    const uint32_t km = keep ? ~((1u << (16 - keep)) - 1u) : 0u;
+                    pl0 &= km;
+                    pl1 &= km;
+                    pl2 &= km;
                 }
             }
+            const uint32_t any = pl0 | pl1 | pl2;
 
             TMARK(2); /* tests */
             /* ---- stage 3: ordered hit bookkeeping ---- */
-            uint32_t cnt;
-            {
-                uint64_t x = nib | (nib >> 1) | (nib >> 2); /* non-zero nibbles */
-                x &= 0x1111111111111111ull;
-                cnt = (uint32_t)__popcll(x);
-            }
+            const uint32_t cnt = (uint32_t)__popc(any);
             const uint32_t incl = wave_incl_scan(cnt, lane);
             uint32_t *wh = wave_hits + NW * (tile & 1u);
             if (lane == 63)
@@ -767,13 +777,14 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                     if (fill) {
                         if (cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
                             /* my hits with rank in [r0, r0 + HCAP) -> hitlist, in position order */
-                            uint64_t x = (nib | (nib >> 1) | (nib >> 2)) & 0x1111111111111111ull;
-                            uint32_t r = my_rank0;
+                            uint32_t x = any, r = my_rank0;
                             while (x) {
-                                const int q = (__ffsll((unsigned long long)x) - 1) >> 2;
-                                x &= x - 1;
-                                if (r >= r0 && r < r0 + HCAP)
-                                    hitlist[r - r0] = (uint32_t)(16 * tid + q) | (((uint32_t)(nib >> (4 * q)) & 7u) << 13);
+                                const int bit = 31 - __clz((int)x); /* highest bit = lowest position */
+                                x &= ~(1u << bit);
+                                if (r >= r0 && r < r0 + HCAP) {
+                                    const uint32_t m = ((pl0 >> bit) & 1u) | (((pl1 >> bit) & 1u) << 1) | (((pl2 >> bit) & 1u) << 2);
+                                    hitlist[r - r0] = (uint32_t)(16 * tid + (15 - bit)) | (m << 13);
+                                }
                                 ++r;
                             }
                         }
