@@ -225,6 +225,21 @@ __host__ __device__ constexpr uint32_t corr_pair(int c, int odd, int pair, bool 
     return out;
 }
 
+/* both halves of a sample pair shifted right by five (v_pk_lshrrev_b16) */
+__device__ __forceinline__ uint32_t pk_shr5(uint32_t pair)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, pair) >> (unsigned short)5);
+}
+
+/* the exact sum of squares from its value modulo 2^32 and the bracketing sum of the truncated squares
+ * (see msd_scan_kernel): the one number congruent to `mod` in [1024 * top, 1024 * top + 2^32) */
+__device__ __forceinline__ unsigned long long power_sum(uint32_t mod, uint32_t top)
+{
+    const unsigned long long low = (unsigned long long)top << 10;
+    return low + (uint32_t)(mod - (uint32_t)low);
+}
+
 __device__ __forceinline__ uint32_t dot2u(uint32_t pair, uint32_t weights, uint32_t acc)
 {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -605,7 +620,12 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
 
     /* running buffer sums (convert.c:78-110), flushed when the workgroup moves to another buffer */
     uint32_t sum_level = 0;
-    unsigned long long sum_power = 0;
+    /* Sum of the squares of at most 256 magnitudes per lane and buffer (16 tiles x 16 samples) without
+     * 64-bit arithmetic in the loop: pw_mod = the sum modulo 2^32 (v_dot2_u32_u16 of a sample pair with
+     * itself wraps), pw_top = the sum of (m >> 5)^2, which fits (2047^2 * 256 < 2^32) and brackets the
+     * true sum: 1024 * pw_top <= sum < 1024 * pw_top + 256 * (64 * 2047 * 31 + 31^2) < 1024 * pw_top + 2^31.
+     * power_sum() puts the two together when the buffer changes. */
+    uint32_t pw_mod = 0, pw_top = 0;
     uint64_t sum_chunk = (uint64_t)tile_lo * T / MSD_CHUNK_SAMPLES;
 
     /* look-behind of the first tile: samples [a0-328, a0) */
@@ -641,7 +661,7 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
             const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
             if (c != sum_chunk) { /* workgroup-uniform */
                 if (P.chunk_sums) {
-                    unsigned long long sl = sum_level, sp = sum_power;
+                    unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) {
                         sl += __shfl_down(sl, o);
@@ -653,7 +673,8 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                     }
                 }
                 sum_level = 0;
-                sum_power = 0;
+                pw_mod = 0;
+                pw_top = 0;
                 sum_chunk = c;
             }
         }
@@ -663,13 +684,14 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
             convert_group<FMT>(cur[k], cur_valid[k], lut, mg);
             const uint4 packed = pack8(mg);
             *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (tid + NT * k)) = packed;
-            sum_level = dot2u(packed.x, 0x00010001u, sum_level); /* two magnitudes per instruction */
-            sum_level = dot2u(packed.y, 0x00010001u, sum_level);
-            sum_level = dot2u(packed.z, 0x00010001u, sum_level);
-            sum_level = dot2u(packed.w, 0x00010001u, sum_level);
+            const uint32_t pk[4] = {packed.x, packed.y, packed.z, packed.w};
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                sum_power += (unsigned long long)(mg[i] * mg[i]);
+            for (int i = 0; i < 4; ++i) { /* two magnitudes per instruction */
+                sum_level = dot2u(pk[i], 0x00010001u, sum_level);
+                pw_mod = dot2u(pk[i], pk[i], pw_mod);
+                const uint32_t top = pk_shr5(pk[i]);
+                pw_top = dot2u(top, top, pw_top);
+            }
         }
         if (tile + 1 < tile_hi) {
 #pragma unroll
@@ -848,7 +870,7 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
     }
 
     if (P.chunk_sums) {
-        unsigned long long sl = sum_level, sp = sum_power;
+        unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sl += __shfl_down(sl, o);

@@ -410,3 +410,25 @@ def test_replay_cli_aggressive_dcfilter(pkg, oracle, torch_cuda, tmp_path):
         assert line == "@%012X%s;" % (int(m["timestampMsg"]), bytes(m["msg"][: m["msgbits"] // 8]).hex())
     bad = subprocess.run([exe, "--ifile", str(f), "--dcfilter", "--path", "magbuf"], capture_output=True, text=True)
     assert bad.returncode != 0 and "fused" in bad.stderr
+
+
+@pytest.mark.parametrize("pattern", ["full-scale", "alternating", "ramp"])
+def test_level_and_power_sums_at_full_scale(pkg, oracle, torch_cuda, pattern):
+    """The scan kernel sums the squared magnitudes of a buffer modulo 2^32 plus a bracketing sum of the
+    truncated squares (msd_kernels.hip power_sum): saturated input makes that wrap hundreds of times per lane."""
+    n = 3 * 131072 + 4097
+    if pattern == "full-scale":
+        iq = np.full(2 * n, 255, dtype=np.uint8)
+    elif pattern == "alternating":
+        iq = np.tile(np.array([255, 0, 128, 127, 0, 0, 255, 255], dtype=np.uint8), (2 * n + 7) // 8)[: 2 * n].copy()
+    else:
+        iq = (np.arange(2 * n, dtype=np.uint32) * 37 // 3).astype(np.uint8)
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=4 * 131072, message_capacity=1 << 12)
+    got = dem.submit_device(d.data_ptr(), n, last=True)
+    want, wstats, wmeans = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 12, want_means=True)
+    assert_same(got, dem.stats(), want, wstats)
+    gm = dem.buffer_means()
+    assert np.array_equal(gm, wmeans[: len(gm)], equal_nan=True) and len(gm) == wstats["buffers"]
+    if pattern == "full-scale":
+        assert gm[0, 1] > 0.99  # mean power of a saturated buffer
