@@ -147,6 +147,8 @@ typedef struct msd_timing {
     uint64_t resolve_passes;   /* passes of the GPU resolve kernel over this batch; 0 = resolved on the host */
     uint64_t resolve_fallback; /* batches the GPU resolve handed to the host resolver (since msd_reset) */
     uint64_t resolve_long_lists; /* passes that had to fetch the complete per-buffer add lists (since msd_reset) */
+    uint64_t timed_batches;    /* batches whose kernel times were measured (msd_set_timing_interval); the *_kernel_ms
+                                  fields are those of the most recent one */
 } msd_timing;
 
 typedef struct msd_ctx msd_ctx;
@@ -194,6 +196,10 @@ int msd_reset(msd_ctx *ctx);
  * by the dropped samples (sampleCounter, sdr_rtlsdr.c:284,299-300) and msd_stats.samples_dropped
  * grows by them (readsb.c:836) when the batch is collected.  -EINVAL after the last batch. */
 int msd_note_dropped(msd_ctx *ctx, uint64_t nsamples);
+/* The kernel times in msd_timing come from three hipEventRecord calls per batch, each of which holds the
+ * stream for about 5 us (1 % of a 64 Mi-sample batch): measure one batch in `every` (default 1 = all,
+ * 0 = none). */
+int msd_set_timing_interval(msd_ctx *ctx, uint32_t every);
 /* Modes.preambleThreshold for the batches launched from now on.  The reference raises it to
  * max(PREAMBLE_THRESHOLD_PIZERO = 75, threshold) while its 15-minute statistics hold dropped samples
  * (demod_2400.c:285-290); that statistics window belongs to the host program, which calls this when

@@ -114,6 +114,7 @@ class Timing(C.Structure):
         ("resolve_passes", C.c_uint64),
         ("resolve_fallback", C.c_uint64),
         ("resolve_long_lists", C.c_uint64),
+        ("timed_batches", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -133,7 +134,7 @@ EXPORTS = [
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
-    "msd_note_dropped", "msd_set_preamble_threshold",
+    "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval",
 ]
 
 _lib = None
@@ -160,6 +161,8 @@ def lib():
         L.msd_reset.argtypes = [C.c_void_p]
         L.msd_note_dropped.restype = C.c_int
         L.msd_note_dropped.argtypes = [C.c_void_p, C.c_uint64]
+        L.msd_set_timing_interval.restype = C.c_int
+        L.msd_set_timing_interval.argtypes = [C.c_void_p, C.c_uint32]
         L.msd_set_preamble_threshold.restype = C.c_int
         L.msd_set_preamble_threshold.argtypes = [C.c_void_p, C.c_int]
         for name in ("msd_launch_device", "msd_launch_host"):
@@ -311,6 +314,10 @@ class Demodulator:
     def note_dropped(self, nsamples):
         """msd_note_dropped: the receiver lost nsamples in front of the next batch (MAGBUF_DISCONTINUOUS)."""
         self._check(lib().msd_note_dropped(self._h, nsamples))
+
+    def set_timing_interval(self, every):
+        """msd_set_timing_interval: record the kernel timing events for one batch in `every` (0: never)."""
+        self._check(lib().msd_set_timing_interval(self._h, every))
 
     def set_preamble_threshold(self, threshold):
         self._check(lib().msd_set_preamble_threshold(self._h, threshold))

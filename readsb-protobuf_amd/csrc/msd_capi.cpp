@@ -41,6 +41,7 @@ struct Slot {
     bool gpu_resolve = false; /* the candidate lists stay in HBM: resolved there (msd_resolve_kernels.hip) */
     bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
     int threshold = 0;             /* Modes.preambleThreshold when the batch was launched */
+    bool timed = false;            /* ev_start / ev_scan / ev_kernels were recorded for this batch */
     bool dc = false;               /* --dcfilter: d_iq points at d_dcmag, the float sums come from d_magsq */
     uint16_t *d_dcmag = nullptr;   /* DC-blocked magnitudes of the batch (what the scan kernel reads) */
     float *d_magsq = nullptr;      /* their clamped squares, for the per-buffer float sums */
@@ -146,6 +147,8 @@ struct msd_ctx {
     uint64_t next_sample = 0;
     bool finished = false;
     uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
+    uint32_t timing_interval = 1; /* msd_set_timing_interval() */
+    uint64_t enqueue_seq = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
     float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
@@ -302,7 +305,11 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
     if (c->cfg.mode_ac)
         HIPCHK(c, hipMemsetAsync(s.d_ac_totals, 0, sizeof(uint64_t) * 4, c->stream));
-    HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
+    /* the three timing events cost about 5 us of stream time each (a barrier packet per record): they are
+     * recorded for one batch in every c->timing_interval */
+    s.timed = c->timing_interval && (c->enqueue_seq++ % c->timing_interval) == 0;
+    if (s.timed)
+        HIPCHK(c, hipEventRecord(s.ev_start, c->stream));
     if (nwg) {
         MsdScanParams p{};
         fill_params(c, s, p);
@@ -328,7 +335,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         int rc = msd_launch_scan(&p, format, nwg, c->stream);
         if (rc)
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-        HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
+        if (s.timed)
+            HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
         const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
                                (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
         rc = msd_launch_gather(c->d_counts, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
@@ -342,7 +350,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
             s.tail_dst = nullptr; /* done */
         if (rc)
             return fail(c, rc, "gather kernel launch failed");
-    } else {
+    } else if (s.timed) {
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
     if (fm && s.nbuffers) {
@@ -369,7 +377,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         if (rc)
             return fail(c, rc, "Mode A/C kernel launch failed");
     }
-    HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
+    if (s.timed)
+        HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
 
     /* totals and per-buffer sums go to pinned host memory from this stream, right behind the kernels */
     if (!lean) {
@@ -516,7 +525,7 @@ int start_download(msd_ctx *c, Slot &s, int format)
     const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
     auto td0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipEventSynchronize(s.ev_totals));
-    if (trace) {
+    if (trace && s.timed) {
         float a = 0, b = 0;
         (void)hipEventElapsedTime(&a, s.ev_start, s.ev_scan);
         (void)hipEventElapsedTime(&b, s.ev_start, s.ev_kernels);
@@ -917,9 +926,9 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             float ms = 0;
             c->timing.hits = H;
             c->timing.tries = Tn;
-            if (hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
-                c->timing.scan_kernel_ms = ms;
-            if (hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
+            if (s.timed && hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
+                c->timing.scan_kernel_ms = ms, c->timing.timed_batches++;
+            if (s.timed && hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
                 c->timing.other_kernels_ms = ms;
             if (hipEventElapsedTime(&ms, s.ev_copy0, s.ev_copy1) == hipSuccess)
                 c->timing.d2h_ms = ms;
@@ -1004,9 +1013,9 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     float ms = 0;
     c->timing.hits = H;
     c->timing.tries = Tn;
-    if (hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
-        c->timing.scan_kernel_ms = ms;
-    if (hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
+    if (s.timed && hipEventElapsedTime(&ms, s.ev_start, s.ev_scan) == hipSuccess)
+        c->timing.scan_kernel_ms = ms, c->timing.timed_batches++;
+    if (s.timed && hipEventElapsedTime(&ms, s.ev_scan, s.ev_kernels) == hipSuccess)
         c->timing.other_kernels_ms = ms;
     if (hipEventElapsedTime(&ms, s.ev_copy0, s.ev_copy1) == hipSuccess)
         c->timing.d2h_ms = ms;
@@ -1443,6 +1452,15 @@ int msd_note_dropped(msd_ctx *c, uint64_t nsamples)
     return 0;
 }
 
+int msd_set_timing_interval(msd_ctx *c, uint32_t every)
+{
+    if (!c)
+        return -EINVAL;
+    c->timing_interval = every;
+    c->enqueue_seq = 0;
+    return 0;
+}
+
 int msd_set_preamble_threshold(msd_ctx *c, int threshold)
 {
     if (!c)
@@ -1681,6 +1699,9 @@ int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength
     s.have_prev = 1;
     s.threshold = c->cfg.preamble_threshold;
     s.dropped_before = 0;
+    s.gpu_resolve = false; /* one buffer with the caller's clock and means: the host resolver */
+    s.resolve_inflight = false;
+    s.dc = false;
     s.batch_first = 0;
     s.nsamples = mlen;
     s.nbuffers = 1;
