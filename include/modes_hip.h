@@ -70,7 +70,7 @@ typedef struct msd_message {
  * decodeModeAMessage for Mode A/C replies (mode_ac.c:168-202).  Unset fields are 0. */
 #define MSD_INVALID_ALTITUDE (-9999) /* readsb.h:130 */
 #define MSD_NON_ICAO_ADDRESS (1u << 24) /* readsb.h:197 */
-typedef struct msd_fields {
+typedef struct msd_fields { /* 128 bytes */
     int32_t altitude_baro;       /* feet; meaningful with altitude_baro_valid */
     uint16_t AC;                 /* 13-bit altitude code (DF0/4/16/20) */
     uint16_t ID;                 /* 13-bit identity code (DF5/21) */
@@ -87,7 +87,7 @@ typedef struct msd_fields {
     uint8_t imf;                 /* setIMF was applied (mode_s.c:770-792) */
     uint32_t addr;               /* msd_message.addr, with MSD_NON_ICAO_ADDRESS where DF18 / IMF / Mode A/C say so */
     /* ---- extended squitter payload, DF17/18 (mode_s.c:736-1058,1373-1474): identification, positions,
-     * velocity, test and status messages; target state (29) and operational status (31) are not decoded.
+     * velocity, test and status messages, target state and operational status.
      * Speeds, headings and movement are delivered as the integers the message carries (the reference
      * turns them into floats with sqrtf / atan2 / fixed tables). ---- */
     uint8_t metype, mesub;
@@ -111,9 +111,55 @@ typedef struct msd_fields {
     int16_t baro_rate, geom_rate; /* ft/min */
     int16_t geom_delta;          /* ft */
     uint8_t geom_delta_valid;
-    uint8_t emergency_valid, emergency; /* ES type 28 subtype 1 */
-    uint8_t pad[3];
+    uint8_t emergency_valid, emergency; /* ES type 28 subtype 1, type 29 version 1 */
+    /* ---- ME type 29, target state and status (mode_s.c:1058-1249), and type 31, aircraft operational
+     * status (:1251-1370).  Headings, QNH and the antenna offset stay the integers the message carries. ---- */
+    uint8_t nav_valid;           /* MSD_NAV_*: which of the nav_* values below were sent */
+    uint8_t nav_altitude_source; /* nav_altitude_source_t, readsb.h:189-195: 0 invalid, 1 unknown, 2 aircraft, 3 MCP, 4 FMS */
+    uint8_t nav_modes;           /* nav_modes_t, readsb.h:180-187: 1 autopilot, 2 VNAV, 4 altitude hold, 8 approach, 16 LNAV, 32 TCAS */
+    uint8_t nav_heading_type;    /* heading_type_t */
+    uint8_t acc_valid;           /* MSD_ACC_*: which of nac_p .. sda were sent (sil counts when sil_type != 0) */
+    uint8_t nac_p, nic_baro, nic_a, nic_c, gva, sda, sil;
+    uint8_t sil_type;            /* AIRCRAFT_META__SIL_TYPE, readsb.pb-c.h:101-106: 0 invalid, 1 unknown, 2 per sample, 3 per hour */
+    uint8_t cc_antenna_offset;   /* operational status v2, surface: ME bits 33-40 */
+    uint8_t pad;
+    uint16_t nav_heading_raw;    /* degrees as sent (version 1 layout) or x 180/256 with MSD_NAV_HEADING_V2 */
+    uint16_t nav_qnh_raw;        /* 800 + (raw - 1) * 0.8 hPa */
+    int32_t nav_mcp_altitude, nav_fms_altitude; /* feet */
+    uint32_t opstatus;           /* MSD_OPS_* */
 } msd_fields;
+#define MSD_NAV_MODES 1u
+#define MSD_NAV_HEADING 2u
+#define MSD_NAV_MCP_ALTITUDE 4u
+#define MSD_NAV_FMS_ALTITUDE 8u
+#define MSD_NAV_QNH 16u
+#define MSD_NAV_HEADING_V2 32u
+#define MSD_ACC_NAC_P 1u
+#define MSD_ACC_NIC_BARO 2u
+#define MSD_ACC_NIC_A 4u
+#define MSD_ACC_NIC_C 8u
+#define MSD_ACC_GVA 16u
+#define MSD_ACC_SDA 32u
+/* msd_fields.opstatus, struct modesMessage.opstatus (readsb.h:492-524): bit 0 valid, 1-3 version, then one bit each */
+#define MSD_OPS_VALID 1u
+#define MSD_OPS_VERSION(x) (((x) >> 1) & 7u)
+#define MSD_OPS_OM_ACAS_RA (1u << 4)
+#define MSD_OPS_OM_IDENT (1u << 5)
+#define MSD_OPS_OM_ATC (1u << 6)
+#define MSD_OPS_OM_SAF (1u << 7)
+#define MSD_OPS_CC_ACAS (1u << 8)
+#define MSD_OPS_CC_CDTI (1u << 9)
+#define MSD_OPS_CC_1090_IN (1u << 10)
+#define MSD_OPS_CC_ARV (1u << 11)
+#define MSD_OPS_CC_TS (1u << 12)
+#define MSD_OPS_CC_TC(x) (((x) >> 13) & 3u)
+#define MSD_OPS_CC_UAT_IN (1u << 15)
+#define MSD_OPS_CC_POA (1u << 16)
+#define MSD_OPS_CC_B2_LOW (1u << 17)
+#define MSD_OPS_CC_LW_VALID (1u << 18)
+#define MSD_OPS_CC_LW(x) (((x) >> 19) & 15u)
+#define MSD_OPS_HRD(x) (((x) >> 23) & 7u) /* heading_type_t */
+#define MSD_OPS_TAH(x) (((x) >> 26) & 7u) /* heading_type_t */
 
 /* struct stats demodulator counters, stats.h:61-80 */
 typedef struct msd_stats {

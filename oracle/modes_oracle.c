@@ -937,6 +937,224 @@ static void es_airborne(const uint8_t *me, orc_fields *f, int check_imf) /* mode
     }
 }
 
+/* ---- ME type 29: decodeESTargetStatus, mode_s.c:1058-1249 ---- */
+enum { NAVALT_INVALID, NAVALT_UNKNOWN, NAVALT_AIRCRAFT, NAVALT_MCP, NAVALT_FMS };            /* readsb.h:189-195 */
+enum { NM_AUTOPILOT = 1, NM_VNAV = 2, NM_ALT_HOLD = 4, NM_APPROACH = 8, NM_LNAV = 16, NM_TCAS = 32 }; /* readsb.h:180-187 */
+enum { HT_INVALID, HT_GROUND_TRACK, HT_TRUE, HT_MAGNETIC, HT_MAGNETIC_OR_TRUE, HT_TRACK_OR_HEADING }; /* readsb.h:158-165 */
+enum { SILT_INVALID, SILT_UNKNOWN, SILT_PER_SAMPLE, SILT_PER_HOUR };                         /* readsb.pb-c.h:101-106 */
+enum { NAVV_MODES = 1, NAVV_HEADING = 2, NAVV_MCP = 4, NAVV_FMS = 8, NAVV_QNH = 16, NAVV_HEADING_V2 = 32 };
+enum { ACCV_NAC_P = 1, ACCV_NIC_BARO = 2, ACCV_NIC_A = 4, ACCV_NIC_C = 8, ACCV_GVA = 16, ACCV_SDA = 32 };
+
+static void es_target_status(const uint8_t *me, orc_fields *f, int check_imf)
+{
+    f->mesub = (uint8_t)getbits(me, 6, 7);
+    if (check_imf && getbits(me, 51, 51))
+        set_imf(f);
+
+    if (f->mesub == 0 && getbits(me, 11, 11) == 0) { /* version 1 */
+        switch (getbits(me, 8, 9)) {
+        case 1: f->nav_altitude_source = NAVALT_MCP; break;
+        case 2: f->nav_altitude_source = NAVALT_AIRCRAFT; break;
+        case 3: f->nav_altitude_source = NAVALT_FMS; break;
+        default: break;
+        }
+        switch (getbits(me, 14, 15)) {
+        case 1:
+            f->nav_valid |= NAVV_MODES;
+            if (f->nav_altitude_source == NAVALT_FMS)
+                f->nav_modes |= NM_VNAV;
+            else
+                f->nav_modes |= NM_AUTOPILOT;
+            break;
+        case 2:
+            f->nav_valid |= NAVV_MODES;
+            if (f->nav_altitude_source == NAVALT_FMS)
+                f->nav_modes |= NM_VNAV;
+            else if (f->nav_altitude_source == NAVALT_AIRCRAFT)
+                f->nav_modes |= NM_ALT_HOLD;
+            else
+                f->nav_modes |= NM_AUTOPILOT;
+            break;
+        default: break;
+        }
+        int alt = -1000 + 100 * (int)getbits(me, 16, 25);
+        switch (f->nav_altitude_source) {
+        case NAVALT_MCP: f->nav_valid |= NAVV_MCP; f->nav_mcp_altitude = alt; break;
+        case NAVALT_FMS: f->nav_valid |= NAVV_FMS; f->nav_fms_altitude = alt; break;
+        default: break;
+        }
+        unsigned h_source = getbits(me, 26, 27);
+        if (h_source != 0) {
+            f->nav_valid |= NAVV_HEADING;
+            f->nav_heading_raw = (uint16_t)getbits(me, 28, 36);
+            f->nav_heading_type = getbits(me, 37, 37) ? HT_GROUND_TRACK : HT_MAGNETIC_OR_TRUE;
+        }
+        switch (getbits(me, 38, 39)) {
+        case 1: case 2:
+            f->nav_valid |= NAVV_MODES;
+            f->nav_modes |= (h_source == 3) ? NM_LNAV : NM_AUTOPILOT;
+            break;
+        default: break;
+        }
+        f->acc_valid |= ACCV_NAC_P;
+        f->nac_p = (uint8_t)getbits(me, 40, 43);
+        f->acc_valid |= ACCV_NIC_BARO;
+        f->nic_baro = (uint8_t)getbits(me, 44, 44);
+        f->sil = (uint8_t)getbits(me, 45, 46);
+        f->sil_type = SILT_UNKNOWN;
+        switch (getbits(me, 52, 53)) {
+        case 1: f->nav_valid |= NAVV_MODES; break;
+        case 2: case 3: f->nav_valid |= NAVV_MODES; f->nav_modes |= NM_TCAS; break;
+        case 0: f->nav_modes |= NM_TCAS; break; /* mode_s.c:1186-1190: set without validating the modes */
+        }
+        f->emergency_valid = 1;
+        f->emergency = (uint8_t)getbits(me, 54, 56);
+    } else if (f->mesub == 1) { /* version 2 */
+        unsigned is_fms = getbits(me, 9, 9);
+        unsigned alt_bits = getbits(me, 10, 20);
+        if (alt_bits != 0) {
+            if (is_fms) {
+                f->nav_valid |= NAVV_FMS;
+                f->nav_fms_altitude = (int32_t)((alt_bits - 1) * 32);
+            } else {
+                f->nav_valid |= NAVV_MCP;
+                f->nav_mcp_altitude = (int32_t)((alt_bits - 1) * 32);
+            }
+        }
+        unsigned baro_bits = getbits(me, 21, 29);
+        if (baro_bits != 0) {
+            f->nav_valid |= NAVV_QNH;
+            f->nav_qnh_raw = (uint16_t)baro_bits; /* 800.0 + (baro_bits - 1) * 0.8 */
+        }
+        if (getbits(me, 30, 30)) {
+            f->nav_valid |= NAVV_HEADING | NAVV_HEADING_V2;
+            f->nav_heading_raw = (uint16_t)getbits(me, 31, 39); /* x 180.0 / 256.0 */
+            f->nav_heading_type = HT_MAGNETIC_OR_TRUE;
+        }
+        f->acc_valid |= ACCV_NAC_P;
+        f->nac_p = (uint8_t)getbits(me, 40, 43);
+        f->acc_valid |= ACCV_NIC_BARO;
+        f->nic_baro = (uint8_t)getbits(me, 44, 44);
+        f->sil = (uint8_t)getbits(me, 45, 46);
+        f->sil_type = SILT_UNKNOWN;
+        if (getbits(me, 47, 47)) {
+            f->nav_valid |= NAVV_MODES;
+            f->nav_modes = (uint8_t)((getbits(me, 48, 48) ? NM_AUTOPILOT : 0) | (getbits(me, 49, 49) ? NM_VNAV : 0) |
+                                     (getbits(me, 50, 50) ? NM_ALT_HOLD : 0) | (getbits(me, 52, 52) ? NM_APPROACH : 0) |
+                                     (getbits(me, 53, 53) ? NM_TCAS : 0) | (getbits(me, 54, 54) ? NM_LNAV : 0));
+        }
+    }
+}
+
+/* ---- ME type 31: decodeESOperationalStatus, mode_s.c:1251-1370; the bit-fields of
+ * modesMessage.opstatus (readsb.h:492-524) are collected in a struct and packed at the end ---- */
+static void es_operational_status(const uint8_t *me, orc_fields *f, int check_imf)
+{
+    struct {
+        unsigned valid, version, om_acas_ra, om_ident, om_atc, om_saf, cc_acas, cc_cdti, cc_1090_in, cc_arv, cc_ts, cc_tc,
+            cc_uat_in, cc_poa, cc_b2_low, cc_lw_valid, cc_lw, hrd, tah;
+    } o;
+    memset(&o, 0, sizeof o);
+    f->mesub = (uint8_t)getbits(me, 6, 8);
+    if (check_imf && getbits(me, 56, 56))
+        set_imf(f);
+    if (f->mesub == 0 || f->mesub == 1) {
+        o.valid = 1;
+        o.version = getbits(me, 41, 43);
+        switch (o.version) {
+        case 0:
+            if (f->mesub == 0 && getbits(me, 9, 10) == 0) {
+                o.cc_acas = !getbits(me, 12, 12);
+                o.cc_cdti = getbits(me, 13, 13);
+            }
+            break;
+        case 1:
+            if (getbits(me, 25, 26) == 0) {
+                o.om_acas_ra = getbits(me, 27, 27);
+                o.om_ident = getbits(me, 28, 28);
+                o.om_atc = getbits(me, 29, 29);
+            }
+            if (f->mesub == 0 && getbits(me, 9, 10) == 0 && getbits(me, 13, 14) == 0) {
+                o.cc_acas = !getbits(me, 11, 11);
+                o.cc_cdti = getbits(me, 12, 12);
+                o.cc_arv = getbits(me, 15, 15);
+                o.cc_ts = getbits(me, 16, 16);
+                o.cc_tc = getbits(me, 17, 18);
+            } else if (f->mesub == 1 && getbits(me, 9, 10) == 0 && getbits(me, 13, 14) == 0) {
+                o.cc_poa = getbits(me, 11, 11);
+                o.cc_cdti = getbits(me, 12, 12);
+                o.cc_b2_low = getbits(me, 15, 15);
+                o.cc_lw_valid = 1;
+                o.cc_lw = getbits(me, 21, 24);
+            }
+            f->acc_valid |= ACCV_NIC_A;
+            f->nic_a = (uint8_t)getbits(me, 44, 44);
+            f->acc_valid |= ACCV_NAC_P;
+            f->nac_p = (uint8_t)getbits(me, 45, 48);
+            f->sil_type = SILT_UNKNOWN;
+            f->sil = (uint8_t)getbits(me, 51, 52);
+            o.hrd = getbits(me, 54, 54) ? HT_MAGNETIC : HT_TRUE;
+            if (f->mesub == 0) {
+                f->acc_valid |= ACCV_NIC_BARO;
+                f->nic_baro = (uint8_t)getbits(me, 53, 53);
+            } else {
+                o.tah = getbits(me, 53, 53) ? o.hrd : HT_GROUND_TRACK;
+            }
+            break;
+        case 2:
+            if (getbits(me, 25, 26) == 0) {
+                o.om_acas_ra = getbits(me, 27, 27);
+                o.om_ident = getbits(me, 28, 28);
+                o.om_atc = getbits(me, 29, 29);
+                o.om_saf = getbits(me, 30, 30);
+                f->acc_valid |= ACCV_SDA;
+                f->sda = (uint8_t)getbits(me, 31, 32);
+            }
+            if (f->mesub == 0 && getbits(me, 9, 10) == 0) {
+                o.cc_acas = getbits(me, 11, 11); /* inverted sense versus v0 / v1 */
+                o.cc_1090_in = getbits(me, 12, 12);
+                o.cc_arv = getbits(me, 15, 15);
+                o.cc_ts = getbits(me, 16, 16);
+                o.cc_tc = getbits(me, 17, 18);
+                o.cc_uat_in = getbits(me, 19, 19);
+            } else if (f->mesub == 1 && getbits(me, 9, 10) == 0) {
+                o.cc_poa = getbits(me, 11, 11);
+                o.cc_1090_in = getbits(me, 12, 12);
+                o.cc_b2_low = getbits(me, 15, 15);
+                o.cc_uat_in = getbits(me, 16, 16);
+                f->nac_v_valid = 1;
+                f->nac_v = (uint8_t)getbits(me, 17, 19);
+                f->acc_valid |= ACCV_NIC_C;
+                f->nic_c = (uint8_t)getbits(me, 20, 20);
+                o.cc_lw_valid = 1;
+                o.cc_lw = getbits(me, 21, 24);
+                f->cc_antenna_offset = (uint8_t)getbits(me, 33, 40);
+            }
+            f->acc_valid |= ACCV_NIC_A;
+            f->nic_a = (uint8_t)getbits(me, 44, 44);
+            f->acc_valid |= ACCV_NAC_P;
+            f->nac_p = (uint8_t)getbits(me, 45, 48);
+            f->sil = (uint8_t)getbits(me, 51, 52);
+            f->sil_type = getbits(me, 55, 55) ? SILT_PER_SAMPLE : SILT_PER_HOUR;
+            o.hrd = getbits(me, 54, 54) ? HT_MAGNETIC : HT_TRUE;
+            if (f->mesub == 0) {
+                f->acc_valid |= ACCV_GVA;
+                f->gva = (uint8_t)getbits(me, 49, 50);
+                f->acc_valid |= ACCV_NIC_BARO;
+                f->nic_baro = (uint8_t)getbits(me, 53, 53);
+            } else {
+                o.tah = getbits(me, 53, 53) ? o.hrd : HT_GROUND_TRACK;
+            }
+            break;
+        default: break;
+        }
+    }
+    f->opstatus = o.valid | o.version << 1 | o.om_acas_ra << 4 | o.om_ident << 5 | o.om_atc << 6 | o.om_saf << 7 |
+                  o.cc_acas << 8 | o.cc_cdti << 9 | o.cc_1090_in << 10 | o.cc_arv << 11 | o.cc_ts << 12 | o.cc_tc << 13 |
+                  o.cc_uat_in << 15 | o.cc_poa << 16 | o.cc_b2_low << 17 | o.cc_lw_valid << 18 | o.cc_lw << 19 |
+                  o.hrd << 23 | o.tah << 26;
+}
+
 static void extended_squitter(const orc_message *mm, orc_fields *f) /* mode_s.c:1373-1474 */
 {
     const uint8_t *me = mm->msg + 4;
@@ -989,7 +1207,9 @@ static void extended_squitter(const orc_message *mm, orc_fields *f) /* mode_s.c:
                 set_imf(f);
         }
         break;
-    default: /* 29 and 31 are not restated; 24, 30 and the rest carry nothing the reference decodes */
+    case 29: es_target_status(me, f, check_imf); break;
+    case 31: es_operational_status(me, f, check_imf); break;
+    default: /* 24, 30 and the rest carry nothing the reference decodes */
         break;
     }
 }
@@ -1075,6 +1295,12 @@ static void fields_mode_ac(orc_fields *mm, unsigned ModeA)
             mm->altitude_baro_valid = 1;
         }
     }
+}
+
+/* the fields of one accepted Mode S message (msgtype 0..31), for known-answer tests */
+void orc_fields_of(const orc_message *mm, orc_fields *out)
+{
+    fields_mode_s(mm, out);
 }
 
 void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap)

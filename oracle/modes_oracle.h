@@ -121,7 +121,7 @@ typedef struct orc_fields {
     uint8_t CA, CC, CF, DR, FS, KE, ND, RI, SL, UM, VS;
     uint8_t source, addrtype, imf;
     uint32_t addr;
-    /* extended squitter (decodeExtendedSquitter, mode_s.c:1373-1474, without types 29 and 31); speeds,
+    /* extended squitter (decodeExtendedSquitter, mode_s.c:1373-1474); speeds,
      * headings and movement as the integers the message carries */
     uint8_t metype, mesub;
     uint8_t cpr_valid, cpr_type, cpr_odd;
@@ -145,10 +145,19 @@ typedef struct orc_fields {
     int16_t geom_delta;
     uint8_t geom_delta_valid;
     uint8_t emergency_valid, emergency;
-    uint8_t pad[3];
+    /* ME types 29 and 31 (decodeESTargetStatus mode_s.c:1058-1249, decodeESOperationalStatus :1251-1370) */
+    uint8_t nav_valid, nav_altitude_source, nav_modes, nav_heading_type;
+    uint8_t acc_valid, nac_p, nic_baro, nic_a, nic_c, gva, sda, sil, sil_type;
+    uint8_t cc_antenna_offset;
+    uint8_t pad;
+    uint16_t nav_heading_raw, nav_qnh_raw;
+    int32_t nav_mcp_altitude, nav_fms_altitude;
+    uint32_t opstatus;
 } orc_fields;
 /* From now on orc_replay / orc_demod_buffer also write the fields of message i to fields[i] (i < cap). */
 void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap);
+/* the fields of one accepted Mode S message (msgtype 0..31) */
+void orc_fields_of(const orc_message *mm, orc_fields *out);
 /* single pieces, for known-answer tests */
 int orc_decode_ac13(unsigned ac13, int *unit);
 unsigned orc_decode_id13(unsigned id13);

@@ -51,10 +51,15 @@ FIELDS_DTYPE = np.dtype(
      ("ns_vel", "<i2"), ("heading_raw", "<u2"), ("heading_type", "u1"), ("movement", "u1"), ("ias", "<u2"),
      ("tas", "<u2"), ("ias_valid", "u1"), ("tas_valid", "u1"), ("baro_rate_valid", "u1"), ("geom_rate_valid", "u1"),
      ("baro_rate", "<i2"), ("geom_rate", "<i2"), ("geom_delta", "<i2"), ("geom_delta_valid", "u1"),
-     ("emergency_valid", "u1"), ("emergency", "u1"), ("pad", "u1", (3,))],
+     ("emergency_valid", "u1"), ("emergency", "u1"),
+     ("nav_valid", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"), ("nav_heading_type", "u1"),
+     ("acc_valid", "u1"), ("nac_p", "u1"), ("nic_baro", "u1"), ("nic_a", "u1"), ("nic_c", "u1"), ("gva", "u1"),
+     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("pad", "u1"),
+     ("nav_heading_raw", "<u2"), ("nav_qnh_raw", "<u2"), ("nav_mcp_altitude", "<i4"), ("nav_fms_altitude", "<i4"),
+     ("opstatus", "<u4")],
     align=True,
 )
-assert FIELDS_DTYPE.itemsize == 100
+assert FIELDS_DTYPE.itemsize == 128
 
 
 class Stats(C.Structure):
@@ -244,6 +249,17 @@ class Oracle:
         lib().orc_demod_buffer(self._h, data.ctypes.data, data.size, sample_ts, sys_ts, mean_level,
                                mean_power, out.ctypes.data, cap, C.byref(n))
         return out[: n.value]
+
+
+def fields_of(message):
+    """orc_fields_of: the decoded fields of one Mode S message record (MESSAGE_DTYPE scalar)."""
+    rec = np.zeros(1, dtype=MESSAGE_DTYPE)
+    rec[0] = message
+    out = np.zeros(1, dtype=FIELDS_DTYPE)
+    lib().orc_fields_of.restype = None
+    lib().orc_fields_of.argtypes = [C.c_void_p, C.c_void_p]
+    lib().orc_fields_of(rec.ctypes.data, out.ctypes.data)
+    return out[0]
 
 
 def checksum(msg: bytes) -> int:

@@ -52,10 +52,15 @@ FIELDS_DTYPE = np.dtype(
      ("ns_vel", "<i2"), ("heading_raw", "<u2"), ("heading_type", "u1"), ("movement", "u1"), ("ias", "<u2"),
      ("tas", "<u2"), ("ias_valid", "u1"), ("tas_valid", "u1"), ("baro_rate_valid", "u1"), ("geom_rate_valid", "u1"),
      ("baro_rate", "<i2"), ("geom_rate", "<i2"), ("geom_delta", "<i2"), ("geom_delta_valid", "u1"),
-     ("emergency_valid", "u1"), ("emergency", "u1"), ("pad", "u1", (3,))],
+     ("emergency_valid", "u1"), ("emergency", "u1"),
+     ("nav_valid", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"), ("nav_heading_type", "u1"),
+     ("acc_valid", "u1"), ("nac_p", "u1"), ("nic_baro", "u1"), ("nic_a", "u1"), ("nic_c", "u1"), ("gva", "u1"),
+     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("pad", "u1"),
+     ("nav_heading_raw", "<u2"), ("nav_qnh_raw", "<u2"), ("nav_mcp_altitude", "<i4"), ("nav_fms_altitude", "<i4"),
+     ("opstatus", "<u4")],
     align=True,
 )
-assert FIELDS_DTYPE.itemsize == 100
+assert FIELDS_DTYPE.itemsize == 128
 CFG_DECODE_FIELDS = 1
 CFG_DC_FILTER = 2
 INVALID_ALTITUDE = -9999

@@ -118,6 +118,152 @@ MSD_HD void msd_fields_set_imf(msd_fields *f)
         f->addrtype = 5; /* ADSR_ICAO -> ADSR_OTHER */
 }
 
+/* ME type 29, target state and status (decodeESTargetStatus, mode_s.c:1058-1249) */
+MSD_HD void msd_fields_es_target_state(const uint8_t *me, int check_imf, msd_fields *f)
+{
+    f->mesub = (uint8_t)msd_field_bits(me, 6, 7); /* two bits of subtype only */
+    if (check_imf && msd_field_bits(me, 51, 51))
+        msd_fields_set_imf(f);
+    if (f->mesub == 0 && !msd_field_bits(me, 11, 11)) { /* the DO-260A layout */
+        const uint32_t vsrc = msd_field_bits(me, 8, 9);
+        const uint32_t src = vsrc == 1 ? 3u /* MCP */ : (vsrc == 2 ? 2u /* aircraft */ : (vsrc == 3 ? 4u /* FMS */ : 0u));
+        f->nav_altitude_source = (uint8_t)src;
+        const uint32_t vmode = msd_field_bits(me, 14, 15); /* 1 acquiring, 2 maintaining */
+        if (vmode == 1 || vmode == 2) {
+            f->nav_valid |= MSD_NAV_MODES;
+            f->nav_modes |= src == 4 ? 2u : ((vmode == 2 && src == 2) ? 4u : 1u); /* VNAV / altitude hold / autopilot */
+        }
+        const int32_t alt = -1000 + 100 * (int32_t)msd_field_bits(me, 16, 25);
+        if (src == 3) {
+            f->nav_valid |= MSD_NAV_MCP_ALTITUDE;
+            f->nav_mcp_altitude = alt;
+        } else if (src == 4) {
+            f->nav_valid |= MSD_NAV_FMS_ALTITUDE;
+            f->nav_fms_altitude = alt;
+        }
+        const uint32_t hsrc = msd_field_bits(me, 26, 27);
+        if (hsrc) {
+            f->nav_valid |= MSD_NAV_HEADING;
+            f->nav_heading_raw = (uint16_t)msd_field_bits(me, 28, 36);
+            f->nav_heading_type = msd_field_bits(me, 37, 37) ? 1 : 4; /* ground track : magnetic or true */
+        }
+        const uint32_t hmode = msd_field_bits(me, 38, 39);
+        if (hmode == 1 || hmode == 2) {
+            f->nav_valid |= MSD_NAV_MODES;
+            f->nav_modes |= hsrc == 3 ? 16u : 1u; /* LNAV when the FMS steers */
+        }
+        f->acc_valid |= MSD_ACC_NAC_P | MSD_ACC_NIC_BARO;
+        f->nac_p = (uint8_t)msd_field_bits(me, 40, 43);
+        f->nic_baro = (uint8_t)msd_field_bits(me, 44, 44);
+        f->sil = (uint8_t)msd_field_bits(me, 45, 46);
+        f->sil_type = 1; /* unknown */
+        const uint32_t tcas = msd_field_bits(me, 52, 53);
+        if (tcas)
+            f->nav_valid |= MSD_NAV_MODES;
+        if (tcas != 1)
+            f->nav_modes |= 32u; /* also for 0: "assume TCAS if we had any other modes", without validating them */
+        f->emergency_valid = 1;
+        f->emergency = (uint8_t)msd_field_bits(me, 54, 56);
+    } else if (f->mesub == 1) { /* DO-260B */
+        const uint32_t alt_bits = msd_field_bits(me, 10, 20);
+        if (alt_bits) {
+            if (msd_field_bits(me, 9, 9)) {
+                f->nav_valid |= MSD_NAV_FMS_ALTITUDE;
+                f->nav_fms_altitude = (int32_t)(alt_bits - 1) * 32;
+            } else {
+                f->nav_valid |= MSD_NAV_MCP_ALTITUDE;
+                f->nav_mcp_altitude = (int32_t)(alt_bits - 1) * 32;
+            }
+        }
+        const uint32_t baro_bits = msd_field_bits(me, 21, 29);
+        if (baro_bits) {
+            f->nav_valid |= MSD_NAV_QNH;
+            f->nav_qnh_raw = (uint16_t)baro_bits;
+        }
+        if (msd_field_bits(me, 30, 30)) {
+            f->nav_valid |= MSD_NAV_HEADING | MSD_NAV_HEADING_V2;
+            f->nav_heading_raw = (uint16_t)msd_field_bits(me, 31, 39);
+            f->nav_heading_type = 4;
+        }
+        f->acc_valid |= MSD_ACC_NAC_P | MSD_ACC_NIC_BARO;
+        f->nac_p = (uint8_t)msd_field_bits(me, 40, 43);
+        f->nic_baro = (uint8_t)msd_field_bits(me, 44, 44);
+        f->sil = (uint8_t)msd_field_bits(me, 45, 46);
+        f->sil_type = 1;
+        if (msd_field_bits(me, 47, 47)) {
+            f->nav_valid |= MSD_NAV_MODES;
+            f->nav_modes = (uint8_t)((msd_field_bits(me, 48, 48) ? 1u : 0u) | (msd_field_bits(me, 49, 49) ? 2u : 0u) |
+                                     (msd_field_bits(me, 50, 50) ? 4u : 0u) | (msd_field_bits(me, 52, 52) ? 8u : 0u) |
+                                     (msd_field_bits(me, 53, 53) ? 32u : 0u) | (msd_field_bits(me, 54, 54) ? 16u : 0u));
+        }
+    }
+}
+
+/* ME type 31, aircraft operational status (decodeESOperationalStatus, mode_s.c:1251-1370) */
+MSD_HD void msd_fields_es_opstatus(const uint8_t *me, int check_imf, msd_fields *f)
+{
+#define MSD_OPS_BIT(n, flag) (msd_field_bits(me, (n), (n)) ? (uint32_t)(flag) : 0u)
+    f->mesub = (uint8_t)msd_field_bits(me, 6, 8);
+    if (check_imf && msd_field_bits(me, 56, 56))
+        msd_fields_set_imf(f);
+    if (f->mesub > 1)
+        return;
+    const uint32_t version = msd_field_bits(me, 41, 43), airborne = f->mesub == 0;
+    uint32_t ops = MSD_OPS_VALID | (version << 1);
+    if (version == 0) {
+        if (airborne && msd_field_bits(me, 9, 10) == 0)
+            ops |= (msd_field_bits(me, 12, 12) ? 0u : MSD_OPS_CC_ACAS) | MSD_OPS_BIT(13, MSD_OPS_CC_CDTI);
+    } else if (version == 1 || version == 2) {
+        if (msd_field_bits(me, 25, 26) == 0) {
+            ops |= MSD_OPS_BIT(27, MSD_OPS_OM_ACAS_RA) | MSD_OPS_BIT(28, MSD_OPS_OM_IDENT) | MSD_OPS_BIT(29, MSD_OPS_OM_ATC);
+            if (version == 2) {
+                ops |= MSD_OPS_BIT(30, MSD_OPS_OM_SAF);
+                f->acc_valid |= MSD_ACC_SDA;
+                f->sda = (uint8_t)msd_field_bits(me, 31, 32);
+            }
+        }
+        const int cc_ok = msd_field_bits(me, 9, 10) == 0 && (version == 2 || msd_field_bits(me, 13, 14) == 0);
+        if (cc_ok && airborne) {
+            /* bit 11 means "ACAS operational" in version 2 and "not ACAS" before */
+            ops |= (version == 2 ? MSD_OPS_BIT(11, MSD_OPS_CC_ACAS) : (msd_field_bits(me, 11, 11) ? 0u : MSD_OPS_CC_ACAS)) |
+                   MSD_OPS_BIT(12, version == 2 ? MSD_OPS_CC_1090_IN : MSD_OPS_CC_CDTI) | MSD_OPS_BIT(15, MSD_OPS_CC_ARV) |
+                   MSD_OPS_BIT(16, MSD_OPS_CC_TS) | (msd_field_bits(me, 17, 18) << 13);
+            if (version == 2)
+                ops |= MSD_OPS_BIT(19, MSD_OPS_CC_UAT_IN);
+        } else if (cc_ok) {
+            ops |= MSD_OPS_BIT(11, MSD_OPS_CC_POA) | MSD_OPS_BIT(12, version == 2 ? MSD_OPS_CC_1090_IN : MSD_OPS_CC_CDTI) |
+                   MSD_OPS_BIT(15, MSD_OPS_CC_B2_LOW) | MSD_OPS_CC_LW_VALID | (msd_field_bits(me, 21, 24) << 19);
+            if (version == 2) {
+                ops |= MSD_OPS_BIT(16, MSD_OPS_CC_UAT_IN);
+                f->nac_v_valid = 1;
+                f->nac_v = (uint8_t)msd_field_bits(me, 17, 19);
+                f->acc_valid |= MSD_ACC_NIC_C;
+                f->nic_c = (uint8_t)msd_field_bits(me, 20, 20);
+                f->cc_antenna_offset = (uint8_t)msd_field_bits(me, 33, 40);
+            }
+        }
+        f->acc_valid |= MSD_ACC_NIC_A | MSD_ACC_NAC_P;
+        f->nic_a = (uint8_t)msd_field_bits(me, 44, 44);
+        f->nac_p = (uint8_t)msd_field_bits(me, 45, 48);
+        f->sil = (uint8_t)msd_field_bits(me, 51, 52);
+        f->sil_type = version == 2 ? (msd_field_bits(me, 55, 55) ? 2 : 3) : 1; /* per sample : per hour; unknown before */
+        const uint32_t hrd = msd_field_bits(me, 54, 54) ? 3u : 2u; /* magnetic : true */
+        ops |= hrd << 23;
+        if (airborne) {
+            if (version == 2) {
+                f->acc_valid |= MSD_ACC_GVA;
+                f->gva = (uint8_t)msd_field_bits(me, 49, 50);
+            }
+            f->acc_valid |= MSD_ACC_NIC_BARO;
+            f->nic_baro = (uint8_t)msd_field_bits(me, 53, 53);
+        } else {
+            ops |= (msd_field_bits(me, 53, 53) ? hrd : 1u /* ground track */) << 26; /* TAH, DO-260B 2.2.3.2.7.2.12 */
+        }
+    }
+    f->opstatus = ops;
+#undef MSD_OPS_BIT
+}
+
 /* decodeExtendedSquitter (mode_s.c:1373-1474) and the per-type decoders it calls; me = msg + 4.
  * f already holds the header fields (CF for DF18, airground from CA for DF17). */
 MSD_HD void msd_fields_es(const uint8_t *me, uint32_t df, msd_fields *f)
@@ -284,9 +430,11 @@ MSD_HD void msd_fields_es(const uint8_t *me, uint32_t df, msd_fields *f)
             if (check_imf && msd_field_bits(me, 56, 56))
                 msd_fields_set_imf(f);
         }
-    }
-    /* 29 (target state and status) and 31 (operational status) are not decoded; 24, 30 and the rest
-     * carry nothing the reference decodes either */
+    } else if (metype == 29)
+        msd_fields_es_target_state(me, check_imf, f);
+    else if (metype == 31)
+        msd_fields_es_opstatus(me, check_imf, f);
+    /* 24 (surface system status), 30 (operational coordination) and the rest carry nothing the reference decodes */
 }
 
 /* a Mode S message (msgtype 0..31, corrected bytes); addr = msd_message.addr */

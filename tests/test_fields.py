@@ -16,7 +16,10 @@ FIELD_NAMES = ("altitude_baro", "AC", "ID", "squawk", "altitude_baro_valid", "al
                "altitude_geom_valid", "altitude_geom_unit", "category", "category_valid", "nac_v_valid", "nac_v",
                "velocity_valid", "heading_valid", "ew_vel", "ns_vel", "heading_raw", "heading_type", "movement", "ias",
                "tas", "ias_valid", "tas_valid", "baro_rate_valid", "geom_rate_valid", "baro_rate", "geom_rate",
-               "geom_delta", "geom_delta_valid", "emergency_valid", "emergency")
+               "geom_delta", "geom_delta_valid", "emergency_valid", "emergency", "nav_valid", "nav_altitude_source",
+               "nav_modes", "nav_heading_type", "acc_valid", "nac_p", "nic_baro", "nic_a", "nic_c", "gva", "sda", "sil",
+               "sil_type", "cc_antenna_offset", "nav_heading_raw", "nav_qnh_raw", "nav_mcp_altitude", "nav_fms_altitude",
+               "opstatus")
 
 
 def code_bits(code13):
@@ -268,3 +271,40 @@ def test_host_decode_matches_oracle_on_replayed_captures(pkg, oracle, name):
         for f in FIELD_NAMES:
             assert got[f] == want[f], (f, int(got[f]), int(want[f]), int(m["msgtype"]))
     assert nac > 0 or not meta["mode_ac"]
+
+
+def test_target_state_published_example(pkg):
+    """ME type 29 subtype 1 (DO-260B target state and status), the example of 'The 1090 MHz riddle': selected
+    altitude 16992 ft from the MCP/FCU, QNH 1012.8 hPa, selected heading 66.8 deg, NACp 9, NICbaro 1, SIL 3,
+    autopilot / VNAV / approach-free / TCAS / LNAV mode bits."""
+    f = pkg.capi.decode_fields(es_record(pkg, "8DA05629EA21485CBF3F8CADAEEB"))
+    assert (f["metype"], f["mesub"]) == (29, 1)
+    assert f["nav_valid"] & 4 and f["nav_mcp_altitude"] == 16992 and not f["nav_valid"] & 8
+    assert f["nav_valid"] & 16 and abs(800.0 + (f["nav_qnh_raw"] - 1) * 0.8 - 1012.8) < 1e-9
+    assert f["nav_valid"] & 2 and f["nav_valid"] & 32 and abs(f["nav_heading_raw"] * 180.0 / 256.0 - 66.8) < 0.05
+    assert (f["nac_p"], f["nic_baro"], f["sil"], f["sil_type"], f["acc_valid"] & 3) == (9, 1, 3, 1, 3)
+    assert f["nav_valid"] & 1 and f["nav_modes"] == (1 | 2 | 16 | 32)  # autopilot, VNAV, LNAV, TCAS
+
+
+def test_target_state_and_operational_status_against_the_oracle(pkg, oracle):
+    """ME types 29 and 31 (mode_s.c:1058-1370), every version and subtype, DF17 and DF18 with every control
+    field: the shared host/device decoder against the oracle's restatement on random payloads."""
+    rng = np.random.default_rng(2931)
+    n = 0
+    for k in range(6000):
+        raw = bytearray(rng.integers(0, 256, 14, dtype=np.uint8).tobytes())
+        df = 17 if k % 3 else 18
+        raw[0] = (df << 3) | int(rng.integers(0, 8))
+        metype = 29 if k % 2 else 31
+        raw[4] = (metype << 3) | (raw[4] & 7)
+        if metype == 31 and k % 5:  # mostly the subtypes that are decoded, and versions 0..2
+            raw[4] = (metype << 3) | int(rng.integers(0, 2))
+            raw[9] = (raw[9] & 0x1F) | (int(rng.integers(0, 3)) << 5)  # ME bits 41-43
+        if metype == 29 and k % 5:
+            raw[4] = (metype << 3) | (int(rng.integers(0, 2)) << 1) | (raw[4] & 1)  # ME bits 6-7: subtype 0 or 1
+        m = es_record(pkg, bytes(raw).hex())
+        got, want = pkg.capi.decode_fields(m), oracle.fields_of(m)
+        for f in FIELD_NAMES:
+            assert got[f] == want[f], (f, bytes(raw).hex(), int(got[f]), int(want[f]))
+        n += bool(want["opstatus"] & 1) + bool(want["nav_valid"] or want["acc_valid"])
+    assert n > 3000
