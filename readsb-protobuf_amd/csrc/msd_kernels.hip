@@ -1091,7 +1091,10 @@ __global__ void __launch_bounds__(256) msd_power_kernel(const MsdScanParams P, c
 /* The same for the GPU resolve stage, which does not know the number of messages on the host when
  * it queues the kernel: PB_WGS workgroups per buffer walk the accepted-message records the resolve
  * kernel left for that buffer, one wavefront per message; out[buffer][MSD_RB_MSG_CAP]. */
-constexpr uint32_t PB_WGS = 8;  /* workgroups per buffer: a buffer rarely holds more than 96 messages */
+#ifndef MSD_PB_WGS
+#define MSD_PB_WGS 4
+#endif
+constexpr uint32_t PB_WGS = MSD_PB_WGS;  /* workgroups per buffer: a buffer rarely holds more than 96 messages */
 
 template <int FMT>
 __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const msd_acc *acc,
@@ -1102,26 +1105,42 @@ __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanPar
         return;
     const uint32_t b = blockIdx.x / PB_WGS, nm = nmsgs[b];
     const int lane = threadIdx.x & 63;
-    for (uint32_t m = (blockIdx.x % PB_WGS) * 4 + (threadIdx.x >> 6); m < nm; m += 4 * PB_WGS) {
-        const msd_acc rec = acc[(size_t)b * MSD_RB_MSG_CAP + m];
-        const int len = (int)rec.len;
-        const int64_t n0 = (int64_t)P.batch_first + (int64_t)rec.pos - (int64_t)MSD_OVERLAP + 19;
-        /* len is 134 or 268: five independent loads per lane instead of a data-dependent loop */
-        uint32_t x[5];
+    /* three messages per trip, so that their record, sample and table loads overlap: the kernel is a chain
+     * of dependent loads (record -> IQ bytes -> magnitude table) and nothing else */
+    constexpr uint32_t PER = 3, STEP = 4 * PB_WGS;
+    for (uint32_t m0 = (blockIdx.x % PB_WGS) * 4 + (threadIdx.x >> 6); m0 < nm; m0 += PER * STEP) {
+        msd_acc rec[PER];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = lane + 64 * u;
-            x[u] = k < len ? stream_mag<FMT>(P, n0 + k, P.lut) : 0u;
+        for (uint32_t u = 0; u < PER; ++u) {
+            const uint32_t m = m0 + u * STEP;
+            rec[u] = acc[(size_t)b * MSD_RB_MSG_CAP + (m < nm ? m : m0)];
+            if (m >= nm)
+                rec[u].len = 0;
         }
-        unsigned long long sum = 0;
+        /* len is 134 or 268: five independent loads per lane instead of a data-dependent loop */
+        uint32_t x[PER][5];
 #pragma unroll
-        for (int u = 0; u < 5; ++u)
-            sum += (unsigned long long)(x[u] * x[u]);
+        for (uint32_t u = 0; u < PER; ++u) {
+            const int64_t n0 = (int64_t)P.batch_first + (int64_t)rec[u].pos - (int64_t)MSD_OVERLAP + 19;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            sum += __shfl_down(sum, o);
-        if (lane == 0)
-            out[(size_t)b * MSD_RB_MSG_CAP + m] = sum;
+            for (int v = 0; v < 5; ++v) {
+                const int k = lane + 64 * v;
+                x[u][v] = k < (int)rec[u].len ? stream_mag<FMT>(P, n0 + k, P.lut) : 0u;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) {
+            unsigned long long sum = 0;
+#pragma unroll
+            for (int v = 0; v < 5; ++v)
+                sum += (unsigned long long)(x[u][v] * x[u][v]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                sum += __shfl_down(sum, o);
+            const uint32_t m = m0 + u * STEP;
+            if (lane == 0 && m < nm)
+                out[(size_t)b * MSD_RB_MSG_CAP + m] = sum;
+        }
     }
 }
 
