@@ -50,8 +50,6 @@ def parse():
                     help="MSD_CFG_DC_FILTER: the DC-blocking converters (sequential by nature, ~0.1 GS/s); use a small --samples")
     ap.add_argument("--timing-interval", type=int, default=4,
                     help="record the kernel timing events on one launch in N (msd_set_timing_interval)")
-    ap.add_argument("--overlap-captures", action="store_true",
-                    help="two contexts on one stream: the next capture starts while the previous one drains")
     return ap.parse_args()
 
 
@@ -94,12 +92,10 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.Stream(device=dev)  # one explicit stream shared by the contexts: their kernels stay in order
-    # Default: one context, a capture is drained completely before the next one starts.
-    # --overlap-captures: two contexts (two receivers) on the same stream, consecutive captures alternate
-    # between them so the first scans of the next capture fill the gaps while the previous one drains.
-    # Measured: no gain as long as everything stays in order on one stream (the scans then sit in front of
-    # the draining capture's resolve passes), so it is not the default.
-    nctx = 2 if args.overlap_captures else 1
+    # One context per GPU.  The passes over the capture run back to back on it: msd_restart() starts the next
+    # pass while the last batches of the current one are still in flight (every pass still begins with an
+    # empty ICAO filter, a zero clock and zero counters, and all K passes are complete before the clock stops).
+    nctx = 1
     dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank, dc_filter=args.dcfilter,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
                             decode_fields=args.fields)
@@ -110,60 +106,31 @@ def main():
 
     DEPTH = int(os.environ.get("MSD_BENCH_DEPTH", pkg.capi.PIPELINE_DEPTH))
 
-    class Capture:
-        """One pass over the capture on one context: launch batch after batch, collect in order."""
-
-        def __init__(self, d, collect_timing):
-            self.d, self.timing = d, collect_timing
-            self.off = self.inflight = self.nmsg = 0
-            d.reset()
-
-        def launch_one(self):
-            m = min(batch, n - self.off)
-            self.d.launch_device(d_iq.data_ptr() + self.off * bps, m, self.off + m >= n)
-            self.inflight += 1
-            self.off += m
-
-        def collect_one(self):
-            self.nmsg += len(self.d.collect_fields(copy=False)[0]) if args.fields else len(self.d.collect(copy=False))
-            if self.timing is not None:
-                self.timing.append(self.d.timing())
-            self.inflight -= 1
-
-        def fill(self):
-            while self.off < n and self.inflight < DEPTH:
-                self.launch_one()
-
-        def run(self):
-            while self.off < n:
-                if self.inflight == DEPTH:
-                    self.collect_one()
-                self.launch_one()
-
-        def drain(self):
-            while self.inflight:
-                self.collect_one()
-
     def run_steps(k, collect_timing=None):
-        pending, nmsg = None, 0
+        """k passes over the capture on one context, back to back: msd_restart() lets the first batches of the
+        next pass queue up behind the last ones of the current pass.  Returns the messages of the last pass."""
+        d, inflight, counts = dems[0], [], {}
+
+        def collect_one():
+            cap_id = inflight.pop(0)
+            got = d.collect_fields(copy=False)[0] if args.fields else d.collect(copy=False)
+            counts[cap_id] = counts.get(cap_id, 0) + len(got)
+            if collect_timing is not None:
+                collect_timing.append(d.timing())
+
         for s in range(k):
-            cap = Capture(dems[s % nctx], collect_timing)
-            cap.fill()
-            if pending is not None:
-                pending.drain()
-                nmsg = pending.nmsg
-            if nctx == 1:
-                pending = None
-            cap.run()
-            if nctx == 1:
-                cap.drain()
-                nmsg = cap.nmsg
-            else:
-                pending = cap
-        if pending is not None:
-            pending.drain()
-            nmsg = pending.nmsg
-        return nmsg
+            d.restart()
+            off = 0
+            while off < n:
+                if len(inflight) == DEPTH:
+                    collect_one()
+                m = min(batch, n - off)
+                d.launch_device(d_iq.data_ptr() + off * bps, m, off + m >= n)
+                inflight.append(s)
+                off += m
+        while inflight:
+            collect_one()
+        return counts.get(k - 1, 0)
 
     def barrier():
         if world > 1:
@@ -219,9 +186,8 @@ def main():
                                                                   "Mode S + Mode A/C" if args.mode_ac else "Mode S only",
                                                                   "--no-fix" if args.fix == 0 else "--fix", args.msgs_per_sec),
                    "samples_per_gpu": n, "batch_samples": batch, "parallelism": "independent capture per GPU, no collective",
-                   "captures": ("one context per GPU, captures strictly one after the other" if nctx == 1 else
-                                "two contexts per GPU on one stream, consecutive captures alternate (the drain of one "
-                                "overlaps the first batches of the next)")},
+                   "captures": "one context per GPU; passes over the capture back to back (msd_restart), each starting "
+                               "from an empty ICAO filter, all complete inside the timed region"},
         "msgs_per_s": round(nmsg_total / (ms_per_step * 1e-3), 1), "messages_per_step": nmsg_total,
         "signal_seconds_per_wall_second": round(value * 1e6 / 2.4e6, 1),
         "roofline": roofline,

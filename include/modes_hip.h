@@ -233,8 +233,15 @@ int msd_submit_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int las
                       msd_message_fn sink, void *user);
 int msd_submit_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last,
                     msd_message_fn sink, void *user);
-/* Forget the stream position, ICAO filter, clock and counters (a new capture). */
+/* Forget the stream position, ICAO filter, clock and counters (a new capture).  -EBUSY while batches are
+ * outstanding. */
 int msd_reset(msd_ctx *ctx);
+/* The same for a receiver that replays one capture after the other: may be called as soon as the running
+ * capture has been closed (last != 0) although its batches are still in flight; the batches launched
+ * afterwards belong to the new capture, whose filter, clock and counters start over when the first of them
+ * is collected -- msd_get_stats() between the last collect of the old capture and the first of the new one
+ * still returns the old capture's counters.  Keeps the GPU busy across the boundary (bench.py). */
+int msd_restart(msd_ctx *ctx);
 /* A live receiver that could not hand `nsamples` samples over (rtlsdrCallback's FIFO-full branch,
  * sdr_rtlsdr.c:281-296; bladeRF the same way, sdr_bladerf.c:317-341) says so before it launches the
  * next batch.  That batch then starts with a MAGBUF_DISCONTINUOUS buffer: its 326-sample look-behind

@@ -139,7 +139,7 @@ EXPORTS = [
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
-    "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval",
+    "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart",
 ]
 
 _lib = None
@@ -164,6 +164,8 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.msd_reset.restype = C.c_int
         L.msd_reset.argtypes = [C.c_void_p]
+        L.msd_restart.restype = C.c_int
+        L.msd_restart.argtypes = [C.c_void_p]
         L.msd_note_dropped.restype = C.c_int
         L.msd_note_dropped.argtypes = [C.c_void_p, C.c_uint64]
         L.msd_set_timing_interval.restype = C.c_int
@@ -315,6 +317,10 @@ class Demodulator:
 
     def reset(self):
         self._check(lib().msd_reset(self._h))
+
+    def restart(self):
+        """msd_restart: a new capture behind one whose last batches are still in flight."""
+        self._check(lib().msd_restart(self._h))
 
     def note_dropped(self, nsamples):
         """msd_note_dropped: the receiver lost nsamples in front of the next batch (MAGBUF_DISCONTINUOUS)."""

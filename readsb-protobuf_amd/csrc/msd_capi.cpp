@@ -42,6 +42,8 @@ struct Slot {
     bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
     int threshold = 0;             /* Modes.preambleThreshold when the batch was launched */
     bool timed = false;            /* ev_start / ev_scan / ev_kernels were recorded for this batch */
+    bool reset_before = false;     /* msd_restart(): first batch of a new capture -- filter, clock and counters start
+                                      over when its turn comes */
     bool dc = false;               /* --dcfilter: d_iq points at d_dcmag, the float sums come from d_magsq */
     uint16_t *d_dcmag = nullptr;   /* DC-blocked magnitudes of the batch (what the scan kernel reads) */
     float *d_magsq = nullptr;      /* their clamped squares, for the per-buffer float sums */
@@ -147,6 +149,7 @@ struct msd_ctx {
     uint64_t next_sample = 0;
     bool finished = false;
     uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
+    bool restart_pending = false; /* msd_restart() since the last launch */
     uint32_t timing_interval = 1; /* msd_set_timing_interval() */
     uint64_t enqueue_seq = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
@@ -820,7 +823,8 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     /* the filter is final for this batch: its successor can start */
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight) {
+        /* (not across a capture boundary: the caller may still want this capture's counters) */
+        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && !nx.reset_before) {
             int rc = gpu_begin(c, nx, c->scan_format);
             if (rc)
                 return rc;
@@ -860,6 +864,11 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
            const uint64_t *ts_override, const double *means_override, uint64_t resolver_first_chunk)
 {
     auto ta = std::chrono::steady_clock::now();
+    if (s.reset_before) { /* msd_restart(): every batch of the previous capture has been delivered */
+        msd_resolver_reset(&c->resolver);
+        memset(&c->timing, 0, sizeof c->timing);
+        s.reset_before = false;
+    }
     int rc = start_download(c, s, format);
     if (rc)
         return rc;
@@ -1057,6 +1066,8 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.last = last;
     s.dropped_before = c->pending_dropped;
     c->pending_dropped = 0;
+    s.reset_before = c->restart_pending;
+    c->restart_pending = false;
     s.threshold = c->cfg.preamble_threshold;
     s.dc = c->dc;
     if (c->dc) { /* the converter proper: IQ -> DC-blocked magnitudes, strictly in stream order */
@@ -1436,6 +1447,25 @@ int msd_reset(msd_ctx *c)
         HIPCHK(c, hipMemset(c->d_dcstate, 0, 2 * sizeof(float)));
     msd_resolver_reset(&c->resolver);
     memset(&c->timing, 0, sizeof c->timing);
+    return 0;
+}
+
+int msd_restart(msd_ctx *c)
+{
+    if (!c)
+        return -EINVAL;
+    if (!c->outstanding)
+        return msd_reset(c);
+    if (!c->finished)
+        return fail(c, -EINVAL, "msd_restart: the running capture has not been closed (last != 0) yet");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->next_sample = 0;
+    c->have_prev = false;
+    c->finished = false;
+    c->pending_dropped = 0;
+    if (c->d_dcstate) /* behind the converter kernels of the capture that is still draining */
+        HIPCHK(c, hipMemsetAsync(c->d_dcstate, 0, 2 * sizeof(float), c->stream));
+    c->restart_pending = true;
     return 0;
 }
 
