@@ -70,7 +70,7 @@ typedef struct msd_message {
  * decodeModeAMessage for Mode A/C replies (mode_ac.c:168-202).  Unset fields are 0. */
 #define MSD_INVALID_ALTITUDE (-9999) /* readsb.h:130 */
 #define MSD_NON_ICAO_ADDRESS (1u << 24) /* readsb.h:197 */
-typedef struct msd_fields { /* 128 bytes */
+typedef struct msd_fields { /* 140 bytes */
     int32_t altitude_baro;       /* feet; meaningful with altitude_baro_valid */
     uint16_t AC;                 /* 13-bit altitude code (DF0/4/16/20) */
     uint16_t ID;                 /* 13-bit identity code (DF5/21) */
@@ -122,12 +122,29 @@ typedef struct msd_fields { /* 128 bytes */
     uint8_t nac_p, nic_baro, nic_a, nic_c, gva, sda, sil;
     uint8_t sil_type;            /* AIRCRAFT_META__SIL_TYPE, readsb.pb-c.h:101-106: 0 invalid, 1 unknown, 2 per sample, 3 per hour */
     uint8_t cc_antenna_offset;   /* operational status v2, surface: ME bits 33-40 */
-    uint8_t pad;
+    uint8_t commb_format;        /* DF20/21: commb_format_t, readsb.h:166-177: 0 unknown, 1 ambiguous, 2 empty response,
+                                    3 datalink caps (BDS 1,0), 4 GICB caps (1,7), 5 aircraft ident (2,0), 6 ACAS RA (3,0),
+                                    7 vertical intent (4,0), 8 track and turn (5,0), 9 heading and speed (6,0) */
     uint16_t nav_heading_raw;    /* degrees as sent (version 1 layout) or x 180/256 with MSD_NAV_HEADING_V2 */
     uint16_t nav_qnh_raw;        /* 800 + (raw - 1) * 0.8 hPa */
     int32_t nav_mcp_altitude, nav_fms_altitude; /* feet */
     uint32_t opstatus;           /* MSD_OPS_* */
+    /* ---- Comm-B (DF20/21 MB field, decodeCommB comm_b.c:50-744): the register is inferred by scoring.
+     * BDS 2,0 fills callsign; 4,0 nav_mcp_altitude / nav_fms_altitude / nav_qnh_raw (MSD_NAV_QNH_COMMB:
+     * 800 + raw * 0.1 hPa) / nav_modes / nav_altitude_source; 5,0 heading_raw (x 90/512 deg, ground track),
+     * tas and the four below; 6,0 heading_raw (magnetic), ias, baro_rate, geom_rate (the inertial rate) and mach ---- */
+    int16_t roll_q;              /* roll = roll_q * 45 / 256 degrees */
+    int16_t track_rate_q;        /* track angle rate = track_rate_q / 32 degrees per second */
+    uint16_t gs;                 /* ground speed, knots */
+    uint16_t mach_raw;           /* Mach = mach_raw * 2.048 / 512 */
+    uint8_t commb_valid;         /* MSD_COMMB_* */
+    uint8_t pad2[3];
 } msd_fields;
+#define MSD_COMMB_ROLL 1u
+#define MSD_COMMB_GS 2u
+#define MSD_COMMB_TRACK_RATE 4u
+#define MSD_COMMB_MACH 8u
+#define MSD_NAV_QNH_COMMB 64u
 #define MSD_NAV_MODES 1u
 #define MSD_NAV_HEADING 2u
 #define MSD_NAV_MCP_ALTITUDE 4u
@@ -273,6 +290,9 @@ int msd_collect_fields(msd_ctx *ctx, msd_fields_fn sink, void *user);
  * previous Mode A/C reply of the same buffer (the reference reuses one message record per buffer, so a
  * reply without altitude inherits the last one's, demod_2400.c:523-528); NULL otherwise. */
 void msd_decode_fields(const msd_message *mm, const msd_fields *carry, msd_fields *out);
+/* The same decoder on the GPU for n messages that came from somewhere else (a Beast feed, a recording):
+ * host arrays in and out, synchronous.  Mode A/C records (msgtype 32) are decoded without a carry. */
+int msd_decode_fields_device(msd_ctx *ctx, const msd_message *msgs, size_t n, msd_fields *out);
 /* The same for samples in host memory -- the streaming ingest behind the reference's reader thread
  * (sdr_ifile.c:192-216, the SDR callbacks of sdr_rtlsdr.c:261-326): the upload of batch k+1 runs on a
  * copy stream while batch k is scanned.  h_iq must stay valid and unchanged until the batch has been

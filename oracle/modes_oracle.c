@@ -1214,6 +1214,458 @@ static void extended_squitter(const orc_message *mm, orc_fields *f) /* mode_s.c:
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Comm-B (comm_b.c): DF20/21 do not name the BDS register their MB field holds, so every known    */
+/* layout is scored and the best unambiguous one is decoded.  Restated decoder by decoder, with    */
+/* the reference's float arithmetic; `store` fills the fields like the reference's second call.    */
+/* ------------------------------------------------------------------------------------------ */
+enum { CB_UNKNOWN, CB_AMBIGUOUS, CB_EMPTY_RESPONSE, CB_DATALINK_CAPS, CB_GICB_CAPS, CB_AIRCRAFT_IDENT, CB_ACAS_RA,
+       CB_VERTICAL_INTENT, CB_TRACK_TURN, CB_HEADING_SPEED }; /* commb_format_t, readsb.h:166-177 */
+enum { CBV_ROLL = 1, CBV_GS = 2, CBV_TRACK_RATE = 4, CBV_MACH = 8 };
+#define NAVV_QNH_COMMB 64
+static unsigned getbit1(const uint8_t *d, unsigned n) { return getbits(d, n, n); }
+
+static int cb_empty(const uint8_t *msg, orc_fields *f, int store) /* comm_b.c:86-98 */
+{
+    for (unsigned i = 0; i < 7; ++i)
+        if (msg[i] != 0)
+            return 0;
+    if (store)
+        f->commb_format = CB_EMPTY_RESPONSE;
+    return 56;
+}
+
+static int cb_bds10(const uint8_t *msg, orc_fields *f, int store) /* :102-122 */
+{
+    if (msg[0] != 0x10)
+        return 0;
+    if (getbits(msg, 10, 14) != 0)
+        return 0;
+    if (store)
+        f->commb_format = CB_DATALINK_CAPS;
+    return 56;
+}
+
+static int cb_bds17(const uint8_t *msg, orc_fields *f, int store) /* :126-203 */
+{
+    if (getbits(msg, 25, 56) != 0)
+        return 0;
+    int score = 0;
+    if (getbit1(msg, 7))
+        score += 1;
+    else
+        score -= 2;
+    static const unsigned unlikely[] = {10, 11, 12, 13, 14, 20, 21, 22};
+    for (unsigned i = 0; i < 8; ++i)
+        if (getbit1(msg, unlikely[i]))
+            score -= 2;
+    if (getbit1(msg, 1) && getbit1(msg, 2) && getbit1(msg, 3) && getbit1(msg, 4) && getbit1(msg, 5)) {
+        score += 5;
+        if (getbit1(msg, 6))
+            score += 1;
+    } else if (!getbit1(msg, 1) && !getbit1(msg, 2) && !getbit1(msg, 3) && !getbit1(msg, 4) && !getbit1(msg, 5) &&
+               !getbit1(msg, 6)) {
+        score += 1;
+    } else {
+        score -= 12;
+    }
+    if (getbit1(msg, 16) && getbit1(msg, 24)) {
+        score += 2;
+        if (getbit1(msg, 9))
+            score += 1;
+    } else if (!getbit1(msg, 16) && !getbit1(msg, 24) && !getbit1(msg, 9)) {
+        score += 1;
+    } else {
+        score -= 6;
+    }
+    if (store)
+        f->commb_format = CB_GICB_CAPS;
+    return score;
+}
+
+static int cb_bds20(const uint8_t *msg, orc_fields *f, int store) /* :207-250 */
+{
+    char callsign[8];
+    if (msg[0] != 0x20)
+        return 0;
+    for (unsigned i = 0; i < 8; ++i)
+        callsign[i] = ais_charset[getbits(msg, 9 + 6 * i, 14 + 6 * i)];
+    int score = 8;
+    int valid = 1;
+    for (unsigned i = 0; i < 8; ++i) {
+        if ((callsign[i] >= 'A' && callsign[i] <= 'Z') || (callsign[i] >= '0' && callsign[i] <= '9') || callsign[i] == ' ')
+            score += 6;
+        else if (callsign[i] == '@')
+            valid = 0;
+        else
+            return 0;
+    }
+    if (store) {
+        f->commb_format = CB_AIRCRAFT_IDENT;
+        if (valid) {
+            memcpy(f->callsign, callsign, 8);
+            f->callsign_valid = 1;
+        }
+    }
+    return score;
+}
+
+static int cb_bds30(const uint8_t *msg, orc_fields *f, int store) /* :254-268 */
+{
+    if (msg[0] != 0x30)
+        return 0;
+    if (store)
+        f->commb_format = CB_ACAS_RA;
+    return 56;
+}
+
+static int cb_bds40(const uint8_t *msg, orc_fields *f, int store) /* :272-434 */
+{
+    unsigned mcp_valid = getbit1(msg, 1), mcp_raw = getbits(msg, 2, 13);
+    unsigned fms_valid = getbit1(msg, 14), fms_raw = getbits(msg, 15, 26);
+    unsigned baro_valid = getbit1(msg, 27), baro_raw = getbits(msg, 28, 39);
+    unsigned reserved_1 = getbits(msg, 40, 47);
+    unsigned mode_valid = getbit1(msg, 48), mode_raw = getbits(msg, 49, 51);
+    unsigned reserved_2 = getbits(msg, 52, 53);
+    unsigned source_valid = getbit1(msg, 54), source_raw = getbits(msg, 55, 56);
+    if (!mcp_valid && !fms_valid && !baro_valid && !mode_valid && !source_valid)
+        return 0;
+    int score = 0;
+    unsigned mcp_alt = 0;
+    if (mcp_valid && mcp_raw != 0) {
+        mcp_alt = mcp_raw * 16;
+        if (mcp_alt >= 1000 && mcp_alt <= 50000)
+            score += 13;
+        else
+            return 0;
+    } else if (!mcp_valid && mcp_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    unsigned fms_alt = 0;
+    if (fms_valid && fms_raw != 0) {
+        fms_alt = fms_raw * 16;
+        if (fms_alt >= 1000 && fms_alt <= 50000)
+            score += 13;
+        else
+            return 0;
+    } else if (!fms_valid && fms_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    float baro_setting = 0;
+    if (baro_valid && baro_raw != 0) {
+        baro_setting = 800 + baro_raw * 0.1;
+        if (baro_setting >= 900 && baro_setting <= 1100)
+            score += 13;
+        else
+            return 0;
+    } else if (!baro_valid && baro_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    if (reserved_1 != 0)
+        return 0;
+    if (mode_valid)
+        score += 4;
+    else if (!mode_valid && mode_raw == 0)
+        score += 1;
+    else
+        return 0;
+    if (reserved_2 != 0)
+        return 0;
+    if (source_valid)
+        score += 3;
+    else if (!source_valid && source_raw == 0)
+        score += 1;
+    else
+        return 0;
+    if (mcp_valid && fms_valid && mcp_alt != fms_alt)
+        score -= 4;
+    if (mcp_valid) {
+        unsigned remainder = mcp_alt % 500;
+        if (!(remainder < 16 || remainder > 484))
+            score -= 4;
+    }
+    if (fms_valid) {
+        unsigned remainder = fms_alt % 500;
+        if (!(remainder < 16 || remainder > 484))
+            score -= 4;
+    }
+    if (store) {
+        f->commb_format = CB_VERTICAL_INTENT;
+        if (mcp_valid) {
+            f->nav_valid |= NAVV_MCP;
+            f->nav_mcp_altitude = (int32_t)mcp_alt;
+        }
+        if (fms_valid) {
+            f->nav_valid |= NAVV_FMS;
+            f->nav_fms_altitude = (int32_t)fms_alt;
+        }
+        if (baro_valid) {
+            f->nav_valid |= NAVV_QNH | NAVV_QNH_COMMB;
+            f->nav_qnh_raw = (uint16_t)baro_raw; /* nav.qnh = 800 + baro_raw * 0.1 */
+        }
+        if (mode_valid) {
+            f->nav_valid |= NAVV_MODES;
+            f->nav_modes = (uint8_t)(((mode_raw & 4) ? NM_VNAV : 0) | ((mode_raw & 2) ? NM_ALT_HOLD : 0) |
+                                     ((mode_raw & 1) ? NM_APPROACH : 0));
+        }
+        if (source_valid) {
+            switch (source_raw) {
+            case 0: f->nav_altitude_source = NAVALT_UNKNOWN; break;
+            case 1: f->nav_altitude_source = NAVALT_AIRCRAFT; break;
+            case 2: f->nav_altitude_source = NAVALT_MCP; break;
+            case 3: f->nav_altitude_source = NAVALT_FMS; break;
+            default: f->nav_altitude_source = NAVALT_INVALID; break;
+            }
+        } else {
+            f->nav_altitude_source = NAVALT_INVALID;
+        }
+    }
+    return score;
+}
+
+static int cb_bds50(const uint8_t *msg, orc_fields *f, int store) /* :438-592 */
+{
+    unsigned roll_valid = getbit1(msg, 1), roll_sign = getbit1(msg, 2), roll_raw = getbits(msg, 3, 11);
+    unsigned track_valid = getbit1(msg, 12), track_sign = getbit1(msg, 13), track_raw = getbits(msg, 14, 23);
+    unsigned gs_valid = getbit1(msg, 24), gs_raw = getbits(msg, 25, 34);
+    unsigned track_rate_valid = getbit1(msg, 35), track_rate_sign = getbit1(msg, 36), track_rate_raw = getbits(msg, 37, 45);
+    unsigned tas_valid = getbit1(msg, 46), tas_raw = getbits(msg, 47, 56);
+    if (!roll_valid || !track_valid || !gs_valid || !tas_valid)
+        return 0;
+    int score = 0;
+    float roll = 0;
+    if (roll_valid) {
+        roll = roll_raw * 45.0 / 256.0;
+        if (roll_sign)
+            roll -= 90.0;
+        if (roll >= -40 && roll < 40)
+            score += 11;
+        else
+            return 0;
+    } else if (!roll_valid && roll_raw == 0 && !roll_sign) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    if (track_valid) {
+        score += 12;
+    } else if (!track_valid && track_raw == 0 && !track_sign) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    unsigned gs = 0;
+    if (gs_valid && gs_raw != 0) {
+        gs = gs_raw * 2;
+        if (gs >= 50 && gs <= 700)
+            score += 11;
+        else
+            return 0;
+    } else if (!gs_valid && gs_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    float track_rate = 0;
+    if (track_rate_valid) {
+        track_rate = track_rate_raw * 8.0 / 256.0;
+        if (track_rate_sign)
+            track_rate -= 16;
+        if (track_rate >= -10.0 && track_rate <= 10.0)
+            score += 11;
+        else
+            return 0;
+    } else if (!track_rate_valid && track_rate_raw == 0 && !track_rate_sign) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    unsigned tas = 0;
+    if (tas_valid && tas_raw != 0) {
+        tas = tas_raw * 2;
+        if (tas >= 50 && tas <= 700)
+            score += 11;
+        else
+            return 0;
+    } else if (!tas_valid && tas_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    if (gs_valid && tas_valid) { /* compares the two flags, not the speeds (comm_b.c:543): never more than 150 */
+        int delta = abs((int)gs_valid - (int)tas_valid);
+        if (delta > 150)
+            score -= 6;
+    }
+    if (roll_valid && tas_valid && tas > 0 && track_rate_valid) {
+        double turn_rate = 68625 * tan(roll * M_PI / 180.0) / (tas * 20 * M_PI);
+        double delta = fabs(turn_rate - track_rate);
+        if (delta > 2.0)
+            score -= 6;
+    }
+    if (store) {
+        f->commb_format = CB_TRACK_TURN;
+        if (roll_valid) {
+            f->commb_valid |= CBV_ROLL;
+            f->roll_q = (int16_t)((int)roll_raw - (roll_sign ? 512 : 0)); /* roll * 256 / 45 */
+        }
+        if (track_valid) {
+            f->heading_valid = 1;
+            f->heading_raw = (uint16_t)(track_raw + (track_sign ? 1024 : 0)); /* (raw * 90 / 512 [+ 180]) * 512 / 90 */
+            f->heading_type = HT_GROUND_TRACK;
+        }
+        if (gs_valid) {
+            f->commb_valid |= CBV_GS;
+            f->gs = (uint16_t)gs;
+        }
+        if (track_rate_valid) {
+            f->commb_valid |= CBV_TRACK_RATE;
+            f->track_rate_q = (int16_t)((int)track_rate_raw - (track_rate_sign ? 512 : 0)); /* rate * 32 */
+        }
+        if (tas_valid) {
+            f->tas_valid = 1;
+            f->tas = (uint16_t)tas;
+        }
+    }
+    return score;
+}
+
+static int cb_bds60(const uint8_t *msg, orc_fields *f, int store) /* :596-744 */
+{
+    unsigned heading_valid = getbit1(msg, 1), heading_sign = getbit1(msg, 2), heading_raw = getbits(msg, 3, 12);
+    unsigned ias_valid = getbit1(msg, 13), ias_raw = getbits(msg, 14, 23);
+    unsigned mach_valid = getbit1(msg, 24), mach_raw = getbits(msg, 25, 34);
+    unsigned baro_rate_valid = getbit1(msg, 35), baro_rate_sign = getbit1(msg, 36), baro_rate_raw = getbits(msg, 37, 45);
+    unsigned inertial_rate_valid = getbit1(msg, 46), inertial_rate_sign = getbit1(msg, 47),
+             inertial_rate_raw = getbits(msg, 48, 56);
+    if (!heading_valid || !ias_valid || !mach_valid || (!baro_rate_valid && !inertial_rate_valid))
+        return 0;
+    int score = 0;
+    if (heading_valid)
+        score += 12;
+    else if (!heading_valid && heading_raw == 0 && !heading_sign)
+        score += 1;
+    else
+        return 0;
+    unsigned ias = 0;
+    if (ias_valid && ias_raw != 0) {
+        ias = ias_raw;
+        if (ias >= 50 && ias <= 700)
+            score += 11;
+        else
+            return 0;
+    } else if (!ias_valid && ias_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    float mach = 0;
+    if (mach_valid && mach_raw != 0) {
+        mach = mach_raw * 2.048 / 512;
+        if (mach >= 0.1 && mach <= 0.9)
+            score += 11;
+        else
+            return 0;
+    } else if (!mach_valid && mach_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    int baro_rate = 0;
+    if (baro_rate_valid) {
+        baro_rate = baro_rate_raw * 32;
+        if (baro_rate_sign)
+            baro_rate -= 16384;
+        if (baro_rate >= -6000 && baro_rate <= 6000)
+            score += 11;
+        else
+            return 0;
+    } else if (!baro_rate_valid && baro_rate_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    int inertial_rate = 0;
+    if (inertial_rate_valid) {
+        inertial_rate = inertial_rate_raw * 32;
+        if (inertial_rate_sign)
+            inertial_rate -= 16384;
+        if (inertial_rate >= -6000 && inertial_rate <= 6000)
+            score += 11;
+        else
+            return 0;
+    } else if (!inertial_rate_valid && inertial_rate_raw == 0) {
+        score += 1;
+    } else {
+        return 0;
+    }
+    if (baro_rate_valid && inertial_rate_valid) {
+        int delta = abs(baro_rate - inertial_rate);
+        if (delta > 2000)
+            score -= 12;
+    }
+    if (store) {
+        f->commb_format = CB_HEADING_SPEED;
+        if (heading_valid) {
+            f->heading_valid = 1;
+            f->heading_raw = (uint16_t)(heading_raw + (heading_sign ? 1024 : 0));
+            f->heading_type = HT_MAGNETIC;
+        }
+        if (ias_valid) {
+            f->ias_valid = 1;
+            f->ias = (uint16_t)ias;
+        }
+        if (mach_valid) {
+            f->commb_valid |= CBV_MACH;
+            f->mach_raw = (uint16_t)mach_raw; /* mach = mach_raw * 2.048 / 512 */
+        }
+        if (baro_rate_valid) {
+            f->baro_rate_valid = 1;
+            f->baro_rate = (int16_t)baro_rate;
+        }
+        if (inertial_rate_valid) {
+            f->geom_rate_valid = 1;
+            f->geom_rate = (int16_t)inertial_rate;
+        }
+    }
+    return score;
+}
+
+/* decodeCommB, comm_b.c:50-84.  um is what mm->UM holds at that point of decodeModesMessage: the field is
+ * only extracted further down (mode_s.c:705 after :669), so the caller passes 0. */
+static void comm_b(const uint8_t *mb, orc_fields *f, unsigned dr, unsigned um, unsigned correctedbits)
+{
+    typedef int (*decoder)(const uint8_t *, orc_fields *, int);
+    static const decoder decoders[] = {cb_empty, cb_bds10, cb_bds20, cb_bds30, cb_bds17, cb_bds40, cb_bds50, cb_bds60};
+    f->commb_format = CB_UNKNOWN;
+    if (dr != 0 || um != 0 || correctedbits > 0)
+        return;
+    int bestScore = 0, ambiguous = 0;
+    decoder bestDecoder = NULL;
+    for (unsigned i = 0; i < sizeof decoders / sizeof decoders[0]; ++i) {
+        int score = decoders[i](mb, f, 0);
+        if (score > bestScore) {
+            bestScore = score;
+            bestDecoder = decoders[i];
+            ambiguous = 0;
+        } else if (score == bestScore) {
+            ambiguous = 1;
+        }
+    }
+    if (bestDecoder) {
+        if (ambiguous)
+            f->commb_format = CB_AMBIGUOUS;
+        else
+            bestDecoder(mb, f, 1);
+    }
+}
+
 static void fields_mode_s(const orc_message *mm, orc_fields *f) /* mode_s.c:557-715 */
 {
     const uint8_t *msg = mm->msg;
@@ -1275,6 +1727,8 @@ static void fields_mode_s(const orc_message *mm, orc_fields *f) /* mode_s.c:557-
     }
     if (t == 17 || t == 18)
         extended_squitter(mm, f);
+    if (t == 20 || t == 21) /* MB, mode_s.c:666-670 */
+        comm_b(msg + 4, f, f->DR, 0, mm->correctedbits);
 }
 
 /* decodeModeAMessage (mode_ac.c:168-202) on the record demodulate2400AC reuses within a buffer */

@@ -149,10 +149,15 @@ typedef struct orc_fields {
     uint8_t nav_valid, nav_altitude_source, nav_modes, nav_heading_type;
     uint8_t acc_valid, nac_p, nic_baro, nic_a, nic_c, gva, sda, sil, sil_type;
     uint8_t cc_antenna_offset;
-    uint8_t pad;
+    uint8_t commb_format; /* commb_format_t, readsb.h:166-177 */
     uint16_t nav_heading_raw, nav_qnh_raw;
     int32_t nav_mcp_altitude, nav_fms_altitude;
     uint32_t opstatus;
+    /* Comm-B (decodeCommB, comm_b.c) */
+    int16_t roll_q, track_rate_q;
+    uint16_t gs, mach_raw;
+    uint8_t commb_valid;
+    uint8_t pad2[3];
 } orc_fields;
 /* From now on orc_replay / orc_demod_buffer also write the fields of message i to fields[i] (i < cap). */
 void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap);

@@ -54,12 +54,13 @@ FIELDS_DTYPE = np.dtype(
      ("emergency_valid", "u1"), ("emergency", "u1"),
      ("nav_valid", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"), ("nav_heading_type", "u1"),
      ("acc_valid", "u1"), ("nac_p", "u1"), ("nic_baro", "u1"), ("nic_a", "u1"), ("nic_c", "u1"), ("gva", "u1"),
-     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("pad", "u1"),
+     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("commb_format", "u1"),
      ("nav_heading_raw", "<u2"), ("nav_qnh_raw", "<u2"), ("nav_mcp_altitude", "<i4"), ("nav_fms_altitude", "<i4"),
-     ("opstatus", "<u4")],
+     ("opstatus", "<u4"), ("roll_q", "<i2"), ("track_rate_q", "<i2"), ("gs", "<u2"), ("mach_raw", "<u2"),
+     ("commb_valid", "u1"), ("pad2", "u1", (3,))],
     align=True,
 )
-assert FIELDS_DTYPE.itemsize == 128
+assert FIELDS_DTYPE.itemsize == 140
 
 
 class Stats(C.Structure):

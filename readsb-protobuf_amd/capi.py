@@ -55,12 +55,13 @@ FIELDS_DTYPE = np.dtype(
      ("emergency_valid", "u1"), ("emergency", "u1"),
      ("nav_valid", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"), ("nav_heading_type", "u1"),
      ("acc_valid", "u1"), ("nac_p", "u1"), ("nic_baro", "u1"), ("nic_a", "u1"), ("nic_c", "u1"), ("gva", "u1"),
-     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("pad", "u1"),
+     ("sda", "u1"), ("sil", "u1"), ("sil_type", "u1"), ("cc_antenna_offset", "u1"), ("commb_format", "u1"),
      ("nav_heading_raw", "<u2"), ("nav_qnh_raw", "<u2"), ("nav_mcp_altitude", "<i4"), ("nav_fms_altitude", "<i4"),
-     ("opstatus", "<u4")],
+     ("opstatus", "<u4"), ("roll_q", "<i2"), ("track_rate_q", "<i2"), ("gs", "<u2"), ("mach_raw", "<u2"),
+     ("commb_valid", "u1"), ("pad2", "u1", (3,))],
     align=True,
 )
-assert FIELDS_DTYPE.itemsize == 128
+assert FIELDS_DTYPE.itemsize == 140
 CFG_DECODE_FIELDS = 1
 CFG_DC_FILTER = 2
 INVALID_ALTITUDE = -9999
@@ -139,7 +140,7 @@ EXPORTS = [
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
-    "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart",
+    "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
 ]
 
 _lib = None
@@ -164,6 +165,8 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.msd_reset.restype = C.c_int
         L.msd_reset.argtypes = [C.c_void_p]
+        L.msd_decode_fields_device.restype = C.c_int
+        L.msd_decode_fields_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.msd_restart.restype = C.c_int
         L.msd_restart.argtypes = [C.c_void_p]
         L.msd_note_dropped.restype = C.c_int
@@ -317,6 +320,13 @@ class Demodulator:
 
     def reset(self):
         self._check(lib().msd_reset(self._h))
+
+    def decode_fields_device(self, messages):
+        """msd_decode_fields_device: the emit kernel's field decoder on an array of message records."""
+        messages = np.ascontiguousarray(messages, dtype=MESSAGE_DTYPE)
+        out = np.zeros(len(messages), dtype=FIELDS_DTYPE)
+        self._check(lib().msd_decode_fields_device(self._h, messages.ctypes.data, len(messages), out.ctypes.data))
+        return out
 
     def restart(self):
         """msd_restart: a new capture behind one whose last batches are still in flight."""

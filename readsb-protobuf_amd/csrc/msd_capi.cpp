@@ -1450,6 +1450,34 @@ int msd_reset(msd_ctx *c)
     return 0;
 }
 
+int msd_decode_fields_device(msd_ctx *c, const msd_message *msgs, size_t n, msd_fields *out)
+{
+    if (!c || (n && (!msgs || !out)) || n > (1u << 24))
+        return -EINVAL;
+    if (n == 0)
+        return 0;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    msd_message *d_in = nullptr;
+    msd_fields *d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_in), n * sizeof *d_in);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof *d_out);
+    int rc = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_in, msgs, n * sizeof *d_in, hipMemcpyHostToDevice, c->aux_stream);
+    if (e == hipSuccess)
+        rc = msd_launch_fields(d_in, d_out, (uint32_t)n, c->aux_stream);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(out, d_out, n * sizeof *d_out, hipMemcpyDeviceToHost, c->aux_stream);
+    if (e == hipSuccess && !rc)
+        e = hipStreamSynchronize(c->aux_stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return fail(c, -EIO, "msd_decode_fields_device: %s", hipGetErrorString(e));
+    return rc ? fail(c, rc, "field kernel launch failed") : 0;
+}
+
 int msd_restart(msd_ctx *c)
 {
     if (!c)

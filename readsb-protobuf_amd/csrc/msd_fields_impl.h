@@ -8,6 +8,7 @@
 #ifndef MSD_FIELDS_IMPL_H
 #define MSD_FIELDS_IMPL_H
 
+#include <math.h>
 #include <stdint.h>
 
 #include "modes_hip.h"
@@ -19,7 +20,7 @@
 #endif
 
 /* bits first..last of the message, numbered from 1 at the most significant bit (mode_s.h:57-102);
- * at most 24 bits, which is all the header fields need */
+ * at most 32 bits that span at most four bytes */
 MSD_HD uint32_t msd_field_bits(const uint8_t *msg, int first, int last)
 {
     const int fb = (first - 1) >> 3, lb = (last - 1) >> 3;
@@ -27,7 +28,7 @@ MSD_HD uint32_t msd_field_bits(const uint8_t *msg, int first, int last)
     for (int i = fb; i <= lb; ++i)
         v = (v << 8) | msg[i];
     v >>= 7 - ((last - 1) & 7);
-    return v & ((1u << (last - first + 1)) - 1u);
+    return v & (uint32_t)((1ull << (last - first + 1)) - 1ull);
 }
 
 /* 13-bit identity code -> four octal digits, hex-coded A4A2A1 B4B2B1 C4C2C1 D4D2D1 (mode_s.c:101-143);
@@ -437,6 +438,295 @@ MSD_HD void msd_fields_es(const uint8_t *me, uint32_t df, msd_fields *f)
     /* 24 (surface system status), 30 (operational coordination) and the rest carry nothing the reference decodes */
 }
 
+/* ---- Comm-B (comm_b.c:50-744).  DF20/21 do not say which BDS register the MB field answers: every known
+ * layout is scored for plausibility, the best one wins, a tie decodes nothing.  All range checks are done on
+ * the raw integers; the thresholds are the reference's float comparisons solved for the raw value
+ * (tests/test_fields.py re-evaluates the float expressions over every raw value). ---- */
+MSD_HD int msd_commb_valid_char(uint32_t six) /* ais_charset: A-Z, 0-9, space */
+{
+    return (six >= 1 && six <= 26) || (six >= 48 && six <= 57) || six == 32;
+}
+
+/* score of layout k (the order of comm_b_decoders, comm_b.c:39-48): 0 empty, 1 BDS 1,0, 2 BDS 2,0, 3 BDS 3,0,
+ * 4 BDS 1,7, 5 BDS 4,0, 6 BDS 5,0, 7 BDS 6,0 */
+MSD_HD int msd_commb_score(const uint8_t *mb, int k)
+{
+#define B1(n) msd_field_bits(mb, (n), (n))
+    switch (k) {
+    case 0: /* comm_b.c:86-98 */
+        for (int i = 0; i < 7; ++i)
+            if (mb[i])
+                return 0;
+        return 56;
+    case 1: /* :102-122 */
+        return (mb[0] == 0x10 && msd_field_bits(mb, 10, 14) == 0) ? 56 : 0;
+    case 2: { /* :207-250 */
+        if (mb[0] != 0x20)
+            return 0;
+        int score = 8;
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t c = msd_field_bits(mb, 9 + 6 * i, 14 + 6 * i);
+            if (msd_commb_valid_char(c))
+                score += 6;
+            else if (c != 0) /* '@' is padding; anything else cannot be a callsign */
+                return 0;
+        }
+        return score;
+    }
+    case 3: /* :254-268 */
+        return mb[0] == 0x30 ? 56 : 0;
+    case 4: { /* BDS 1,7, :126-203 */
+        if (msd_field_bits(mb, 25, 56) != 0)
+            return 0;
+        int score = B1(7) ? 1 : -2;
+        score -= 2 * (int)(B1(10) + B1(11) + B1(12) + B1(13) + B1(14) + B1(20) + B1(21) + B1(22));
+        const uint32_t es = msd_field_bits(mb, 1, 5);
+        if (es == 31)
+            score += 5 + (int)B1(6);
+        else if (es == 0 && !B1(6))
+            score += 1;
+        else
+            score -= 12;
+        if (B1(16) && B1(24))
+            score += 2 + (int)B1(9);
+        else if (!B1(16) && !B1(24) && !B1(9))
+            score += 1;
+        else
+            score -= 6;
+        return score;
+    }
+    case 5: { /* BDS 4,0, :272-434 */
+        const uint32_t mcp_v = B1(1), mcp = msd_field_bits(mb, 2, 13), fms_v = B1(14), fms = msd_field_bits(mb, 15, 26);
+        const uint32_t baro_v = B1(27), baro = msd_field_bits(mb, 28, 39), mode_v = B1(48), mode = msd_field_bits(mb, 49, 51);
+        const uint32_t src_v = B1(54), src = msd_field_bits(mb, 55, 56);
+        if (!mcp_v && !fms_v && !baro_v && !mode_v && !src_v)
+            return 0;
+        if (msd_field_bits(mb, 40, 47) || msd_field_bits(mb, 52, 53))
+            return 0;
+        int score = 0;
+        const uint32_t alt[2] = {mcp * 16, fms * 16}, altv[2] = {mcp_v, fms_v};
+        for (int i = 0; i < 2; ++i) {
+            if (altv[i] && alt[i]) {
+                if (alt[i] < 1000 || alt[i] > 50000)
+                    return 0;
+                score += 13;
+            } else if (!altv[i] && !alt[i]) {
+                score += 1;
+            } else {
+                return 0;
+            }
+        }
+        if (baro_v && baro) { /* 900 <= 800 + raw * 0.1 <= 1100 */
+            if (baro < 1000 || baro > 3000)
+                return 0;
+            score += 13;
+        } else if (!baro_v && !baro) {
+            score += 1;
+        } else {
+            return 0;
+        }
+        if (mode_v)
+            score += 4;
+        else if (!mode)
+            score += 1;
+        else
+            return 0;
+        if (src_v)
+            score += 3;
+        else if (!src)
+            score += 1;
+        else
+            return 0;
+        if (mcp_v && fms_v && alt[0] != alt[1])
+            score -= 4;
+        for (int i = 0; i < 2; ++i)
+            if (altv[i]) {
+                const uint32_t rem = alt[i] % 500;
+                if (!(rem < 16 || rem > 484))
+                    score -= 4; /* selected altitudes are multiples of 500 ft */
+            }
+        return score;
+    }
+    case 6: { /* BDS 5,0, :438-592 */
+        const uint32_t roll_v = B1(1), roll_s = B1(2), roll = msd_field_bits(mb, 3, 11);
+        const uint32_t trk_v = B1(12), gs_v = B1(24), gs = msd_field_bits(mb, 25, 34) * 2;
+        const uint32_t tr_v = B1(35), tr_s = B1(36), tr = msd_field_bits(mb, 37, 45);
+        const uint32_t tas_v = B1(46), tas = msd_field_bits(mb, 47, 56) * 2;
+        if (!roll_v || !trk_v || !gs_v || !tas_v)
+            return 0;
+        /* -40 <= roll * 45/256 (- 90) < 40 */
+        if (roll_s ? roll < 285 : roll > 227)
+            return 0;
+        int score = 11 + 12;
+        if (gs == 0 || gs < 50 || gs > 700) /* valid with raw 0 is rejected as well (:496-508) */
+            return 0;
+        score += 11;
+        const int trq = (int)tr - (tr_s ? 512 : 0); /* x 1/32 degrees per second */
+        if (tr_v) {
+            if (trq < -320 || trq > 320)
+                return 0;
+            score += 11;
+        } else if (tr == 0 && !tr_s) {
+            score += 1;
+        } else {
+            return 0;
+        }
+        if (tas == 0 || tas < 50 || tas > 700)
+            return 0;
+        score += 11;
+        /* (the ground speed / airspeed consistency check compares the two valid bits and never fires, :542-548) */
+        if (tr_v) { /* turn rate a coordinated turn at this bank and speed would have, :550-557 */
+            const float rollf = (float)((double)roll * 45.0 / 256.0 - (roll_s ? 90.0 : 0.0));
+            const float ratef = (float)trq / 32.0f;
+            const double turn_rate = 68625 * tan(rollf * 3.14159265358979323846 / 180.0) / (tas * 20 * 3.14159265358979323846);
+            if (fabs(turn_rate - ratef) > 2.0)
+                score -= 6;
+        }
+        return score;
+    }
+    default: { /* BDS 6,0, :596-744 */
+        const uint32_t hdg_v = B1(1), ias_v = B1(13), ias = msd_field_bits(mb, 14, 23), mach_v = B1(24), mach = msd_field_bits(mb, 25, 34);
+        const uint32_t br_v = B1(35), br_s = B1(36), br = msd_field_bits(mb, 37, 45);
+        const uint32_t ir_v = B1(46), ir_s = B1(47), ir = msd_field_bits(mb, 48, 56);
+        if (!hdg_v || !ias_v || !mach_v || (!br_v && !ir_v))
+            return 0;
+        int score = 12;
+        if (ias < 50 || ias > 700)
+            return 0;
+        score += 11;
+        if (mach < 25 || mach > 225) /* 0.1 <= raw * 2.048 / 512 <= 0.9 */
+            return 0;
+        score += 11;
+        const int baro_rate = (int)br * 32 - (br_s ? 16384 : 0), inertial_rate = (int)ir * 32 - (ir_s ? 16384 : 0);
+        if (br_v) {
+            if (baro_rate < -6000 || baro_rate > 6000)
+                return 0;
+            score += 11;
+        } else if (br == 0) { /* the sign bit is not looked at here (:684) */
+            score += 1;
+        } else {
+            return 0;
+        }
+        if (ir_v) {
+            if (inertial_rate < -6000 || inertial_rate > 6000)
+                return 0;
+            score += 11;
+        } else if (ir == 0) {
+            score += 1;
+        } else {
+            return 0;
+        }
+        if (br_v && ir_v && (baro_rate > inertial_rate ? baro_rate - inertial_rate : inertial_rate - baro_rate) > 2000)
+            score -= 12;
+        return score;
+    }
+    }
+#undef B1
+}
+
+MSD_HD void msd_fields_commb(const uint8_t *mb, msd_fields *f)
+{
+    f->commb_format = 0;
+    /* "If DR or UM are set, this message is probably noise" (comm_b.c:53-58) -- but UM is only extracted after
+     * the MB field (mode_s.c:669 before :705), so it still is zero when the reference looks: DR alone decides.
+     * (DF20/21 are never bit-corrected either.) */
+    if (f->DR != 0)
+        return;
+    int best = 0, best_k = -1, ties = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int sc = msd_commb_score(mb, k);
+        if (sc > best) {
+            best = sc;
+            best_k = k;
+            ties = 0;
+        } else if (sc == best) {
+            ties = 1;
+        }
+    }
+    if (best_k < 0)
+        return;
+    if (ties) {
+        f->commb_format = 1;
+        return;
+    }
+#define B1(n) msd_field_bits(mb, (n), (n))
+    switch (best_k) {
+    case 0: f->commb_format = 2; break;
+    case 1: f->commb_format = 3; break;
+    case 4: f->commb_format = 4; break;
+    case 3: f->commb_format = 6; break;
+    case 2: {
+        const char *ais = "@ABCDEFGHIJKLMNOPQRSTUVWXYZ[\\]^_ !\"#$%&'()*+,-./0123456789:;<=>?";
+        f->commb_format = 5;
+        int valid = 1;
+        for (int i = 0; i < 8; ++i)
+            if (msd_field_bits(mb, 9 + 6 * i, 14 + 6 * i) == 0)
+                valid = 0; /* padding: a BDS 2,0 all right, but no callsign to use */
+        if (valid) {
+            for (int i = 0; i < 8; ++i)
+                f->callsign[i] = ais[msd_field_bits(mb, 9 + 6 * i, 14 + 6 * i)];
+            f->callsign_valid = 1;
+        }
+        break;
+    }
+    case 5:
+        f->commb_format = 7;
+        if (B1(1)) {
+            f->nav_valid |= MSD_NAV_MCP_ALTITUDE;
+            f->nav_mcp_altitude = (int32_t)msd_field_bits(mb, 2, 13) * 16;
+        }
+        if (B1(14)) {
+            f->nav_valid |= MSD_NAV_FMS_ALTITUDE;
+            f->nav_fms_altitude = (int32_t)msd_field_bits(mb, 15, 26) * 16;
+        }
+        if (B1(27)) {
+            f->nav_valid |= MSD_NAV_QNH | MSD_NAV_QNH_COMMB;
+            f->nav_qnh_raw = (uint16_t)msd_field_bits(mb, 28, 39);
+        }
+        if (B1(48)) {
+            const uint32_t m = msd_field_bits(mb, 49, 51);
+            f->nav_valid |= MSD_NAV_MODES;
+            f->nav_modes = (uint8_t)(((m & 4u) ? 2u : 0u) | ((m & 2u) ? 4u : 0u) | ((m & 1u) ? 8u : 0u)); /* VNAV, hold, approach */
+        }
+        f->nav_altitude_source = B1(54) ? (uint8_t)(1u + msd_field_bits(mb, 55, 56)) : 0; /* unknown, aircraft, MCP, FMS */
+        break;
+    case 6:
+        f->commb_format = 8;
+        f->commb_valid |= MSD_COMMB_ROLL | MSD_COMMB_GS;
+        f->roll_q = (int16_t)((int)msd_field_bits(mb, 3, 11) - (B1(2) ? 512 : 0));
+        f->heading_valid = 1;
+        f->heading_raw = (uint16_t)(msd_field_bits(mb, 14, 23) + (B1(13) ? 1024u : 0u)); /* + 180 degrees */
+        f->heading_type = 1; /* ground track */
+        f->gs = (uint16_t)(msd_field_bits(mb, 25, 34) * 2);
+        if (B1(35)) {
+            f->commb_valid |= MSD_COMMB_TRACK_RATE;
+            f->track_rate_q = (int16_t)((int)msd_field_bits(mb, 37, 45) - (B1(36) ? 512 : 0));
+        }
+        f->tas_valid = 1;
+        f->tas = (uint16_t)(msd_field_bits(mb, 47, 56) * 2);
+        break;
+    default:
+        f->commb_format = 9;
+        f->heading_valid = 1;
+        f->heading_raw = (uint16_t)(msd_field_bits(mb, 3, 12) + (B1(2) ? 1024u : 0u));
+        f->heading_type = 3; /* magnetic */
+        f->ias_valid = 1;
+        f->ias = (uint16_t)msd_field_bits(mb, 14, 23);
+        f->commb_valid |= MSD_COMMB_MACH;
+        f->mach_raw = (uint16_t)msd_field_bits(mb, 25, 34);
+        if (B1(35)) {
+            f->baro_rate_valid = 1;
+            f->baro_rate = (int16_t)((int)msd_field_bits(mb, 37, 45) * 32 - (B1(36) ? 16384 : 0));
+        }
+        if (B1(46)) { /* INS-derived: a "geometric" rate like elsewhere */
+            f->geom_rate_valid = 1;
+            f->geom_rate = (int16_t)((int)msd_field_bits(mb, 48, 56) * 32 - (B1(47) ? 16384 : 0));
+        }
+        break;
+    }
+#undef B1
+}
+
 /* a Mode S message (msgtype 0..31, corrected bytes); addr = msd_message.addr */
 MSD_HD void msd_fields_mode_s(const uint8_t *msg, uint32_t df, uint32_t addr, msd_fields *f)
 {
@@ -494,6 +784,8 @@ MSD_HD void msd_fields_mode_s(const uint8_t *msg, uint32_t df, uint32_t addr, ms
     }
     if (df == 17 || df == 18) /* ME, mode_s.c:678-682 */
         msd_fields_es(msg + 4, df, f);
+    if (df == 20 || df == 21) /* MB, mode_s.c:666-670 */
+        msd_fields_commb(msg + 4, f);
 }
 
 /* a Mode A/C reply (mode_ac.c:168-202).  `carry` is the state demodulate2400AC's message record is in

@@ -92,6 +92,8 @@ typedef struct msd_wire {
  * from the counts) */
 int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_wire *dense,
                     msd_fields *fields /* NULL: no field decode */, uint32_t cap, hipStream_t stream);
+/* the field decoder of the emit kernel on its own: out[i] = fields of in[i] (device pointers) */
+int msd_launch_fields(const msd_message *d_in, msd_fields *d_out, uint32_t n, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
 /* Regions -> dense ordered lists (every workgroup sums the counts in front of it); the last

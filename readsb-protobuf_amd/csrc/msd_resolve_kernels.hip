@@ -999,6 +999,29 @@ extern "C" int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch 
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+/* msd_decode_fields_device: the field decoder alone, one thread per Mode S message */
+__global__ void __launch_bounds__(256) msd_fields_kernel(const msd_message *in, msd_fields *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const msd_message mm = in[i];
+    msd_fields f;
+    if (mm.msgtype == 32)
+        msd_fields_mode_ac(((uint32_t)mm.msg[0] << 8) | mm.msg[1], nullptr, &f);
+    else
+        msd_fields_mode_s(mm.msg, mm.msgtype, mm.addr, &f);
+    out[i] = f;
+}
+
+extern "C" int msd_launch_fields(const msd_message *d_in, msd_fields *d_out, uint32_t n, hipStream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(msd_fields_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_in, d_out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream)
 {
     if (ntodo == 0)

@@ -18,8 +18,8 @@ FIELD_NAMES = ("altitude_baro", "AC", "ID", "squawk", "altitude_baro_valid", "al
                "tas", "ias_valid", "tas_valid", "baro_rate_valid", "geom_rate_valid", "baro_rate", "geom_rate",
                "geom_delta", "geom_delta_valid", "emergency_valid", "emergency", "nav_valid", "nav_altitude_source",
                "nav_modes", "nav_heading_type", "acc_valid", "nac_p", "nic_baro", "nic_a", "nic_c", "gva", "sda", "sil",
-               "sil_type", "cc_antenna_offset", "nav_heading_raw", "nav_qnh_raw", "nav_mcp_altitude", "nav_fms_altitude",
-               "opstatus")
+               "sil_type", "cc_antenna_offset", "commb_format", "nav_heading_raw", "nav_qnh_raw", "nav_mcp_altitude",
+               "nav_fms_altitude", "opstatus", "roll_q", "track_rate_q", "gs", "mach_raw", "commb_valid")
 
 
 def code_bits(code13):
@@ -308,3 +308,135 @@ def test_target_state_and_operational_status_against_the_oracle(pkg, oracle):
             assert got[f] == want[f], (f, bytes(raw).hex(), int(got[f]), int(want[f]))
         n += bool(want["opstatus"] & 1) + bool(want["nav_valid"] or want["acc_valid"])
     assert n > 3000
+
+
+def test_comm_b_published_examples(pkg):
+    """Comm-B register inference and decode (comm_b.c) on the examples of 'The 1090 MHz riddle' / pyModeS:
+    BDS 5,0 roll 2.1 deg, track 114.258 deg, 438 kt over ground, 0.125 deg/s, TAS 424 kt; BDS 6,0 heading
+    42.715 deg, IAS 252 kt, Mach 0.42, -1920 ft/min both rates; BDS 4,0 MCP and FMS 3008 ft, QNH 1020.0 hPa;
+    BDS 2,0 callsigns."""
+    f = pkg.capi.decode_fields(es_record(pkg, "A000139381951536E024D4CCF6B5"))
+    assert (f["commb_format"], f["commb_valid"], f["heading_valid"], f["heading_type"], f["tas_valid"]) == (8, 7, 1, 1, 1)
+    assert (round(f["roll_q"] * 45 / 256, 1), f["heading_raw"] * 90 / 512, f["gs"], f["track_rate_q"] / 32, f["tas"]) == \
+           (2.1, 114.2578125, 438, 0.125, 424)
+    f = pkg.capi.decode_fields(es_record(pkg, "A00004128F39F91A7E27C46ADC21"))
+    assert (f["commb_format"], f["commb_valid"], f["heading_type"], f["ias_valid"], f["ias"]) == (9, 8, 3, 1, 252)
+    assert (f["heading_raw"] * 90 / 512, round(f["mach_raw"] * 2.048 / 512, 3)) == (42.71484375, 0.42)
+    assert (f["baro_rate_valid"], f["baro_rate"], f["geom_rate_valid"], f["geom_rate"]) == (1, -1920, 1, -1920)
+    f = pkg.capi.decode_fields(es_record(pkg, "A000029C85E42F313000007047D3"))
+    assert (f["commb_format"], f["nav_mcp_altitude"], f["nav_fms_altitude"], 800 + f["nav_qnh_raw"] * 0.1) == (7, 3008, 3008, 1020.0)
+    assert f["nav_valid"] & (4 | 8 | 16 | 64) == (4 | 8 | 16 | 64)
+    for hx, cs in (("A000083E202CC371C31DE0AA1CCF", b"KLM1017 "), ("A0001838201584F23468207CDFA5", b"EXS2MF  ")):
+        f = pkg.capi.decode_fields(es_record(pkg, hx))
+        assert (f["commb_format"], f["callsign_valid"], f["callsign"]) == (5, 1, cs)
+    # a GICB capability report (BDS 1,7) must have its last 32 bits clear (comm_b.c:129-132)
+    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA818000000000" + "000000"))["commb_format"] == 4
+    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA818080000001" + "000000"))["commb_format"] != 4
+    # an all-zero MB field is "empty response"; DR set: not looked at at all
+    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "00" * 7 + "000000"))["commb_format"] == 2
+    assert pkg.capi.decode_fields(es_record(pkg, "A0080000" + "00" * 7 + "000000"))["commb_format"] == 0
+
+
+def test_comm_b_integer_thresholds_equal_the_float_comparisons():
+    """The device decoder tests raw integers where comm_b.c compares floats: same verdict for every raw value
+    (float32 results of double expressions, as the reference's C computes them)."""
+    f32 = np.float32
+    for raw in range(4096):  # BDS 4,0 pressure setting, comm_b.c:324-333
+        setting = f32(800 + raw * 0.1)
+        assert (setting >= 900 and setting <= 1100) == (1000 <= raw <= 3000) or raw == 0
+    for raw in range(1024):  # BDS 6,0 Mach, :651-660
+        mach = f32(raw * 2.048 / 512)
+        assert (float(mach) >= 0.1 and float(mach) <= 0.9) == (25 <= raw <= 225), raw
+    for raw in range(512):
+        for sign in (0, 1):
+            roll = f32(raw * 45.0 / 256.0)
+            if sign:
+                roll = f32(float(roll) - 90.0)
+            assert (roll >= -40 and roll < 40) == ((raw >= 285) if sign else (raw <= 227)), (raw, sign)  # :464-476
+            rate = f32(raw * 8.0 / 256.0)
+            if sign:
+                rate = f32(rate - f32(16))
+            assert (rate >= -10.0 and rate <= 10.0) == (-320 <= raw - 512 * sign <= 320), (raw, sign)  # :512-524
+
+
+def make_commb(rng, kind):
+    """an MB field that looks like BDS `kind` (plausible values, sometimes off the edge)"""
+    def put(bits, first, last, value):
+        for i in range(last - first + 1):
+            bits[first - 1 + i] = (value >> (last - first - i)) & 1
+    bits = [0] * 56
+    edge = rng.random() < 0.25
+    if kind == 10:
+        put(bits, 1, 8, 0x10)
+        put(bits, 9, 56, int(rng.integers(0, 1 << 48)))
+        if not edge:
+            put(bits, 10, 14, 0)
+    elif kind == 17:
+        put(bits, 1, 24, int(rng.integers(0, 1 << 24)) if edge else int(rng.choice([0xFA8180, 0x020000, 0xFE8101, 0xFA0000])))
+    elif kind == 20:
+        put(bits, 1, 8, 0x20)
+        chars = [int(rng.choice([1, 2, 11, 12, 13, 26, 32, 48, 49, 55, 57])) for _ in range(8)]
+        if edge:
+            chars[int(rng.integers(0, 8))] = int(rng.choice([0, 27, 33, 63]))
+        for i, c in enumerate(chars):
+            put(bits, 9 + 6 * i, 14 + 6 * i, c)
+    elif kind == 30:
+        put(bits, 1, 8, 0x30)
+        put(bits, 9, 56, int(rng.integers(0, 1 << 48)))
+    elif kind == 40:
+        for v, lo in ((1, 2), (14, 15)):
+            if rng.random() < 0.8:
+                bits[v - 1] = 1
+                alt = int(rng.choice([3008, 36000, 35984, 12000, 500, 51200, 10240])) if not edge else int(rng.integers(0, 65536))
+                put(bits, lo, lo + 11, (alt // 16) & 0xFFF)
+        if rng.random() < 0.8:
+            bits[26] = 1
+            put(bits, 28, 39, int(rng.integers(990, 3010)) if not edge else int(rng.integers(0, 4096)))
+        if rng.random() < 0.5:
+            bits[47] = 1
+            put(bits, 49, 51, int(rng.integers(0, 8)))
+        if rng.random() < 0.5:
+            bits[53] = 1
+            put(bits, 55, 56, int(rng.integers(0, 4)))
+        if edge and rng.random() < 0.3:
+            put(bits, 40, 47, 1)
+    elif kind == 50:
+        bits[0] = bits[11] = bits[23] = bits[45] = 1
+        roll = int(rng.integers(-230, 230)) if not edge else int(rng.integers(-512, 512))
+        put(bits, 2, 11, roll & 0x3FF)
+        put(bits, 13, 23, int(rng.integers(0, 2048)))
+        put(bits, 25, 34, int(rng.integers(20, 360)) if not edge else int(rng.integers(0, 1024)))
+        if rng.random() < 0.8:
+            bits[34] = 1
+            put(bits, 36, 45, int(rng.integers(-330, 330)) & 0x3FF)
+        put(bits, 47, 56, int(rng.integers(20, 360)) if not edge else int(rng.integers(0, 1024)))
+    else:
+        bits[0] = bits[12] = bits[23] = 1
+        put(bits, 2, 12, int(rng.integers(0, 2048)))
+        put(bits, 14, 23, int(rng.integers(40, 710)) if not edge else int(rng.integers(0, 1024)))
+        put(bits, 25, 34, int(rng.integers(20, 230)) if not edge else int(rng.integers(0, 1024)))
+        for v, lo in ((35, 36), (46, 47)):
+            if rng.random() < 0.8:
+                bits[v - 1] = 1
+                put(bits, lo, lo + 9, int(rng.integers(-200, 200)) & 0x3FF)
+    return int("".join(map(str, bits)), 2).to_bytes(7, "big")
+
+
+def test_comm_b_against_the_oracle(pkg, oracle):
+    """decodeCommB (comm_b.c:50-744): the integer decoder shared by the emit kernel and the host against the
+    oracle's float restatement -- plausible and borderline contents of every register, and random MB fields."""
+    rng = np.random.default_rng(4050)
+    seen = np.zeros(10, dtype=int)
+    for k in range(12000):
+        kind = (10, 17, 20, 30, 40, 50, 60, 0, 40, 50, 60, -1)[k % 12]
+        mb = (make_commb(rng, kind) if kind > 0 else
+              rng.integers(0, 256, 7, dtype=np.uint8).tobytes() if kind == 0 else bytes(7) if k % 24 else b"\x00" * 6 + b"\x01")
+        df = 20 if k % 2 else 21
+        head = bytes([(df << 3) | int(rng.integers(0, 8)), 0 if k % 16 else int(rng.integers(0, 256)) & 0xF8,
+                      int(rng.integers(0, 256)), int(rng.integers(0, 256))])
+        m = es_record(pkg, (head + mb + b"\x00\x00\x00").hex())
+        got, want = pkg.capi.decode_fields(m), oracle.fields_of(m)
+        for f in FIELD_NAMES:
+            assert got[f] == want[f], (f, m["msg"].tobytes().hex(), int(got[f]), int(want[f]))
+        seen[want["commb_format"]] += 1
+    assert (seen[2:] > 50).all() and seen[1] > 10, seen  # every format, and ambiguity, occurred
