@@ -330,8 +330,8 @@ def test_comm_b_published_examples(pkg):
         f = pkg.capi.decode_fields(es_record(pkg, hx))
         assert (f["commb_format"], f["callsign_valid"], f["callsign"]) == (5, 1, cs)
     # a GICB capability report (BDS 1,7) must have its last 32 bits clear (comm_b.c:129-132)
-    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA818000000000" + "000000"))["commb_format"] == 4
-    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA818080000001" + "000000"))["commb_format"] != 4
+    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA010100000000" + "000000"))["commb_format"] == 4
+    assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "FA010180000001" + "000000"))["commb_format"] != 4
     # an all-zero MB field is "empty response"; DR set: not looked at at all
     assert pkg.capi.decode_fields(es_record(pkg, "A0000000" + "00" * 7 + "000000"))["commb_format"] == 2
     assert pkg.capi.decode_fields(es_record(pkg, "A0080000" + "00" * 7 + "000000"))["commb_format"] == 0
