@@ -2,8 +2,8 @@
  * (device) and the host paths: what decodeModesMessage fills in after its CRC switch without looking
  * into the ME / MB payloads (mode_s.c:557-715), decodeAC13Field / decodeID13Field (mode_s.c:101-183),
  * the Gillham altitude of mode_ac.c:101-163, and decodeModeAMessage (mode_ac.c:168-202).
- * Second stage: the extended squitter payload of DF17/18 (decodeExtendedSquitter, mode_s.c:736-1058,
- * 1373-1474) except target state (type 29) and operational status (type 31); Comm-B is not decoded.
+ * Then the payloads: the extended squitter of DF17/18 (decodeExtendedSquitter and its type decoders,
+ * mode_s.c:736-1474) and the Comm-B register inference of DF20/21 (decodeCommB, comm_b.c).
  * SURVEY.md 8(f) rank 1. */
 #ifndef MSD_FIELDS_IMPL_H
 #define MSD_FIELDS_IMPL_H
