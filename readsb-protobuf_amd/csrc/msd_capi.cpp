@@ -151,6 +151,10 @@ struct msd_ctx {
     uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
     bool restart_pending = false; /* msd_restart() since the last launch */
     uint32_t timing_interval = 1; /* msd_set_timing_interval() */
+    /* experiment knobs, read from the environment once in msd_create */
+    bool trace = false;      /* MSD_RESOLVE_TRACE */
+    bool repass_aux = false; /* MSD_REPASS_AUX */
+    int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
@@ -331,10 +335,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.counts = c->d_counts;
         p.chunk_sums = s.d_sums;
         p.timers = c->d_timers;
-        {
-            const char *dbg = getenv("MSD_DEBUG_FLAGS");
-            p.debug_flags = dbg ? atoi(dbg) : 0;
-        }
+        p.debug_flags = c->debug_flags;
         int rc = msd_launch_scan(&p, format, nwg, c->stream);
         if (rc)
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -369,10 +370,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
                                      c->stream));
         MsdScanParams p{};
         fill_params(c, s, p);
-        {
-            const char *dbg = getenv("MSD_DEBUG_FLAGS");
-            p.debug_flags = dbg ? atoi(dbg) : 0;
-        }
+        p.debug_flags = c->debug_flags;
         int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
                                host_noise != nullptr ? 1 : (s.dc ? 2 : 0),
                                c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
@@ -525,7 +523,7 @@ int start_download(msd_ctx *c, Slot &s, int format)
 {
     if (s.download_started)
         return 0;
-    const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+    const bool trace = c->trace;
     auto td0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipEventSynchronize(s.ev_totals));
     if (trace && s.timed) {
@@ -750,7 +748,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
 {
     const uint32_t n = s.nbuffers;
     const GpuCtl g = gpu_ctl(c, s);
-    const bool trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+    const bool trace = c->trace;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     double t_wait = 0, t_replay = 0;
@@ -788,7 +786,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
-        hipStream_t ps = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
+        hipStream_t ps = c->repass_aux ? c->aux_stream : c->stream;
         rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
@@ -814,7 +812,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return rc;
         records_current = false;
     }
-    hipStream_t rs = getenv("MSD_REPASS_AUX") ? c->aux_stream : c->stream;
+    hipStream_t rs = c->repass_aux ? c->aux_stream : c->stream;
     if (!records_current && total) {
         int rc = gpu_queue_emit(c, s, format, rs);
         if (rc)
@@ -910,8 +908,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     }
 
     auto t0 = std::chrono::steady_clock::now();
-    const char *dbgflags = getenv("MSD_DEBUG_FLAGS"); /* perf experiments with incomplete candidates */
-    const bool skip_resolve = dbgflags && (atoi(dbgflags) & 0x1c);
+    const bool skip_resolve = (c->debug_flags & 0x1c) != 0; /* perf experiments with incomplete candidates */
     if (s.gpu_resolve) {
         rc = (ts_override || skip_resolve) ? 1 : finish_gpu(c, s, format, sink, user);
         s.resolve_inflight = false;
@@ -927,7 +924,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
                         return rc;
                 }
             }
-            if (getenv("MSD_RESOLVE_TRACE")) {
+            if (c->trace) {
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                 fprintf(stderr, "finish: wait-download %.3f  means %.3f  gpu resolve+power+sink %.3f ms\n", ms(ta, tb),
                         ms(tb, t0), ms(t0, t1));
@@ -1012,7 +1009,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     } else if (sink)
         for (size_t i = 0; i < nm; ++i)
             sink(&c->out_msgs[i], user);
-    if (getenv("MSD_RESOLVE_TRACE")) {
+    if (c->trace) {
         auto t3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "finish: wait-download %.3f  next-download+means %.3f  resolve %.3f  power %.3f  sink %.3f ms\n",
@@ -1090,7 +1087,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         s.busy = false;
         return rc;
     }
-    if (getenv("MSD_RESOLVE_TRACE")) {
+    if (c->trace) {
         static const auto t_origin = std::chrono::steady_clock::now();
         fprintf(stderr, "launch: at %.3f ms, enqueue %.3f ms\n",
                 std::chrono::duration<double, std::milli>(tl0 - t_origin).count(),
@@ -1371,6 +1368,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMemset(c->d_dcstate, 0, 2 * sizeof(float))); /* convert.c:476-477 */
     }
     {
+        c->trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+        c->resolver.trace = c->trace;
+        c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
+        if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
+            c->debug_flags = atoi(dbg);
         const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
         c->gpu_resolve = g ? atoi(g) != 0 : true;
         c->want_fields = (cfg->flags & MSD_CFG_DECODE_FIELDS) != 0;

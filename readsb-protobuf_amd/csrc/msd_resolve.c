@@ -742,7 +742,7 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
     }
     const int serial = !bs->pool || bs->pool->nthreads == 0 || nbuffers < 4;
     msd_filter work;
-    const int trace = getenv("MSD_RESOLVE_TRACE") != NULL;
+    const int trace = r->trace;
     double t_par = 0, t_seq = 0, t0 = trace ? now_ms() : 0;
     uint32_t npass = 0;
     if (serial) {
@@ -913,7 +913,7 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
                            uint32_t *ntodo)
 {
     struct msd_batch_state *bs = r->batch;
-    const int trace_replay = getenv("MSD_RESOLVE_TRACE") != NULL;
+    const int trace_replay = r->trace;
     *npatches = 0;
     if (npred > MSD_PRED_LIST)
         return -1; /* thousands of new aircraft in one batch: the table overflowed */
