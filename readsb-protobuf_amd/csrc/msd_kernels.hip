@@ -1190,14 +1190,113 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
     }
 }
 
-/* mean_level / mean_power of the float converters are *sequential* float sums
- * (convert.c:228-252): float addition is not associative, so the 131072 additions of a buffer are a
- * dependent chain.  One workgroup per buffer: two wavefronts turn samples into level and power values
- * in LDS, chunk by chunk and one chunk ahead; one lane of a third wavefront adds the levels up in
- * order, one lane of a fourth the powers (a lone wavefront issues a dependent v_add_f32 about every
- * 11 cycles, so each chain gets its own SIMD; ~0.7 ms per buffer, all buffers of a batch at once). */
+/* mean_level / mean_power of the float converters are *sequential* float sums (convert.c:228-252):
+ * s = fl(s + x) for the 131072 magnitudes (and squares) of a buffer in order, and float addition is not
+ * associative.  Added one after the other that is a dependent chain of 131072 v_add_f32 (about 11 cycles
+ * each from a lone wavefront: 0.6 ms per buffer).  But the chain has structure: while s stays inside one
+ * binade [2^e, 2^(e+1)) it is a multiple of u = 2^(e-23) and fl(s + x) = s + (floor(x/u) + r) * u, where the
+ * rounding r depends on x and, in a tie, on the parity of s/u only.  An element is therefore a function
+ *     S -> S + c(S mod 2),   S = s/u an integer,  c(0), c(1) two integers,
+ * such functions compose to functions of the same form, and composition is associative: a wavefront
+ * composes 16 elements per lane, scans the 64 lane functions in order (shuffles) and knows S after every
+ * lane -- exactly, as long as S stays below 2^24.  Where it does not (the sum enters the next binade, about
+ * fifteen times per buffer) the lanes in front of that point are applied, that lane's 16 elements are added
+ * with real float additions, and the rest of the block starts over with the new u; the same for the first
+ * samples of a buffer, while s is still tiny or zero.  Bit-identical to the sequential sum.
+ * One workgroup per buffer: wavefronts 2 and 3 turn samples into level and power values in LDS, chunk by
+ * chunk and one chunk ahead; wavefront 0 sums the levels, wavefront 1 the powers. */
 constexpr int MSD_FMT_MAGSQ = 100; /* internal source "format" of the float sums: f32 magnitude squares */
-constexpr int FM_THREADS = 256, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 12, FM_CHUNK = FM_PRODUCERS * FM_PER;
+constexpr int FM_THREADS = 256, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 16, FM_CHUNK = FM_PRODUCERS * FM_PER;
+constexpr int FS_PER = 16, FS_BLOCK = 64 * FS_PER; /* elements per lane and per scan */
+static_assert(FM_CHUNK % FS_BLOCK == 0, "a chunk is a whole number of scan blocks");
+constexpr uint32_t FS_SAT = 1u << 26; /* increments saturate here: anything >= 2^24 means "left the binade" */
+
+/* What element x (a non-negative float <= 1, as bits) adds to S when s has exponent e >= -7: base, plus one
+ * more if `tie` and the sum in front of the rounding is odd.  Branch-free: x / u = m * 2^-sh with
+ * sh = e - exponent(x) >= -7; t = m << 7 and sh + 7 keep every shift inside 0..31, and an x below u / 2
+ * (sh > 24) counts as zero.  base is clamped so that sixteen of them cannot wrap. */
+__device__ __forceinline__ void fsum_element(uint32_t xb, int e, uint32_t &base, uint32_t &tie)
+{
+    const uint32_t ef = xb >> 23;
+    const int sh = e - (ef ? (int)ef - 127 : -126);
+    const uint32_t m = sh > 24 ? 0u : ((xb & 0x7fffffu) | (ef ? 0x800000u : 0u));
+    const uint32_t k = (uint32_t)(min(sh, 24) + 7), t = m << 7, P = 1u << k;
+    const uint32_t a = t >> k, rem2 = (t & (P - 1u)) << 1;
+    tie = rem2 == P ? ((a & 1u) ? 2u : 1u) : 0u; /* 1: rounds up after an odd S, 2: after an even S */
+    base = min(a + (rem2 > P ? 1u : 0u), FS_SAT);
+}
+
+/* s += x[0] + ... in order, x = the registers of lane `who` (uniform loop, plain v_add_f32) */
+__device__ __forceinline__ float fsum_sequential(float s, const float (&x)[FS_PER], int who)
+{
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k) {
+        const float t = __shfl(x[k], who, 64);
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(t));
+    }
+    return s;
+}
+
+/* s after the FS_BLOCK elements the wavefront holds (lane L: elements 16 L .. 16 L + 15); all lanes return it */
+__device__ __forceinline__ float fsum_block(float s, const float (&x)[FS_PER], int lane)
+{
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k)
+        nz |= x[k] != 0.0f;
+    int from = 0; /* lanes in front of `from` are done */
+    while (from < 64) {
+        const uint64_t todo = ~0ull << from;
+        const uint64_t nzmask = __ballot(nz) & todo;
+        if (!nzmask)
+            break; /* adding zeros changes nothing */
+        const uint32_t sb = __float_as_uint(s);
+        const int e = (int)(sb >> 23) - 127;
+        if (e < -7) { /* zero or tiny: skip the zeros, add one lane's elements the slow way */
+            const int z = __ffsll((unsigned long long)nzmask) - 1;
+            s = fsum_sequential(s, x, z);
+            from = z + 1;
+            continue;
+        }
+        /* this lane's sixteen elements as one function: c0 = increment of S if S is even in front of them,
+         * c1 if it is odd.  What an element adds is worked out first (independent instructions); the
+         * chain through the parity is three instructions per element and parity. */
+        uint32_t base[FS_PER], tie[FS_PER];
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k)
+            fsum_element(__float_as_uint(x[k]), e, base[k], tie[k]);
+        uint32_t c0 = 0, c1 = 1; /* running S relative to an even / odd start (c1 carries the start's 1) */
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k) {
+            c0 += base[k] + ((tie[k] >> (~c0 & 1u)) & 1u); /* tie 1 fires on odd, 2 on even */
+            c1 += base[k] + ((tie[k] >> (~c1 & 1u)) & 1u);
+        }
+        c1 -= 1u;
+        if (lane < from)
+            c0 = c1 = 0; /* already applied: the identity */
+        c0 = min(c0, FS_SAT);
+        c1 = min(c1, FS_SAT);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { /* ordered composition: (lanes .. L-d) then (L-d+1 .. L) */
+            const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
+            if (lane >= d) {
+                const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
+                c0 = min(n0, FS_SAT);
+                c1 = min(n1, FS_SAT);
+            }
+        }
+        const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+        const uint32_t S = S0 + ((S0 & 1u) ? c1 : c0); /* after this lane's elements, if nothing left the binade */
+        const uint64_t bad = __ballot(S >= (1u << 24)) & todo;
+        const int stop = bad ? __ffsll((unsigned long long)bad) - 1 : 64;
+        const uint32_t Sb = stop ? (uint32_t)__shfl((int)S, stop - 1, 64) : S0; /* lanes < from are identities */
+        s = __uint_as_float((sb & 0xff800000u) | (Sb & 0x7fffffu));
+        if (stop < 64)
+            s = fsum_sequential(s, x, stop);
+        from = stop + 1;
+    }
+    return s;
+}
 
 template <int FMT>
 __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8_t *iq, uint64_t nsamples,
@@ -1245,45 +1344,20 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
                     vals[c & 1][1][i] = magsq;
                 }
             }
-        } else if ((tid & 63) == 0 && c > 0) { /* the two adders: chunk c - 1, strictly in order */
-            const uint32_t base = (c - 1) * FM_CHUNK;
-            const uint32_t cnt = n - base < (uint32_t)FM_CHUNK ? n - base : (uint32_t)FM_CHUNK;
+        } else if (c > 0) { /* wavefront 0: levels, wavefront 1: powers; chunk c - 1 */
             const float *v = vals[(c - 1) & 1][tid >> 6];
-            const float4 *v4 = reinterpret_cast<const float4 *>(v);
-            uint32_t i = 0;
-            /* plain v_add_f32, one after the other (nothing for the compiler to re-associate or pack) */
-#define FM_ADD(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sum) : "v"(x))
-#define FM_ADD4(X) FM_ADD((X).x); FM_ADD((X).y); FM_ADD((X).z); FM_ADD((X).w);
-            if (cnt >= 32) { /* the loads of the next 32 values are in flight while these are added */
-                float4 x[8];
+            const int lane = tid & 63;
+#pragma unroll 1
+            for (int blk = 0; blk < FM_CHUNK / FS_BLOCK; ++blk) {
+                float x[FS_PER];
+                const float4 *v4 = reinterpret_cast<const float4 *>(v + blk * FS_BLOCK + lane * FS_PER);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[u] = v4[u];
-                for (; i + 64 <= cnt; i += 32) {
-                    float4 nx[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        nx[u] = v4[(i >> 2) + 8 + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        FM_ADD4(x[u])
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        x[u] = nx[u];
+                for (int k = 0; k < FS_PER / 4; ++k) {
+                    const float4 q = v4[k];
+                    x[4 * k] = q.x; x[4 * k + 1] = q.y; x[4 * k + 2] = q.z; x[4 * k + 3] = q.w;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    FM_ADD4(x[u])
-                }
-                i += 32;
+                sum = fsum_block(sum, x, lane);
             }
-            for (; i < cnt; ++i) {
-                const float t = v[i];
-                FM_ADD(t);
-            }
-#undef FM_ADD4
-#undef FM_ADD
         }
         __syncthreads();
     }
