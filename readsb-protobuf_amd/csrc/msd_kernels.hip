@@ -1203,10 +1203,11 @@ __global__ void __launch_bounds__(256) msd_convert_kernel(const uint8_t *iq, uin
  * fifteen times per buffer) the lanes in front of that point are applied, that lane's 16 elements are added
  * with real float additions, and the rest of the block starts over with the new u; the same for the first
  * samples of a buffer, while s is still tiny or zero.  Bit-identical to the sequential sum.
- * One workgroup per buffer: wavefronts 2 and 3 turn samples into level and power values in LDS, chunk by
- * chunk and one chunk ahead; wavefront 0 sums the levels, wavefront 1 the powers. */
+ * One workgroup per buffer: wavefronts 2..7 turn samples into level and power values in LDS (the correctly
+ * rounded square root makes that the bigger half of the work), chunk by chunk and one chunk ahead; wavefront 0
+ * sums the levels, wavefront 1 the powers. */
 constexpr int MSD_FMT_MAGSQ = 100; /* internal source "format" of the float sums: f32 magnitude squares */
-constexpr int FM_THREADS = 256, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 16, FM_CHUNK = FM_PRODUCERS * FM_PER;
+constexpr int FM_THREADS = 512, FM_PRODUCERS = FM_THREADS - 128, FM_PER = 8, FM_CHUNK = FM_PRODUCERS * FM_PER;
 constexpr int FS_PER = 16, FS_BLOCK = 64 * FS_PER; /* elements per lane and per scan */
 static_assert(FM_CHUNK % FS_BLOCK == 0, "a chunk is a whole number of scan blocks");
 constexpr uint32_t FS_SAT = 1u << 26; /* increments saturate here: anything >= 2^24 means "left the binade" */
