@@ -1249,35 +1249,26 @@ static int cb_bds10(const uint8_t *msg, orc_fields *f, int store) /* :102-122 */
 static int cb_bds17(const uint8_t *msg, orc_fields *f, int store) /* :126-203 */
 {
     if (getbits(msg, 25, 56) != 0)
-        return 0;
-    int score = 0;
-    if (getbit1(msg, 7))
+        return 0; /* reserved */
+    /* capability bits that are almost never set cost two points each; BDS 2,0 (bit 7) is on almost everything */
+    static const unsigned rare[] = {10, 11, 12, 13, 14, 20, 21, 22};
+    int score = getbit1(msg, 7) ? 1 : -2;
+    for (unsigned i = 0; i < sizeof rare / sizeof rare[0]; ++i)
+        score -= 2 * (int)getbit1(msg, rare[i]);
+    const unsigned es = getbits(msg, 1, 5); /* the five extended squitter registers come together or not at all */
+    if (es == 0x1f)
+        score += 5 + (int)getbit1(msg, 6);
+    else if (es == 0 && !getbit1(msg, 6))
         score += 1;
     else
-        score -= 2;
-    static const unsigned unlikely[] = {10, 11, 12, 13, 14, 20, 21, 22};
-    for (unsigned i = 0; i < 8; ++i)
-        if (getbit1(msg, unlikely[i]))
-            score -= 2;
-    if (getbit1(msg, 1) && getbit1(msg, 2) && getbit1(msg, 3) && getbit1(msg, 4) && getbit1(msg, 5)) {
-        score += 5;
-        if (getbit1(msg, 6))
-            score += 1;
-    } else if (!getbit1(msg, 1) && !getbit1(msg, 2) && !getbit1(msg, 3) && !getbit1(msg, 4) && !getbit1(msg, 5) &&
-               !getbit1(msg, 6)) {
-        score += 1;
-    } else {
         score -= 12;
-    }
-    if (getbit1(msg, 16) && getbit1(msg, 24)) {
-        score += 2;
-        if (getbit1(msg, 9))
-            score += 1;
-    } else if (!getbit1(msg, 16) && !getbit1(msg, 24) && !getbit1(msg, 9)) {
+    const unsigned turn = getbit1(msg, 16), speed = getbit1(msg, 24), intent = getbit1(msg, 9);
+    if (turn && speed)
+        score += 2 + (int)intent;
+    else if (!turn && !speed && !intent)
         score += 1;
-    } else {
+    else
         score -= 6;
-    }
     if (store)
         f->commb_format = CB_GICB_CAPS;
     return score;
@@ -1285,25 +1276,24 @@ static int cb_bds17(const uint8_t *msg, orc_fields *f, int store) /* :126-203 */
 
 static int cb_bds20(const uint8_t *msg, orc_fields *f, int store) /* :207-250 */
 {
-    char callsign[8];
     if (msg[0] != 0x20)
         return 0;
-    for (unsigned i = 0; i < 8; ++i)
-        callsign[i] = ais_charset[getbits(msg, 9 + 6 * i, 14 + 6 * i)];
-    int score = 8;
-    int valid = 1;
+    char cs[8];
+    int score = 8, usable = 1;
     for (unsigned i = 0; i < 8; ++i) {
-        if ((callsign[i] >= 'A' && callsign[i] <= 'Z') || (callsign[i] >= '0' && callsign[i] <= '9') || callsign[i] == ' ')
+        cs[i] = ais_charset[getbits(msg, 9 + 6 * i, 14 + 6 * i)];
+        const int alnum = (cs[i] >= 'A' && cs[i] <= 'Z') || (cs[i] >= '0' && cs[i] <= '9') || cs[i] == ' ';
+        if (alnum)
             score += 6;
-        else if (callsign[i] == '@')
-            valid = 0;
+        else if (cs[i] == '@')
+            usable = 0; /* padding: still a BDS 2,0, but no callsign to take */
         else
             return 0;
     }
     if (store) {
         f->commb_format = CB_AIRCRAFT_IDENT;
-        if (valid) {
-            memcpy(f->callsign, callsign, 8);
+        if (usable) {
+            memcpy(f->callsign, cs, 8);
             f->callsign_valid = 1;
         }
     }
@@ -1319,317 +1309,158 @@ static int cb_bds30(const uint8_t *msg, orc_fields *f, int store) /* :254-268 */
     return 56;
 }
 
+/* The shape every value of BDS 4,0 / 5,0 / 6,0 is tested in: a status bit in front of a raw value.
+ * Status set (and, where `needs_value`, a non-zero raw value): the decoded value must be plausible and then
+ * earns `points`; status clear and nothing in the field (`field_bits`: the raw value, with the sign bit where
+ * the reference looks at it): one point; any other combination: not this register.  Returns 0 to give up. */
+static int cb_field(unsigned status, unsigned field_bits, unsigned raw, int needs_value, int plausible, int points,
+                    int *score)
+{
+    if (status && (!needs_value || raw != 0)) {
+        if (!plausible)
+            return 0;
+        *score += points;
+        return 1;
+    }
+    if (!status && field_bits == 0) {
+        *score += 1;
+        return 1;
+    }
+    return 0;
+}
+
 static int cb_bds40(const uint8_t *msg, orc_fields *f, int store) /* :272-434 */
 {
-    unsigned mcp_valid = getbit1(msg, 1), mcp_raw = getbits(msg, 2, 13);
-    unsigned fms_valid = getbit1(msg, 14), fms_raw = getbits(msg, 15, 26);
-    unsigned baro_valid = getbit1(msg, 27), baro_raw = getbits(msg, 28, 39);
-    unsigned reserved_1 = getbits(msg, 40, 47);
-    unsigned mode_valid = getbit1(msg, 48), mode_raw = getbits(msg, 49, 51);
-    unsigned reserved_2 = getbits(msg, 52, 53);
-    unsigned source_valid = getbit1(msg, 54), source_raw = getbits(msg, 55, 56);
-    if (!mcp_valid && !fms_valid && !baro_valid && !mode_valid && !source_valid)
+    const unsigned mcp_on = getbit1(msg, 1), mcp = getbits(msg, 2, 13), fms_on = getbit1(msg, 14), fms = getbits(msg, 15, 26);
+    const unsigned qnh_on = getbit1(msg, 27), qnh = getbits(msg, 28, 39), mode_on = getbit1(msg, 48), mode = getbits(msg, 49, 51);
+    const unsigned src_on = getbit1(msg, 54), src = getbits(msg, 55, 56);
+    if (!(mcp_on || fms_on || qnh_on || mode_on || src_on))
         return 0;
+    const unsigned mcp_alt = mcp * 16, fms_alt = fms * 16; /* feet */
+    const float baro_setting = 800 + qnh * 0.1;           /* hPa, as the reference computes it */
     int score = 0;
-    unsigned mcp_alt = 0;
-    if (mcp_valid && mcp_raw != 0) {
-        mcp_alt = mcp_raw * 16;
-        if (mcp_alt >= 1000 && mcp_alt <= 50000)
-            score += 13;
-        else
-            return 0;
-    } else if (!mcp_valid && mcp_raw == 0) {
-        score += 1;
-    } else {
+    if (!cb_field(mcp_on, mcp, mcp, 1, mcp_alt >= 1000 && mcp_alt <= 50000, 13, &score) ||
+        !cb_field(fms_on, fms, fms, 1, fms_alt >= 1000 && fms_alt <= 50000, 13, &score) ||
+        !cb_field(qnh_on, qnh, qnh, 1, baro_setting >= 900 && baro_setting <= 1100, 13, &score))
         return 0;
-    }
-    unsigned fms_alt = 0;
-    if (fms_valid && fms_raw != 0) {
-        fms_alt = fms_raw * 16;
-        if (fms_alt >= 1000 && fms_alt <= 50000)
-            score += 13;
-        else
-            return 0;
-    } else if (!fms_valid && fms_raw == 0) {
-        score += 1;
-    } else {
+    if (getbits(msg, 40, 47) != 0 || getbits(msg, 52, 53) != 0)
+        return 0; /* reserved */
+    if (!cb_field(mode_on, mode, mode, 0, 1, 4, &score) || !cb_field(src_on, src, src, 0, 1, 3, &score))
         return 0;
-    }
-    float baro_setting = 0;
-    if (baro_valid && baro_raw != 0) {
-        baro_setting = 800 + baro_raw * 0.1;
-        if (baro_setting >= 900 && baro_setting <= 1100)
-            score += 13;
-        else
-            return 0;
-    } else if (!baro_valid && baro_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    if (reserved_1 != 0)
-        return 0;
-    if (mode_valid)
-        score += 4;
-    else if (!mode_valid && mode_raw == 0)
-        score += 1;
-    else
-        return 0;
-    if (reserved_2 != 0)
-        return 0;
-    if (source_valid)
-        score += 3;
-    else if (!source_valid && source_raw == 0)
-        score += 1;
-    else
-        return 0;
-    if (mcp_valid && fms_valid && mcp_alt != fms_alt)
+    if (mcp_on && fms_on && mcp_alt != fms_alt)
         score -= 4;
-    if (mcp_valid) {
-        unsigned remainder = mcp_alt % 500;
-        if (!(remainder < 16 || remainder > 484))
+    const unsigned alts[2] = {mcp_alt, fms_alt}, on[2] = {mcp_on, fms_on};
+    for (int i = 0; i < 2; ++i) /* people select multiples of 500 ft */
+        if (on[i] && !(alts[i] % 500 < 16 || alts[i] % 500 > 484))
             score -= 4;
-    }
-    if (fms_valid) {
-        unsigned remainder = fms_alt % 500;
-        if (!(remainder < 16 || remainder > 484))
-            score -= 4;
-    }
     if (store) {
+        static const uint8_t source_of[4] = {NAVALT_UNKNOWN, NAVALT_AIRCRAFT, NAVALT_MCP, NAVALT_FMS};
         f->commb_format = CB_VERTICAL_INTENT;
-        if (mcp_valid) {
+        if (mcp_on) {
             f->nav_valid |= NAVV_MCP;
             f->nav_mcp_altitude = (int32_t)mcp_alt;
         }
-        if (fms_valid) {
+        if (fms_on) {
             f->nav_valid |= NAVV_FMS;
             f->nav_fms_altitude = (int32_t)fms_alt;
         }
-        if (baro_valid) {
+        if (qnh_on) {
             f->nav_valid |= NAVV_QNH | NAVV_QNH_COMMB;
-            f->nav_qnh_raw = (uint16_t)baro_raw; /* nav.qnh = 800 + baro_raw * 0.1 */
+            f->nav_qnh_raw = (uint16_t)qnh; /* nav.qnh = 800 + raw * 0.1 */
         }
-        if (mode_valid) {
+        if (mode_on) {
             f->nav_valid |= NAVV_MODES;
-            f->nav_modes = (uint8_t)(((mode_raw & 4) ? NM_VNAV : 0) | ((mode_raw & 2) ? NM_ALT_HOLD : 0) |
-                                     ((mode_raw & 1) ? NM_APPROACH : 0));
+            f->nav_modes = (uint8_t)(((mode & 4) ? NM_VNAV : 0) | ((mode & 2) ? NM_ALT_HOLD : 0) | ((mode & 1) ? NM_APPROACH : 0));
         }
-        if (source_valid) {
-            switch (source_raw) {
-            case 0: f->nav_altitude_source = NAVALT_UNKNOWN; break;
-            case 1: f->nav_altitude_source = NAVALT_AIRCRAFT; break;
-            case 2: f->nav_altitude_source = NAVALT_MCP; break;
-            case 3: f->nav_altitude_source = NAVALT_FMS; break;
-            default: f->nav_altitude_source = NAVALT_INVALID; break;
-            }
-        } else {
-            f->nav_altitude_source = NAVALT_INVALID;
-        }
+        f->nav_altitude_source = src_on ? source_of[src] : NAVALT_INVALID;
     }
     return score;
 }
 
 static int cb_bds50(const uint8_t *msg, orc_fields *f, int store) /* :438-592 */
 {
-    unsigned roll_valid = getbit1(msg, 1), roll_sign = getbit1(msg, 2), roll_raw = getbits(msg, 3, 11);
-    unsigned track_valid = getbit1(msg, 12), track_sign = getbit1(msg, 13), track_raw = getbits(msg, 14, 23);
-    unsigned gs_valid = getbit1(msg, 24), gs_raw = getbits(msg, 25, 34);
-    unsigned track_rate_valid = getbit1(msg, 35), track_rate_sign = getbit1(msg, 36), track_rate_raw = getbits(msg, 37, 45);
-    unsigned tas_valid = getbit1(msg, 46), tas_raw = getbits(msg, 47, 56);
-    if (!roll_valid || !track_valid || !gs_valid || !tas_valid)
+    const unsigned roll_on = getbit1(msg, 1), roll_neg = getbit1(msg, 2), roll_raw = getbits(msg, 3, 11);
+    const unsigned trk_on = getbit1(msg, 12), trk_west = getbit1(msg, 13), trk_raw = getbits(msg, 14, 23);
+    const unsigned gs_on = getbit1(msg, 24), gs_raw = getbits(msg, 25, 34);
+    const unsigned rate_on = getbit1(msg, 35), rate_neg = getbit1(msg, 36), rate_raw = getbits(msg, 37, 45);
+    const unsigned tas_on = getbit1(msg, 46), tas_raw = getbits(msg, 47, 56);
+    if (!roll_on || !trk_on || !gs_on || !tas_on)
         return 0;
+    float roll = roll_raw * 45.0 / 256.0;
+    if (roll_neg)
+        roll -= 90.0;
+    float track_rate = rate_raw * 8.0 / 256.0;
+    if (rate_neg)
+        track_rate -= 16;
+    const unsigned gs = gs_raw * 2, tas = tas_raw * 2;
     int score = 0;
-    float roll = 0;
-    if (roll_valid) {
-        roll = roll_raw * 45.0 / 256.0;
-        if (roll_sign)
-            roll -= 90.0;
-        if (roll >= -40 && roll < 40)
-            score += 11;
-        else
-            return 0;
-    } else if (!roll_valid && roll_raw == 0 && !roll_sign) {
-        score += 1;
-    } else {
+    if (!cb_field(roll_on, roll_raw | roll_neg, roll_raw, 0, roll >= -40 && roll < 40, 11, &score) ||
+        !cb_field(trk_on, trk_raw | trk_west, trk_raw, 0, 1, 12, &score) ||
+        !cb_field(gs_on, gs_raw, gs_raw, 1, gs >= 50 && gs <= 700, 11, &score) ||
+        !cb_field(rate_on, rate_raw | rate_neg, rate_raw, 0, track_rate >= -10.0 && track_rate <= 10.0, 11, &score) ||
+        !cb_field(tas_on, tas_raw, tas_raw, 1, tas >= 50 && tas <= 700, 11, &score))
         return 0;
-    }
-    if (track_valid) {
-        score += 12;
-    } else if (!track_valid && track_raw == 0 && !track_sign) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    unsigned gs = 0;
-    if (gs_valid && gs_raw != 0) {
-        gs = gs_raw * 2;
-        if (gs >= 50 && gs <= 700)
-            score += 11;
-        else
-            return 0;
-    } else if (!gs_valid && gs_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    float track_rate = 0;
-    if (track_rate_valid) {
-        track_rate = track_rate_raw * 8.0 / 256.0;
-        if (track_rate_sign)
-            track_rate -= 16;
-        if (track_rate >= -10.0 && track_rate <= 10.0)
-            score += 11;
-        else
-            return 0;
-    } else if (!track_rate_valid && track_rate_raw == 0 && !track_rate_sign) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    unsigned tas = 0;
-    if (tas_valid && tas_raw != 0) {
-        tas = tas_raw * 2;
-        if (tas >= 50 && tas <= 700)
-            score += 11;
-        else
-            return 0;
-    } else if (!tas_valid && tas_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    if (gs_valid && tas_valid) { /* compares the two flags, not the speeds (comm_b.c:543): never more than 150 */
-        int delta = abs((int)gs_valid - (int)tas_valid);
-        if (delta > 150)
-            score -= 6;
-    }
-    if (roll_valid && tas_valid && tas > 0 && track_rate_valid) {
-        double turn_rate = 68625 * tan(roll * M_PI / 180.0) / (tas * 20 * M_PI);
-        double delta = fabs(turn_rate - track_rate);
-        if (delta > 2.0)
+    /* comm_b.c:542-548 means to compare ground speed and airspeed but subtracts their status bits: |1 - 1| is
+     * never more than 150, the penalty never applies */
+    if (abs((int)gs_on - (int)tas_on) > 150)
+        score -= 6;
+    if (rate_on && tas > 0) { /* the turn rate a coordinated turn at this bank and speed has */
+        const double turn_rate = 68625 * tan(roll * M_PI / 180.0) / (tas * 20 * M_PI);
+        if (fabs(turn_rate - track_rate) > 2.0)
             score -= 6;
     }
     if (store) {
         f->commb_format = CB_TRACK_TURN;
-        if (roll_valid) {
-            f->commb_valid |= CBV_ROLL;
-            f->roll_q = (int16_t)((int)roll_raw - (roll_sign ? 512 : 0)); /* roll * 256 / 45 */
-        }
-        if (track_valid) {
-            f->heading_valid = 1;
-            f->heading_raw = (uint16_t)(track_raw + (track_sign ? 1024 : 0)); /* (raw * 90 / 512 [+ 180]) * 512 / 90 */
-            f->heading_type = HT_GROUND_TRACK;
-        }
-        if (gs_valid) {
-            f->commb_valid |= CBV_GS;
-            f->gs = (uint16_t)gs;
-        }
-        if (track_rate_valid) {
+        f->commb_valid |= CBV_ROLL | CBV_GS;
+        f->roll_q = (int16_t)((int)roll_raw - (roll_neg ? 512 : 0)); /* roll * 256 / 45 */
+        f->heading_valid = 1;
+        f->heading_raw = (uint16_t)(trk_raw + (trk_west ? 1024 : 0)); /* (raw * 90 / 512 [+ 180]) * 512 / 90 */
+        f->heading_type = HT_GROUND_TRACK;
+        f->gs = (uint16_t)gs;
+        if (rate_on) {
             f->commb_valid |= CBV_TRACK_RATE;
-            f->track_rate_q = (int16_t)((int)track_rate_raw - (track_rate_sign ? 512 : 0)); /* rate * 32 */
+            f->track_rate_q = (int16_t)((int)rate_raw - (rate_neg ? 512 : 0)); /* rate * 32 */
         }
-        if (tas_valid) {
-            f->tas_valid = 1;
-            f->tas = (uint16_t)tas;
-        }
+        f->tas_valid = 1;
+        f->tas = (uint16_t)tas;
     }
     return score;
 }
 
 static int cb_bds60(const uint8_t *msg, orc_fields *f, int store) /* :596-744 */
 {
-    unsigned heading_valid = getbit1(msg, 1), heading_sign = getbit1(msg, 2), heading_raw = getbits(msg, 3, 12);
-    unsigned ias_valid = getbit1(msg, 13), ias_raw = getbits(msg, 14, 23);
-    unsigned mach_valid = getbit1(msg, 24), mach_raw = getbits(msg, 25, 34);
-    unsigned baro_rate_valid = getbit1(msg, 35), baro_rate_sign = getbit1(msg, 36), baro_rate_raw = getbits(msg, 37, 45);
-    unsigned inertial_rate_valid = getbit1(msg, 46), inertial_rate_sign = getbit1(msg, 47),
-             inertial_rate_raw = getbits(msg, 48, 56);
-    if (!heading_valid || !ias_valid || !mach_valid || (!baro_rate_valid && !inertial_rate_valid))
+    const unsigned hdg_on = getbit1(msg, 1), hdg_west = getbit1(msg, 2), hdg_raw = getbits(msg, 3, 12);
+    const unsigned ias_on = getbit1(msg, 13), ias = getbits(msg, 14, 23);
+    const unsigned mach_on = getbit1(msg, 24), mach_raw = getbits(msg, 25, 34);
+    const unsigned baro_on = getbit1(msg, 35), baro_neg = getbit1(msg, 36), baro_raw = getbits(msg, 37, 45);
+    const unsigned ins_on = getbit1(msg, 46), ins_neg = getbit1(msg, 47), ins_raw = getbits(msg, 48, 56);
+    if (!hdg_on || !ias_on || !mach_on || (!baro_on && !ins_on))
         return 0;
+    const float mach = mach_raw * 2.048 / 512;
+    const int baro_rate = (int)baro_raw * 32 - (baro_neg ? 16384 : 0), inertial_rate = (int)ins_raw * 32 - (ins_neg ? 16384 : 0);
     int score = 0;
-    if (heading_valid)
-        score += 12;
-    else if (!heading_valid && heading_raw == 0 && !heading_sign)
-        score += 1;
-    else
+    if (!cb_field(hdg_on, hdg_raw | hdg_west, hdg_raw, 0, 1, 12, &score) ||
+        !cb_field(ias_on, ias, ias, 1, ias >= 50 && ias <= 700, 11, &score) ||
+        !cb_field(mach_on, mach_raw, mach_raw, 1, mach >= 0.1 && mach <= 0.9, 11, &score) ||
+        !cb_field(baro_on, baro_raw, baro_raw, 0, baro_rate >= -6000 && baro_rate <= 6000, 11, &score) || /* (sign bit not */
+        !cb_field(ins_on, ins_raw, ins_raw, 0, inertial_rate >= -6000 && inertial_rate <= 6000, 11, &score)) /* looked at) */
         return 0;
-    unsigned ias = 0;
-    if (ias_valid && ias_raw != 0) {
-        ias = ias_raw;
-        if (ias >= 50 && ias <= 700)
-            score += 11;
-        else
-            return 0;
-    } else if (!ias_valid && ias_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    float mach = 0;
-    if (mach_valid && mach_raw != 0) {
-        mach = mach_raw * 2.048 / 512;
-        if (mach >= 0.1 && mach <= 0.9)
-            score += 11;
-        else
-            return 0;
-    } else if (!mach_valid && mach_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    int baro_rate = 0;
-    if (baro_rate_valid) {
-        baro_rate = baro_rate_raw * 32;
-        if (baro_rate_sign)
-            baro_rate -= 16384;
-        if (baro_rate >= -6000 && baro_rate <= 6000)
-            score += 11;
-        else
-            return 0;
-    } else if (!baro_rate_valid && baro_rate_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    int inertial_rate = 0;
-    if (inertial_rate_valid) {
-        inertial_rate = inertial_rate_raw * 32;
-        if (inertial_rate_sign)
-            inertial_rate -= 16384;
-        if (inertial_rate >= -6000 && inertial_rate <= 6000)
-            score += 11;
-        else
-            return 0;
-    } else if (!inertial_rate_valid && inertial_rate_raw == 0) {
-        score += 1;
-    } else {
-        return 0;
-    }
-    if (baro_rate_valid && inertial_rate_valid) {
-        int delta = abs(baro_rate - inertial_rate);
-        if (delta > 2000)
-            score -= 12;
-    }
+    if (baro_on && ins_on && abs(baro_rate - inertial_rate) > 2000)
+        score -= 12;
     if (store) {
         f->commb_format = CB_HEADING_SPEED;
-        if (heading_valid) {
-            f->heading_valid = 1;
-            f->heading_raw = (uint16_t)(heading_raw + (heading_sign ? 1024 : 0));
-            f->heading_type = HT_MAGNETIC;
-        }
-        if (ias_valid) {
-            f->ias_valid = 1;
-            f->ias = (uint16_t)ias;
-        }
-        if (mach_valid) {
-            f->commb_valid |= CBV_MACH;
-            f->mach_raw = (uint16_t)mach_raw; /* mach = mach_raw * 2.048 / 512 */
-        }
-        if (baro_rate_valid) {
+        f->heading_valid = 1;
+        f->heading_raw = (uint16_t)(hdg_raw + (hdg_west ? 1024 : 0));
+        f->heading_type = HT_MAGNETIC;
+        f->ias_valid = 1;
+        f->ias = (uint16_t)ias;
+        f->commb_valid |= CBV_MACH;
+        f->mach_raw = (uint16_t)mach_raw; /* mach = mach_raw * 2.048 / 512 */
+        if (baro_on) {
             f->baro_rate_valid = 1;
             f->baro_rate = (int16_t)baro_rate;
         }
-        if (inertial_rate_valid) {
+        if (ins_on) { /* INS-derived: a "geometric" rate like elsewhere */
             f->geom_rate_valid = 1;
             f->geom_rate = (int16_t)inertial_rate;
         }
