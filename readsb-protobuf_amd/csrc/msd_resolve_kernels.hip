@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int RT = 256;    /* threads per workgroup (one workgroup per buffer) */
+constexpr int RT = 512;    /* threads per workgroup (one workgroup per buffer) */
 constexpr int SEG = 1024;  /* hits staged per segment */
 constexpr uint32_t VACANT = 0xFFFFFFFFu;
 constexpr uint32_t SLOTS = 8192u;
