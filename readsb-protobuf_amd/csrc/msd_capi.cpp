@@ -848,12 +848,26 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
                 "power stats %.3f ms\n", npass, early ? " (first one queued early)" : "", t_wait, t_replay, tms(e0, e1),
                 tms(e1, tnow()));
-    if (c->fsink)
+    /* delivery; the library's own array sinks take the whole batch with one copy instead of 35 000 calls */
+    static_assert(sizeof(msd_wire) == sizeof(msd_message), "the records are msd_message arrays");
+    if (c->fsink == msd_array_fields_sink) {
+        msd_array_fields_sink_state *st = static_cast<msd_array_fields_sink_state *>(c->fuser);
+        const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
+        memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
+        memcpy(st->fields + st->count, s.h_fields, k * sizeof(msd_fields));
+        st->count += total;
+    } else if (c->fsink) {
         for (uint32_t i = 0; i < total; ++i)
             c->fsink(&s.h_wire[i].mm, &s.h_fields[i], c->fuser);
-    else if (sink)
+    } else if (sink == msd_array_sink) {
+        msd_array_sink_state *st = static_cast<msd_array_sink_state *>(user);
+        const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
+        memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
+        st->count += total;
+    } else if (sink) {
         for (uint32_t i = 0; i < total; ++i)
             sink(&s.h_wire[i].mm, user);
+    }
     return 0;
 }
 
