@@ -434,7 +434,8 @@ def test_level_and_power_sums_at_full_scale(pkg, oracle, torch_cuda, pattern):
         assert gm[0, 1] > 0.99  # mean power of a saturated buffer
 
 
-def test_restart_behind_a_draining_capture(pkg, oracle, torch_cuda):
+@pytest.mark.parametrize("dc", [False, True])
+def test_restart_behind_a_draining_capture(pkg, oracle, torch_cuda, dc):
     """msd_restart: the first batches of a new capture are launched while the last ones of the previous capture
     are still in flight; each capture must come out as if it had run alone (empty filter, zero clock, zero
     counters), and the old capture's counters stay readable until the new one's first batch is collected."""
@@ -443,7 +444,7 @@ def test_restart_behind_a_draining_capture(pkg, oracle, torch_cuda):
     for seed, n in ((501, 9 * C + 77), (502, 6 * C), (503, 5 * C + 1)):
         iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=seed, msgs_per_sec=7000, n_aircraft=40), n)
         caps.append((iq, n, torch_cuda.from_numpy(iq).to("cuda:0")))
-    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=4 * C, message_capacity=1 << 16)
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=4 * C, message_capacity=1 << 16, dc_filter=dc)
     inflight, got, stats = [], {}, {}
 
     def collect_one():
@@ -465,7 +466,7 @@ def test_restart_behind_a_draining_capture(pkg, oracle, torch_cuda):
     while inflight:
         collect_one()
     for cid, (iq, n, d) in enumerate(caps):
-        want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 16)
+        want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0, dc_filter=dc).replay(iq, cap=1 << 16)
         assert len(want) > 100
         assert_same(np.concatenate(got[cid]), stats[cid], want, wstats)
     with pytest.raises(pkg.MsdError):
