@@ -105,15 +105,16 @@ struct msd_ctx {
     int bps = 2;
     msd_tables *tables = nullptr;
     uint16_t *d_lut = nullptr;
-    uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr;
+    uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr, *d_slicer = nullptr;
     uint64_t *d_fix2[2] = {nullptr, nullptr}; /* two-bit correction tables for 56 / 112 bits (nfix_crc == 2) */
     uint32_t fix2_lg[2] = {0, 0};
     /* per-workgroup candidate regions (shared by all batches: stream order serialises them) */
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
-    msd_wg_counts *d_counts = nullptr;
-    uint32_t max_wg = 0, max_buffers = 0;
+    msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
+    msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
+    uint32_t max_wg = 0, max_buffers = 0;  /* max_wg: most regions a scan is split into */
     /* Mode A/C candidate regions */
     msd_ac_hit *d_ac_regions = nullptr;
     uint64_t ac_arena = 0;
@@ -244,6 +245,7 @@ void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
     p.lut = c->d_lut;
     p.crc_tab = c->d_crc;
     p.syn56 = c->d_syn56;
+    p.slicer = c->d_slicer;
     p.syn112 = c->d_syn112;
     p.nsyn56 = c->tables->nsyn56;
     p.nsyn112 = c->tables->nsyn112;
@@ -290,9 +292,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
     const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
     const uint32_t ntiles = (uint32_t)ntiles64;
-    uint32_t target_wg = (uint32_t)c->cu_count * MSD_WGS_PER_CU;
-    if (target_wg > c->max_wg)
-        target_wg = c->max_wg;
+    /* one region per wavefront: MSD_SCAN_WAVES per CU */
+    uint32_t target_wg = c->max_wg;
     uint32_t tpw = ntiles ? (ntiles + target_wg - 1) / target_wg : 1;
     if (tpw == 0)
         tpw = 1;
@@ -333,6 +334,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.hcap = (uint32_t)hcap;
         p.tcap = (uint32_t)tcap;
         p.counts = c->d_counts;
+        p.wg_totals = c->d_wg_totals;
         p.chunk_sums = s.d_sums;
         p.timers = c->d_timers;
         p.debug_flags = c->debug_flags;
@@ -343,7 +345,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
             HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
         const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
                                (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
-        rc = msd_launch_gather(c->d_counts, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
+        rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
                                s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers,
                                lean ? s.h_totals : nullptr, lean ? s.h_sums : nullptr, s.d_pred,
                                s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0,
@@ -1194,10 +1196,10 @@ void destroy(msd_ctx *c)
             if (*e)
                 (void)hipEventDestroy(*e);
     }
-    (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112);
+    (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_dcstate);
-    (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts);
+    (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
     (void)hipFree(c->d_snaps);
@@ -1306,6 +1308,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_syn112), sizeof c->tables->syn112 + 16));
     CK(hipMemcpy(c->d_lut, c->tables->uc8_folded, sizeof c->tables->uc8_folded, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_crc, c->tables->crc_byte, sizeof c->tables->crc_byte, hipMemcpyHostToDevice));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_slicer), sizeof c->tables->slicer));
+    CK(hipMemcpy(c->d_slicer, c->tables->slicer, sizeof c->tables->slicer, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn56, c->tables->syn56, sizeof c->tables->syn56, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn112, c->tables->syn112, sizeof c->tables->syn112, hipMemcpyHostToDevice));
     if (cfg->nfix_crc == 2) { /* --aggressive, crc.c:374-379 */
@@ -1335,11 +1339,12 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     }
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
-    c->max_wg = (uint32_t)c->cu_count * MSD_WGS_PER_CU;
+    c->max_wg = (uint32_t)c->cu_count * MSD_SCAN_WAVES;
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_wg_counts)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_region_counts)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_wg_totals), (size_t)c->cu_count * sizeof(msd_wg_totals)));
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
         c->ac_max_wg = (uint32_t)c->cu_count * 8u;

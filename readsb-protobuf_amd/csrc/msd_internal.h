@@ -25,16 +25,14 @@ extern "C" {
 #endif
 
 /* geometry of the scan kernel (overridable at build time for experiments) */
-#ifndef MSD_SCAN_THREADS
-#define MSD_SCAN_THREADS 512 /* threads per workgroup */
+#ifndef MSD_SCAN_WAVES
+#define MSD_SCAN_WAVES 16 /* wavefronts per workgroup; one workgroup per CU (they share the UC8 table in LDS) */
 #endif
-#ifndef MSD_WGS_PER_CU
-#define MSD_WGS_PER_CU 2
-#endif
+#define MSD_SCAN_THREADS (64 * MSD_SCAN_WAVES)
 #ifndef MSD_LUT_GLOBAL
 #define MSD_LUT_GLOBAL 0 /* 1: read the UC8 table through the vector cache instead of LDS */
 #endif
-#define MSD_TILE (16u * MSD_SCAN_THREADS) /* scan positions per tile: 16 per thread */
+#define MSD_TILE 1024u /* scan positions per wavefront tile: 16 per lane */
 #define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */
 #define MSD_MAX_BATCH_SAMPLES (1ull << 28) /* hit positions are 28-bit, batch-relative */
 
@@ -75,6 +73,18 @@ typedef struct msd_wg_counts {
     uint32_t overflow;
     uint32_t pad;
 } msd_wg_counts;
+
+/* The scan kernel is wave-autonomous: every wavefront owns a contiguous run of tiles (a "region") and
+ * its own slice of the candidate arenas.  Per region: the counts, and where the region starts within its
+ * workgroup's output (the workgroup's last act); per workgroup: the totals the gather kernel sums. */
+typedef struct msd_region_counts {
+    uint32_t nhits, ntries, overflow;
+    uint32_t hbase, tbase; /* hits / tries of the workgroup's earlier regions */
+    uint32_t pad[3];
+} msd_region_counts;
+typedef struct msd_wg_totals {
+    uint32_t nhits, ntries, overflow, pad;
+} msd_wg_totals;
 
 /* ---- GPU resolve stage (msd_resolve_kernels.hip) ---- */
 #define MSD_RB_MSG_CAP 1024u   /* accepted Mode S messages of one buffer: at most 131072/135 = 970 */
@@ -122,6 +132,26 @@ typedef struct msd_acc {
 } msd_acc;
 
 /* ---- host tables (msd_tables.c) ---- */
+/* Tables of the bit slicer / CRC of the scan kernel, one block of dwords copied to LDS:
+ *  - the message is sliced five bits at a time ("groups"): 12 samples hold exactly five bits, so bit
+ *    5g + k of a try with trial phase tp = 4 + q sits at t = 99 + q + 60 g + 12 k twelfths of a sample
+ *    behind pa = &m[j + 2], i.e. correlator t % 5 (demod_2400.c:73-93) at sample pa + t / 5
+ *    (demod_2400.c:98-177 in closed form).  Every group evaluates each of the five correlators exactly
+ *    once; which bit of the group a correlator yields, and at which sample, depends on q only:
+ *      MSD_SL_QOFF[q]      five 6-bit fields, field c = byte offset of correlator c's first tap from
+ *                          &pa[12 g]
+ *      MSD_SL_PERM[q][x]   x = the five correlator verdicts (correlator 0 in bit 4) -> the group's
+ *                          five message bits (first bit in bit 4)
+ *  - modesChecksum (crc.c:67-82) is linear, so the syndrome is the xor of per-group contributions:
+ *      MSD_SL_GLONG[g][v]  syndrome of a 112-bit message that is zero but for group g = v
+ *      MSD_SL_GSHORT[g][v] same for a 56-bit message (groups past the end contribute nothing). */
+#define MSD_SL_GLONG 0u
+#define MSD_SL_GLONG_ROWS 23u
+#define MSD_SL_GSHORT (MSD_SL_GLONG + 32u * MSD_SL_GLONG_ROWS)
+#define MSD_SL_GSHORT_ROWS 13u
+#define MSD_SL_QOFF (MSD_SL_GSHORT + 32u * MSD_SL_GSHORT_ROWS)
+#define MSD_SL_PERM (MSD_SL_QOFF + 8u) /* bytes [5][32] */
+#define MSD_SLICER_WORDS (MSD_SL_PERM + 40u)
 #define MSD_LUT_STRIDE 136u /* folded UC8 table row pitch in u16 (bank spread) */
 typedef struct msd_tables {
     uint16_t uc8_folded[128 * MSD_LUT_STRIDE]; /* [fold(Q)][fold(I)] of convert.c:35-61 */
@@ -129,6 +159,7 @@ typedef struct msd_tables {
     uint32_t crc_byte[256];                    /* crc.c:42-55 */
     uint32_t syn56[51], syn112[107];           /* sorted: syndrome | bit << 24 (crc.c:184-354) */
     uint32_t nsyn56, nsyn112;
+    uint32_t slicer[MSD_SLICER_WORDS];         /* see MSD_SL_* */
 } msd_tables;
 void msd_tables_build(msd_tables *t, int nfix_crc);
 /* two-bit correction (msd_tables.c); the caller frees the table */

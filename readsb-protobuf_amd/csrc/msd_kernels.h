@@ -17,20 +17,22 @@ typedef struct MsdScanParams {
     int threshold;            /* Modes.preambleThreshold */
     uint64_t batch_first;     /* absolute index of iq[0]; multiple of MSD_CHUNK_SAMPLES */
     uint64_t nsamples;
-    uint32_t ntiles;
-    uint32_t tiles_per_wg;
+    uint32_t ntiles;       /* tiles of MSD_TILE scan positions */
+    uint32_t tiles_per_wg; /* tiles per region (= per wavefront of the scan kernel) */
     const uint16_t *lut;
     const uint32_t *crc_tab;
     const uint32_t *syn56;
     const uint32_t *syn112;
     uint32_t nsyn56, nsyn112;
+    const uint32_t *slicer; /* msd_tables.slicer: MSD_SLICER_WORDS dwords */
     const uint64_t *fix2_56, *fix2_112; /* --aggressive: the two-bit correction hash tables (msd_fix2_table);
                                            NULL otherwise */
     uint32_t fix2_lg56, fix2_lg112;
     msd_hit *hits;
     msd_try *tries;
-    uint32_t hcap, tcap; /* per-workgroup region capacities */
-    msd_wg_counts *counts;
+    uint32_t hcap, tcap; /* per-region capacities */
+    msd_region_counts *counts; /* [scan workgroups * MSD_SCAN_WAVES] */
+    msd_wg_totals *wg_totals;  /* [scan workgroups] */
     uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
     unsigned long long *timers; /* MSD_KERNEL_TIMING builds only */
     int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
@@ -95,13 +97,15 @@ int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned
 /* the field decoder of the emit kernel on its own: out[i] = fields of in[i] (device pointers) */
 int msd_launch_fields(const msd_message *d_in, msd_fields *d_out, uint32_t n, hipStream_t stream);
 size_t msd_scan_lds_bytes(int format);
-int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream);
-/* Regions -> dense ordered lists (every workgroup sums the counts in front of it); the last
+/* nregions wavefronts, MSD_SCAN_WAVES per workgroup */
+int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipStream_t stream);
+/* Regions -> dense ordered lists, one workgroup per region (nwg = the scan's nregions); the last
  * workgroup leaves the totals in `totals` and, if h_totals / h_sums are not NULL, writes them and the
  * per-buffer level/power sums to those pinned host addresses and zeroes the device sums for the slot's
  * next batch.  wipe[0..wipe_bytes) (a multiple of 16) is set to all-ones, tail_bytes (a multiple of
  * 4) are copied from tail_src to tail_dst on the way. */
-int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *totals, const msd_hit *hits,
+int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_totals, uint32_t nwg, uint64_t *totals,
+                      const msd_hit *hits,
                       const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,
                       msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
                       uint64_t *h_sums, void *wipe, uint32_t wipe_bytes, const void *tail_src, void *tail_dst,

@@ -1,7 +1,7 @@
 /*
  * msd_kernels.hip -- CDNA4 (gfx950) kernels of the Mode S / Mode A/C candidate stage.
  *
- * msd_scan_kernel fuses, per tile of 8192 scan positions:
+ * msd_scan_kernel fuses, per tile of 1024 scan positions:
  *   IQ -> u16 magnitude            convert.c:63-111 (UC8 table), :215-253 / :332-370 (float)
  *   preamble pre-check + 3 tests   demod_2400.c:276-330
  *   5-phase PPM bit slicing        demod_2400.c:73-229 (closed form t = 95 + tp + 12k)
@@ -11,19 +11,22 @@
  * per thousand samples.  No MFMA: there is no dense contraction anywhere on this path.
  *
  * Work decomposition
- *   - persistent 512-thread workgroups (8 wavefronts), each owning a contiguous run of tiles; the
- *     328-sample look-behind of a tile is carried over inside LDS from the previous tile, and the
- *     next tile's IQ is prefetched into registers while the current one is processed;
+ *   - wave-autonomous: one 1024-thread workgroup per CU only shares the constant tables (the UC8
+ *     magnitude table above all); after they are in LDS the 16 wavefronts never meet again -- there
+ *     is no workgroup barrier in the loop.  Every wavefront owns a contiguous run of 1024-position
+ *     tiles (a "region"), a private 6.3 KB block of LDS and a private slice of the candidate arenas;
+ *     the 328-sample look-behind of a tile is carried over inside LDS from the previous tile, and
+ *     the next tile's IQ is prefetched into registers while the current one is processed;
  *   - the scan gives every lane 16 consecutive positions (register-tiled sliding window: 5 LDS
  *     reads of 16 B feed 16 positions x 19 taps);
- *   - everything after the scan is wave-autonomous: each wavefront compacts its own 1024
- *     positions' hits (lane prefix sums over ballots / shuffles), slices, CRCs and classifies them
- *     in its private LDS scratch with no workgroup barrier; slicing loops are arranged so that the
- *     PPM phase is uniform across the wavefront (trial phase in the DF step, (tp + byte) mod 5 in
- *     the payload step), which makes every correlator tap a compile-time LDS offset;
- *   - hits are appended in position order to a workgroup-private region, tries through a
- *     workgroup cursor in LDS -- no global atomics; msd_offsets_kernel / msd_gather_kernel then
- *     concatenate the regions into the dense, ordered lists the resolve stage walks.
+ *   - the candidate stage works on a tile's hits in rounds of up to 64 (one per lane): the bit
+ *     slicer is phase-agnostic -- 12 samples hold exactly five message bits, so a lane slices a
+ *     "group" of five bits by evaluating each of the five correlators once, at a sample offset and
+ *     into a bit position that depend on the trial phase only through two small tables -- which
+ *     lets any lane take any (try, group) item; the CRC is put together from per-group syndrome
+ *     tables (modesChecksum is linear) with LDS atomics;
+ *   - hits and tries leave in position order through wave-uniform cursors -- no global atomics;
+ *     msd_gather_kernel concatenates the regions into the dense, ordered lists the resolve stage walks.
  */
 #include <hip/hip_runtime.h>
 
@@ -53,39 +56,41 @@ __device__ unsigned long long g_msd_tlast_dummy;
 
 namespace {
 
-constexpr int NT = MSD_SCAN_THREADS;  /* 512 threads = 8 wavefronts */
-constexpr int NW = NT / 64;
-constexpr int T = MSD_TILE;           /* 8192 scan positions per tile */
+constexpr int WAVES = MSD_SCAN_WAVES; /* wavefronts per workgroup, one workgroup per CU */
+constexpr int NT = MSD_SCAN_THREADS;
+constexpr int WT = MSD_TILE;          /* 1024 scan positions per wavefront tile, 16 per lane */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
-constexpr int GPT = T / 8 / NT;       /* 8-sample load groups per thread per tile (2) */
-constexpr int HCAP = NT / 2;          /* hits per candidate round */
-constexpr int SCAP = NT;               /* tries with a known DF per round; a round that would need
-                                         more is retried with half the hits (5 * HCAP / 4 < SCAP) */
+constexpr int GPT = WT / 8 / 64;      /* 8-sample load groups per lane per tile (2) */
+constexpr int HC = 64;                /* hits per candidate round: one per lane */
+constexpr int SC = 64;                /* tries with a known DF per round: one per lane in step C; a round
+                                         that would need more is retried with half the hits */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
-static_assert(T == NT * 16, "each thread scans 16 consecutive positions");
-static_assert(T % (8 * NT) == 0 && FRONT % 8 == 0, "whole load groups");
-static_assert(MSD_CHUNK_SAMPLES % T == 0, "a tile never straddles two buffers");
+static_assert(WT == 64 * 16, "each lane scans 16 consecutive positions");
+static_assert(WT % (8 * 64) == 0 && FRONT % 8 == 0, "whole load groups");
+static_assert(MSD_CHUNK_SAMPLES % WT == 0, "a tile never straddles two buffers");
 
-/* ---- dynamic LDS carve-up (all offsets multiples of 16) ---- */
-constexpr int OFF_MAGS = 0;                               /* u16[FRONT + T + 8] */
-constexpr int OFF_CRC = OFF_MAGS + (FRONT + T + 8) * 2;   /* u32[256] */
-constexpr int OFF_SYN = OFF_CRC + 1024;                   /* u32[160] */
-constexpr int OFF_MISC = OFF_SYN + 640;                   /* u32[64]: wave hit counts, try cursor */
-constexpr int OFF_CAND = OFF_MISC + 256;                  /* candidate-stage scratch */
-constexpr int CS_HITS = 0;                                /* u32[HCAP]: position | mask << 13 */
-constexpr int CS_SIDX = CS_HITS + HCAP * 4;               /* u16[HCAP][5]: try slot or 0xffff */
-constexpr int CS_PLIST = CS_SIDX + HCAP * 5 * 2;          /* u8[5][HCAP]: hits that try phase q */
-constexpr int CS_SMETA = CS_PLIST + HCAP * 5;             /* u32[SCAP] */
-constexpr int CS_SMSG = CS_SMETA + SCAP * 4;              /* u8[SCAP][16] */
-constexpr int CS_SRES = CS_SMSG + SCAP * 16;              /* u32[SCAP][2]: addr, crc */
-constexpr int CS_MISC = CS_SRES + SCAP * 8;               /* u32[32]: counters */
-constexpr int CS_BYTES = CS_MISC + 128;
-constexpr int OFF_LUT = OFF_CAND + CS_BYTES;              /* u16[128 * LUT_STRIDE], UC8 only */
+/* ---- dynamic LDS: tables shared by the workgroup, one private block per wavefront, the UC8 table ---- */
+constexpr int OFF_SYN = 0;                                  /* u32[160] */
+constexpr int OFF_SL = OFF_SYN + 640;                       /* u32[MSD_SLICER_WORDS] */
+constexpr int OFF_WGC = OFF_SL + MSD_SLICER_WORDS * 4;      /* u32[WAVES][4]: the regions' counts, at the end */
+constexpr int OFF_WAVE = (OFF_WGC + WAVES * 16 + 15) & ~15;
+constexpr int W_MAGS = 0;                                   /* u16[FRONT + WT + 8] */
+constexpr int W_HITS = W_MAGS + (FRONT + WT + 8) * 2;       /* u32[HC]: position | tests << 13 */
+constexpr int W_TRYL = W_HITS + HC * 4;                     /* u16[5 * HC]: hit | q << 8 */
+constexpr int W_SIDX = W_TRYL + HC * 5 * 2;                 /* u16[HC][8]: slot of try (hit, q), 0xffff = none */
+constexpr int W_SMETA = W_SIDX + HC * 8 * 2;                /* u32[SC] */
+constexpr int W_SMSG = W_SMETA + SC * 4;                    /* uint4[SC] */
+constexpr int W_SCRC = W_SMSG + SC * 16;                    /* u32[SC] */
+constexpr int W_SRES = W_SCRC + SC * 4;                     /* u32[SC][2]: addr, crc */
+constexpr int W_BYTES = W_SRES + SC * 8;
+constexpr int OFF_LUT = OFF_WAVE + WAVES * W_BYTES;         /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
 constexpr int LDS_UC8 = OFF_LUT + (MSD_LUT_GLOBAL ? 0 : 128 * LUT_STRIDE * 2);
-static_assert(OFF_CRC % 16 == 0 && OFF_CAND % 16 == 0 && CS_SMSG % 16 == 0 && CS_SRES % 16 == 0 &&
-              CS_BYTES % 16 == 0 && OFF_LUT % 16 == 0, "LDS carve offsets must stay 16-byte aligned");
+static_assert(OFF_WAVE % 16 == 0 && W_SMSG % 16 == 0 && W_BYTES % 16 == 0 && OFF_LUT % 16 == 0 && W_SIDX % 4 == 0,
+              "LDS carve offsets must stay aligned");
+static_assert(LDS_UC8 <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
+
 
 /* (b - 127.5)^2 only depends on k = b-128 (b >= 128) or 127-b (b < 128) */
 __device__ __forceinline__ uint32_t fold8(uint32_t b)
@@ -197,33 +202,6 @@ __device__ __forceinline__ uint4 pack8(const uint32_t (&mg)[8])
     return p;
 }
 
-/* demod_2400.c:73-93 with a compile-time correlator index */
-template <int C>
-__device__ __forceinline__ int correlate(int m0, int m1, int m2, int m3)
-{
-    if (C == 0) return 18 * m0 - 15 * m1 - 3 * m2;
-    if (C == 1) return 14 * m0 - 5 * m1 - 9 * m2;
-    if (C == 2) return 16 * m0 + 5 * m1 - 20 * m2;
-    if (C == 3) return 7 * m0 + 11 * m1 - 18 * m2;
-    return 4 * m0 + 15 * m1 - 20 * m2 + m3;
-}
-
-/* the weights of correlator c (demod_2400.c:73-93) that fall on sample pair `pair` of a window whose first
- * sample is the low (odd = 0) or the high (odd = 1) half of pair 0: positive ones or, negated, the
- * negative ones, packed like the samples (low half = even sample) */
-__host__ __device__ constexpr uint32_t corr_pair(int c, int odd, int pair, bool positive)
-{
-    constexpr int W[5][4] = {{18, -15, -3, 0}, {14, -5, -9, 0}, {16, 5, -20, 0}, {7, 11, -18, 0}, {4, 15, -20, 1}};
-    uint32_t out = 0;
-    for (int e = 0; e < 4; ++e) {
-        const int w = W[c][e], s = odd + e; /* sample index within the pairs */
-        if ((s >> 1) != pair)
-            continue;
-        const int m = positive ? (w > 0 ? w : 0) : (w < 0 ? -w : 0);
-        out |= (uint32_t)m << (16 * (s & 1));
-    }
-    return out;
-}
 
 /* both halves of a sample pair shifted right by five (v_pk_lshrrev_b16) */
 __device__ __forceinline__ uint32_t pk_shr5(uint32_t pair)
@@ -246,51 +224,10 @@ __device__ __forceinline__ uint32_t dot2u(uint32_t pair, uint32_t weights, uint3
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pair), __builtin_bit_cast(us2, weights), acc, false);
 }
 
-/* One message byte whose first bit sits at PPM phase PH (0..4) of sample mags[first]: bit k is
- * correlator (PH + 12k) % 5 at sample first + (PH + 12k) / 5  (demod_2400.c:98-177 in closed
- * form).  With PH uniform across the wavefront every tap is a compile-time offset.  The 21 samples
- * the eight correlators share are fetched as 11 naturally aligned dwords and shifted by the
- * parity of `first` (unaligned wide LDS reads are replayed at 64 cycles each on gfx950). */
-template <int PH>
-__device__ __forceinline__ uint32_t slice_byte_phase(const uint16_t *mags, uint32_t first)
-{
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(mags + (first & ~1u));
-    const uint32_t sh = (first & 1u) * 16u;
-    uint32_t d[11], a[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k)
-        d[k] = w[k];
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-        a[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
-    a[10] = d[10] >> sh;
-    /* a[k] holds samples 2k (low half) and 2k+1 of the byte's window.  A correlator is a weighted sum of
-     * three or four consecutive samples; its positive and its negative weights are summed separately
-     * with v_dot2_u32_u16 straight from the packed pairs (two samples per instruction, nothing to
-     * unpack) and the bit is pos > neg -- the same integers as demod_2400.c:73-93, just not subtracted. */
-    uint32_t v = 0;
-#define MSD_BIT(K)                                                                                   \
-    {                                                                                                \
-        constexpr int t = PH + 12 * (K);                                                             \
-        constexpr int i = t / 5, c = t % 5, j = i >> 1, odd = i & 1;                                 \
-        uint32_t pos = 0, neg = 0;                                                                   \
-        if (corr_pair(c, odd, 0, true)) pos = dot2u(a[j], corr_pair(c, odd, 0, true), pos);          \
-        if (corr_pair(c, odd, 1, true)) pos = dot2u(a[j + 1], corr_pair(c, odd, 1, true), pos);      \
-        if (corr_pair(c, odd, 2, true)) pos = dot2u(a[(j + 2 > 10) ? 10 : j + 2], corr_pair(c, odd, 2, true), pos); \
-        if (corr_pair(c, odd, 0, false)) neg = dot2u(a[j], corr_pair(c, odd, 0, false), neg);        \
-        if (corr_pair(c, odd, 1, false)) neg = dot2u(a[j + 1], corr_pair(c, odd, 1, false), neg);    \
-        if (corr_pair(c, odd, 2, false)) neg = dot2u(a[(j + 2 > 10) ? 10 : j + 2], corr_pair(c, odd, 2, false), neg); \
-        v = v + v + (pos > neg ? 1u : 0u);                                                           \
-    }
-    MSD_BIT(0) MSD_BIT(1) MSD_BIT(2) MSD_BIT(3) MSD_BIT(4) MSD_BIT(5) MSD_BIT(6) MSD_BIT(7)
-#undef MSD_BIT
-    return v;
-}
-
 /* demod_2400.c:193-205 */
 __device__ __forceinline__ uint32_t bytes_for_df(uint32_t df)
 {
-    /* short: 0,4,5,11  long: 16,17,18,20,21,24  else give up after one byte */
+    /* short: 0,4,5,11  long: 16,17,18,20,21,24  else give up after the DF */
     const uint32_t short_set = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     const uint32_t long_set = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);
     if ((short_set >> df) & 1u)
@@ -300,29 +237,28 @@ __device__ __forceinline__ uint32_t bytes_for_df(uint32_t df)
     return 1;
 }
 
-/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector memory
- * counter (s_waitcnt vmcnt(0)), which would make every barrier wait for the IQ prefetch of the next
- * tile and for the candidate-record stores; nothing in this kernel hands global data from one
- * thread to another, so waiting for LDS (lgkmcnt) is all the ordering it needs. */
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+/* Inclusive prefix sum over the 64 lanes with DPP moves only (no LDS round trips): four shifted adds
+ * inside each row of 16, then the last lane of row 0 / 2 into rows 1 / 3 and lane 31 into rows 2, 3. */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
     uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
-        if (lane >= o)
-            x += y;
-    }
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1, 3 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2, 3 */
     return x;
 }
 
-/* order LDS traffic between lanes of one wavefront (they run in lock step; this only stops the
- * compiler from moving accesses across the exchange point) */
+__device__ __forceinline__ uint32_t wave_last(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+/* order LDS traffic between lanes of one wavefront (they run in lock step and the LDS executes a
+ * wavefront's accesses in order; this only stops the compiler from moving accesses across the
+ * exchange point) */
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -330,134 +266,200 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* The workgroup-cooperative candidate stage for one round of up to HCAP hits (hitlist[0..nh), in
- * position order).  All NT threads call it; `tcur` is the workgroup-uniform try cursor.
- *
- *   step A  first byte of every tried phase -> DF -> message length.  Work is laid out as
- *           (phase q, hit) so that each wavefront pass has one trial phase: every correlator tap
- *           is then a compile-time LDS offset (demod_2400.c:183-205).
- *   step B  remaining bytes of the tries with a known DF, one lane per (try, byte), passes grouped
- *           by PPM phase class d = (tp + byte) mod 5 for the same reason (demod_2400.c:98-177).
- *   step C  CRC-24, syndrome lookup and the filter-independent part of scoreModesMessage, one lane
- *           per try (crc.c:67-82,389-412; mode_s.c:311-409).
- *   step D  records out: per hit, its live tries in phase order at consecutive indices. */
-template <bool FIX2>
-__device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, const uint16_t *mags,
-                                                    const uint32_t *crc_tab, const uint32_t *syn,
-                                                    unsigned char *cs, int tid, uint32_t nh, uint64_t tile_pos0,
-                                                    msd_hit *hit_out, bool hits_fit, msd_try *my_tries,
-                                                    uint32_t *try_cursor
-#ifdef MSD_KERNEL_TIMING
-                                                    , unsigned long long *tacc, unsigned long long *tlast
-#endif
-                                                    )
+/* `plane = 2 * plane + verdict` for every lane in one v_addc_co_u32: the verdicts of the wavefront are a
+ * lane mask in scalar registers (v_cmp), used as the carry-in */
+#define MSD_PUSH(PLANE, MASK) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(PLANE) : "s"(MASK) : "vcc")
+
+/* One correlator of demod_2400.c:73-93 on the samples at LDS byte address p: is the bit a one?
+ * (`18 m0 - 15 m1 - 3 m2 > 0` and so on, with the negative terms moved to the other side.)  The
+ * samples are read one by one on purpose: p is only 2-byte aligned, and a misaligned ds_read_b32/b64
+ * -- which the compiler would merge them into -- is replayed lane by lane on gfx950 (measured: 9x). */
+template <int C>
+__device__ __forceinline__ bool corr_is_one(const unsigned char *p)
 {
-    /* the wavefront index is uniform: keep it (and everything derived from it) in scalar registers */
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t *hitlist = reinterpret_cast<const uint32_t *>(cs + CS_HITS);
-    uint16_t *survidx = reinterpret_cast<uint16_t *>(cs + CS_SIDX);
-    uint32_t *smeta = reinterpret_cast<uint32_t *>(cs + CS_SMETA);
-    uint8_t *smsg = cs + CS_SMSG;
-    uint32_t *sres = reinterpret_cast<uint32_t *>(cs + CS_SRES);
-    uint32_t *nsurv_p = reinterpret_cast<uint32_t *>(cs + CS_MISC);
-    const uint32_t *pcount = nsurv_p + 16;
-    const uint8_t *plist = cs + CS_PLIST;
+    /* (an explicit LDS pointer: the compiler does not infer the address space of a volatile access and
+     * would emit flat loads) */
+    typedef __attribute__((address_space(3))) const volatile uint16_t lds_sample;
+    lds_sample *m = (lds_sample *)p;
+    const uint32_t s0 = m[0], s1 = m[1], s2 = m[2];
+    if (C == 0) return 18u * s0 > 15u * s1 + 3u * s2;
+    if (C == 1) return 14u * s0 > 5u * s1 + 9u * s2;
+    if (C == 2) return 16u * s0 + 5u * s1 > 20u * s2;
+    if (C == 3) return 7u * s0 + 11u * s1 > 18u * s2;
+    const uint32_t s3 = m[3];
+    return 4u * s0 + 15u * s1 + s3 > 20u * s2;
+}
+
+/* The five correlator verdicts of one 5-bit group (correlator 0 in bit 4); a[c] = LDS address of
+ * correlator c's first tap for the try's first group of this call, EXTRA = 24 bytes per further group
+ * (12 samples hold exactly five bits, so every group repeats the same five (correlator, offset) pairs). */
+template <int EXTRA>
+__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5])
+{
+    uint32_t code = 0;
+    const uint64_t b0 = __ballot(corr_is_one<0>(a[0] + EXTRA));
+    MSD_PUSH(code, b0);
+    const uint64_t b1 = __ballot(corr_is_one<1>(a[1] + EXTRA));
+    MSD_PUSH(code, b1);
+    const uint64_t b2 = __ballot(corr_is_one<2>(a[2] + EXTRA));
+    MSD_PUSH(code, b2);
+    const uint64_t b3 = __ballot(corr_is_one<3>(a[3] + EXTRA));
+    MSD_PUSH(code, b3);
+    const uint64_t b4 = __ballot(corr_is_one<4>(a[4] + EXTRA));
+    MSD_PUSH(code, b4);
+    return code;
+}
+
+/* Everything a wavefront needs besides its parameters: its private LDS block and the shared tables. */
+struct WaveCtx {
+    unsigned char *w;          /* the wavefront's private LDS block (W_* offsets) */
+    const uint32_t *syn;       /* sorted single-bit syndrome tables */
+    const uint32_t *sl;        /* slicer / CRC tables (MSD_SL_*) */
+    int lane;
+};
+
+/* The candidate stage for one round of up to HC hits of a tile (hitl[0..nh), in position order, one per
+ * lane).  Entirely wave-synchronous: no workgroup barrier, every exchange goes through the wavefront's
+ * own LDS block.
+ *
+ *   tries   every hit expands into the trial phases its preamble tests ask for (demod_2400.c:298-330)
+ *   step A  the first five bits of every try = the DF -> message length (demod_2400.c:183-205);
+ *           tries with a known DF get a slot: short ones from slot 0 up, long ones from slot SC-1 down
+ *   step B  the rest of the message, one lane per (slot, pair of 5-bit groups); every item also
+ *           looks up its groups' share of the syndrome (modesChecksum is linear) -- LDS atomics
+ *           put the message bits and the CRC together (crc.c:67-82)
+ *   step C  syndrome lookup and the filter-independent part of scoreModesMessage, one lane per slot
+ *           (crc.c:389-412; mode_s.c:311-409)
+ *   step D  records out: per hit, its live tries in phase order at consecutive indices.
+ * Returns false if the round has more than SC tries with a known DF (the caller halves it). */
+template <bool FIX2>
+__device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const WaveCtx &X, uint32_t nh, uint64_t tile_pos0,
+                                                msd_hit *hit_out, uint32_t hits_room, msd_try *my_tries,
+                                                uint32_t &tcur)
+{
+    const int lane = X.lane;
+    const unsigned char *mbytes = X.w + W_MAGS;
+    const uint32_t *hitl = reinterpret_cast<const uint32_t *>(X.w + W_HITS);
+    uint16_t *tryl = reinterpret_cast<uint16_t *>(X.w + W_TRYL);
+    uint16_t *sidx = reinterpret_cast<uint16_t *>(X.w + W_SIDX);
+    uint32_t *smeta = reinterpret_cast<uint32_t *>(X.w + W_SMETA);
+    uint32_t *smsg32 = reinterpret_cast<uint32_t *>(X.w + W_SMSG);
+    uint32_t *scrc = reinterpret_cast<uint32_t *>(X.w + W_SCRC);
+    uint32_t *sres = reinterpret_cast<uint32_t *>(X.w + W_SRES);
+    const uint8_t *perm = reinterpret_cast<const uint8_t *>(X.sl + MSD_SL_PERM);
+
+    /* ---- tries: lane h expands hit h ---- */
+    uint32_t my_hit = 0, my_m = 0;
+    {
+        *reinterpret_cast<uint4 *>(sidx + 8 * lane) = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if ((uint32_t)lane < nh) {
+            my_hit = hitl[lane];
+            my_m = my_hit >> 13;
+        }
+    }
+    const uint32_t nt = 2u * (my_m & 1u) + (my_m & 2u) + ((my_m >> 2) & 1u);
+    const uint32_t tincl = wave_incl_scan(nt);
+    const uint32_t ntry = wave_last(tincl);
+    {
+        uint32_t k = tincl - nt;
+        if (my_m & 1u) {
+            tryl[k] = (uint16_t)lane;
+            tryl[k + 1] = (uint16_t)(lane | (1 << 8));
+            k += 2;
+        }
+        if (my_m & 2u) {
+            tryl[k] = (uint16_t)(lane | (2 << 8));
+            tryl[k + 1] = (uint16_t)(lane | (3 << 8));
+            k += 2;
+        }
+        if (my_m & 4u)
+            tryl[k] = (uint16_t)(lane | (4 << 8));
+    }
+    wave_lds_sync();
 
     /* ---- step A ---- */
-    {
-        /* chunk c covers 64 entries of one phase list; chunks are dealt to the wavefronts round robin */
-        uint32_t c = 0;
-#define MSD_STEP_A(Q)                                                                                   \
-        {                                                                                                   \
-            const uint32_t n = pcount[Q];                                                                   \
-            for (uint32_t off = 0; off < n; off += 64, ++c) {                                               \
-                if ((c % NW) != (uint32_t)wave || off + (uint32_t)lane >= n)                                \
-                    continue;                                                                               \
-                const uint32_t h = plist[(Q) * HCAP + off + (uint32_t)lane];                                \
-                const uint32_t pos = hitlist[h] & 0x1fffu;                                                  \
-                /* pa[d] = mags[pos + 2 + d]; the first data sample of trial phase tp = 4 + Q is at */      \
-                /* pa + (95 + tp) / 5 with PPM phase (95 + tp) % 5 */                                       \
-                const uint32_t b0 = slice_byte_phase<(99 + (Q)) % 5>(mags, pos + 2u + (99u + (Q)) / 5u);    \
-                const uint32_t nb = bytes_for_df(b0 >> 3);                                                  \
-                if (nb > 1) {                                                                               \
-                    const uint32_t u = atomicAdd(nsurv_p, 1u);                                              \
-                    if (u < (uint32_t)SCAP) {                                                               \
-                        smeta[u] = pos | ((uint32_t)(Q) << 13) | (nb << 16) | (h << 20);                    \
-                        smsg[16 * u] = (uint8_t)b0;                                                         \
-                        survidx[h * 5 + (Q)] = (uint16_t)u;                                                 \
-                    }                                                                                       \
-                }                                                                                           \
-            }                                                                                               \
-        }
-        MSD_STEP_A(0) MSD_STEP_A(1) MSD_STEP_A(2) MSD_STEP_A(3) MSD_STEP_A(4)
-#undef MSD_STEP_A
-    }
-    lds_barrier();
-    if (*nsurv_p > (uint32_t)SCAP)
-        return 0xffffffffu; /* workgroup-uniform: the caller retries with fewer hits */
-    const uint32_t nsurv = (P.debug_flags & 4) ? 0u : *nsurv_p;
-
-    TMARKF(6); /* step A + barrier */
-    /* ---- step B ---- */
-    if (!(P.debug_flags & 8)) {
-        const uint32_t nchunk = (nsurv + 20u) / 21u;
-        for (uint32_t x = (uint32_t)wave; x < 5u * nchunk; x += NW) {
-            const uint32_t d = x % 5u, chunk = x / 5u;
-            const uint32_t u = chunk * 21u + (uint32_t)lane / 3u, m = (uint32_t)lane % 3u;
-            if (lane < 63 && u < nsurv) {
-                const uint32_t me = smeta[u];
-                const uint32_t tp = 4u + ((me >> 13) & 7u), nbytes = (me >> 16) & 15u;
-                const uint32_t b = ((d + 10u - tp) % 5u) + 5u * m;
-                if (b >= 1 && b < nbytes) {
-                    const uint32_t t0 = 95u + tp + 96u * b; /* t0 % 5 == d */
-                    const uint32_t first = (me & 0x1fffu) + 2u + t0 / 5u;
-                    uint32_t v;
-                    switch (d) { /* wave-uniform */
-                    case 0: v = slice_byte_phase<0>(mags, first); break;
-                    case 1: v = slice_byte_phase<1>(mags, first); break;
-                    case 2: v = slice_byte_phase<2>(mags, first); break;
-                    case 3: v = slice_byte_phase<3>(mags, first); break;
-                    default: v = slice_byte_phase<4>(mags, first); break;
-                    }
-                    smsg[16 * u + b] = (uint8_t)v;
-                }
-            }
-        }
-    }
-    lds_barrier();
-
-    TMARKF(7); /* step B + barrier */
-    /* ---- step C ---- */
-    for (uint32_t u = (uint32_t)tid; u < ((P.debug_flags & 16) ? 0u : nsurv); u += NT) {
-        const uint32_t me = smeta[u];
-        const int n = (int)((me >> 16) & 15u);
-        const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
-        uint32_t w[4] = {m4.x, m4.y, m4.z, m4.w};
-        if (n == 7) { /* bytes 7.. were never sliced */
-            w[1] &= 0x00ffffffu;
-            w[2] = 0;
-            w[3] = 0;
-        } else {
-            w[3] &= 0x0000ffffu;
-        }
-        const uint32_t orall = w[0] | w[1] | w[2] | w[3];
-        uint32_t rem = 0;
+    uint32_t ns = 0, nl = 0; /* wave-uniform: short / long slots handed out */
+    for (uint32_t i0 = 0; i0 < ntry; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool act = i < ntry;
+        const uint32_t e = act ? tryl[i] : 0u;
+        const uint32_t h = e & 0xffu, q = e >> 8;
+        const uint32_t pos = hitl[h] & 0x1fffu;
+        const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
+        /* pa[0] = mags[pos + 2]: the tile stages 328 samples ahead, the reference's overlap is 326 */
+        const unsigned char *base = mbytes + 2u * pos + 4u;
+        const unsigned char *a[5];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            if (i < n - 3) {
-                const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                rem = ((rem << 8) ^ crc_tab[byte ^ (rem >> 16)]) & 0xffffffu;
+        for (int c = 0; c < 5; ++c)
+            a[c] = base + ((qoff >> (6 * c)) & 63u);
+        const uint32_t df = perm[q * 32u + group_verdicts<0>(a)];
+        const uint32_t nb = bytes_for_df(df);
+        const bool is_s = act && nb == 7, is_l = act && nb == 14;
+        const uint64_t bs = __ballot(is_s), bl = __ballot(is_l);
+        const uint32_t rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs, 0u));
+        const uint32_t rl = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+        const uint32_t u = is_s ? ns + rs : (uint32_t)(SC - 1) - (nl + rl);
+        ns += (uint32_t)__popcll(bs);
+        nl += (uint32_t)__popcll(bl);
+        if (ns + nl > (uint32_t)SC)
+            return false; /* wave-uniform */
+        if (is_s || is_l) {
+            smeta[u] = pos | (q << 13) | (nb << 16) | (h << 20);
+            *reinterpret_cast<uint4 *>(smsg32 + 4u * u) = make_uint4(df << 27, 0u, 0u, 0u);
+            scrc[u] = X.sl[(is_l ? MSD_SL_GLONG : MSD_SL_GSHORT) + df];
+            sidx[h * 8u + q] = (uint16_t)u;
+        }
+    }
+    wave_lds_sync();
+
+    /* ---- step B: item = (slot, groups 2 it + 1 and 2 it + 2); a short message has 6 items (bits 5..55,
+     * the last one holds a single bit), a long one 11 (bits 5..111, the last one holds seven) ---- */
+    if (!(P.debug_flags & 4)) {
+        const uint32_t short_items = 6u * ns, nitems = short_items + 11u * nl;
+        for (uint32_t i0 = 0; i0 < nitems; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool act = i < nitems;
+            const bool lng = i >= short_items;
+            const uint32_t j = act ? (lng ? i - short_items : i) : 0u;
+            const uint32_t t = (j * (lng ? 5958u : 10923u)) >> 16; /* j / 11 or j / 6 (j < 704) */
+            const uint32_t it = j - t * (lng ? 11u : 6u);
+            const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
+            const uint32_t me = smeta[u];
+            const uint32_t pos = me & 0x1fffu, q = (me >> 13) & 7u;
+            const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
+            const uint32_t g1 = 2u * it + 1u;
+            const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
+            const unsigned char *a[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                a[c] = base + ((qoff >> (6 * c)) & 63u);
+            const uint32_t c1 = group_verdicts<0>(a), c2 = group_verdicts<24>(a);
+            uint32_t val = ((uint32_t)perm[q * 32u + c1] << 5) | perm[q * 32u + c2];
+            if (it == (lng ? 10u : 5u))
+                val &= lng ? 0x3f8u : 0x200u; /* bits past the end of the message */
+            if (act) {
+                const uint32_t gbase = (lng ? MSD_SL_GLONG : MSD_SL_GSHORT) + 32u * g1;
+                const uint32_t syn = X.sl[gbase + (val >> 5)] ^ X.sl[gbase + 32u + (val & 31u)];
+                atomicXor(&scrc[u], syn);
+                /* message bit n lives in bit 31 - (n & 31) of word n >> 5 until step C */
+                const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << 22;
+                atomicOr(&smsg32[4u * u + (n0 >> 5)], top >> s);
+                const uint32_t spill = __builtin_amdgcn_alignbit(top, 0u, s); /* top << (32 - s), 0 if s == 0 */
+                if (s > 22u)
+                    atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], spill);
             }
         }
-        uint32_t tail;
-        if (n == 7) /* bytes 4,5,6 */
-            tail = ((w[1] & 0xffu) << 16) | (w[1] & 0xff00u) | ((w[1] >> 16) & 0xffu);
-        else        /* bytes 11,12,13 */
-            tail = (((w[2] >> 24) & 0xffu) << 16) | ((w[3] & 0xffu) << 8) | ((w[3] >> 8) & 0xffu);
-        const uint32_t crc = rem ^ tail;
-        const uint32_t df = (w[0] & 0xffu) >> 3;
-        const uint32_t aa = (((w[0] >> 8) & 0xffu) << 16) | (((w[0] >> 16) & 0xffu) << 8) | (w[0] >> 24);
-        bool alive = (orall != 0); /* mode_s.c:325 */
+    }
+    wave_lds_sync();
+
+    /* ---- step C: lane = slot ---- */
+    if ((uint32_t)lane < ns || (uint32_t)lane >= (uint32_t)SC - nl) {
+        const uint32_t u = (uint32_t)lane;
+        const uint32_t me = smeta[u];
+        const uint4 m4 = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
+        const uint32_t crc = scrc[u];
+        const uint32_t df = m4.x >> 27, aa = m4.x & 0xffffffu;
+        bool alive = (m4.x | m4.y | m4.z | m4.w) != 0; /* mode_s.c:325 */
         uint32_t addr = crc, errbit = 0xffu, errbit2 = 0xffu;
         if (alive && (df == 11 || df == 17 || df == 18)) {
             addr = aa;
@@ -466,7 +468,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
                 alive = false;
                 if (FIX2) {
                     /* --aggressive: modesChecksumDiagnose against the (2, 4) tables, a hash probe in
-                     * global memory (they do not fit next to the rest in LDS; 10 / 82 KiB, L2-resident) */
+                     * global memory (10 / 82 KiB, L2-resident) */
                     const uint64_t *tab = (df == 11) ? P.fix2_56 : P.fix2_112;
                     const uint32_t lg = (df == 11) ? P.fix2_lg56 : P.fix2_lg112;
                     uint32_t slot = MSD_FIX2_HASH(syndrome, lg);
@@ -486,7 +488,7 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
                 } else {
                     /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted single-bit
                      * table, or give up */
-                    const uint32_t *tab = (df == 11) ? syn : syn + 51;
+                    const uint32_t *tab = (df == 11) ? X.syn : X.syn + 51;
                     int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
                     while (lo2 < hi2) {
                         const int mid = (lo2 + hi2) >> 1;
@@ -510,53 +512,42 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
         }
         const uint32_t q = (me >> 13) & 7u, h = me >> 20;
         if (alive) {
-            *reinterpret_cast<uint4 *>(smsg + 16 * u) =
-                make_uint4(w[0], w[1], w[2], (w[3] & 0xffffu) | ((4u + q) << 16) | (errbit << 24));
+            /* the record holds the message as bytes, first byte first */
+            *reinterpret_cast<uint4 *>(smsg32 + 4u * u) =
+                make_uint4(__builtin_bswap32(m4.x), __builtin_bswap32(m4.y), __builtin_bswap32(m4.z),
+                           (__builtin_bswap32(m4.w) & 0xffffu) | ((4u + q) << 16) | (errbit << 24));
             sres[2 * u] = addr;
             sres[2 * u + 1] = crc | (errbit2 << 24); /* the CRC has 24 bits */
         } else {
-            survidx[h * 5 + q] = 0xffffu; /* scores -2 whatever the filter holds */
+            sidx[h * 8u + q] = 0xffffu; /* scores -2 whatever the filter holds */
         }
     }
-    lds_barrier();
+    wave_lds_sync();
 
-    TMARKF(8); /* step C + barrier */
-    /* ---- step D ---- */
-    uint32_t nl = 0, mask = 0, pos = 0;
-    if ((uint32_t)tid < nh) {
-        const uint32_t e = hitlist[tid];
-        pos = e & 0x1fffu;
-        mask = e >> 13;
+    /* ---- step D: lane = hit ---- */
+    uint32_t nlive = 0;
+    if ((uint32_t)lane < nh) {
 #pragma unroll
         for (int q = 0; q < 5; ++q)
-            nl += survidx[tid * 5 + q] != 0xffffu ? 1u : 0u;
+            nlive += sidx[lane * 8 + q] != 0xffffu ? 1u : 0u;
     }
-    /* try indices need not be ordered across wavefronts (a hit record names its first try), so
-     * every wavefront reserves its own range from the workgroup cursor: no barrier */
-    const uint32_t incl = wave_incl_scan(nl, lane);
-    const uint32_t wave_total = __shfl(incl, 63);
-    uint32_t tbase = 0;
-    if (wave_total) {
-        if (lane == 0)
-            tbase = atomicAdd(try_cursor, wave_total);
-        tbase = __shfl(tbase, 0);
-    }
-    TMARKF(9); /* step D: counts, scan, reservation */
-    if ((uint32_t)tid < nh) {
-        uint32_t idx = tbase + incl - nl;
-        if (hits_fit) {
-            msd_hit rec = (tile_pos0 + pos) | ((msd_hit)mask << 28) | ((msd_hit)nl << 31);
-            if (nl)
+    const uint32_t lincl = wave_incl_scan(nlive);
+    if ((uint32_t)lane < nh) {
+        const uint32_t pos = my_hit & 0x1fffu;
+        uint32_t idx = tcur + lincl - nlive;
+        if ((uint32_t)lane < hits_room) {
+            msd_hit rec = (tile_pos0 + pos) | ((msd_hit)my_m << 28) | ((msd_hit)nlive << 31);
+            if (nlive)
                 rec |= (msd_hit)idx << 34;
-            hit_out[tid] = rec;
+            hit_out[lane] = rec;
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const uint32_t u = survidx[tid * 5 + q];
+            const uint32_t u = sidx[lane * 8 + q];
             if (u != 0xffffu) {
                 if (idx < P.tcap) {
                     uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
-                    dst[0] = *reinterpret_cast<const uint4 *>(smsg + 16 * u);
+                    dst[0] = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
                     const uint32_t cw = sres[2 * u + 1];
                     dst[1] = make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos), cw >> 24);
                 }
@@ -564,126 +555,95 @@ __device__ __forceinline__ uint32_t candidate_round(const MsdScanParams &P, cons
             }
         }
     }
-    return 0;
+    tcur += wave_last(lincl);
+    wave_lds_sync();
+    return true;
 }
 
-template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */>
-__global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel(const MsdScanParams P)
+/* One wavefront's share of the batch: the tiles [tile_lo, tile_hi) of WT scan positions each. */
+template <int FMT, bool FIX2>
+__device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCtx &X, const uint16_t *lut,
+                                            uint32_t region, uint32_t tile_lo, uint32_t tile_hi, uint32_t &hits_total,
+                                            uint32_t &tries_total)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *mags = reinterpret_cast<uint16_t *>(smem + OFF_MAGS);
-    uint32_t *crc_tab = reinterpret_cast<uint32_t *>(smem + OFF_CRC);
-    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + OFF_MISC);
-    uint16_t *lds_lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
-    const uint16_t *lut = MSD_LUT_GLOBAL ? P.lut : lds_lut;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wg = blockIdx.x;
-    unsigned char *cs = smem + OFF_CAND;
-    uint32_t *wave_hits = misc;         /* [2][NW], double buffered by tile parity */
-    uint32_t *try_cursor = misc + 32;   /* workgroup cursor into its try region */
-
-    /* constant tables -> LDS, once per persistent workgroup */
-    for (int i = tid; i < 256; i += NT)
-        crc_tab[i] = P.crc_tab[i];
-    for (int i = tid; i < 160; i += NT)
-        syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
-                          : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
-    if (FMT == MSD_FMT_UC8 && !MSD_LUT_GLOBAL) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
-        uint4 *l = reinterpret_cast<uint4 *>(lds_lut);
-        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
-            l[i] = g[i];
-    }
-
-    if (tid == 0)
-        *try_cursor = 0;
-    const uint32_t tile_lo = wg * P.tiles_per_wg;
-    uint32_t tile_hi = tile_lo + P.tiles_per_wg;
-    if (tile_hi > P.ntiles)
-        tile_hi = P.ntiles;
-    if (tile_lo >= tile_hi) { /* workgroup-uniform */
-        if (tid == 0) {
-            msd_wg_counts c = {0, 0, 0, 0};
-            P.counts[wg] = c;
-        }
-        return;
-    }
-    lds_barrier();
+    const int lane = X.lane;
+    uint16_t *mags = reinterpret_cast<uint16_t *>(X.w + W_MAGS);
+    uint32_t *hitl = reinterpret_cast<uint32_t *>(X.w + W_HITS);
     const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
+    msd_hit *const my_hits = P.hits + (size_t)region * P.hcap;
+    msd_try *const my_tries = P.tries + (size_t)region * P.tcap;
+    uint32_t hcur = 0, tcur = 0; /* wave-uniform cursors into the region's slices of the arenas */
 
-    uint32_t hcur = 0; /* workgroup-uniform cursor into this workgroup's hit region */
-    TDECL
-    msd_hit *const my_hits = P.hits + (size_t)wg * P.hcap;
-    msd_try *const my_tries = P.tries + (size_t)wg * P.tcap;
-
-    /* running buffer sums (convert.c:78-110), flushed when the workgroup moves to another buffer */
+    /* running buffer sums (convert.c:78-110), flushed when the wavefront moves to another buffer */
     uint32_t sum_level = 0;
-    /* Sum of the squares of at most 256 magnitudes per lane and buffer (16 tiles x 16 samples) without
-     * 64-bit arithmetic in the loop: pw_mod = the sum modulo 2^32 (v_dot2_u32_u16 of a sample pair with
-     * itself wraps), pw_top = the sum of (m >> 5)^2, which fits (2047^2 * 256 < 2^32) and brackets the
-     * true sum: 1024 * pw_top <= sum < 1024 * pw_top + 256 * (64 * 2047 * 31 + 31^2) < 1024 * pw_top + 2^31.
-     * power_sum() puts the two together when the buffer changes. */
-    uint32_t pw_mod = 0, pw_top = 0;
-    uint64_t sum_chunk = (uint64_t)tile_lo * T / MSD_CHUNK_SAMPLES;
+    /* Sum of the squares of at most 256 magnitudes per lane (16 tiles x 16 samples) without 64-bit
+     * arithmetic in the loop: pw_mod = the sum modulo 2^32 (v_dot2_u32_u16 of a sample pair with itself
+     * wraps), pw_top = the sum of (m >> 5)^2, which fits (2047^2 * 256 < 2^32) and brackets the true
+     * sum: 1024 * pw_top <= sum < 1024 * pw_top + 256 * (64 * 2047 * 31 + 31^2) < 1024 * pw_top + 2^31.
+     * power_sum() puts the two together when the buffer changes or after 16 tiles. */
+    uint32_t pw_mod = 0, pw_top = 0, sum_tiles = 0;
+    uint64_t sum_chunk = (uint64_t)tile_lo * WT / MSD_CHUNK_SAMPLES;
+    auto flush_sums = [&]() {
+        if (P.chunk_sums) {
+            unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sl += __shfl_down(sl, o);
+                sp += __shfl_down(sp, o);
+            }
+            if (lane == 0 && (sl | sp)) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
+            }
+        }
+        sum_level = 0;
+        pw_mod = 0;
+        pw_top = 0;
+        sum_tiles = 0;
+    };
 
-    /* look-behind of the first tile: samples [a0-328, a0) */
+    /* look-behind of the first tile: samples [a0 - 328, a0) */
     {
-        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * T;
-        if (tid < FRONT / 8) {
+        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * WT;
+        if (lane < FRONT / 8) {
             RawGroup<FMT> r;
-            const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * tid, r);
+            const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * lane, r);
             uint32_t mg[8];
             convert_group<FMT>(r, valid, lut, mg);
-            *reinterpret_cast<uint4 *>(mags + 8 * tid) = pack8(mg);
+            *reinterpret_cast<uint4 *>(mags + 8 * lane) = pack8(mg);
         }
     }
     RawGroup<FMT> cur[GPT], nxt[GPT];
     uint32_t cur_valid[GPT], nxt_valid[GPT];
     {
-        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * T;
+        const uint64_t a0 = P.batch_first + (uint64_t)tile_lo * WT;
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
-            cur_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + 8 * (tid + NT * k), cur[k]);
+            cur_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + 8 * (lane + 64 * k), cur[k]);
             nxt_valid[k] = 0;
             nxt[k] = cur[k];
         }
     }
 
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
-        const uint64_t tile_pos0 = (uint64_t)tile * T; /* first scan position, batch-relative */
+        const uint64_t tile_pos0 = (uint64_t)tile * WT; /* first scan position, batch-relative */
         const uint64_t a0 = P.batch_first + tile_pos0;
 
-        TMARK(0); /* loop top */
         /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
         {
             const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
-            if (c != sum_chunk) { /* workgroup-uniform */
-                if (P.chunk_sums) {
-                    unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        sl += __shfl_down(sl, o);
-                        sp += __shfl_down(sp, o);
-                    }
-                    if (lane == 0 && (sl | sp)) {
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
-                    }
-                }
-                sum_level = 0;
-                pw_mod = 0;
-                pw_top = 0;
+            if (c != sum_chunk || sum_tiles == 16) { /* wave-uniform */
+                flush_sums();
                 sum_chunk = c;
             }
+            ++sum_tiles;
         }
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             uint32_t mg[8];
             convert_group<FMT>(cur[k], cur_valid[k], lut, mg);
             const uint4 packed = pack8(mg);
-            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (tid + NT * k)) = packed;
+            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) = packed;
             const uint32_t pk[4] = {packed.x, packed.y, packed.z, packed.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { /* two magnitudes per instruction */
@@ -694,18 +654,36 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
             }
         }
         if (tile + 1 < tile_hi) {
+            /* one unconditional load per group from a selected address (see fetch_group); tiles that lie
+             * wholly inside the batch -- all but the last -- take the short way */
+            const int64_t rel = (int64_t)(tile_pos0 + WT);
+            if ((uint64_t)rel + WT <= (P.nsamples & ~7ull)) { /* wave-uniform */
+                constexpr int BPS = RawGroup<FMT>::WORDS / 2;
 #pragma unroll
-            for (int k = 0; k < GPT; ++k)
-                nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + T + 8 * (tid + NT * k), nxt[k]);
+                for (int k = 0; k < GPT; ++k) {
+                    const uint8_t *src = P.iq + (rel + 8 * (lane + 64 * k)) * BPS;
+                    const uint4 a = *reinterpret_cast<const uint4 *>(src);
+                    nxt[k].w[0] = a.x; nxt[k].w[1] = a.y; nxt[k].w[2] = a.z; nxt[k].w[3] = a.w;
+                    if (BPS == 4) {
+                        const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
+                        nxt[k].w[4 % RawGroup<FMT>::WORDS] = b.x; nxt[k].w[5 % RawGroup<FMT>::WORDS] = b.y;
+                        nxt[k].w[6 % RawGroup<FMT>::WORDS] = b.z; nxt[k].w[7 % RawGroup<FMT>::WORDS] = b.w;
+                    }
+                    nxt_valid[k] = 0xffu;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < GPT; ++k)
+                    nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + WT + 8 * (lane + 64 * k), nxt[k]);
+            }
         }
-        lds_barrier();
-        TMARK(1); /* conversion + barrier */
+        wave_lds_sync();
 
         if (!(P.debug_flags & 2)) {
             /* ---- stage 2: preamble tests for my 16 consecutive positions (demod_2400.c:257-335) ---- */
             uint32_t v[20];
             {
-                const uint4 *src = reinterpret_cast<const uint4 *>(mags + 16 * tid);
+                const uint4 *src = reinterpret_cast<const uint4 *>(mags + 16 * lane);
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const uint4 q = src[k];
@@ -719,16 +697,12 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                 sm[2 * k] = (int)(v[k] & 0xffffu);
                 sm[2 * k + 1] = (int)(v[k] >> 16);
             }
-            /* one bit plane per test, position q at bit 15 - q: every verdict is a lane mask in scalar
-             * registers (v_cmp + s_and), and `plane = 2 * plane + verdict` is one v_addc_co_u32 with that
-             * mask as the carry-in */
+            /* one bit plane per test, position q at bit 15 - q */
             uint32_t pl0 = 0, pl1 = 0, pl2 = 0;
-#define MSD_PUSH(PLANE, MASK) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(PLANE) : "s"(MASK) : "vcc")
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                /* pa[d] = mags[p + 2 + d]: the tile stages 328 samples ahead, the reference's
-                 * overlap is 326.  Branch-free on purpose: with 64 lanes some lane almost always
-                 * passes the pre-check, so a branch only adds exec-mask bookkeeping. */
+                /* pa[d] = mags[p + 2 + d].  Branch-free on purpose: with 64 lanes some lane almost
+                 * always passes the pre-check, so a branch only adds exec-mask bookkeeping. */
 #define PA(d) (sm[q + 2 + (d)])
                 const uint64_t pre = __ballot(PA(1) > PA(7)) & __ballot(PA(12) > PA(14)) & __ballot(PA(12) > PA(15));
                 const uint32_t base_noise = (uint32_t)(PA(5) + PA(8) + PA(16) + PA(17) + PA(18));
@@ -745,10 +719,9 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
                 MSD_PUSH(pl1, f1);
                 MSD_PUSH(pl2, f2);
             }
-#undef MSD_PUSH
             /* positions past the last one the reference scans */
             {
-                const uint64_t first = a0 + 16ull * tid;
+                const uint64_t first = a0 + 16ull * lane;
                 if (first + 16 > batch_end) {
                     const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
                     const uint32_t km = keep ? ~((1u << (16 - keep)) - 1u) : 0u;
@@ -759,139 +732,223 @@ __global__ void __launch_bounds__(NT, MSD_WGS_PER_CU * NT / 256) msd_scan_kernel
             }
             const uint32_t any = pl0 | pl1 | pl2;
 
-            TMARK(2); /* tests */
-            /* ---- stage 3: ordered hit bookkeeping ---- */
+            /* ---- stage 3: ranks of my hits among the wavefront's (position order) ---- */
             const uint32_t cnt = (uint32_t)__popc(any);
-            const uint32_t incl = wave_incl_scan(cnt, lane);
-            uint32_t *wh = wave_hits + NW * (tile & 1u);
-            if (lane == 63)
-                wh[wave] = incl;
-            { /* clear the candidate round scratch (nobody reads it between here and the barrier) */
-                uint32_t *sidx32z = reinterpret_cast<uint32_t *>(cs + CS_SIDX);
-                for (int i = tid; i < HCAP * 5 / 2; i += NT)
-                    sidx32z[i] = 0xffffffffu;
-                if (tid < 32)
-                    reinterpret_cast<uint32_t *>(cs + CS_MISC)[tid] = 0;
-            }
-            lds_barrier();
-            TMARK(3); /* hit bookkeeping + barrier */
-            uint32_t wave_base = 0, H = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const uint32_t s = wh[i];
-                if (i < wave)
-                    wave_base += s;
-                H += s;
-            }
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t H = wave_last(incl);
 
             if (!(P.debug_flags & 1) && H) {
-                /* ---- stage 4: workgroup-cooperative candidate rounds ---- */
-                const uint32_t my_rank0 = wave_base + incl - cnt;
-                uint32_t *hitlist = reinterpret_cast<uint32_t *>(cs + CS_HITS);
-                uint32_t *sidx32 = reinterpret_cast<uint32_t *>(cs + CS_SIDX);
-                uint8_t *plist = cs + CS_PLIST;
-                uint32_t *cmisc = reinterpret_cast<uint32_t *>(cs + CS_MISC);
+                /* ---- stage 4: candidate rounds of up to HC hits ---- */
+                const uint32_t my_rank0 = incl - cnt;
                 uint32_t r0 = 0;
                 bool fill = true;
-                uint32_t nh = (H < (uint32_t)HCAP) ? H : (uint32_t)HCAP;
+                uint32_t nh = (H < (uint32_t)HC) ? H : (uint32_t)HC;
                 while (r0 < H) {
-                    /* (the round's counters and try-slot table were cleared before the last barrier) */
                     if (fill) {
-                        if (cnt && my_rank0 < r0 + HCAP && my_rank0 + cnt > r0) {
-                            /* my hits with rank in [r0, r0 + HCAP) -> hitlist, in position order */
+                        if (cnt && my_rank0 < r0 + HC && my_rank0 + cnt > r0) {
+                            /* my hits with rank in [r0, r0 + HC) -> hitl, in position order */
                             uint32_t x = any, r = my_rank0;
                             while (x) {
                                 const int bit = 31 - __clz((int)x); /* highest bit = lowest position */
                                 x &= ~(1u << bit);
-                                if (r >= r0 && r < r0 + HCAP) {
+                                if (r >= r0 && r < r0 + HC) {
                                     const uint32_t m = ((pl0 >> bit) & 1u) | (((pl1 >> bit) & 1u) << 1) | (((pl2 >> bit) & 1u) << 2);
-                                    hitlist[r - r0] = (uint32_t)(16 * tid + (15 - bit)) | (m << 13);
+                                    hitl[r - r0] = (uint32_t)(16 * lane + (15 - bit)) | (m << 13);
                                 }
                                 ++r;
                             }
                         }
-                        lds_barrier();
-                        TMARK(4); /* fill + barrier */
+                        wave_lds_sync();
                     }
-                    /* per-phase lists of the hits that try that phase (any order), one thread per hit */
-                    if ((uint32_t)tid < nh) {
-                        const uint32_t m = hitlist[tid] >> 13;
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            const bool tried = (q < 2) ? (m & 1u) : ((q < 4) ? (m & 2u) : (m & 4u));
-                            if (tried)
-                                plist[q * HCAP + atomicAdd(&cmisc[16 + q], 1u)] = (uint8_t)tid;
-                        }
-                    }
-                    lds_barrier();
-                    TMARK(5); /* plist + barrier */
                     const uint32_t out0 = hcur + r0;
-                    const uint32_t got = candidate_round<FIX2>(P, mags, crc_tab, syn, cs, tid, nh, tile_pos0,
-                                                         my_hits + out0, out0 + nh <= P.hcap, my_tries, try_cursor
-#ifdef MSD_KERNEL_TIMING
-                                                         , tacc_, &tlast_
-#endif
-                                                         );
-                    if (got == 0xffffffffu) { /* too many tries with a known DF: halve the round */
-                        nh = (nh + 1) / 2;
+                    const uint32_t room = out0 < P.hcap ? P.hcap - out0 : 0u;
+                    if (!candidate_round<FIX2>(P, X, nh, tile_pos0, my_hits + out0, room, my_tries, tcur)) {
+                        nh = (nh + 1) / 2; /* too many tries with a known DF: halve the round */
                         fill = false;
+                        wave_lds_sync();
                     } else {
                         r0 += nh;
-                        nh = (H - r0 < (uint32_t)HCAP) ? (H - r0) : (uint32_t)HCAP;
+                        nh = (H - r0 < (uint32_t)HC) ? (H - r0) : (uint32_t)HC;
                         fill = true;
-                    }
-                    if (r0 < H) { /* another round: clear its scratch behind a barrier */
-                        lds_barrier();
-                        for (int i = tid; i < HCAP * 5 / 2; i += NT)
-                            sidx32[i] = 0xffffffffu;
-                        if (tid < 32)
-                            cmisc[tid] = 0;
-                        lds_barrier();
                     }
                 }
             }
             hcur += H;
         }
 
-        TMARK(10); /* candidates: rest */
         /* ---- carry the last 328 magnitudes over as the next tile's look-behind ---- */
         uint4 carry = make_uint4(0, 0, 0, 0);
-        if (tid < FRONT / 8)
-            carry = *reinterpret_cast<const uint4 *>(mags + T + 8 * tid);
-        lds_barrier();
-        TMARK(11); /* carry barrier */
-        if (tid < FRONT / 8)
-            *reinterpret_cast<uint4 *>(mags + 8 * tid) = carry;
+        if (lane < FRONT / 8)
+            carry = *reinterpret_cast<const uint4 *>(mags + WT + 8 * lane);
+        wave_lds_sync();
+        if (lane < FRONT / 8)
+            *reinterpret_cast<uint4 *>(mags + 8 * lane) = carry;
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             cur[k] = nxt[k];
             cur_valid[k] = nxt_valid[k];
         }
     }
+    flush_sums();
+    hits_total = hcur;
+    tries_total = tcur;
+}
 
-    if (P.chunk_sums) {
-        unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sl += __shfl_down(sl, o);
-            sp += __shfl_down(sp, o);
-        }
-        if (lane == 0 && (sl | sp)) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
-        }
+template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */>
+__global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);
+    uint32_t *sl = reinterpret_cast<uint32_t *>(smem + OFF_SL);
+    uint32_t *wgc = reinterpret_cast<uint32_t *>(smem + OFF_WGC);
+    uint16_t *lds_lut = reinterpret_cast<uint16_t *>(smem + OFF_LUT);
+    const uint16_t *lut = MSD_LUT_GLOBAL ? P.lut : lds_lut;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    /* constant tables -> LDS, once per workgroup */
+    for (int i = tid; i < 160; i += NT)
+        syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
+                          : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
+    for (int i = tid; i < (int)MSD_SLICER_WORDS; i += NT)
+        sl[i] = P.slicer[i];
+    if (FMT == MSD_FMT_UC8 && !MSD_LUT_GLOBAL) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(P.lut);
+        uint4 *l = reinterpret_cast<uint4 *>(lds_lut);
+        for (int i = tid; i < 128 * LUT_STRIDE * 2 / 16; i += NT)
+            l[i] = g[i];
     }
-    TFLUSH
-    lds_barrier();
-    if (tid == 0) {
-        msd_wg_counts c;
-        c.nhits = hcur;
-        c.ntries = *try_cursor;
-        c.overflow = (hcur > P.hcap || c.ntries > P.tcap) ? 1u : 0u;
-        c.pad = 0;
-        P.counts[wg] = c;
+    __syncthreads();
+
+    /* from here to the end of the batch the wavefronts do not meet again */
+    const uint32_t region = blockIdx.x * WAVES + (uint32_t)wave;
+    const uint32_t tile_lo = region * P.tiles_per_wg;
+    uint32_t tile_hi = tile_lo + P.tiles_per_wg;
+    if (tile_hi > P.ntiles)
+        tile_hi = P.ntiles;
+    uint32_t nhits = 0, ntries = 0;
+    if (tile_lo < tile_hi) { /* wave-uniform */
+        WaveCtx X;
+        X.w = smem + OFF_WAVE + wave * W_BYTES;
+        X.syn = syn;
+        X.sl = sl;
+        X.lane = lane;
+        scan_region<FMT, FIX2>(P, X, lut, region, tile_lo, tile_hi, nhits, ntries);
+    }
+    if (lane == 0) {
+        wgc[4 * wave] = nhits;
+        wgc[4 * wave + 1] = ntries;
+        wgc[4 * wave + 2] = (nhits > P.hcap || ntries > P.tcap) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid < WAVES) {
+        msd_region_counts c = {};
+        uint32_t hb = 0, tb = 0, ovf = 0;
+        for (int i = 0; i < WAVES; ++i) {
+            if (i == tid) {
+                c.hbase = hb;
+                c.tbase = tb;
+            }
+            hb += wgc[4 * i];
+            tb += wgc[4 * i + 1];
+            ovf |= wgc[4 * i + 2];
+        }
+        c.nhits = wgc[4 * tid];
+        c.ntries = wgc[4 * tid + 1];
+        c.overflow = wgc[4 * tid + 2];
+        P.counts[blockIdx.x * WAVES + tid] = c;
+        if (tid == 0) {
+            msd_wg_totals t = {hb, tb, ovf, 0};
+            P.wg_totals[blockIdx.x] = t;
+        }
     }
 }
+
+/* dense[offset + i] = region[i] for every region (= wavefront of the scan kernel); the try index inside a
+ * hit record is made dense too.  grid = one workgroup per region; a region's offset is the totals of the
+ * scan workgroups in front of its own plus what the scan kernel left in its counts. */
+__global__ void __launch_bounds__(256) msd_gather_kernel(const msd_region_counts *counts, const msd_wg_totals *wgt,
+                                                         const msd_hit *hits, const msd_try *tries, uint32_t hcap,
+                                                         uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,
+                                                         msd_try *dense_tries, uint64_t dense_tcap, uint64_t *totals,
+                                                         uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
+                                                         uint64_t *h_sums, uint4 *wipe, uint32_t wipe_n,
+                                                         const uint32_t *tail_src, uint32_t *tail_dst,
+                                                         uint32_t tail_words)
+{
+    __shared__ unsigned long long ph[4], pt[4];
+    __shared__ uint32_t povf[4];
+    const uint32_t w = blockIdx.x, nreg = gridDim.x, tid = threadIdx.x;
+    const uint32_t my_wg = w / WAVES, nswg = (nreg + WAVES - 1) / WAVES;
+    unsigned long long h = 0, t = 0;
+    uint32_t ovf = 0;
+    const bool last = w + 1 == nreg;
+    for (uint32_t i = tid; i < (last ? nswg : my_wg); i += 256) { /* the last workgroup also owes the totals */
+        const msd_wg_totals c = wgt[i];
+        if (i < my_wg) {
+            h += c.nhits;
+            t += c.ntries;
+        }
+        ovf |= c.overflow;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        h += __shfl_down(h, d, 64);
+        t += __shfl_down(t, d, 64);
+        ovf |= __shfl_down(ovf, d, 64);
+    }
+    if ((tid & 63) == 0) {
+        ph[tid >> 6] = h;
+        pt[tid >> 6] = t;
+        povf[tid >> 6] = ovf;
+    }
+    __syncthreads();
+    const msd_region_counts mine = counts[w];
+    const uint64_t ho = ph[0] + ph[1] + ph[2] + ph[3] + mine.hbase, to = pt[0] + pt[1] + pt[2] + pt[3] + mine.tbase;
+    const uint32_t nh = mine.nhits < hcap ? mine.nhits : hcap;
+    const uint32_t nt = mine.ntries < tcap ? mine.ntries : tcap;
+    if (last) {
+        /* list totals and per-buffer level/power sums straight to pinned host memory (a copy on another
+         * stream would queue behind the following scans); the device sums are zeroed for the slot's next batch */
+        if (tid == 0) {
+            const uint64_t ah = ho + mine.nhits, at = to + mine.ntries;
+            const uint64_t o = (povf[0] | povf[1] | povf[2] | povf[3]) ? 1 : 0;
+            totals[0] = ah;
+            totals[1] = at;
+            totals[2] = o;
+            if (h_totals) {
+                h_totals[0] = ah;
+                h_totals[1] = at;
+                h_totals[2] = o;
+            }
+        }
+        if (h_sums)
+            for (uint32_t i = tid; i < 2 * nbuffers; i += 256) {
+                h_sums[i] = sums[i];
+                sums[i] = 0;
+            }
+    }
+    if (w == 0) /* the last samples of the batch, kept for the look-behind of the next one */
+        for (uint32_t i = tid; i < tail_words; i += 256)
+            tail_dst[i] = tail_src[i];
+    /* all-ones into a scratch table of the slot's resolve stage (the prediction table), spread over the grid */
+    for (uint32_t i = w * blockDim.x + tid; i < wipe_n; i += nreg * blockDim.x)
+        wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const msd_hit *hs = hits + (size_t)w * hcap;
+    for (uint32_t i = tid; i < nh; i += blockDim.x) {
+        msd_hit hr = hs[i];
+        if (MSD_HIT_NLIVE(hr))
+            hr += (msd_hit)to << 34;
+        if (ho + i < dense_hcap)
+            dense_hits[ho + i] = hr;
+    }
+    const uint4 *ts = reinterpret_cast<const uint4 *>(tries + (size_t)w * tcap);
+    uint4 *td = reinterpret_cast<uint4 *>(dense_tries);
+    for (uint32_t i = tid; i < 2 * nt; i += blockDim.x)
+        if (to + (i >> 1) < dense_tcap)
+            td[2 * to + i] = ts[i];
+}
+
 
 /* exclusive offsets of the per-workgroup regions in the dense lists; single workgroup */
 __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *counts, uint32_t nwg,
@@ -951,88 +1008,6 @@ __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *c
     }
 }
 
-/* dense[offset[w] + i] = region[w][i]; the try index inside a hit record is made dense too.
- * grid = nwg workgroups */
-__global__ void __launch_bounds__(256) msd_gather_kernel(const msd_wg_counts *counts, const msd_hit *hits,
-                                                         const msd_try *tries, uint32_t hcap, uint32_t tcap,
-                                                         msd_hit *dense_hits, uint64_t dense_hcap,
-                                                         msd_try *dense_tries, uint64_t dense_tcap, uint64_t *totals,
-                                                         uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
-                                                         uint64_t *h_sums, uint4 *wipe, uint32_t wipe_n,
-                                                         const uint32_t *tail_src, uint32_t *tail_dst,
-                                                         uint32_t tail_words)
-{
-    __shared__ unsigned long long ph[4], pt[4];
-    __shared__ uint32_t povf[4];
-    const uint32_t w = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x;
-    /* this workgroup's offsets in the dense lists: the counts of all workgroups in front of it */
-    unsigned long long h = 0, t = 0;
-    uint32_t ovf = 0;
-    const bool last = w + 1 == nwg;
-    for (uint32_t i = tid; i < (last ? nwg : w); i += 256) { /* the last workgroup also owes the totals */
-        const msd_wg_counts c = counts[i];
-        if (i < w) {
-            h += c.nhits;
-            t += c.ntries;
-        }
-        ovf |= c.overflow;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        h += __shfl_down(h, d, 64);
-        t += __shfl_down(t, d, 64);
-        ovf |= __shfl_down(ovf, d, 64);
-    }
-    if ((tid & 63) == 0) {
-        ph[tid >> 6] = h;
-        pt[tid >> 6] = t;
-        povf[tid >> 6] = ovf;
-    }
-    __syncthreads();
-    const uint64_t ho = ph[0] + ph[1] + ph[2] + ph[3], to = pt[0] + pt[1] + pt[2] + pt[3];
-    const uint32_t nh = counts[w].nhits < hcap ? counts[w].nhits : hcap;
-    const uint32_t nt = counts[w].ntries < tcap ? counts[w].ntries : tcap;
-    if (last) {
-        /* list totals and per-buffer level/power sums straight to pinned host memory (a copy on another
-         * stream would queue behind the following scans); the device sums are zeroed for the slot's next batch */
-        if (tid == 0) {
-            const uint64_t ah = ho + counts[w].nhits, at = to + counts[w].ntries;
-            const uint64_t o = (povf[0] | povf[1] | povf[2] | povf[3] | counts[w].overflow) ? 1 : 0;
-            totals[0] = ah;
-            totals[1] = at;
-            totals[2] = o;
-            if (h_totals) {
-                h_totals[0] = ah;
-                h_totals[1] = at;
-                h_totals[2] = o;
-            }
-        }
-        if (h_sums)
-            for (uint32_t i = tid; i < 2 * nbuffers; i += 256) {
-                h_sums[i] = sums[i];
-                sums[i] = 0;
-            }
-    }
-    if (w == 0) /* the last samples of the batch, kept for the look-behind of the next one */
-        for (uint32_t i = tid; i < tail_words; i += 256)
-            tail_dst[i] = tail_src[i];
-    /* all-ones into a scratch table of the slot's resolve stage (the prediction table), spread over the grid */
-    for (uint32_t i = w * blockDim.x + tid; i < wipe_n; i += nwg * blockDim.x)
-        wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    const msd_hit *hs = hits + (size_t)w * hcap;
-    for (uint32_t i = tid; i < nh; i += blockDim.x) {
-        msd_hit hr = hs[i];
-        if (MSD_HIT_NLIVE(hr))
-            hr += (msd_hit)to << 34;
-        if (ho + i < dense_hcap)
-            dense_hits[ho + i] = hr;
-    }
-    const uint4 *ts = reinterpret_cast<const uint4 *>(tries + (size_t)w * tcap);
-    uint4 *td = reinterpret_cast<uint4 *>(dense_tries);
-    for (uint32_t i = tid; i < 2 * nt; i += blockDim.x)
-        if (to + (i >> 1) < dense_tcap)
-            td[2 * to + i] = ts[i];
-}
 
 /* one magnitude of the stream, by absolute sample index (used by the small follow-up kernels) */
 template <int FMT>
@@ -1720,7 +1695,7 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
                 mask |= (pass ? 1u : 0u) << k;
             }
             const uint32_t mine_n = (uint32_t)__builtin_popcount(mask);
-            const uint32_t incl = wave_incl_scan(mine_n, lane);
+            const uint32_t incl = wave_incl_scan(mine_n);
             if (lane == 63)
                 kcount32[wave] = incl;
             __syncthreads();
@@ -1802,9 +1777,10 @@ extern "C" size_t msd_scan_lds_bytes(int format)
 }
 
 template <int FMT, bool FIX2>
-static int launch_scan_fix(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
+static int launch_scan_fix(const MsdScanParams *p, uint32_t nregions, hipStream_t stream)
 {
     const size_t lds = msd_scan_lds_bytes(FMT);
+    const uint32_t nwg = (nregions + WAVES - 1) / WAVES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT, FIX2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
@@ -1814,29 +1790,31 @@ static int launch_scan_fix(const MsdScanParams *p, uint32_t nwg, hipStream_t str
 }
 
 template <int FMT>
-static int launch_scan_fmt(const MsdScanParams *p, uint32_t nwg, hipStream_t stream)
+static int launch_scan_fmt(const MsdScanParams *p, uint32_t nregions, hipStream_t stream)
 {
-    return p->fix2_112 ? launch_scan_fix<FMT, true>(p, nwg, stream) : launch_scan_fix<FMT, false>(p, nwg, stream);
+    return p->fix2_112 ? launch_scan_fix<FMT, true>(p, nregions, stream)
+                       : launch_scan_fix<FMT, false>(p, nregions, stream);
 }
 
-extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nwg, hipStream_t stream)
+extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipStream_t stream)
 {
     switch (format) {
-    case MSD_FMT_UC8: return launch_scan_fmt<MSD_FMT_UC8>(p, nwg, stream);
-    case MSD_FMT_SC16: return launch_scan_fmt<MSD_FMT_SC16>(p, nwg, stream);
-    case MSD_FMT_SC16Q11: return launch_scan_fmt<MSD_FMT_SC16Q11>(p, nwg, stream);
-    case MSD_FMT_MAG16: return launch_scan_fmt<MSD_FMT_MAG16>(p, nwg, stream);
+    case MSD_FMT_UC8: return launch_scan_fmt<MSD_FMT_UC8>(p, nregions, stream);
+    case MSD_FMT_SC16: return launch_scan_fmt<MSD_FMT_SC16>(p, nregions, stream);
+    case MSD_FMT_SC16Q11: return launch_scan_fmt<MSD_FMT_SC16Q11>(p, nregions, stream);
+    case MSD_FMT_MAG16: return launch_scan_fmt<MSD_FMT_MAG16>(p, nregions, stream);
     default: return -22;
     }
 }
 
-extern "C" int msd_launch_gather(const msd_wg_counts *counts, uint32_t nwg, uint64_t *totals, const msd_hit *hits,
+extern "C" int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_totals, uint32_t nwg,
+                                 uint64_t *totals, const msd_hit *hits,
                                  const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
                                  uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums,
                                  uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums, void *wipe, uint32_t wipe_bytes,
                                  const void *tail_src, void *tail_dst, uint32_t tail_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, hits, tries, hcap, tcap, dense_hits,
+    hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, wg_totals, hits, tries, hcap, tcap, dense_hits,
                        dense_hcap, dense_tries, dense_tcap, totals, sums, nbuffers, h_totals, h_sums,
                        static_cast<uint4 *>(wipe), wipe_bytes / 16, static_cast<const uint32_t *>(tail_src),
                        static_cast<uint32_t *>(tail_dst), tail_bytes / 4);

@@ -40,6 +40,8 @@ uint32_t msd_crc24(const msd_tables *t, const uint8_t *msg, int nbits)
     return rem ^ ((uint32_t)msg[n - 3] << 16) ^ ((uint32_t)msg[n - 2] << 8) ^ msg[n - 1];
 }
 
+static void build_slicer_tables(msd_tables *t);
+
 static int cmp_u24(const void *a, const void *b)
 {
     uint32_t x = *(const uint32_t *)a & 0xffffffu, y = *(const uint32_t *)b & 0xffffffu;
@@ -63,6 +65,8 @@ void msd_tables_build(msd_tables *t, int nfix_crc)
         t->crc_byte[b] = c & 0xffffffu;
     }
 
+    build_slicer_tables(t);
+
     if (nfix_crc >= 1) {
         /* crc.c:367-372 with max_correct = max_detect = 1: one entry per bit 5..bits-1 holding the
          * syndrome of that single-bit error, sorted by syndrome.  Packed as syndrome | bit << 24. */
@@ -81,6 +85,45 @@ void msd_tables_build(msd_tables *t, int nfix_crc)
             else
                 t->nsyn112 = n;
         }
+    }
+}
+
+/* The slicer / CRC tables of the scan kernel (layout: MSD_SL_* in msd_internal.h). */
+static void build_slicer_tables(msd_tables *t)
+{
+    uint8_t *perm = (uint8_t *)&t->slicer[MSD_SL_PERM];
+    for (int q = 0; q < 5; ++q) {
+        /* bit k of group 0 of trial phase 4 + q: t = 95 + (4 + q) + 12 k twelfths behind pa[0] */
+        uint32_t qoff = 0;
+        int bit_of[5];
+        for (int k = 0; k < 5; ++k) {
+            const int tt = 99 + q + 12 * k, c = tt % 5, sample = tt / 5;
+            bit_of[c] = k;
+            qoff |= (uint32_t)(2 * sample) << (6 * c);
+        }
+        t->slicer[MSD_SL_QOFF + q] = qoff;
+        for (int x = 0; x < 32; ++x) {
+            int v = 0;
+            for (int c = 0; c < 5; ++c)
+                if ((x >> (4 - c)) & 1)
+                    v |= 1 << (4 - bit_of[c]);
+            perm[q * 32 + x] = (uint8_t)v;
+        }
+    }
+    for (int bits = 56; bits <= 112; bits += 56) {
+        const uint32_t base = bits == 112 ? MSD_SL_GLONG : MSD_SL_GSHORT;
+        const uint32_t rows = bits == 112 ? MSD_SL_GLONG_ROWS : MSD_SL_GSHORT_ROWS;
+        for (uint32_t g = 0; g < rows; ++g)
+            for (int v = 0; v < 32; ++v) {
+                uint8_t msg[14];
+                memset(msg, 0, sizeof msg);
+                for (int k = 0; k < 5; ++k) {
+                    const int n = 5 * (int)g + k;
+                    if (n < bits && ((v >> (4 - k)) & 1))
+                        msg[n >> 3] |= (uint8_t)(0x80u >> (n & 7));
+                }
+                t->slicer[base + 32 * g + (uint32_t)v] = msd_crc24(t, msg, bits);
+            }
     }
 }
 
@@ -186,5 +229,38 @@ int msd_tables_selftest(const msd_tables *t)
         for (int i = 0; i < 256; ++i)
             if (t->uc8_full[i + 256 * q] != t->uc8_folded[fold(q) * MSD_LUT_STRIDE + fold(i)])
                 ++bad;
+    /* slicer tables against the closed form of demod_2400.c:98-177: bit n of trial phase 4 + q is
+     * correlator t % 5 at sample pa + t / 5 with t = 95 + (4 + q) + 12 n */
+    const uint8_t *perm = (const uint8_t *)&t->slicer[MSD_SL_PERM];
+    for (int q = 0; q < 5; ++q)
+        for (int n = 0; n < 112; ++n) {
+            const int g = n / 5, k = n % 5, tt = 99 + q + 12 * n, c = tt % 5;
+            const int sample = 12 * g + (int)((t->slicer[MSD_SL_QOFF + q] >> (6 * c)) & 63u) / 2;
+            if (sample != tt / 5 || perm[q * 32 + (1 << (4 - c))] != (1 << (4 - k)))
+                ++bad;
+        }
+    /* per-group syndromes against modesChecksum on pseudo-random messages */
+    uint32_t x = 0x2545F491u;
+    for (int trial = 0; trial < 2000; ++trial) {
+        uint8_t msg[14];
+        const int bits = (trial & 1) ? 112 : 56;
+        memset(msg, 0, sizeof msg);
+        for (int i = 0; i < bits / 8; ++i) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            msg[i] = (uint8_t)(x >> 11);
+        }
+        uint32_t syn = 0;
+        for (int g = 0; 5 * g < bits; ++g) {
+            int v = 0;
+            for (int k = 0; k < 5; ++k) {
+                const int n = 5 * g + k;
+                if (n < bits && (msg[n >> 3] & (0x80u >> (n & 7))))
+                    v |= 1 << (4 - k);
+            }
+            syn ^= t->slicer[(bits == 112 ? MSD_SL_GLONG : MSD_SL_GSHORT) + 32 * (uint32_t)g + (uint32_t)v];
+        }
+        if (syn != msd_crc24(t, msg, bits))
+            ++bad;
+    }
     return bad;
 }
