@@ -20,7 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "modes_hip.h"
@@ -34,6 +38,58 @@ namespace {
 constexpr uint64_t MIN_HIT_ARENA = 131072;      /* every position of one buffer */
 constexpr uint64_t MIN_TRY_ARENA = 131072 * 5;  /* every phase of every position of one buffer */
 constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
+
+/* One helper thread per context for the per-message part of finishing a batch (signal level, power
+ * statistics, the copy into the caller's arrays), so that it overlaps with the calling thread queueing
+ * the next batch's resolve.  At most one job at a time; run() returns at once, wait() joins it. */
+struct Helper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool pending = false, stop = false;
+    int device = 0;
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return pending || stop; });
+            if (stop)
+                return;
+            lk.unlock();
+            job();
+            lk.lock();
+            pending = false;
+            cv.notify_all();
+        }
+    }
+    void run(std::function<void()> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!th.joinable())
+            th = std::thread([this] { loop(); });
+        job = std::move(f);
+        pending = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !pending; });
+    }
+    void shutdown()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !pending; });
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable())
+            th.join();
+    }
+};
 
 struct Slot {
     bool busy = false;
@@ -100,7 +156,7 @@ struct Slot {
 
 struct msd_ctx {
     msd_config cfg{};
-    hipStream_t stream = nullptr, copy_stream = nullptr, aux_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, aux_stream = nullptr, emit_stream = nullptr;
     bool own_stream = false;
     int bps = 2;
     msd_tables *tables = nullptr;
@@ -155,6 +211,7 @@ struct msd_ctx {
     /* experiment knobs, read from the environment once in msd_create */
     bool trace = false;      /* MSD_RESOLVE_TRACE */
     bool repass_aux = false; /* MSD_REPASS_AUX */
+    bool chain_inline = false; /* MSD_CHAIN_INLINE: resolve chain in order on the scan stream (the round-1 layout) */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
@@ -171,6 +228,8 @@ struct msd_ctx {
     std::vector<uint64_t> out_req;
     std::vector<uint32_t> out_buf;
     int cu_count = 256;
+    Helper helper;
+    bool no_helper = false; /* MSD_NO_HELPER: everything on the calling thread */
     char err[256] = {0};
 };
 
@@ -727,12 +786,22 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
         g.h_valid[b] = slot_valid(s, b);
     msd_gpu_resolve_begin(&c->resolver, s.nbuffers, g.h_valid, g.h_ts, g.h_snap, g.h_todo, &s.resolve_ntodo);
     c->snaps_uploaded = 0;
+    /* The scan stream carries scans (and their gathers) only, back to back.  Prediction + resolve run on
+     * the high-priority chain stream behind the batch's own scan (ev_totals), power + records on a third
+     * one behind the resolve: they share the GPU with the next batch's scan instead of delaying it. */
+    hipStream_t ks = c->chain_inline ? c->stream : c->aux_stream;
+    hipStream_t es = c->chain_inline ? c->stream : c->emit_stream;
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
-    if (!rc)
-        rc = gpu_queue_pass(c, s, c->stream, true);
+    if (rc)
+        return rc;
+    if (ks != c->stream)
+        HIPCHK(c, hipStreamWaitEvent(ks, s.ev_totals, 0));
+    rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
-        HIPCHK(c, hipEventRecord(s.ev_resolve, c->stream));
-        rc = gpu_queue_emit(c, s, format, c->stream);
+        HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
+        if (es != ks)
+            HIPCHK(c, hipStreamWaitEvent(es, s.ev_resolve, 0));
+        rc = gpu_queue_emit(c, s, format, es);
     }
     if (rc)
         return rc;
@@ -788,7 +857,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
-        hipStream_t ps = c->repass_aux ? c->aux_stream : c->stream;
+        hipStream_t ps = (c->repass_aux || !c->chain_inline) ? c->aux_stream : c->stream;
         rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
@@ -814,30 +883,62 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return rc;
         records_current = false;
     }
-    hipStream_t rs = c->repass_aux ? c->aux_stream : c->stream;
+    hipStream_t rs = c->chain_inline ? (c->repass_aux ? c->aux_stream : c->stream) : c->emit_stream;
     if (!records_current && total) {
+        if (!c->chain_inline) /* behind the last pass (or, if only the arrays grew, behind nothing new) */
+            HIPCHK(c, hipStreamWaitEvent(rs, wait_for, 0));
         int rc = gpu_queue_emit(c, s, format, rs);
         if (rc)
             return rc;
     }
+    /* The per-message half -- wait for the records, signal level and the order-sensitive power
+     * statistics (demod_2400.c:386-408,422-427), the copy into the caller's arrays -- goes to the helper
+     * thread; it touches this batch's records and the power fields of the statistics only. */
+    int fetch_rc = 0;
+    double t_power = 0;
+    static_assert(sizeof(msd_wire) == sizeof(msd_message), "the records are msd_message arrays");
+    auto deliver = [&, total, n]() {
+        fetch_rc = fetch_records(c, s, total);
+        if (fetch_rc)
+            return;
+        auto p0 = tnow();
+        msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), &s.h_wire[0].mm, sizeof(msd_wire), nullptr,
+                          c->out_buf.data(), &s.h_wire[0].mm.signalLevel, sizeof(msd_wire), total);
+        t_power = tms(p0, tnow());
+        /* the library's own array sinks take the whole batch with one copy instead of 35 000 calls */
+        if (c->fsink == msd_array_fields_sink) {
+            msd_array_fields_sink_state *st = static_cast<msd_array_fields_sink_state *>(c->fuser);
+            const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
+            memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
+            memcpy(st->fields + st->count, s.h_fields, k * sizeof(msd_fields));
+            st->count += total;
+        } else if (!c->fsink && sink == msd_array_sink) {
+            msd_array_sink_state *st = static_cast<msd_array_sink_state *>(user);
+            const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
+            memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
+            st->count += total;
+        }
+    };
+    const bool threaded = !c->no_helper;
+    if (threaded)
+        c->helper.run(deliver);
     /* the filter is final for this batch: its successor can start */
+    int begin_rc = 0;
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
         /* (not across a capture boundary: the caller may still want this capture's counters) */
-        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && !nx.reset_before) {
-            int rc = gpu_begin(c, nx, c->scan_format);
-            if (rc)
-                return rc;
-        }
-    }
-    {
-        int rc = fetch_records(c, s, total);
-        if (rc)
-            return rc;
+        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && !nx.reset_before)
+            begin_rc = gpu_begin(c, nx, c->scan_format);
     }
     auto e1 = tnow();
-    msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), &s.h_wire[0].mm, sizeof(msd_wire), nullptr,
-                      c->out_buf.data(), &s.h_wire[0].mm.signalLevel, sizeof(msd_wire), total);
+    if (threaded)
+        c->helper.wait();
+    else
+        deliver();
+    if (begin_rc)
+        return begin_rc;
+    if (fetch_rc)
+        return fetch_rc;
     if (trace) {
         double cyc[8] = {0};
         for (uint32_t b = 0; b < n; ++b)
@@ -845,28 +946,15 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
                 cyc[k] += s.h_rbuf[b].cyc[k];
         fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f stage %.1f eval %.1f walk %.1f count %.1f\n",
                 cyc[0] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100);
-    }
-    if (trace)
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
-                "power stats %.3f ms\n", npass, early ? " (first one queued early)" : "", t_wait, t_replay, tms(e0, e1),
-                tms(e1, tnow()));
-    /* delivery; the library's own array sinks take the whole batch with one copy instead of 35 000 calls */
-    static_assert(sizeof(msd_wire) == sizeof(msd_message), "the records are msd_message arrays");
-    if (c->fsink == msd_array_fields_sink) {
-        msd_array_fields_sink_state *st = static_cast<msd_array_fields_sink_state *>(c->fuser);
-        const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
-        memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
-        memcpy(st->fields + st->count, s.h_fields, k * sizeof(msd_fields));
-        st->count += total;
-    } else if (c->fsink) {
+                "power stats %.3f ms (helper), then waited %.3f ms for it\n", npass, early ? " (first one queued early)" : "",
+                t_wait, t_replay, tms(e0, e1), t_power, tms(e1, tnow()));
+    }
+    /* callback sinks run on the calling thread, in order */
+    if (c->fsink && c->fsink != msd_array_fields_sink) {
         for (uint32_t i = 0; i < total; ++i)
             c->fsink(&s.h_wire[i].mm, &s.h_fields[i], c->fuser);
-    } else if (sink == msd_array_sink) {
-        msd_array_sink_state *st = static_cast<msd_array_sink_state *>(user);
-        const size_t room = st->count < st->cap ? st->cap - st->count : 0, k = total < room ? total : room;
-        memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
-        st->count += total;
-    } else if (sink) {
+    } else if (!c->fsink && sink && sink != msd_array_sink) {
         for (uint32_t i = 0; i < total; ++i)
             sink(&s.h_wire[i].mm, user);
     }
@@ -1150,6 +1238,7 @@ void destroy(msd_ctx *c)
 {
     if (!c)
         return;
+    c->helper.shutdown();
     (void)hipSetDevice(c->cfg.device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
@@ -1157,6 +1246,8 @@ void destroy(msd_ctx *c)
         (void)hipStreamSynchronize(c->copy_stream);
     if (c->aux_stream)
         (void)hipStreamSynchronize(c->aux_stream);
+    if (c->emit_stream)
+        (void)hipStreamSynchronize(c->emit_stream);
     if (c->d_timers) {
         unsigned long long t[16];
         if (hipMemcpy(t, c->d_timers, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1218,6 +1309,8 @@ void destroy(msd_ctx *c)
         (void)hipStreamDestroy(c->copy_stream);
     if (c->aux_stream)
         (void)hipStreamDestroy(c->aux_stream);
+    if (c->emit_stream)
+        (void)hipStreamDestroy(c->emit_stream);
     if (c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
     msd_resolver_free(&c->resolver);
@@ -1290,6 +1383,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
+        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, greatest));
     }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
@@ -1339,12 +1433,12 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     }
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
-    c->max_wg = (uint32_t)c->cu_count * MSD_SCAN_WAVES;
+    c->max_wg = (uint32_t)c->cu_count * MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU;
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_region_counts)));
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_wg_totals), (size_t)c->cu_count * sizeof(msd_wg_totals)));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_wg_totals), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
         c->ac_max_wg = (uint32_t)c->cu_count * 8u;
@@ -1390,6 +1484,9 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
         c->resolver.trace = c->trace;
         c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
+        { const char *ci = getenv("MSD_CHAIN_INLINE"); c->chain_inline = ci && *ci && *ci != '0'; }
+        c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
+        c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);
         const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */

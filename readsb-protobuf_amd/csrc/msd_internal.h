@@ -28,6 +28,9 @@ extern "C" {
 #ifndef MSD_SCAN_WAVES
 #define MSD_SCAN_WAVES 16 /* wavefronts per workgroup; one workgroup per CU (they share the UC8 table in LDS) */
 #endif
+#ifndef MSD_SCAN_WGS_PER_CU
+#define MSD_SCAN_WGS_PER_CU 1 /* workgroups the scan's LDS footprint allows per CU (sizes the number of regions) */
+#endif
 #define MSD_SCAN_THREADS (64 * MSD_SCAN_WAVES)
 #ifndef MSD_LUT_GLOBAL
 #define MSD_LUT_GLOBAL 0 /* 1: read the UC8 table through the vector cache instead of LDS */

@@ -795,7 +795,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 }
 
 template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */>
-__global__ void __launch_bounds__(NT) msd_scan_kernel(const MsdScanParams P)
+__global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3) / 4) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);

@@ -773,9 +773,13 @@ __device__ inline void emit_rows(msd_wire *dense, msd_fields *fields, const msd_
 
 /* The accepted messages of buffer b as 64-byte records (msd_message + signal power sum), dense over
  * the batch; one DMA then takes them to the host while the next scan runs. */
+/* FIELDS = false (no MSD_CFG_DECODE_FIELDS): 14 KB of LDS and few registers, so that the workgroups fit
+ * next to a resident scan workgroup and the records leave while the next batch is scanned. */
+template <bool FIELDS>
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
-                                                       msd_wire *dense, msd_fields *fields, uint32_t cap)
+                                                       msd_wire *dense, msd_fields *fields_arg, uint32_t cap)
 {
+    msd_fields *const fields = FIELDS ? fields_arg : nullptr;
     if (P.totals[2] || (P.ac && P.ac_totals[2]))
         return;
     const uint32_t b = blockIdx.x;
@@ -798,7 +802,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
      * words: the destination is host memory, where a lane-strided struct store costs a PCIe write per
      * piece */
     __shared__ msd_wire sh_rec[256];
-    __shared__ msd_fields sh_f[256];
+    __shared__ msd_fields sh_f[FIELDS ? 256 : 1];
     for (uint32_t m0 = 0; m0 < nm; m0 += 256) {
         const uint32_t m = m0 + threadIdx.x;
         if (m < nm) {
@@ -833,7 +837,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
             mm.pad = 0;
             sh_rec[threadIdx.x].mm = mm;
-            if (fields) /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
+            if (FIELDS) /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
                 msd_fields_mode_s(mm.msg, df, mm.addr, &sh_f[threadIdx.x]);
         }
         __syncthreads();
@@ -845,7 +849,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
         const uint32_t na = P.nac[b];
         const uint32_t *acc_ac = P.acc_ac + (size_t)b * MSD_RB_AC_CAP;
         __shared__ uint32_t has_alt[MSD_RB_AC_CAP / 32]; /* replies that carry an altitude of their own */
-        if (fields) {
+        if (FIELDS) {
             for (uint32_t i = threadIdx.x; i < MSD_RB_AC_CAP / 32; i += blockDim.x)
                 has_alt[i] = 0;
             __syncthreads();
@@ -879,7 +883,7 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
                 mm.iid = 0;
                 mm.pad = 0;
                 sh_rec[threadIdx.x].mm = mm;
-                if (fields) {
+                if (FIELDS) {
                     /* the reference's one message record per buffer keeps the last decoded altitude
                      * (demod_2400.c:523-528): find the last earlier reply of this buffer that had one */
                     msd_fields carry;
@@ -1035,6 +1039,9 @@ extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, con
 {
     if (nbuffers == 0)
         return 0;
-    hipLaunchKernelGGL(msd_emit_kernel, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
+    if (fields)
+        hipLaunchKernelGGL(msd_emit_kernel<true>, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
+    else
+        hipLaunchKernelGGL(msd_emit_kernel<false>, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }

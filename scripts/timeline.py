@@ -8,11 +8,11 @@ d = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 nrows = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 ev = []
-for f in glob.glob(d + "/*/*kernel_trace.csv"):
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:28]
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id")))
-for f in glob.glob(d + "/*/*memory_copy_trace.csv"):
+for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "")[12:], None))
 ev.sort()
