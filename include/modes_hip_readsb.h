@@ -1,0 +1,150 @@
+/*
+ * modes_hip_readsb.h -- the reference-shaped host boundary of the MI355X Mode S receive path
+ * (libmsd_host.so, plain C): the three interfaces readsb's hot path sits behind, with the
+ * reference's own signatures, so that a readsb maintainer binds them by name:
+ *
+ *   converter          convert.h:27-45   struct converter_state, iq_convert_fn, init_converter,
+ *                                        cleanup_converter
+ *   mag_buf FIFO       fifo.h:57-120     struct mag_buf, fifo_create .. fifo_release
+ *   "ifile" front-end  sdr.c:41-50,78-98 the five-function sdr_handler (sdr_ifile.h)
+ *
+ * Everything here is a thin host-C layer over the C-ABI of modes_hip.h; the signal processing runs
+ * in the HIP kernels behind it.  Included after the reference's own convert.h (CONVERT_H defined)
+ * the converter entry points are declared with the reference's types themselves.
+ */
+#ifndef MODES_HIP_READSB_H
+#define MODES_HIP_READSB_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#include "modes_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* converter (convert.h:27-45)                                                                */
+/* ------------------------------------------------------------------------------------------ */
+struct converter_state; /* opaque, as in convert.h:27; here it carries the GPU context */
+
+#ifdef CONVERT_H /* the reference's convert.h is in scope: its own types */
+typedef input_format_t msd_input_format_t;
+typedef iq_convert_fn msd_iq_convert_fn;
+#else
+typedef enum { MSD_INPUT_UC8 = 0, MSD_INPUT_SC16, MSD_INPUT_SC16Q11 } msd_input_format_t; /* convert.h:29-31 */
+typedef void (*msd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned nsamples,
+                                  struct converter_state *state, double *out_mean_level,
+                                  double *out_mean_power); /* convert.h:33-38 */
+#endif
+
+/* init_converter (convert.h:40-43, convert.c:446-491): returns the converter for `format` and a state
+ * for it, or NULL (no GPU; filter_dc != 0 -- the stateful DC-blocking converters only exist inside
+ * the stream interface, MSD_CFG_DC_FILTER; unknown format).  The returned function converts on the
+ * GPU and writes magnitudes and means bit-identical to convert_uc8_nodc / convert_sc16_nodc /
+ * convert_sc16q11_nodc (convert.c:63-111,215-253,332-370); either out pointer may be NULL
+ * (convert.c:104-110).  It is void like the reference's: after a device failure the magnitudes are
+ * zero and msd_converter_error(state) says why. */
+msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_rate, int filter_dc,
+                                     struct converter_state **out_state);
+void msd_cleanup_converter(struct converter_state *state); /* convert.h:45 */
+/* the GPU device the next msd_init_converter uses (default 0); the context behind a state, for callers
+ * that want to demodulate with the same one (msd_demodulate_magbuf); the last error text or "" */
+void msd_converter_set_device(int device);
+msd_ctx *msd_converter_context(struct converter_state *state);
+const char *msd_converter_error(const struct converter_state *state);
+
+/* ------------------------------------------------------------------------------------------ */
+/* mag_buf FIFO (fifo.h:57-120)                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum {
+    MSD_MAGBUF_DISCONTINUOUS = 1, /* fifo.h:30-32 */
+} msd_mag_buf_flags;
+
+/* struct mag_buf, fifo.h:57-73 (field for field; `next` is kept for the layout and always NULL) */
+struct msd_mag_buf {
+    uint16_t *data;
+    unsigned totalLength;
+    unsigned validLength;
+    unsigned overlap;
+    uint64_t sampleTimestamp;
+    uint64_t sysTimestamp;
+    msd_mag_buf_flags flags;
+    double mean_level;
+    double mean_power;
+    unsigned dropped;
+    struct msd_mag_buf *next;
+};
+
+/* Same calls, same meaning as fifo.h:80-120.  Two defects of fifo.c are not reproduced (SURVEY.md
+ * 8(b)): every enqueued buffer is delivered, in order, however deep the queue (fifo.c:192-197 never
+ * advances its tail pointer and loses buffers once two are queued), and a timeout really times out
+ * (fifo.c:141,219 test pthread_cond_timedwait's result with `< 0`, which never holds). */
+bool msd_fifo_create(unsigned buffer_count, unsigned buffer_size, unsigned overlap); /* fifo.h:80 */
+void msd_fifo_destroy(void);                                                         /* fifo.h:84 */
+void msd_fifo_drain(void);                                                           /* fifo.h:87 */
+void msd_fifo_halt(void);                                                            /* fifo.h:94 */
+struct msd_mag_buf *msd_fifo_acquire(uint32_t timeout_ms);                           /* fifo.h:99 */
+void msd_fifo_enqueue(struct msd_mag_buf *buf);                                      /* fifo.h:111 */
+struct msd_mag_buf *msd_fifo_dequeue(uint32_t timeout_ms);                           /* fifo.h:117 */
+void msd_fifo_release(struct msd_mag_buf *buf);                                      /* fifo.h:120 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* "ifile" SDR front-end (sdr.c:41-50,78-98; sdr_ifile.c)                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* Shaped like the reference's handler so it can be registered in sdr_handlers[]:
+ *     { msd_ifileInitConfig, msd_ifileHandleOption, msd_ifileOpen, msd_ifileRun, msd_ifileClose,
+ *       "ifile", SDR_IFILE, 0 }
+ * Two run modes:
+ *   MSD_IFILE_MAGBUF  the literal drop-in: blocks of 131072 samples are converted on the GPU (the
+ *                     msd_init_converter function), pushed through the mag_buf FIFO, and the consumer
+ *                     calls the demodulate2400-shaped msd_demodulate_magbuf per buffer;
+ *   MSD_IFILE_FUSED   the fast path: many blocks per call go straight to msd_launch_host, which runs
+ *                     the fused convert+demodulate kernel; magnitudes never leave the GPU.
+ * Both deliver the same ordered messages. */
+enum { MSD_OPT_IFILE_NAME = 1, MSD_OPT_IFILE_FORMAT, MSD_OPT_IFILE_THROTTLE, MSD_OPT_IFILE_MODE };
+enum { MSD_IFILE_FUSED = 0, MSD_IFILE_MAGBUF = 1 };
+
+/* receiver options the handler cannot see from its own options (Modes.* in the reference) */
+typedef struct msd_receiver_options {
+    int preamble_threshold; /* Modes.preambleThreshold */
+    int nfix_crc;           /* Modes.nfix_crc */
+    int mode_ac;            /* Modes.mode_ac */
+    int device;
+    unsigned batch_buffers; /* fused mode: buffers per GPU batch (default 64) */
+    msd_message_fn sink;    /* useModesMessage */
+    void *sink_user;
+    int dc_filter;          /* Modes.dc_filter (--dcfilter, readsb.c:486); fused mode only */
+} msd_receiver_options;
+
+/* What the reference's handler reaches through the global `Modes` and sdr.h (sdr_ifile.c:86,178-184,236):
+ * any of them may be NULL. */
+typedef struct msd_ifile_hooks {
+    int (*should_exit)(void);    /* `Modes.exit`: polled between blocks, ends msd_ifileRun */
+    void (*monitor)(void);       /* sdrMonitor(), once per block (sdr_ifile.c:184) */
+    void (*at_eof)(void);        /* `Modes.exit = 1` once the last block has been delivered (sdr_ifile.c:236) */
+    void (*device_selected)(void); /* `Modes.sdr_type = SDR_IFILE` when the file name option arrives (sdr_ifile.c:86) */
+} msd_ifile_hooks;
+
+void msd_ifileInitConfig(void);                    /* sdr_ifile.c:70-80 */
+/* sdr_ifile.c:82-107.  `key` is compared with the values registered through msd_ifileSetOptionKeys --
+ * the reference's OptIfileName / OptIfileFormat / OptIfileThrottle (readsb.h:615-617; enum values only
+ * the reference's own build knows) -- or, before any registration, with MSD_OPT_IFILE_*.  Unknown keys
+ * are accepted and ignored, as the reference's handler does. */
+bool msd_ifileHandleOption(int key, char *arg);
+bool msd_ifileOpen(void);                          /* sdr_ifile.c:115-162 */
+void msd_ifileRun(void);                           /* sdr_ifile.c:164-237 (blocks until EOF or should_exit) */
+void msd_ifileClose(void);                         /* sdr_ifile.c:239-255 */
+/* registrations survive msd_ifileInitConfig (they describe the host program, not a run); mode_key < 0:
+ * no option selects the run mode */
+void msd_ifileSetOptionKeys(int name_key, int format_key, int throttle_key, int mode_key);
+void msd_ifileSetHooks(const msd_ifile_hooks *hooks);
+void msd_ifileSetReceiver(const msd_receiver_options *opt);
+int msd_ifileGetStats(msd_stats *st);
+const char *msd_ifileLastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -100,6 +100,19 @@ def build(force=False):
     return _LIB
 
 
+REF_DIR = "/root/reference"
+REF_FIFO = os.path.join(_HERE, "_ref", "libref_fifo.so")
+
+
+def build_ref():
+    """oracle/_ref: the reference's own fifo.c, compiled where it lies (the only hot-path file of the
+    reference that builds in this image, see oracle/Makefile).  Returns the library path, or None when
+    neither the reference tree nor a prebuilt library is there (the GPU box has only the latter)."""
+    if os.path.isdir(REF_DIR):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_ref"])
+    return REF_FIFO if os.path.exists(REF_FIFO) else None
+
+
 _lib = None
 
 

@@ -1,7 +1,17 @@
-/* msd_fifo.c -- see msd_fifo.h.  A bounded producer/consumer queue of preallocated magnitude
- * buffers with the reference's overlap rule (fifo.c:179-188): each enqueued buffer is prefixed with
- * the last `overlap` samples of the previous one (zeros for the first or a discontinuous one). */
-#define _GNU_SOURCE
+/*
+ * msd_fifo.c -- the magnitude-buffer queue between the reader thread and the demodulator, written
+ * against the contract of fifo.h:34-120 (not against fifo.c): a producer acquires an unused buffer,
+ * fills data[overlap..validLength) and enqueues it; the queue completes data[0..overlap) with the
+ * last `overlap` samples of the buffer enqueued before it (zeros for the first one and after a
+ * discontinuity); the consumer dequeues in order and releases.
+ *
+ * Layout: one allocation for all sample arrays, an array of buffer records, a ring of record
+ * indices for the queued buffers (oldest first) and a stack of indices for the unused ones.  One
+ * mutex, one condition variable that every state change broadcasts on; every waiter re-checks its
+ * own predicate.  The overlap samples travel in a side array (`carry`), so no buffer ever refers to
+ * another one.
+ */
+#define _POSIX_C_SOURCE 200809L
 #include "msd_fifo.h"
 
 #include <errno.h>
@@ -12,173 +22,173 @@
 
 static struct {
     pthread_mutex_t mu;
-    pthread_cond_t not_empty, empty, have_free;
-    struct msd_mag_buf *head, *tail, *freelist;
-    bool halted;
-    unsigned overlap;
-    uint16_t *carry;
-} Q = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
-       NULL, NULL, NULL, false, 0, NULL};
+    pthread_cond_t changed;
+    struct msd_mag_buf *rec; /* [count] */
+    uint16_t *samples;       /* [count][size] */
+    unsigned count, size, overlap;
+    unsigned *ring;          /* indices of the queued buffers */
+    unsigned ring_first, ring_len;
+    unsigned *unused;        /* stack of indices */
+    unsigned unused_len;
+    uint16_t *carry;         /* the newest enqueued buffer's last `overlap` samples */
+    bool carry_valid;
+    bool halted, ready;
+} Q = {.mu = PTHREAD_MUTEX_INITIALIZER, .changed = PTHREAD_COND_INITIALIZER};
 
-static void deadline_after(uint32_t timeout_ms, struct timespec *ts)
+static void deadline_after(uint32_t ms, struct timespec *ts)
 {
-    clock_gettime(CLOCK_REALTIME, ts);
-    ts->tv_sec += timeout_ms / 1000;
-    ts->tv_nsec += (long)(timeout_ms % 1000) * 1000000L;
+    clock_gettime(CLOCK_REALTIME, ts); /* pthread_cond_timedwait's default clock */
+    ts->tv_sec += ms / 1000u;
+    ts->tv_nsec += (long)(ms % 1000u) * 1000000L;
     if (ts->tv_nsec >= 1000000000L) {
-        ts->tv_sec += 1;
         ts->tv_nsec -= 1000000000L;
+        ts->tv_sec += 1;
     }
 }
 
-static void free_list(struct msd_mag_buf *b)
+/* waits (mutex held) until *flag_a or *len is non-zero, or the deadline passes; ms == 0: no wait */
+static void wait_for(const bool *stop, const unsigned *len, uint32_t ms)
 {
-    while (b) {
-        struct msd_mag_buf *n = b->next;
-        free(b->data);
-        free(b);
-        b = n;
-    }
-}
-
-void msd_fifo_destroy(void)
-{
-    free_list(Q.head);
-    free_list(Q.freelist);
-    Q.head = Q.tail = Q.freelist = NULL;
-    free(Q.carry);
-    Q.carry = NULL;
-    Q.halted = false;
+    if (*stop || *len || !ms)
+        return;
+    struct timespec until;
+    deadline_after(ms, &until);
+    while (!*stop && !*len)
+        if (pthread_cond_timedwait(&Q.changed, &Q.mu, &until) == ETIMEDOUT)
+            break;
 }
 
 bool msd_fifo_create(unsigned buffer_count, unsigned buffer_size, unsigned overlap)
 {
-    Q.carry = calloc(overlap ? overlap : 1, sizeof Q.carry[0]);
-    if (!Q.carry)
+    if (Q.ready || !buffer_count || buffer_size < overlap)
         return false;
+    Q.rec = calloc(buffer_count, sizeof *Q.rec);
+    Q.samples = calloc((size_t)buffer_count * buffer_size, sizeof *Q.samples);
+    Q.ring = calloc(buffer_count, sizeof *Q.ring);
+    Q.unused = calloc(buffer_count, sizeof *Q.unused);
+    Q.carry = calloc(overlap ? overlap : 1, sizeof *Q.carry);
+    if (!Q.rec || !Q.samples || !Q.ring || !Q.unused || !Q.carry) {
+        free(Q.rec); free(Q.samples); free(Q.ring); free(Q.unused); free(Q.carry);
+        Q.rec = NULL; Q.samples = NULL; Q.ring = NULL; Q.unused = NULL; Q.carry = NULL;
+        return false;
+    }
+    Q.count = buffer_count;
+    Q.size = buffer_size;
     Q.overlap = overlap;
     for (unsigned i = 0; i < buffer_count; ++i) {
-        struct msd_mag_buf *b = calloc(1, sizeof *b);
-        if (b)
-            b->data = calloc(buffer_size, sizeof b->data[0]);
-        if (!b || !b->data) {
-            free(b);
-            msd_fifo_destroy();
-            return false;
-        }
-        b->totalLength = buffer_size;
-        b->next = Q.freelist;
-        Q.freelist = b;
+        Q.rec[i].data = Q.samples + (size_t)i * buffer_size;
+        Q.rec[i].totalLength = buffer_size;
+        Q.unused[i] = buffer_count - 1 - i; /* buffer 0 is handed out first */
     }
+    Q.unused_len = buffer_count;
+    Q.ring_first = Q.ring_len = 0;
+    Q.carry_valid = false;
+    Q.halted = false;
+    Q.ready = true;
     return true;
+}
+
+void msd_fifo_destroy(void)
+{
+    if (!Q.ready)
+        return;
+    free(Q.rec); free(Q.samples); free(Q.ring); free(Q.unused); free(Q.carry);
+    Q.rec = NULL; Q.samples = NULL; Q.ring = NULL; Q.unused = NULL; Q.carry = NULL;
+    Q.count = Q.ring_len = Q.unused_len = 0;
+    Q.ready = false;
 }
 
 void msd_fifo_drain(void)
 {
     pthread_mutex_lock(&Q.mu);
-    while (Q.head && !Q.halted)
-        pthread_cond_wait(&Q.empty, &Q.mu);
+    while (Q.ready && !Q.halted && Q.ring_len)
+        pthread_cond_wait(&Q.changed, &Q.mu);
     pthread_mutex_unlock(&Q.mu);
 }
 
 void msd_fifo_halt(void)
 {
     pthread_mutex_lock(&Q.mu);
-    while (Q.head) {
-        struct msd_mag_buf *b = Q.head;
-        Q.head = b->next;
-        b->next = Q.freelist;
-        Q.freelist = b;
-    }
-    Q.tail = NULL;
     Q.halted = true;
-    pthread_cond_broadcast(&Q.not_empty);
-    pthread_cond_broadcast(&Q.empty);
-    pthread_cond_broadcast(&Q.have_free);
+    while (Q.ring_len) { /* what was queued is unused again */
+        Q.unused[Q.unused_len++] = Q.ring[Q.ring_first];
+        Q.ring_first = (Q.ring_first + 1) % Q.count;
+        Q.ring_len--;
+    }
+    pthread_cond_broadcast(&Q.changed);
     pthread_mutex_unlock(&Q.mu);
 }
 
 struct msd_mag_buf *msd_fifo_acquire(uint32_t timeout_ms)
 {
-    struct timespec until;
-    if (timeout_ms)
-        deadline_after(timeout_ms, &until);
     struct msd_mag_buf *b = NULL;
     pthread_mutex_lock(&Q.mu);
-    while (!Q.halted && !Q.freelist) {
-        if (!timeout_ms || pthread_cond_timedwait(&Q.have_free, &Q.mu, &until) == ETIMEDOUT)
-            break;
-    }
-    if (!Q.halted && Q.freelist) {
-        b = Q.freelist;
-        Q.freelist = b->next;
-        b->overlap = Q.overlap; /* fifo.c:152-158 */
-        b->validLength = Q.overlap;
-        b->sampleTimestamp = 0;
-        b->sysTimestamp = 0;
-        b->flags = 0;
-        b->next = NULL;
-    }
-    pthread_mutex_unlock(&Q.mu);
-    return b;
-}
-
-void msd_fifo_enqueue(struct msd_mag_buf *b)
-{
-    pthread_mutex_lock(&Q.mu);
-    if (Q.halted) {
-        b->next = Q.freelist;
-        Q.freelist = b;
-        pthread_mutex_unlock(&Q.mu);
-        return;
-    }
-    const size_t bytes = Q.overlap * sizeof b->data[0];
-    if (b->flags & MSD_MAGBUF_DISCONTINUOUS)
-        memset(b->data, 0, bytes);
-    else
-        memcpy(b->data, Q.carry, bytes);
-    memcpy(Q.carry, &b->data[b->validLength - Q.overlap], bytes);
-    b->next = NULL;
-    if (!Q.head) {
-        Q.head = Q.tail = b;
-        pthread_cond_signal(&Q.not_empty);
-    } else {
-        Q.tail->next = b;
-        Q.tail = b; /* the line fifo.c:192-197 is missing */
-    }
-    pthread_mutex_unlock(&Q.mu);
-}
-
-struct msd_mag_buf *msd_fifo_dequeue(uint32_t timeout_ms)
-{
-    struct timespec until;
-    if (timeout_ms)
-        deadline_after(timeout_ms, &until);
-    struct msd_mag_buf *b = NULL;
-    pthread_mutex_lock(&Q.mu);
-    while (!Q.head && !Q.halted) {
-        if (!timeout_ms || pthread_cond_timedwait(&Q.not_empty, &Q.mu, &until) == ETIMEDOUT)
-            break;
-    }
-    if (!Q.halted && Q.head) {
-        b = Q.head;
-        Q.head = b->next;
-        b->next = NULL;
-        if (!Q.head) {
-            Q.tail = NULL;
-            pthread_cond_broadcast(&Q.empty);
+    if (Q.ready) {
+        wait_for(&Q.halted, &Q.unused_len, timeout_ms);
+        if (!Q.halted && Q.unused_len) {
+            b = &Q.rec[Q.unused[--Q.unused_len]];
+            b->overlap = Q.overlap; /* fifo.h:99-111: a buffer starts out holding only its overlap region */
+            b->validLength = Q.overlap;
+            b->sampleTimestamp = 0;
+            b->sysTimestamp = 0;
+            b->flags = (msd_mag_buf_flags)0;
+            b->dropped = 0;
+            b->next = NULL;
         }
     }
     pthread_mutex_unlock(&Q.mu);
     return b;
 }
 
-void msd_fifo_release(struct msd_mag_buf *b)
+void msd_fifo_enqueue(struct msd_mag_buf *buf)
 {
+    if (!buf)
+        return;
+    const unsigned idx = (unsigned)(buf - Q.rec);
     pthread_mutex_lock(&Q.mu);
-    if (!Q.freelist)
-        pthread_cond_signal(&Q.have_free);
-    b->next = Q.freelist;
-    Q.freelist = b;
+    if (Q.halted) { /* fifo.h:92: produced buffers go straight back */
+        Q.unused[Q.unused_len++] = idx;
+    } else {
+        /* the region in front of the new samples: the previous buffer's tail, or silence at the start
+         * of the stream and behind a gap (fifo.h:34-55, MAGBUF_DISCONTINUOUS) */
+        if (Q.carry_valid && !(buf->flags & MSD_MAGBUF_DISCONTINUOUS))
+            memcpy(buf->data, Q.carry, Q.overlap * sizeof *buf->data);
+        else
+            memset(buf->data, 0, Q.overlap * sizeof *buf->data);
+        if (buf->validLength >= Q.overlap) {
+            memcpy(Q.carry, buf->data + (buf->validLength - Q.overlap), Q.overlap * sizeof *buf->data);
+            Q.carry_valid = true;
+        }
+        Q.ring[(Q.ring_first + Q.ring_len) % Q.count] = idx;
+        Q.ring_len++;
+    }
+    pthread_cond_broadcast(&Q.changed);
+    pthread_mutex_unlock(&Q.mu);
+}
+
+struct msd_mag_buf *msd_fifo_dequeue(uint32_t timeout_ms)
+{
+    struct msd_mag_buf *b = NULL;
+    pthread_mutex_lock(&Q.mu);
+    if (Q.ready) {
+        wait_for(&Q.halted, &Q.ring_len, timeout_ms);
+        if (!Q.halted && Q.ring_len) {
+            b = &Q.rec[Q.ring[Q.ring_first]];
+            Q.ring_first = (Q.ring_first + 1) % Q.count;
+            Q.ring_len--;
+            pthread_cond_broadcast(&Q.changed); /* msd_fifo_drain watches the queue length */
+        }
+    }
+    pthread_mutex_unlock(&Q.mu);
+    return b;
+}
+
+void msd_fifo_release(struct msd_mag_buf *buf)
+{
+    if (!buf)
+        return;
+    pthread_mutex_lock(&Q.mu);
+    Q.unused[Q.unused_len++] = (unsigned)(buf - Q.rec);
+    pthread_cond_broadcast(&Q.changed);
     pthread_mutex_unlock(&Q.mu);
 }

@@ -46,6 +46,13 @@ static void write_beast(const msd_message *mm, void *user)
     g_count++;
 }
 
+/* This tool plays readsb's part towards the handler: its own option keys (as readsb.h:615-617 are readsb's)
+ * and the hooks that stand for Modes.exit / sdrMonitor() (sdr_ifile.c:178-184,236). */
+enum { OptIfileName = 615, OptIfileFormat, OptIfileThrottle, OptIfilePath };
+static volatile int g_exit; /* Modes.exit */
+static int host_should_exit(void) { return g_exit; }
+static void host_at_eof(void) { g_exit = 1; }
+
 int main(int argc, char **argv)
 {
     msd_receiver_options rx;
@@ -57,17 +64,20 @@ int main(int argc, char **argv)
     rx.sink_user = stdout;
     int want_stats = 0;
 
+    const msd_ifile_hooks hooks = {host_should_exit, NULL, host_at_eof, NULL};
+    msd_ifileSetOptionKeys(OptIfileName, OptIfileFormat, OptIfileThrottle, OptIfilePath);
+    msd_ifileSetHooks(&hooks);
     msd_ifileInitConfig();
     for (int i = 1; i < argc; ++i) {
         const char *a = argv[i];
         char *next = (i + 1 < argc) ? argv[i + 1] : NULL;
-        if (!strcmp(a, "--ifile") && next) { msd_ifileHandleOption(MSD_OPT_IFILE_NAME, next); ++i; }
+        if (!strcmp(a, "--ifile") && next) { msd_ifileHandleOption(OptIfileName, next); ++i; }
         else if (!strcmp(a, "--iformat") && next) {
-            if (!msd_ifileHandleOption(MSD_OPT_IFILE_FORMAT, next)) { fprintf(stderr, "%s\n", msd_ifileLastError()); return 1; }
+            if (!msd_ifileHandleOption(OptIfileFormat, next)) { fprintf(stderr, "%s\n", msd_ifileLastError()); return 1; }
             ++i;
         }
-        else if (!strcmp(a, "--throttle")) msd_ifileHandleOption(MSD_OPT_IFILE_THROTTLE, NULL);
-        else if (!strcmp(a, "--path") && next) { msd_ifileHandleOption(MSD_OPT_IFILE_MODE, next); ++i; }
+        else if (!strcmp(a, "--throttle")) msd_ifileHandleOption(OptIfileThrottle, NULL);
+        else if (!strcmp(a, "--path") && next) { msd_ifileHandleOption(OptIfilePath, next); ++i; }
         else if (!strcmp(a, "--fix")) rx.nfix_crc = 1;
         else if (!strcmp(a, "--no-fix")) rx.nfix_crc = 0;
         else if (!strcmp(a, "--aggressive")) rx.nfix_crc = 2; /* readsb.c:542 */
@@ -100,6 +110,10 @@ int main(int argc, char **argv)
     msd_ifileRun();
     if (msd_ifileLastError()[0])
         fprintf(stderr, "%s\n", msd_ifileLastError());
+    if (!g_exit) { /* readsb.c:279-281: a reader that returns without the exit flag set is an abnormal exit */
+        fprintf(stderr, "reader returned without signalling the end of the capture\n");
+        return 2;
+    }
     if (want_stats) {
         msd_stats st;
         if (msd_ifileGetStats(&st) == 0) {

@@ -27,15 +27,45 @@ static struct {
     msd_ctx *ctx;
     char err[256];
     volatile int exit_flag;
+    /* magbuf mode: the converter of msd_init_converter (convert.h:40-43) and its state, like sdr_ifile.c:58-68 */
+    msd_iq_convert_fn converter;
+    struct converter_state *converter_state;
     /* buffers handed to the consumer and not yet demodulated (the GPU context is shared) */
     pthread_mutex_t mu;
     pthread_cond_t idle;
     int in_flight;
 } F;
 
+/* what describes the host program rather than a run: survives msd_ifileInitConfig */
+static struct {
+    int name_key, format_key, throttle_key, mode_key;
+    msd_ifile_hooks hooks;
+} G = {MSD_OPT_IFILE_NAME, MSD_OPT_IFILE_FORMAT, MSD_OPT_IFILE_THROTTLE, MSD_OPT_IFILE_MODE, {NULL, NULL, NULL, NULL}};
+
 const char *msd_ifileLastError(void)
 {
     return F.err;
+}
+
+void msd_ifileSetOptionKeys(int name_key, int format_key, int throttle_key, int mode_key)
+{
+    G.name_key = name_key;
+    G.format_key = format_key;
+    G.throttle_key = throttle_key;
+    G.mode_key = mode_key;
+}
+
+void msd_ifileSetHooks(const msd_ifile_hooks *hooks)
+{
+    if (hooks)
+        G.hooks = *hooks;
+    else
+        memset(&G.hooks, 0, sizeof G.hooks);
+}
+
+static bool host_wants_exit(void)
+{
+    return G.hooks.should_exit && G.hooks.should_exit();
 }
 
 void msd_ifileInitConfig(void)
@@ -57,12 +87,18 @@ void msd_ifileSetReceiver(const msd_receiver_options *opt)
 
 bool msd_ifileHandleOption(int key, char *arg)
 {
-    switch (key) {
-    case MSD_OPT_IFILE_NAME:
+    /* the keys are whatever the host program's option table uses (readsb.h:615-617), see
+     * msd_ifileSetOptionKeys; like sdr_ifile.c:82-107 anything else is accepted and ignored */
+    if (key == G.name_key) {
         free(F.filename);
-        F.filename = strdup(arg);
-        break;
-    case MSD_OPT_IFILE_FORMAT:
+        F.filename = arg ? strdup(arg) : NULL;
+        if (G.hooks.device_selected)
+            G.hooks.device_selected(); /* Modes.sdr_type = SDR_IFILE, sdr_ifile.c:86 */
+    } else if (key == G.format_key) {
+        if (!arg) {
+            snprintf(F.err, sizeof F.err, "Input format missing (supported values: UC8, SC16, SC16Q11)");
+            return false;
+        }
         if (!strcasecmp(arg, "uc8"))
             F.format = MSD_FMT_UC8;
         else if (!strcasecmp(arg, "sc16"))
@@ -73,13 +109,10 @@ bool msd_ifileHandleOption(int key, char *arg)
             snprintf(F.err, sizeof F.err, "Input format '%s' not understood (supported values: UC8, SC16, SC16Q11)", arg);
             return false;
         }
-        break;
-    case MSD_OPT_IFILE_THROTTLE:
+    } else if (key == G.throttle_key) {
         F.throttle = true;
-        break;
-    case MSD_OPT_IFILE_MODE:
-        F.mode = (!strcasecmp(arg, "magbuf")) ? MSD_IFILE_MAGBUF : MSD_IFILE_FUSED;
-        break;
+    } else if (G.mode_key >= 0 && key == G.mode_key) {
+        F.mode = (arg && !strcasecmp(arg, "magbuf")) ? MSD_IFILE_MAGBUF : MSD_IFILE_FUSED;
     }
     return true;
 }
@@ -103,6 +136,23 @@ bool msd_ifileOpen(void)
         snprintf(F.err, sizeof F.err, "ifile: failed to allocate read buffer");
         msd_ifileClose();
         return false;
+    }
+    if (F.mode == MSD_IFILE_MAGBUF) {
+        /* the literal drop-in: the converter comes from init_converter's twin (sdr_ifile.c:150-153) and
+         * keeps its own state; the demodulator's context is created below, as for the fused path */
+        if (F.rx.dc_filter) {
+            snprintf(F.err, sizeof F.err, "ifile: --dcfilter needs the fused path");
+            msd_ifileClose();
+            return false;
+        }
+        msd_converter_set_device(F.rx.device);
+        F.converter = msd_init_converter((msd_input_format_t)(F.format == MSD_FMT_UC8 ? 0 : F.format == MSD_FMT_SC16 ? 1 : 2),
+                                         2400000.0, 0, &F.converter_state);
+        if (!F.converter) {
+            snprintf(F.err, sizeof F.err, "ifile: can't initialize sample converter");
+            msd_ifileClose();
+            return false;
+        }
     }
     msd_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -180,10 +230,12 @@ static void run_magbuf(void)
     pthread_create(&consumer, NULL, magbuf_consumer, NULL);
     uint64_t sample_counter = 0;
     bool eof = false;
-    while (!eof) {
+    while (!eof && !host_wants_exit()) {
         struct msd_mag_buf *out = msd_fifo_acquire(100);
         if (!out)
             continue;
+        if (G.hooks.monitor)
+            G.hooks.monitor(); /* sdrMonitor(), sdr_ifile.c:184 */
         out->sampleTimestamp = (uint64_t)(sample_counter * 12e6 / 2400000.0); /* sdr_ifile.c:187 */
         out->sysTimestamp = out->sampleTimestamp / 12000U;                    /* startup_time = 0 */
         const size_t want = (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample;
@@ -191,9 +243,10 @@ static void run_magbuf(void)
         if (got < want)
             eof = true;
         const unsigned samples = (unsigned)(got / F.bytes_per_sample);
-        int rc = msd_convert(F.ctx, F.readbuf, &out->data[out->overlap], samples, &out->mean_level, &out->mean_power);
-        if (rc)
-            snprintf(F.err, sizeof F.err, "convert: %s", msd_last_error(F.ctx));
+        F.converter(F.readbuf, &out->data[out->overlap], samples, F.converter_state, &out->mean_level,
+                    &out->mean_power); /* sdr_ifile.c:214 */
+        if (msd_converter_error(F.converter_state)[0])
+            snprintf(F.err, sizeof F.err, "%s", msd_converter_error(F.converter_state));
         out->validLength = out->overlap + samples;
         out->flags = 0;
         pthread_mutex_lock(&F.mu);
@@ -232,7 +285,9 @@ static void run_fused(void)
         bool eof = false;
         int in_flight = 0;
         unsigned k = 0;
-        while (!eof) {
+        while (!eof && !host_wants_exit()) {
+            if (G.hooks.monitor)
+                G.hooks.monitor(); /* sdrMonitor(), sdr_ifile.c:184 */
             char *buf = ring[k++ % RING]; /* the batch that used it RING turns ago has been collected */
             const size_t got = read_fully(buf, F.readbuf_bytes);
             if (got < F.readbuf_bytes)
@@ -271,6 +326,8 @@ void msd_ifileRun(void)
         run_magbuf();
     else
         run_fused();
+    if (G.hooks.at_eof)
+        G.hooks.at_eof(); /* Modes.exit = 1, sdr_ifile.c:236 */
 }
 
 int msd_ifileGetStats(msd_stats *st)
@@ -280,6 +337,11 @@ int msd_ifileGetStats(msd_stats *st)
 
 void msd_ifileClose(void)
 {
+    if (F.converter) { /* sdr_ifile.c:240-244 */
+        msd_cleanup_converter(F.converter_state);
+        F.converter = NULL;
+        F.converter_state = NULL;
+    }
     if (F.ctx) {
         msd_destroy(F.ctx);
         F.ctx = NULL;

@@ -30,12 +30,35 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.capi.EXPORTS) == declared_functions()
 
 
+def declared_host_functions():
+    text = open(os.path.join(ROOT, "include", "modes_hip_readsb.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msd_[A-Za-z_0-9]+)\s*\(", text)))
+
+
 def test_host_boundary_library_exports(pkg):
+    """libmsd_host.so exports everything include/modes_hip_readsb.h declares: the converter factory
+    (convert.h:40-45), the mag_buf FIFO (fifo.h:80-120) and the ifile handler (sdr.c:41-50)."""
     host = C.CDLL(os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "libmsd_host.so"))
-    for name in ("msd_fifo_create", "msd_fifo_destroy", "msd_fifo_drain", "msd_fifo_halt", "msd_fifo_acquire",
-                 "msd_fifo_enqueue", "msd_fifo_dequeue", "msd_fifo_release", "msd_ifileInitConfig",
-                 "msd_ifileHandleOption", "msd_ifileOpen", "msd_ifileRun", "msd_ifileClose"):
-        assert hasattr(host, name), name
+    names = declared_host_functions()
+    for must in ("msd_init_converter", "msd_cleanup_converter", "msd_fifo_create", "msd_fifo_destroy", "msd_fifo_drain",
+                 "msd_fifo_halt", "msd_fifo_acquire", "msd_fifo_enqueue", "msd_fifo_dequeue", "msd_fifo_release",
+                 "msd_ifileInitConfig", "msd_ifileHandleOption", "msd_ifileOpen", "msd_ifileRun", "msd_ifileClose",
+                 "msd_ifileSetOptionKeys", "msd_ifileSetHooks"):
+        assert must in names, must
+    for name in names:
+        assert hasattr(host, name), f"{name} is declared in modes_hip_readsb.h but not exported"
+
+
+def test_converter_factory_without_a_gpu_returns_null_like_the_reference(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    host = C.CDLL(os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "libmsd_host.so"))
+    host.msd_init_converter.restype = C.c_void_p
+    host.msd_init_converter.argtypes = [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_void_p)]
+    state = C.c_void_p(1)
+    assert host.msd_init_converter(0, 2400000.0, 0, C.byref(state)) is None and state.value is None
 
 
 def test_message_struct_layout_matches_numpy_mirror(pkg, oracle):

@@ -1,0 +1,40 @@
+"""The reference-shaped host boundary (include/modes_hip_readsb.h) seen from C written against the
+reference's own declarations: tests/c/boundary_check.c must compile with -Werror -- the exported
+converter factory is assignable to the reference's iq_convert_fn / init_converter types, the ifile
+handler takes the reference's option keys through msd_ifileSetOptionKeys -- and run."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "readsb-protobuf_amd", "csrc")
+
+
+def build_check(tmp_path):
+    exe = str(tmp_path / "boundary_check")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "boundary_check.c"), "-o", exe, "-L" + CSRC, "-lmsd_host",
+                           "-lmodes_hip", "-Wl,-rpath," + CSRC, "-lpthread", "-lm"])
+    return exe
+
+
+def test_boundary_compiles_against_reference_style_declarations_and_runs(pkg, tmp_path):
+    exe = build_check(tmp_path)
+    capture = tmp_path / "tiny.uc8"
+    np.full(2 * 4096, 127, dtype=np.uint8).tofile(capture)
+    out = subprocess.run([exe, str(capture)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "boundary ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_boundary_check_on_the_gpu(pkg, tmp_path, torch_cuda):
+    """With a device: the converter obtained through the reference-typed factory converts, the handler
+    runs a capture to its end and calls the exit / monitor / EOF hooks."""
+    exe = build_check(tmp_path)
+    capture = tmp_path / "small.uc8"
+    rng = np.random.default_rng(3)
+    rng.integers(100, 156, size=2 * (131072 + 5000), dtype=np.uint8).tofile(capture)
+    out = subprocess.run([exe, str(capture)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "boundary ok" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,129 @@
+"""The two literal drop-in entries of the C-ABI, directly: the iq_convert_fn-shaped converter
+(msd_convert, convert.h:33-38) against the oracle's converters on exhaustive / lattice inputs, and the
+demodulate2400-shaped entry (msd_demodulate_magbuf, demod_2400.h:37-38) fed buffer by buffer from
+Python for the float formats and Mode A/C."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_same_messages, fmt_ids
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 131072
+
+
+def convert_both(pkg, oracle, fmt, iq_bytes, nsamples):
+    f, of = fmt_ids(pkg, oracle, fmt)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK)
+    orc = oracle.Oracle(of, 58, 1, 0)
+    out_g, out_o = [], []
+    for off in range(0, max(nsamples, 1), CHUNK):          # one block of MODES_MAG_BUF_SAMPLES per call, sdr_ifile.c:214
+        n = min(CHUNK, nsamples - off)
+        bps = 2 if fmt == "uc8" else 4
+        part = iq_bytes[off * bps:(off + n) * bps]
+        out_g.append(dem.convert(part if n else np.zeros(16, np.uint8), n))
+        out_o.append(orc.convert(part if n else np.zeros(16, np.uint8), n))
+    return out_g, out_o
+
+
+def assert_blocks_equal(out_g, out_o):
+    for (mg, lg, pg), (mo, lo, po) in zip(out_g, out_o):
+        assert np.array_equal(mg, mo)
+        assert np.array_equal(np.float64(lg), np.float64(lo), equal_nan=True), (lg, lo)
+        assert np.array_equal(np.float64(pg), np.float64(po), equal_nan=True), (pg, po)
+
+
+def test_uc8_converter_on_all_65536_byte_pairs(pkg, oracle, torch_cuda):
+    """Every (I, Q) byte pair once (convert.c:35-61's whole table), in an order that spreads the pairs over
+    the blocks, plus a second pass in natural order: magnitudes and both means bit for bit."""
+    pairs = np.arange(65536, dtype=np.uint32)
+    shuffled = np.random.default_rng(1).permutation(pairs)
+    both = np.concatenate([shuffled, pairs])
+    iq = np.empty(2 * both.size, dtype=np.uint8)
+    iq[0::2] = both & 0xFF          # I
+    iq[1::2] = both >> 8            # Q
+    out_g, out_o = convert_both(pkg, oracle, "uc8", iq, both.size)
+    assert_blocks_equal(out_g, out_o)
+    mags = np.concatenate([m for m, _, _ in out_g])[65536:]
+    assert np.array_equal(mags, oracle.uc8_table())   # the reference's table itself, slot = I + 256 Q
+
+
+@pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
+def test_s16_converters_on_a_lattice_of_2_24_pairs(pkg, oracle, torch_cuda, fmt):
+    """convert.c:215-253 / :332-370 on 4096 x 4096 (I, Q) pairs: every value the 12-bit ADCs behind SC16Q11
+    produce (-2048..2047) and, for SC16, a lattice over the whole int16 range that holds both ends, zero,
+    the values around the clamp at magsq > 1 and odd steps in between."""
+    if fmt == "sc16q11":
+        axis = np.arange(-2048, 2048, dtype=np.int32)
+    else:
+        axis = np.arange(-32768, 32768, 16, dtype=np.int32)       # 4096 values, holds -32768 and 0
+        special = [-32767, -23171, -23170, -1, 1, 15, 23170, 23171, 32766, 32767]
+        axis[np.arange(len(special)) * 97 + 33] = special
+    i_vals, q_vals = np.meshgrid(axis, axis, indexing="ij")
+    order = np.random.default_rng(2).permutation(i_vals.size)   # sequential float sums see a mixed stream
+    iq16 = np.empty(2 * i_vals.size, dtype=np.int16)
+    iq16[0::2] = i_vals.reshape(-1)[order]
+    iq16[1::2] = q_vals.reshape(-1)[order]
+    out_g, out_o = convert_both(pkg, oracle, fmt, iq16.view(np.uint8), i_vals.size)
+    assert_blocks_equal(out_g, out_o)
+    mags = np.concatenate([m for m, _, _ in out_g])
+    assert mags.max() == 65535 and mags.min() == 0
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 131071])
+def test_converter_ragged_lengths_and_null_out_pointers(pkg, oracle, torch_cuda, fmt, n):
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    rng = np.random.default_rng(n + 5)
+    iq = rng.integers(0, 256, size=max(n, 4) * bps, dtype=np.uint8)
+    out_g, out_o = convert_both(pkg, oracle, fmt, iq, n)
+    assert_blocks_equal(out_g, out_o)          # n = 0: both means are 0/0 = NaN (convert.c:105-109)
+    # either out pointer may be NULL (convert.c:104-110)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK)
+    mag = np.zeros(max(n, 1), dtype=np.uint16)
+    rc = pkg.capi.lib().msd_convert(dem._h, iq.ctypes.data, mag.ctypes.data, n, None, None)
+    assert rc == 0 and np.array_equal(mag[:n], out_o[0][0])
+    lvl = C.c_double()
+    assert pkg.capi.lib().msd_convert(dem._h, iq.ctypes.data, mag.ctypes.data, n, C.byref(lvl), None) == 0
+    assert np.array_equal(np.float64(lvl.value), np.float64(out_o[0][1]), equal_nan=True)
+
+
+def magbuf_feed(pkg, oracle, fmt, iq, n, nfix, mode_ac):
+    """What the reference's reader thread + consumer loop do with the two entries (sdr_ifile.c:187-216,
+    fifo.c:179-188, readsb.c:826-833): convert a block, put the previous tail in front, demodulate."""
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    conv = pkg.Demodulator(fmt=f, nfix_crc=nfix, max_batch_samples=CHUNK)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=CHUNK, message_capacity=1 << 15)
+    overlap = pkg.capi.OVERLAP
+    carry = np.zeros(overlap, dtype=np.uint16)
+    out, counter = [], 0
+    nblocks = n // CHUNK + 1                     # a capture ends with a short (possibly empty) block
+    for b in range(nblocks):
+        m = min(CHUNK, n - b * CHUNK)
+        part = iq[b * CHUNK * bps:(b * CHUNK + m) * bps]
+        mag, level, power = conv.convert(part if m else np.zeros(16, np.uint8), m)
+        data = np.concatenate([carry, mag])
+        ts = counter * 5                          # sampleCounter * 12e6 / 2.4e6
+        out.append(dem.demodulate_magbuf(data, overlap + m, overlap, ts, ts // 12000, level, power))
+        carry = data[-overlap:] if data.size >= overlap else carry
+        counter += m
+    return np.concatenate(out), dem.stats()
+
+
+@pytest.mark.parametrize("fmt,mode_ac,nfix", [("sc16q11", 1, 1), ("sc16", 0, 0), ("uc8", 1, 1)])
+def test_magbuf_entry_from_python(pkg, oracle, torch_cuda, fmt, mode_ac, nfix):
+    f, of = fmt_ids(pkg, oracle, fmt)
+    n = 5 * CHUNK + 4321
+    cfg = pkg.siggen.make_cfg(seed=77, fmt=f, msgs_per_sec=3000, n_aircraft=40, ac_per_sec=1500 if mode_ac else 0)
+    iq = pkg.siggen.generate(cfg, n)
+    got, gstats = magbuf_feed(pkg, oracle, fmt, iq, n, nfix, mode_ac)
+    want, wstats = oracle.Oracle(of, 58, nfix, mode_ac).replay(iq, cap=1 << 16)
+    assert len(want) > 100 and (not mode_ac or (want["msgtype"] == 32).sum() > 10)
+    assert_same_messages(got, want)
+    for k in ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_modeac",
+              "demod_preamblePhase", "demod_bestPhase"):
+        assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
