@@ -6,7 +6,12 @@
  * only; one context per receiver / GPU / host thread; no shared mutable globals (the reference
  * keeps this state in file statics: readsb.c:60 `Modes`, convert.c:33, icao_filter.c:38-40,
  * crc.c:84-88).  All functions return 0 or a negative errno-style code, never throw, and never
- * print; the last error text of a context is available from msd_last_error().
+ * print (the experiment switches MSD_RESOLVE_TRACE / MSD_KERNEL_TIMING of DESIGN.md 6.1 aside, which write
+ * timings to stderr when the caller sets them); the last error text of a context is available from
+ * msd_last_error(ctx), the reason of the calling thread's last failed msd_create from msd_last_error(NULL).
+ * After a batch could not be finished (msd_collect / msd_submit_* returned a negative code) the context
+ * accepts msd_reset() and msd_destroy() only; a failed msd_launch_* consumed nothing (samples reported
+ * with msd_note_dropped and a pending msd_restart still apply to the next launch).
  *
  * The library needs an AMD GPU (gfx950) at run time.  There is no CPU fallback: msd_create()
  * fails with -ENODEV when no device is present.
@@ -274,6 +279,7 @@ int msd_set_timing_interval(msd_ctx *ctx, uint32_t every);
  * max(PREAMBLE_THRESHOLD_PIZERO = 75, threshold) while its 15-minute statistics hold dropped samples
  * (demod_2400.c:285-290); that statistics window belongs to the host program, which calls this when
  * it opens and closes.  -EINVAL outside 1..255. */
+#define MSD_MAX_PREAMBLE_THRESHOLD 400 /* --preamble-threshold is clamped to 40..400, readsb.c:503-505 */
 int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
 
 /* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the

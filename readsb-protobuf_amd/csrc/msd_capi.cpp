@@ -211,6 +211,7 @@ struct msd_ctx {
     /* experiment knobs, read from the environment once in msd_create */
     bool trace = false;      /* MSD_RESOLVE_TRACE */
     bool repass_aux = false; /* MSD_REPASS_AUX */
+    bool resolve_inline = false; /* MSD_RESOLVE_INLINE: predict + resolve in order on the scan stream, records on their own */
     bool chain_inline = false; /* MSD_CHAIN_INLINE: resolve chain in order on the scan stream (the round-1 layout) */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
@@ -229,11 +230,16 @@ struct msd_ctx {
     std::vector<uint32_t> out_buf;
     int cu_count = 256;
     Helper helper;
+    bool failed = false;    /* a batch could not be finished: only msd_reset() / msd_destroy() are accepted */
     bool no_helper = false; /* MSD_NO_HELPER: everything on the calling thread */
     char err[256] = {0};
 };
 
 namespace {
+
+/* why the calling thread's last msd_create failed (there is no context to hold the text yet);
+ * msd_last_error(NULL) returns it */
+thread_local char g_create_err[256] = {0};
 
 int fail(msd_ctx *c, int code, const char *fmt, ...)
 {
@@ -789,7 +795,7 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     /* The scan stream carries scans (and their gathers) only, back to back.  Prediction + resolve run on
      * the high-priority chain stream behind the batch's own scan (ev_totals), power + records on a third
      * one behind the resolve: they share the GPU with the next batch's scan instead of delaying it. */
-    hipStream_t ks = c->chain_inline ? c->stream : c->aux_stream;
+    hipStream_t ks = (c->chain_inline || c->resolve_inline) ? c->stream : c->aux_stream;
     hipStream_t es = c->chain_inline ? c->stream : c->emit_stream;
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (rc)
@@ -857,7 +863,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
-        hipStream_t ps = (c->repass_aux || !c->chain_inline) ? c->aux_stream : c->stream;
+        hipStream_t ps = (c->repass_aux || !(c->chain_inline || c->resolve_inline)) ? c->aux_stream : c->stream;
         rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
@@ -1138,6 +1144,8 @@ int check_batch(msd_ctx *c, const void *p, uint64_t nsamples, int last)
 {
     if (!c)
         return -EINVAL;
+    if (c->failed)
+        return -EIO;
     if (c->finished)
         return fail(c, -EINVAL, "capture already finished; call msd_reset()");
     if (nsamples > c->cfg.max_batch_samples || nsamples > MSD_MAX_BATCH_SAMPLES)
@@ -1187,8 +1195,12 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.tail_dst = nsamples >= (uint64_t)TAIL_SAMPLES ? c->d_tail[tail_nxt] : nullptr;
     auto tl0 = std::chrono::steady_clock::now();
     rc = enqueue(c, s, c->scan_format, nullptr);
-    if (rc) {
+    if (rc) { /* nothing was consumed: the dropped samples and a pending restart wait for the next launch */
         s.busy = false;
+        c->pending_dropped += s.dropped_before;
+        c->restart_pending = c->restart_pending || s.reset_before;
+        s.dropped_before = 0;
+        s.reset_before = false;
         return rc;
     }
     if (c->trace) {
@@ -1225,10 +1237,17 @@ int collect(msd_ctx *c, msd_message_fn sink, void *user)
 {
     if (!c)
         return -EINVAL;
+    if (c->failed)
+        return -EIO; /* msd_last_error() still says why; msd_reset() starts over */
     if (c->outstanding == 0)
         return fail(c, -ENODATA, "no batch outstanding");
     Slot &s = c->slots[c->head];
     int rc = finish(c, s, c->scan_format, sink, user, nullptr, nullptr, s.batch_first / MSD_CHUNK_SAMPLES);
+    if (rc < 0) { /* the batch is lost and the filter / clocks are in an unknown state: the context refuses further
+                     batches until msd_reset() */
+        c->failed = true;
+        s.busy = false;
+    }
     c->head = (c->head + 1) % MSD_PIPELINE_DEPTH;
     c->outstanding--;
     return rc;
@@ -1336,8 +1355,12 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         return -EINVAL;
     *out = nullptr;
     if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
-        cfg->preamble_threshold <= 0 || ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16))
+        cfg->preamble_threshold < 1 || cfg->preamble_threshold > MSD_MAX_PREAMBLE_THRESHOLD ||
+        ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16)) {
+        snprintf(g_create_err, sizeof g_create_err, "msd_create: invalid configuration");
         return -EINVAL;
+    }
+    g_create_err[0] = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return -ENODEV; /* no GPU: there is deliberately no CPU fallback */
@@ -1362,7 +1385,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     do {                                                                      \
         hipError_t e_ = (call);                                               \
         if (e_ != hipSuccess) {                                               \
-            fprintf(stderr, "msd_create: %s: %s\n", #call, hipGetErrorString(e_)); \
+            snprintf(g_create_err, sizeof g_create_err, "msd_create: %s: %s", #call, hipGetErrorString(e_)); \
             destroy(c);                                                       \
             return -EIO;                                                      \
         }                                                                     \
@@ -1383,7 +1406,10 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
-        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, greatest));
+        /* MSD_EMIT_PRIORITY (experiment): 0 = lowest, 1 = default, 2 = highest (default) */
+        const char *ep = getenv("MSD_EMIT_PRIORITY");
+        const int eprio = ep && *ep == '0' ? least : (ep && *ep == '1' ? (least + greatest) / 2 : greatest);
+        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, eprio));
     }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
@@ -1486,6 +1512,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
         { const char *ci = getenv("MSD_CHAIN_INLINE"); c->chain_inline = ci && *ci && *ci != '0'; }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
+        { const char *ri = getenv("MSD_RESOLVE_INLINE"); c->resolve_inline = ri && *ri && *ri != '0'; }
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);
@@ -1547,16 +1574,26 @@ void msd_destroy(msd_ctx *ctx)
 
 const char *msd_last_error(const msd_ctx *ctx)
 {
-    return ctx ? ctx->err : "null context";
+    return ctx ? ctx->err : g_create_err; /* NULL: why this thread's last msd_create failed */
 }
 
 int msd_reset(msd_ctx *c)
 {
     if (!c)
         return -EINVAL;
-    if (c->outstanding)
+    if (c->outstanding && !c->failed)
         return fail(c, -EBUSY, "batches outstanding");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->failed) { /* drop whatever was in flight when a batch failed */
+        HIPCHK(c, hipDeviceSynchronize());
+        for (Slot &s : c->slots) {
+            s.busy = false;
+            s.resolve_inflight = false;
+        }
+        c->head = 0;
+        c->outstanding = 0;
+        c->failed = false;
+    }
     c->next_sample = 0;
     c->have_prev = false;
     c->finished = false;
@@ -1619,6 +1656,8 @@ int msd_note_dropped(msd_ctx *c, uint64_t nsamples)
 {
     if (!c)
         return -EINVAL;
+    if (c->failed)
+        return -EIO;
     if (c->finished)
         return fail(c, -EINVAL, "capture already finished; call msd_reset()");
     if (nsamples) {
@@ -1641,8 +1680,8 @@ int msd_set_preamble_threshold(msd_ctx *c, int threshold)
 {
     if (!c)
         return -EINVAL;
-    if (threshold < 1 || threshold > 255)
-        return fail(c, -EINVAL, "preamble threshold %d outside 1..255", threshold);
+    if (threshold < 1 || threshold > MSD_MAX_PREAMBLE_THRESHOLD)
+        return fail(c, -EINVAL, "preamble threshold %d outside 1..%d", threshold, MSD_MAX_PREAMBLE_THRESHOLD);
     c->cfg.preamble_threshold = threshold;
     return 0;
 }

@@ -149,7 +149,7 @@ typedef struct msd_acc {
  *      MSD_SL_GLONG[g][v]  syndrome of a 112-bit message that is zero but for group g = v
  *      MSD_SL_GSHORT[g][v] same for a 56-bit message (groups past the end contribute nothing). */
 #define MSD_SL_GLONG 0u
-#define MSD_SL_GLONG_ROWS 23u
+#define MSD_SL_GLONG_ROWS 25u
 #define MSD_SL_GSHORT (MSD_SL_GLONG + 32u * MSD_SL_GLONG_ROWS)
 #define MSD_SL_GSHORT_ROWS 13u
 #define MSD_SL_QOFF (MSD_SL_GSHORT + 32u * MSD_SL_GSHORT_ROWS)

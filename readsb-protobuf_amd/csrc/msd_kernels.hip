@@ -273,7 +273,9 @@ __device__ __forceinline__ void wave_lds_sync()
 /* One correlator of demod_2400.c:73-93 on the samples at LDS byte address p: is the bit a one?
  * (`18 m0 - 15 m1 - 3 m2 > 0` and so on, with the negative terms moved to the other side.)  The
  * samples are read one by one on purpose: p is only 2-byte aligned, and a misaligned ds_read_b32/b64
- * -- which the compiler would merge them into -- is replayed lane by lane on gfx950 (measured: 9x). */
+ * -- which the compiler would merge them into -- is replayed lane by lane on gfx950 (measured: 9x).
+ * (Loading them straight into the halves of packed pairs for v_dot2_u32_u16 does not work here: with
+ * SRAM ECC a ds_read_u16_d16_hi zeroes the other half of its destination instead of keeping it.) */
 template <int C>
 __device__ __forceinline__ bool corr_is_one(const unsigned char *p)
 {
@@ -412,41 +414,43 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     }
     wave_lds_sync();
 
-    /* ---- step B: item = (slot, groups 2 it + 1 and 2 it + 2); a short message has 6 items (bits 5..55,
-     * the last one holds a single bit), a long one 11 (bits 5..111, the last one holds seven) ---- */
+    /* ---- step B: item = (slot, four consecutive groups from 4 it + 1 on); a short message has 3 items
+     * (bits 5..55: the last one holds 11 bits), a long one 6 (bits 5..111: the last one holds 7) ---- */
     if (!(P.debug_flags & 4)) {
-        const uint32_t short_items = 6u * ns, nitems = short_items + 11u * nl;
+        const uint32_t short_items = 3u * ns, nitems = short_items + 6u * nl;
         for (uint32_t i0 = 0; i0 < nitems; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool act = i < nitems;
             const bool lng = i >= short_items;
             const uint32_t j = act ? (lng ? i - short_items : i) : 0u;
-            const uint32_t t = (j * (lng ? 5958u : 10923u)) >> 16; /* j / 11 or j / 6 (j < 704) */
-            const uint32_t it = j - t * (lng ? 11u : 6u);
+            const uint32_t t = (j * (lng ? 10923u : 21846u)) >> 16; /* j / 6 or j / 3 (j < 384) */
+            const uint32_t it = j - t * (lng ? 6u : 3u);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
-            const uint32_t pos = me & 0x1fffu, q = (me >> 13) & 7u;
+            const uint32_t pos = me & 0x3ffu, q = (me >> 13) & 7u;
             const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
-            const uint32_t g1 = 2u * it + 1u;
+            const uint32_t g1 = 4u * it + 1u;
             const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
             const unsigned char *a[5];
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 a[c] = base + ((qoff >> (6 * c)) & 63u);
-            const uint32_t c1 = group_verdicts<0>(a), c2 = group_verdicts<24>(a);
-            uint32_t val = ((uint32_t)perm[q * 32u + c1] << 5) | perm[q * 32u + c2];
-            if (it == (lng ? 10u : 5u))
-                val &= lng ? 0x3f8u : 0x200u; /* bits past the end of the message */
+            const uint8_t *pq = perm + q * 32u;
+            const uint32_t v0 = pq[group_verdicts<0>(a)], v1 = pq[group_verdicts<24>(a)];
+            const uint32_t v2 = pq[group_verdicts<48>(a)], v3 = pq[group_verdicts<72>(a)];
+            uint32_t val = (v0 << 15) | (v1 << 10) | (v2 << 5) | v3; /* message bits 5 g1 .. 5 g1 + 19 */
+            if (it == (lng ? 5u : 2u))
+                val &= lng ? 0xfe000u : 0xffe00u; /* bits past the end of the message */
             if (act) {
-                const uint32_t gbase = (lng ? MSD_SL_GLONG : MSD_SL_GSHORT) + 32u * g1;
-                const uint32_t syn = X.sl[gbase + (val >> 5)] ^ X.sl[gbase + 32u + (val & 31u)];
+                const uint32_t *gt = X.sl + (lng ? MSD_SL_GLONG : MSD_SL_GSHORT) + 32u * g1;
+                const uint32_t syn = gt[val >> 15] ^ gt[32u + ((val >> 10) & 31u)] ^ gt[64u + ((val >> 5) & 31u)] ^
+                                     gt[96u + (val & 31u)];
                 atomicXor(&scrc[u], syn);
                 /* message bit n lives in bit 31 - (n & 31) of word n >> 5 until step C */
-                const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << 22;
+                const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << 12;
                 atomicOr(&smsg32[4u * u + (n0 >> 5)], top >> s);
-                const uint32_t spill = __builtin_amdgcn_alignbit(top, 0u, s); /* top << (32 - s), 0 if s == 0 */
-                if (s > 22u)
-                    atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], spill);
+                if (s > 12u)
+                    atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], __builtin_amdgcn_alignbit(top, 0u, s)); /* top << (32 - s) */
             }
         }
     }

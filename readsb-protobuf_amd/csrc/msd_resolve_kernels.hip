@@ -23,8 +23,14 @@
 
 namespace {
 
-constexpr int RT = 512;    /* threads per workgroup (one workgroup per buffer) */
-constexpr int SEG = 1024;  /* hits staged per segment */
+#ifndef MSD_RESOLVE_WG
+#define MSD_RESOLVE_WG 512
+#endif
+#ifndef MSD_RESOLVE_SEG
+#define MSD_RESOLVE_SEG 1024
+#endif
+constexpr int RT = MSD_RESOLVE_WG;   /* threads per workgroup (one workgroup per buffer) */
+constexpr int SEG = MSD_RESOLVE_SEG; /* hits staged per segment */
 constexpr uint32_t VACANT = 0xFFFFFFFFu;
 constexpr uint32_t SLOTS = 8192u;
 
@@ -147,7 +153,7 @@ __device__ __forceinline__ uint32_t pred_lookup(const uint32_t *key, const uint3
     }
 }
 
-constexpr uint32_t TCAP = 2048;   /* tries staged per segment; a segment is cut short where they would not fit */
+constexpr uint32_t TCAP = 2 * SEG; /* tries staged per segment; a segment is cut short where they would not fit */
 constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
 
