@@ -285,7 +285,7 @@ int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
 /* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the
  * oldest outstanding batch, runs the ordered resolve and delivers its messages.  At most
  * MSD_PIPELINE_DEPTH batches may be outstanding. ---- */
-#define MSD_PIPELINE_DEPTH 3
+#define MSD_PIPELINE_DEPTH 4
 int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
 int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
 /* msd_collect with the header fields next to every message; the context must have been created with

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmodes_hip.so")
 FMT_UC8, FMT_SC16, FMT_SC16Q11, FMT_MAG16 = 0, 1, 2, 3
 CHUNK = 131072
 OVERLAP = 326
-PIPELINE_DEPTH = 3
+PIPELINE_DEPTH = 4
 
 MESSAGE_DTYPE = np.dtype(
     [

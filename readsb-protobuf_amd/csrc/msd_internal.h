@@ -33,9 +33,13 @@ extern "C" {
 #endif
 #define MSD_SCAN_THREADS (64 * MSD_SCAN_WAVES)
 #ifndef MSD_LUT_GLOBAL
-#define MSD_LUT_GLOBAL 0 /* 1: read the UC8 table through the vector cache instead of LDS */
+#define MSD_LUT_GLOBAL 1 /* 1: the UC8 table is read through the vector cache (34 KB, L1/L2-resident; measured as fast
+                            as the LDS copy inside the full kernel, and it leaves the LDS to the wavefronts' tiles);
+                            0: a copy in LDS (needs MSD_TILE 1024) */
 #endif
-#define MSD_TILE 1024u /* scan positions per wavefront tile: 16 per lane */
+#ifndef MSD_TILE
+#define MSD_TILE 2048u /* scan positions per wavefront tile: 2048 (two runs of 16 per lane) or 1024 */
+#endif
 #define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */
 #define MSD_MAX_BATCH_SAMPLES (1ull << 28) /* hit positions are 28-bit, batch-relative */
 

@@ -60,13 +60,14 @@ constexpr int WAVES = MSD_SCAN_WAVES; /* wavefronts per workgroup, one workgroup
 constexpr int NT = MSD_SCAN_THREADS;
 constexpr int WT = MSD_TILE;          /* 1024 scan positions per wavefront tile, 16 per lane */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
-constexpr int GPT = WT / 8 / 64;      /* 8-sample load groups per lane per tile (2) */
+constexpr int NH = WT / 1024;         /* runs of 16 consecutive positions per lane and tile */
+constexpr int GPT = WT / 8 / 64;      /* 8-sample load groups per lane per tile (2 per run) */
 constexpr int HC = 64;                /* hits per candidate round: one per lane */
 constexpr int SC = 64;                /* tries with a known DF per round: one per lane in step C; a round
                                          that would need more is retried with half the hits */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
-static_assert(WT == 64 * 16, "each lane scans 16 consecutive positions");
+static_assert(WT == 64 * 16 * NH && (NH == 1 || NH == 2), "each lane scans NH runs of 16 consecutive positions");
 static_assert(WT % (8 * 64) == 0 && FRONT % 8 == 0, "whole load groups");
 static_assert(MSD_CHUNK_SAMPLES % WT == 0, "a tile never straddles two buffers");
 
@@ -427,7 +428,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             const uint32_t it = j - t * (lng ? 6u : 3u);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
-            const uint32_t pos = me & 0x3ffu, q = (me >> 13) & 7u;
+            const uint32_t pos = me & (uint32_t)(WT - 1), q = (me >> 13) & 7u;
             const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
             const uint32_t g1 = 4u * it + 1u;
             const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
@@ -584,7 +585,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
      * arithmetic in the loop: pw_mod = the sum modulo 2^32 (v_dot2_u32_u16 of a sample pair with itself
      * wraps), pw_top = the sum of (m >> 5)^2, which fits (2047^2 * 256 < 2^32) and brackets the true
      * sum: 1024 * pw_top <= sum < 1024 * pw_top + 256 * (64 * 2047 * 31 + 31^2) < 1024 * pw_top + 2^31.
-     * power_sum() puts the two together when the buffer changes or after 16 tiles. */
+     * power_sum() puts the two together when the buffer changes or after 256 samples per lane. */
     uint32_t pw_mod = 0, pw_top = 0, sum_tiles = 0;
     uint64_t sum_chunk = (uint64_t)tile_lo * WT / MSD_CHUNK_SAMPLES;
     auto flush_sums = [&]() {
@@ -636,7 +637,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
         {
             const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
-            if (c != sum_chunk || sum_tiles == 16) { /* wave-uniform */
+            if (c != sum_chunk || sum_tiles == 16 / NH) { /* wave-uniform */
                 flush_sums();
                 sum_chunk = c;
             }
@@ -684,82 +685,94 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         wave_lds_sync();
 
         if (!(P.debug_flags & 2)) {
-            /* ---- stage 2: preamble tests for my 16 consecutive positions (demod_2400.c:257-335) ---- */
-            uint32_t v[20];
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(mags + 16 * lane);
+            /* ---- stage 2: preamble tests for my NH runs of 16 consecutive positions (demod_2400.c:257-335) ---- */
+            /* one bit plane per test and run, position q at bit 15 - q */
+            uint32_t pl0[NH], pl1[NH], pl2[NH], any[NH], cnt[NH], rank0[NH];
+            uint32_t H = 0;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const uint4 q = src[k];
-                    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            for (int h = 0; h < NH; ++h) {
+                uint32_t v[20];
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(mags + 1024 * h + 16 * lane);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const uint4 q = src[k];
+                        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+                    }
                 }
-            }
-            /* all 36 samples this lane's 16 positions touch, unpacked once */
-            int sm[40];
+                /* all 36 samples this run's 16 positions touch, unpacked once */
+                int sm[40];
 #pragma unroll
-            for (int k = 0; k < 20; ++k) {
-                sm[2 * k] = (int)(v[k] & 0xffffu);
-                sm[2 * k + 1] = (int)(v[k] >> 16);
-            }
-            /* one bit plane per test, position q at bit 15 - q */
-            uint32_t pl0 = 0, pl1 = 0, pl2 = 0;
+                for (int k = 0; k < 20; ++k) {
+                    sm[2 * k] = (int)(v[k] & 0xffffu);
+                    sm[2 * k + 1] = (int)(v[k] >> 16);
+                }
+                uint32_t p0 = 0, p1 = 0, p2 = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                /* pa[d] = mags[p + 2 + d].  Branch-free on purpose: with 64 lanes some lane almost
-                 * always passes the pre-check, so a branch only adds exec-mask bookkeeping. */
+                for (int q = 0; q < 16; ++q) {
+                    /* pa[d] = mags[p + 2 + d].  Branch-free on purpose: with 64 lanes some lane almost
+                     * always passes the pre-check, so a branch only adds exec-mask bookkeeping. */
 #define PA(d) (sm[q + 2 + (d)])
-                const uint64_t pre = __ballot(PA(1) > PA(7)) & __ballot(PA(12) > PA(14)) & __ballot(PA(12) > PA(15));
-                const uint32_t base_noise = (uint32_t)(PA(5) + PA(8) + PA(16) + PA(17) + PA(18));
-                const int ref_level = (int)(__umul24(base_noise, (uint32_t)P.threshold) >> 5); /* < 2^24 each */
-                const int diff_2_3 = PA(2) - PA(3);
-                const int sum_1_4 = PA(1) + PA(4);
-                const int diff_10_11 = PA(10) - PA(11);
-                const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
-                const uint64_t f0 = pre & __ballot(common3456 - diff_10_11 >= ref_level);
-                const uint64_t f1 = pre & __ballot(common3456 + diff_10_11 >= ref_level);
-                const uint64_t f2 = pre & __ballot(sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level);
+                    const uint64_t pre = __ballot(PA(1) > PA(7)) & __ballot(PA(12) > PA(14)) & __ballot(PA(12) > PA(15));
+                    const uint32_t base_noise = (uint32_t)(PA(5) + PA(8) + PA(16) + PA(17) + PA(18));
+                    const int ref_level = (int)(__umul24(base_noise, (uint32_t)P.threshold) >> 5); /* < 2^24 each */
+                    const int diff_2_3 = PA(2) - PA(3);
+                    const int sum_1_4 = PA(1) + PA(4);
+                    const int diff_10_11 = PA(10) - PA(11);
+                    const int common3456 = sum_1_4 - diff_2_3 + PA(9) + PA(12);
+                    const uint64_t f0 = pre & __ballot(common3456 - diff_10_11 >= ref_level);
+                    const uint64_t f1 = pre & __ballot(common3456 + diff_10_11 >= ref_level);
+                    const uint64_t f2 = pre & __ballot(sum_1_4 + 2 * diff_2_3 + diff_10_11 + PA(12) >= ref_level);
 #undef PA
-                MSD_PUSH(pl0, f0);
-                MSD_PUSH(pl1, f1);
-                MSD_PUSH(pl2, f2);
-            }
-            /* positions past the last one the reference scans */
-            {
-                const uint64_t first = a0 + 16ull * lane;
-                if (first + 16 > batch_end) {
-                    const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
-                    const uint32_t km = keep ? ~((1u << (16 - keep)) - 1u) : 0u;
-                    pl0 &= km;
-                    pl1 &= km;
-                    pl2 &= km;
+                    MSD_PUSH(p0, f0);
+                    MSD_PUSH(p1, f1);
+                    MSD_PUSH(p2, f2);
                 }
-            }
-            const uint32_t any = pl0 | pl1 | pl2;
+                /* positions past the last one the reference scans */
+                {
+                    const uint64_t first = a0 + 1024ull * h + 16ull * lane;
+                    if (first + 16 > batch_end) {
+                        const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
+                        const uint32_t km = keep ? ~((1u << (16 - keep)) - 1u) : 0u;
+                        p0 &= km;
+                        p1 &= km;
+                        p2 &= km;
+                    }
+                }
+                pl0[h] = p0;
+                pl1[h] = p1;
+                pl2[h] = p2;
+                any[h] = p0 | p1 | p2;
 
-            /* ---- stage 3: ranks of my hits among the wavefront's (position order) ---- */
-            const uint32_t cnt = (uint32_t)__popc(any);
-            const uint32_t incl = wave_incl_scan(cnt);
-            const uint32_t H = wave_last(incl);
+                /* ---- stage 3: ranks of my hits among the wavefront's (position order: run, lane, bit) ---- */
+                cnt[h] = (uint32_t)__popc(any[h]);
+                const uint32_t incl = wave_incl_scan(cnt[h]);
+                rank0[h] = H + incl - cnt[h];
+                H += wave_last(incl);
+            }
 
             if (!(P.debug_flags & 1) && H) {
                 /* ---- stage 4: candidate rounds of up to HC hits ---- */
-                const uint32_t my_rank0 = incl - cnt;
                 uint32_t r0 = 0;
                 bool fill = true;
                 uint32_t nh = (H < (uint32_t)HC) ? H : (uint32_t)HC;
                 while (r0 < H) {
                     if (fill) {
-                        if (cnt && my_rank0 < r0 + HC && my_rank0 + cnt > r0) {
-                            /* my hits with rank in [r0, r0 + HC) -> hitl, in position order */
-                            uint32_t x = any, r = my_rank0;
-                            while (x) {
-                                const int bit = 31 - __clz((int)x); /* highest bit = lowest position */
-                                x &= ~(1u << bit);
-                                if (r >= r0 && r < r0 + HC) {
-                                    const uint32_t m = ((pl0 >> bit) & 1u) | (((pl1 >> bit) & 1u) << 1) | (((pl2 >> bit) & 1u) << 2);
-                                    hitl[r - r0] = (uint32_t)(16 * lane + (15 - bit)) | (m << 13);
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            if (cnt[h] && rank0[h] < r0 + HC && rank0[h] + cnt[h] > r0) {
+                                /* my hits with rank in [r0, r0 + HC) -> hitl, in position order */
+                                uint32_t x = any[h], r = rank0[h];
+                                while (x) {
+                                    const int bit = 31 - __clz((int)x); /* highest bit = lowest position */
+                                    x &= ~(1u << bit);
+                                    if (r >= r0 && r < r0 + HC) {
+                                        const uint32_t m = ((pl0[h] >> bit) & 1u) | (((pl1[h] >> bit) & 1u) << 1) |
+                                                           (((pl2[h] >> bit) & 1u) << 2);
+                                        hitl[r - r0] = (uint32_t)(1024 * h + 16 * lane + (15 - bit)) | (m << 13);
+                                    }
+                                    ++r;
                                 }
-                                ++r;
                             }
                         }
                         wave_lds_sync();
@@ -1084,9 +1097,10 @@ __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanPar
         return;
     const uint32_t b = blockIdx.x / PB_WGS, nm = nmsgs[b];
     const int lane = threadIdx.x & 63;
-    /* three messages per trip, so that their record, sample and table loads overlap: the kernel is a chain
-     * of dependent loads (record -> IQ bytes -> magnitude table) and nothing else */
-    constexpr uint32_t PER = 3, STEP = 4 * PB_WGS;
+    /* six messages per trip, so that their record, sample and table loads overlap: the kernel is a chain
+     * of dependent loads (record -> IQ bytes -> magnitude table) and nothing else; a buffer's ~70 messages
+     * are one trip for its PB_WGS x 4 wavefronts */
+    constexpr uint32_t PER = 6, STEP = 4 * PB_WGS;
     for (uint32_t m0 = (blockIdx.x % PB_WGS) * 4 + (threadIdx.x >> 6); m0 < nm; m0 += PER * STEP) {
         msd_acc rec[PER];
 #pragma unroll
@@ -1109,16 +1123,19 @@ __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanPar
         }
 #pragma unroll
         for (uint32_t u = 0; u < PER; ++u) {
-            unsigned long long sum = 0;
+            /* the sum of at most 320 squares < 2^32 as two 32-bit sums (low and high halves of the squares),
+             * each reduced over the wavefront with DPP adds: no 64-bit shuffles through the LDS */
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
-            for (int v = 0; v < 5; ++v)
-                sum += (unsigned long long)(x[u][v] * x[u][v]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                sum += __shfl_down(sum, o);
+            for (int v = 0; v < 5; ++v) {
+                const uint32_t sq = x[u][v] * x[u][v];
+                lo += sq & 0xffffu;
+                hi += sq >> 16;
+            }
+            const uint32_t lo_all = wave_last(wave_incl_scan(lo)), hi_all = wave_last(wave_incl_scan(hi));
             const uint32_t m = m0 + u * STEP;
             if (lane == 0 && m < nm)
-                out[(size_t)b * MSD_RB_MSG_CAP + m] = sum;
+                out[(size_t)b * MSD_RB_MSG_CAP + m] = (unsigned long long)lo_all + ((unsigned long long)hi_all << 16);
         }
     }
 }
