@@ -355,7 +355,8 @@ size_t bps_of(int format)
 /* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
 int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
-    const uint64_t ntiles64 = (s.nsamples + MSD_TILE - 1) / MSD_TILE;
+    const uint64_t tile = msd_scan_tile(format);
+    const uint64_t ntiles64 = (s.nsamples + tile - 1) / tile;
     const uint32_t ntiles = (uint32_t)ntiles64;
     /* one region per wavefront: MSD_SCAN_WAVES per CU */
     uint32_t target_wg = c->max_wg;
@@ -392,10 +393,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.tries = c->d_region_tries;
         /* a tile can never produce more than one hit per position and five tries per hit */
         uint64_t hcap = c->hit_arena / nwg, tcap = c->try_arena / nwg;
-        if (hcap > (uint64_t)tpw * MSD_TILE)
-            hcap = (uint64_t)tpw * MSD_TILE;
-        if (tcap > (uint64_t)tpw * MSD_TILE * 5)
-            tcap = (uint64_t)tpw * MSD_TILE * 5;
+        if (hcap > (uint64_t)tpw * tile)
+            hcap = (uint64_t)tpw * tile;
+        if (tcap > (uint64_t)tpw * tile * 5)
+            tcap = (uint64_t)tpw * tile * 5;
         p.hcap = (uint32_t)hcap;
         p.tcap = (uint32_t)tcap;
         p.counts = c->d_counts;

@@ -17,7 +17,7 @@ typedef struct MsdScanParams {
     int threshold;            /* Modes.preambleThreshold */
     uint64_t batch_first;     /* absolute index of iq[0]; multiple of MSD_CHUNK_SAMPLES */
     uint64_t nsamples;
-    uint32_t ntiles;       /* tiles of MSD_TILE scan positions */
+    uint32_t ntiles;       /* tiles of msd_scan_tile(format) scan positions */
     uint32_t tiles_per_wg; /* tiles per region (= per wavefront of the scan kernel) */
     const uint16_t *lut;
     const uint32_t *crc_tab;
@@ -96,6 +96,7 @@ int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned
                     msd_fields *fields /* NULL: no field decode */, uint32_t cap, hipStream_t stream);
 /* the field decoder of the emit kernel on its own: out[i] = fields of in[i] (device pointers) */
 int msd_launch_fields(const msd_message *d_in, msd_fields *d_out, uint32_t n, hipStream_t stream);
+uint32_t msd_scan_tile(int format); /* scan positions per tile of the scan kernel for this sample format */
 size_t msd_scan_lds_bytes(int format);
 /* nregions wavefronts, MSD_SCAN_WAVES per workgroup */
 int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipStream_t stream);

@@ -58,26 +58,30 @@ namespace {
 
 constexpr int WAVES = MSD_SCAN_WAVES; /* wavefronts per workgroup, one workgroup per CU */
 constexpr int NT = MSD_SCAN_THREADS;
-constexpr int WT = MSD_TILE;          /* 1024 scan positions per wavefront tile, 16 per lane */
+constexpr int WT_MAX = MSD_TILE;      /* scan positions per wavefront tile: 16 per lane and run, see tile_runs() */
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
-constexpr int NH = WT / 1024;         /* runs of 16 consecutive positions per lane and tile */
-constexpr int GPT = WT / 8 / 64;      /* 8-sample load groups per lane per tile (2 per run) */
+/* runs of 16 consecutive positions per lane and tile: two for the byte formats; the 16-bit IQ formats hold
+ * twice the raw data per sample in registers (current and prefetched tile) and stay at one */
+__host__ __device__ constexpr int tile_runs(int fmt)
+{
+    return (fmt == MSD_FMT_SC16 || fmt == MSD_FMT_SC16Q11) ? 1 : WT_MAX / 1024;
+}
 constexpr int HC = 64;                /* hits per candidate round: one per lane */
 constexpr int SC = 64;                /* tries with a known DF per round: one per lane in step C; a round
                                          that would need more is retried with half the hits */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
-static_assert(WT == 64 * 16 * NH && (NH == 1 || NH == 2), "each lane scans NH runs of 16 consecutive positions");
-static_assert(WT % (8 * 64) == 0 && FRONT % 8 == 0, "whole load groups");
-static_assert(MSD_CHUNK_SAMPLES % WT == 0, "a tile never straddles two buffers");
+static_assert(WT_MAX == 1024 || WT_MAX == 2048, "each lane scans one or two runs of 16 consecutive positions");
+static_assert(FRONT % 8 == 0, "whole load groups");
+static_assert(MSD_CHUNK_SAMPLES % WT_MAX == 0, "a tile never straddles two buffers");
 
 /* ---- dynamic LDS: tables shared by the workgroup, one private block per wavefront, the UC8 table ---- */
 constexpr int OFF_SYN = 0;                                  /* u32[160] */
 constexpr int OFF_SL = OFF_SYN + 640;                       /* u32[MSD_SLICER_WORDS] */
 constexpr int OFF_WGC = OFF_SL + MSD_SLICER_WORDS * 4;      /* u32[WAVES][4]: the regions' counts, at the end */
 constexpr int OFF_WAVE = (OFF_WGC + WAVES * 16 + 15) & ~15;
-constexpr int W_MAGS = 0;                                   /* u16[FRONT + WT + 8] */
-constexpr int W_HITS = W_MAGS + (FRONT + WT + 8) * 2;       /* u32[HC]: position | tests << 13 */
+constexpr int W_MAGS = 0;                                   /* u16[FRONT + WT_MAX + 8] */
+constexpr int W_HITS = W_MAGS + (FRONT + WT_MAX + 8) * 2;   /* u32[HC]: position | tests << 13 */
 constexpr int W_TRYL = W_HITS + HC * 4;                     /* u16[5 * HC]: hit | q << 8 */
 constexpr int W_SIDX = W_TRYL + HC * 5 * 2;                 /* u16[HC][8]: slot of try (hit, q), 0xffff = none */
 constexpr int W_SMETA = W_SIDX + HC * 8 * 2;                /* u32[SC] */
@@ -428,7 +432,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             const uint32_t it = j - t * (lng ? 6u : 3u);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
-            const uint32_t pos = me & (uint32_t)(WT - 1), q = (me >> 13) & 7u;
+            const uint32_t pos = me & (uint32_t)(WT_MAX - 1), q = (me >> 13) & 7u;
             const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
             const uint32_t g1 = 4u * it + 1u;
             const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
@@ -565,12 +569,14 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     return true;
 }
 
-/* One wavefront's share of the batch: the tiles [tile_lo, tile_hi) of WT scan positions each. */
+/* One wavefront's share of the batch: the tiles [tile_lo, tile_hi) of 1024 * tile_runs(FMT) scan positions each. */
 template <int FMT, bool FIX2>
 __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCtx &X, const uint16_t *lut,
                                             uint32_t region, uint32_t tile_lo, uint32_t tile_hi, uint32_t &hits_total,
                                             uint32_t &tries_total)
 {
+    constexpr int NH = tile_runs(FMT), WT = 1024 * NH; /* scan positions per tile */
+    constexpr int GPT = WT / 8 / 64;                   /* 8-sample load groups per lane per tile (2 per run) */
     const int lane = X.lane;
     uint16_t *mags = reinterpret_cast<uint16_t *>(X.w + W_MAGS);
     uint32_t *hitl = reinterpret_cast<uint32_t *>(X.w + W_HITS);
@@ -1791,6 +1797,11 @@ __global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts 
 /* ------------------------------------------------------------------------------------------ */
 /* launchers (C linkage, used by msd_capi.cpp)                                                */
 /* ------------------------------------------------------------------------------------------ */
+
+extern "C" uint32_t msd_scan_tile(int format)
+{
+    return 1024u * (uint32_t)tile_runs(format);
+}
 
 extern "C" size_t msd_scan_lds_bytes(int format)
 {
