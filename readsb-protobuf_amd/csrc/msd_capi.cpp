@@ -113,7 +113,7 @@ struct Slot {
     uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
     msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
-    hipEvent_t ev_resolve = nullptr, ev_records = nullptr;
+    hipEvent_t ev_resolve = nullptr, ev_records = nullptr, ev_power = nullptr;
     /* batch description */
     const uint8_t *d_iq = nullptr;
     const uint8_t *d_prev = nullptr;
@@ -211,8 +211,9 @@ struct msd_ctx {
     /* experiment knobs, read from the environment once in msd_create */
     bool trace = false;      /* MSD_RESOLVE_TRACE */
     bool repass_aux = false; /* MSD_REPASS_AUX */
+    bool emit_side_only = false; /* MSD_EMIT_SIDE_ONLY: everything in order on the scan stream but the record kernel */
     bool resolve_inline = false; /* MSD_RESOLVE_INLINE: predict + resolve in order on the scan stream, records on their own */
-    bool chain_inline = false; /* MSD_CHAIN_INLINE: resolve chain in order on the scan stream (the round-1 layout) */
+    bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
@@ -737,16 +738,21 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
 
 /* message records and signal power of every buffer on `ks` (device memory); ev_records marks the
  * end.  The host fetches them with one DMA once it knows how many there are (fetch_records). */
-int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ks)
+int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t ks)
 {
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
     MsdScanParams p{};
     fill_params(c, s, p);
+    /* the signal power on `ps`, the records on `ks` behind it */
     int rc = msd_launch_power_buffers(&p, format, s.d_acc, s.d_tries, s.d_nmsgs, s.nbuffers, s.d_totals,
-                                      reinterpret_cast<unsigned long long *>(s.d_powr), ks);
+                                      reinterpret_cast<unsigned long long *>(s.d_powr), ps);
     if (rc)
         return fail(c, rc, "power kernel launch failed");
+    if (ps != ks) {
+        HIPCHK(c, hipEventRecord(s.ev_power, ps));
+        HIPCHK(c, hipStreamWaitEvent(ks, s.ev_power, 0));
+    }
     rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr),
                          c->records_dma ? s.d_wire : s.h_wire, c->want_fields ? s.h_fields : nullptr,
                          (uint32_t)s.req_cap, ks);
@@ -796,8 +802,9 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     /* The scan stream carries scans (and their gathers) only, back to back.  Prediction + resolve run on
      * the high-priority chain stream behind the batch's own scan (ev_totals), power + records on a third
      * one behind the resolve: they share the GPU with the next batch's scan instead of delaying it. */
-    hipStream_t ks = (c->chain_inline || c->resolve_inline) ? c->stream : c->aux_stream;
+    hipStream_t ks = (c->chain_inline || c->resolve_inline || c->emit_side_only) ? c->stream : c->aux_stream;
     hipStream_t es = c->chain_inline ? c->stream : c->emit_stream;
+    hipStream_t pws = c->emit_side_only ? c->stream : es; /* the signal power kernel */
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (rc)
         return rc;
@@ -806,9 +813,9 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
-        if (es != ks)
-            HIPCHK(c, hipStreamWaitEvent(es, s.ev_resolve, 0));
-        rc = gpu_queue_emit(c, s, format, es);
+        if (pws != ks)
+            HIPCHK(c, hipStreamWaitEvent(pws, s.ev_resolve, 0));
+        rc = gpu_queue_emit(c, s, format, pws, es);
     }
     if (rc)
         return rc;
@@ -864,7 +871,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
-        hipStream_t ps = (c->repass_aux || !(c->chain_inline || c->resolve_inline)) ? c->aux_stream : c->stream;
+        hipStream_t ps = (c->repass_aux || !(c->chain_inline || c->resolve_inline || c->emit_side_only)) ? c->aux_stream : c->stream;
         rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
@@ -894,7 +901,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     if (!records_current && total) {
         if (!c->chain_inline) /* behind the last pass (or, if only the arrays grew, behind nothing new) */
             HIPCHK(c, hipStreamWaitEvent(rs, wait_for, 0));
-        int rc = gpu_queue_emit(c, s, format, rs);
+        int rc = gpu_queue_emit(c, s, format, rs, rs);
         if (rc)
             return rc;
     }
@@ -1297,6 +1304,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_dcmag); (void)hipFree(s.d_magsq);
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
+        if (s.ev_power) (void)hipEventDestroy(s.ev_power);
         if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
         (void)hipFree(s.d_upload);
         (void)hipFree(s.d_wire);
@@ -1511,8 +1519,13 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
         c->resolver.trace = c->trace;
         c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
-        { const char *ci = getenv("MSD_CHAIN_INLINE"); c->chain_inline = ci && *ci && *ci != '0'; }
+        /* Default: the whole chain in order on the scan stream.  MSD_CHAIN_INLINE=0 moves prediction + resolve
+         * to a high-priority stream and power + records to a third one; that overlaps them with the next scan
+         * (+3..7 % whole-job rate, measured) but every co-running kernel slows the scan by about its own
+         * duration, so the scan kernel's own launches get 10-15 % longer. */
+        { const char *ci = getenv("MSD_CHAIN_INLINE"); c->chain_inline = !(ci && *ci == '0'); }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
+        { const char *eo = getenv("MSD_EMIT_SIDE_ONLY"); c->emit_side_only = eo && *eo && *eo != '0'; }
         { const char *ri = getenv("MSD_RESOLVE_INLINE"); c->resolve_inline = ri && *ri && *ri != '0'; }
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
@@ -1543,6 +1556,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             memset(s.h_ctl, 0, ctl_bytes);
             CK(hipEventCreateWithFlags(&s.ev_resolve, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&s.ev_records, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&s.ev_power, hipEventDisableTiming));
         }
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));

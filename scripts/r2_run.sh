@@ -12,6 +12,6 @@ benchq) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OU
 timing) (cd readsb-protobuf_amd/csrc && MSD_EXTRA_DEFS=-DMSD_KERNEL_TIMING bash build.sh > /dev/null 2>&1); MSD_KERNEL_TIMING=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/timing.json 2> $OUT/timing.err; grep "section cycles" $OUT/timing.err; (cd readsb-protobuf_amd/csrc && bash build.sh > /dev/null 2>&1);;
 ablate) for f in ${ABL:-0 4 1 2}; do echo -n "flags=$f: "; MSD_DEBUG_FLAGS=$f timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'])"; done;;
 variant) # build with $VDEFS, quick bench (scan stream alone: MSD_CHAIN_INLINE), rebuild default
-  (cd readsb-protobuf_amd/csrc && MSD_EXTRA_DEFS="$VDEFS" bash build.sh > /dev/null 2>&1); for f in ${ABL:-0}; do echo -n "[$VDEFS] flags=$f: "; MSD_CHAIN_INLINE=$INL MSD_DEBUG_FLAGS=$f timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'])"; done; (cd readsb-protobuf_amd/csrc && bash build.sh > /dev/null 2>&1);;
+  (cd readsb-protobuf_amd/csrc && MSD_EXTRA_DEFS="$VDEFS" bash build.sh > /dev/null 2>&1); for f in ${ABL:-0}; do echo -n "[$VDEFS] flags=$f: "; MSD_CHAIN_INLINE=${INL:-1} MSD_DEBUG_FLAGS=$f timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'])"; done; (cd readsb-protobuf_amd/csrc && bash build.sh > /dev/null 2>&1);;
 esac
 done
