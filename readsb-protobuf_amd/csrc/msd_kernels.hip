@@ -273,46 +273,44 @@ __device__ __forceinline__ void wave_lds_sync()
 
 /* `plane = 2 * plane + verdict` for every lane in one v_addc_co_u32: the verdicts of the wavefront are a
  * lane mask in scalar registers (v_cmp), used as the carry-in */
-#define MSD_PUSH(PLANE, MASK) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(PLANE) : "s"(MASK) : "vcc")
+#define MSD_PUSH(PLANE, MASK) asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(PLANE) : "s"(MASK) : "vcc")
 
-/* One correlator of demod_2400.c:73-93 on the samples at LDS byte address p: is the bit a one?
- * (`18 m0 - 15 m1 - 3 m2 > 0` and so on, with the negative terms moved to the other side.)  The
- * samples are read one by one on purpose: p is only 2-byte aligned, and a misaligned ds_read_b32/b64
- * -- which the compiler would merge them into -- is replayed lane by lane on gfx950 (measured: 9x).
- * (Loading them straight into the halves of packed pairs for v_dot2_u32_u16 does not work here: with
- * SRAM ECC a ds_read_u16_d16_hi zeroes the other half of its destination instead of keeping it.) */
-template <int C>
-__device__ __forceinline__ bool corr_is_one(const unsigned char *p)
+/* The five correlators of demod_2400.c:73-93 on one 5-bit group: correlator c looks at three (c == 4:
+ * four) consecutive samples from LDS byte address a[c] + EXTRA; is its bit a one?  (`18 m0 - 15 m1 -
+ * 3 m2 > 0` and so on, with the negative terms moved to the other side.)  Returns the five verdicts,
+ * correlator 0 in bit 4; EXTRA = 24 bytes per further group of the same try (12 samples hold exactly
+ * five bits, so every group repeats the same five (correlator, offset) pairs).
+ * The samples are read one by one on purpose: the addresses are only 2-byte aligned, and a misaligned
+ * ds_read_b32/b64 -- which the compiler would merge them into -- is replayed lane by lane on gfx950
+ * (measured: 9x).  All sixteen loads are issued before the first verdict is worked out, so a group
+ * costs one LDS latency, not five.  (Loading the samples straight into the halves of packed pairs for
+ * v_dot2_u32_u16 does not work here: with SRAM ECC a ds_read_u16_d16_hi zeroes the other half of its
+ * destination instead of keeping it.) */
+template <int EXTRA>
+__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5])
 {
     /* (an explicit LDS pointer: the compiler does not infer the address space of a volatile access and
      * would emit flat loads) */
     typedef __attribute__((address_space(3))) const volatile uint16_t lds_sample;
-    lds_sample *m = (lds_sample *)p;
-    const uint32_t s0 = m[0], s1 = m[1], s2 = m[2];
-    if (C == 0) return 18u * s0 > 15u * s1 + 3u * s2;
-    if (C == 1) return 14u * s0 > 5u * s1 + 9u * s2;
-    if (C == 2) return 16u * s0 + 5u * s1 > 20u * s2;
-    if (C == 3) return 7u * s0 + 11u * s1 > 18u * s2;
-    const uint32_t s3 = m[3];
-    return 4u * s0 + 15u * s1 + s3 > 20u * s2;
-}
-
-/* The five correlator verdicts of one 5-bit group (correlator 0 in bit 4); a[c] = LDS address of
- * correlator c's first tap for the try's first group of this call, EXTRA = 24 bytes per further group
- * (12 samples hold exactly five bits, so every group repeats the same five (correlator, offset) pairs). */
-template <int EXTRA>
-__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5])
-{
+    uint32_t m[5][4];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        lds_sample *p = (lds_sample *)(a[c] + EXTRA);
+        m[c][0] = p[0];
+        m[c][1] = p[1];
+        m[c][2] = p[2];
+        m[c][3] = c == 4 ? p[3] : 0u;
+    }
     uint32_t code = 0;
-    const uint64_t b0 = __ballot(corr_is_one<0>(a[0] + EXTRA));
+    const uint64_t b0 = __ballot(18u * m[0][0] > 15u * m[0][1] + 3u * m[0][2]);
     MSD_PUSH(code, b0);
-    const uint64_t b1 = __ballot(corr_is_one<1>(a[1] + EXTRA));
+    const uint64_t b1 = __ballot(14u * m[1][0] > 5u * m[1][1] + 9u * m[1][2]);
     MSD_PUSH(code, b1);
-    const uint64_t b2 = __ballot(corr_is_one<2>(a[2] + EXTRA));
+    const uint64_t b2 = __ballot(16u * m[2][0] + 5u * m[2][1] > 20u * m[2][2]);
     MSD_PUSH(code, b2);
-    const uint64_t b3 = __ballot(corr_is_one<3>(a[3] + EXTRA));
+    const uint64_t b3 = __ballot(7u * m[3][0] + 11u * m[3][1] > 18u * m[3][2]);
     MSD_PUSH(code, b3);
-    const uint64_t b4 = __ballot(corr_is_one<4>(a[4] + EXTRA));
+    const uint64_t b4 = __ballot(4u * m[4][0] + 15u * m[4][1] + m[4][3] > 20u * m[4][2]);
     MSD_PUSH(code, b4);
     return code;
 }
