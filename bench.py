@@ -168,13 +168,15 @@ def main():
     # scripts/pmc_traffic.sh; the summary is committed under profiles/).  FETCH_SIZE is doubled as
     # MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as is.
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile) and args.format == "uc8":
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+    tfile = os.path.join(ROOT, "profiles", tfiles[-1]) if tfiles else ""  # the latest round's measurement
+    if tfile and args.format == "uc8":
         t = json.load(open(tfile))
         if t.get("samples_per_launch") == launch_samples:
             traffic = int((2 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
     roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC, %s)" % (os.path.basename(tfile) if traffic else "not measured for this workload"),
                 "algorithmic_bytes_per_launch": launch_samples * bps, "kernel": "msd_scan_kernel",
                 "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
                 "algorithmic_bytes_per_sample": bps, "launches_timed": len(scan_ms), "launches": len(timings)}

@@ -67,8 +67,12 @@ typedef struct msd_message {
 /* msd_config.flags */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
-                                   374-423).  Their state and float sums run through the stream strictly in order,
-                                   which bounds this mode at about 0.1 Gsamples/s; not with MSD_FMT_MAG16 */
+                                   374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums
+                                   run through the stream strictly in order -- one dependent float chain per channel
+                                   -- which bounds it at 0.064 Gsamples/s measured (27x real time for one receiver;
+                                   one host core runs the same recurrence about ten times faster).  It exists so
+                                   that the option is there behind the same stream interface; not with
+                                   MSD_FMT_MAG16 */
 
 /* Header fields of an accepted message: what decodeModesMessage assigns after its CRC switch without
  * looking into the ME / MB payloads (mode_s.c:557-715, decodeAC13Field / decodeID13Field :101-183), and

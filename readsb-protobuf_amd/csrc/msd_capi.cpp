@@ -1519,11 +1519,19 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
         c->resolver.trace = c->trace;
         c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
-        /* Default: the whole chain in order on the scan stream.  MSD_CHAIN_INLINE=0 moves prediction + resolve
-         * to a high-priority stream and power + records to a third one; that overlaps them with the next scan
-         * (+3..7 % whole-job rate, measured) but every co-running kernel slows the scan by about its own
-         * duration, so the scan kernel's own launches get 10-15 % longer. */
-        { const char *ci = getenv("MSD_CHAIN_INLINE"); c->chain_inline = !(ci && *ci == '0'); }
+        /* Where the resolve chain (prediction, resolve, power, records) runs.  In order on the
+         * scan stream when that stream carries nothing but scans (UC8 / magnitudes, Mode S only): a kernel that
+         * shares the GPU with a scan slows it by about its own duration, so side streams buy 2 % there and make
+         * the scan launches 15 % longer.  On side streams (prediction + resolve on a high-priority one, power +
+         * records on a third) when the scan stream also carries the latency-bound float-sum or Mode A/C
+         * kernels, which the chain overlaps well: +13..17 % whole-job rate, measured.  MSD_CHAIN_INLINE=0/1
+         * overrides. */
+        {
+            const char *ci = getenv("MSD_CHAIN_INLINE");
+            const bool follow_ups = cfg->mode_ac || cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11 ||
+                                    (cfg->flags & MSD_CFG_DC_FILTER);
+            c->chain_inline = ci && *ci ? *ci != '0' : !follow_ups;
+        }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
         { const char *eo = getenv("MSD_EMIT_SIDE_ONLY"); c->emit_side_only = eo && *eo && *eo != '0'; }
         { const char *ri = getenv("MSD_RESOLVE_INLINE"); c->resolve_inline = ri && *ri && *ri != '0'; }
