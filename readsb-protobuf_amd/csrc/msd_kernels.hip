@@ -30,6 +30,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "msd_internal.h"
 #include "msd_kernels.h"
 
@@ -1366,6 +1368,241 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
         out[2 * b + (tid >> 6)] = sum;
 }
 
+/* ---- the same sums with the whole workgroup working on them ----
+ * msd_float_means_kernel leaves a buffer's two sums to one wavefront each, 128 blocks of 1024 elements one
+ * after the other.  A block's 1024 elements are ONE function of the same S -> S + c(S mod 2) form (the
+ * ordered composition of its lanes' functions), valid while the sum stays in the binade the function was
+ * built for -- and the binade at the start of a block can be predicted: the sums only grow, so an ordinary
+ * (unordered, approximate) prefix sum of the blocks' totals tells the exponent of the exact sum at every
+ * block boundary unless that sum sits within rounding of a power of two.  So:
+ *   pass 1  all eight wavefronts: approximate total of every block (level and power)
+ *   prefix  predicted exponent at the start of every block; blocks inside which the exponent changes
+ *           (about one per binade the sum passes through) and the first ones (tiny sums) are "slow"
+ *   pass 2  all eight wavefronts: the composite function (c0, c1) of every other block under its
+ *           predicted exponent
+ *   apply   one wavefront per sum walks the 128 blocks in order: a block whose prediction holds (exponent
+ *           as predicted, result still inside the binade) is one add; slow blocks and mispredictions are
+ *           summed exactly with fsum_block.  Bit-identical to the sequential sum by construction: every
+ *           shortcut is verified against the exact state before it is used. */
+constexpr int FB_MAX = 128; /* blocks of FS_BLOCK elements per buffer (MSD_CHUNK_SAMPLES / 1024) */
+
+/* the block's elements in fsum_block's layout: lane L holds elements 16 L .. 16 L + 15 */
+template <int FMT, bool APPROX /* the native square root: good enough to predict a binade */>
+__device__ __forceinline__ void fm_block_values(const uint32_t *src, uint32_t n, uint32_t blk, int lane, float inv,
+                                                float (&lvl)[FS_PER], float (&pwr)[FS_PER])
+{
+    const uint32_t g0 = blk * FS_BLOCK + (uint32_t)lane * FS_PER;
+    uint32_t w[FS_PER];
+    if (g0 + FS_PER <= n) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(src + g0);
+#pragma unroll
+        for (int k = 0; k < FS_PER / 4; ++k) {
+            const uint4 v = q[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k)
+            w[k] = g0 + k < n ? src[g0 + k] : 0u; /* past the end: zero samples add nothing */
+    }
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k) {
+        float m = 0.0f, magsq = 0.0f;
+        if (FMT == MSD_FMT_MAGSQ) { /* --dcfilter: the clamped squares msd_dcfilter_kernel left */
+            magsq = g0 + k < n ? __uint_as_float(w[k]) : 0.0f;
+            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : __builtin_sqrtf(magsq);
+        } else if (g0 + k < n) {
+            const int I = (int)(int16_t)(w[k] & 0xffffu), Q = (int)(int16_t)(w[k] >> 16);
+            const float fi = (float)I * inv, fq = (float)Q * inv;
+            const float sq_i = fi * fi, sq_q = fq * fq;
+            magsq = sq_i + sq_q;
+            if (magsq > 1.0f)
+                magsq = 1.0f;
+            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : __builtin_sqrtf(magsq);
+        }
+        lvl[k] = m;
+        pwr[k] = magsq;
+    }
+}
+
+/* the composite function of the wavefront's 1024 elements for a sum with exponent e: increment of S for an
+ * even / odd S in front of the block; FS_SAT or more = "leaves the binade" (all lanes return it) */
+__device__ __forceinline__ void fsum_block_function(const float (&x)[FS_PER], int e, int lane, uint32_t &f0, uint32_t &f1)
+{
+    uint32_t base[FS_PER], tie[FS_PER];
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k)
+        fsum_element(__float_as_uint(x[k]), e, base[k], tie[k]);
+    uint32_t c0 = 0, c1 = 1;
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k) {
+        c0 += base[k] + ((tie[k] >> (~c0 & 1u)) & 1u);
+        c1 += base[k] + ((tie[k] >> (~c1 & 1u)) & 1u);
+    }
+    c1 -= 1u;
+    c0 = min(c0, FS_SAT);
+    c1 = min(c1, FS_SAT);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { /* ordered composition: (lanes .. L-d) then (L-d+1 .. L) */
+        const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
+        if (lane >= d) {
+            const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
+            c0 = min(n0, FS_SAT);
+            c1 = min(n1, FS_SAT);
+        }
+    }
+    f0 = (uint32_t)__shfl((int)c0, 63, 64);
+    f1 = (uint32_t)__shfl((int)c1, 63, 64);
+}
+
+/* The same for a block without ties, with the adder itself: for a sum with exponent e >= 1 (so that no
+ * element, x <= 1, can lift it out of its binade on its own) and unit u = 2^(e-23), what an element adds is
+ * a + [f > 1/2] + [f == 1/2 and the sum in front of it is odd], x / u = a + f.  fl(2^e + x) - 2^e is that
+ * for an even sum, fl((2^e + u) + x) - (2^e + u) for an odd one (both differences are exact); they differ
+ * exactly when the element is a tie.  Without a tie in the block its function is "add the total", an
+ * integer sum.  Returns false (wave-uniform) if some element is a tie: the caller then builds the general
+ * function.  total is clamped so that 64 of them fit; anything >= 2^24 means "leaves the binade". */
+__device__ __forceinline__ bool fsum_block_total(const float (&x)[FS_PER], int e, uint32_t &total)
+{
+    const float A = __uint_as_float((uint32_t)(e + 127) << 23);        /* 2^e */
+    const float B = __uint_as_float(((uint32_t)(e + 127) << 23) | 1u); /* 2^e + u */
+    const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23); /* 1 / u */
+    uint32_t mine = 0;
+    bool tie = false;
+#pragma unroll
+    for (int k = 0; k < FS_PER; ++k) {
+        const float t0 = (A + x[k]) - A, t1 = (B + x[k]) - B;
+        tie |= t0 != t1;
+        mine += (uint32_t)(t0 * scale);
+    }
+    if (__ballot(tie))
+        return false;
+    total = wave_last(wave_incl_scan(min(mine, 1u << 25)));
+    return true;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
+                                                                      uint64_t buffer_len, uint32_t nbuffers,
+                                                                      float *out /* [nbuffers][2] */)
+{
+    __shared__ float blk_tot[2][FB_MAX];    /* approximate totals, then approximate prefix at the block's start */
+    __shared__ uint32_t blk_f0[2][FB_MAX], blk_f1[2][FB_MAX];
+    __shared__ int blk_e[2][FB_MAX];        /* predicted exponent at the block's start; INT_MIN: slow block */
+    const uint32_t b = blockIdx.x;
+    if (b >= nbuffers)
+        return;
+    const uint64_t first = (uint64_t)b * buffer_len;
+    uint64_t n64 = nsamples > first ? nsamples - first : 0;
+    if (n64 > buffer_len)
+        n64 = buffer_len;
+    const uint32_t n = (uint32_t)n64;
+    const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = FM_THREADS / 64;
+    const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK; /* <= FB_MAX: buffer_len <= MSD_CHUNK_SAMPLES */
+    constexpr int SLOW = -2147483647 - 1;
+
+    /* pass 1 */
+    for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
+        float lvl[FS_PER], pwr[FS_PER];
+        fm_block_values<FMT, true>(src, n, blk, lane, inv, lvl, pwr);
+        float sl = 0.0f, sp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k) {
+            sl += lvl[k];
+            sp += pwr[k];
+        }
+        sl = wave_sum_f32(sl);
+        sp = wave_sum_f32(sp);
+        if (lane == 0) {
+            blk_tot[0][blk] = sl;
+            blk_tot[1][blk] = sp;
+        }
+    }
+    __syncthreads();
+    /* prefix: thread 0 level, thread 64 power (128 dependent adds: nothing next to the rest) */
+    if (lane == 0 && wave < 2) {
+        float run = 0.0f;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const float tot = blk_tot[wave][blk], next = run + tot;
+            const int e0 = (int)(__float_as_uint(run) >> 23) - 127, e1 = (int)(__float_as_uint(next) >> 23) - 127;
+            /* a block inside which the sum changes its exponent, or whose sum is still tiny, is summed exactly;
+             * so is a block that starts within 2^-12 of a power of two (the approximate prefix could be on the
+             * wrong side of it -- and if it still is, the apply loop notices) */
+            const uint32_t mant = __float_as_uint(run) & 0x7fffffu;
+            const bool near_edge = mant < 0x800u || mant > 0x7ff800u;
+            blk_e[wave][blk] = (e0 != e1 || e0 < -7 || near_edge || tot == 0.0f) ? SLOW : e0;
+            run = next;
+        }
+    }
+    __syncthreads();
+    /* pass 2 */
+    for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
+        const int el = blk_e[0][blk], ep = blk_e[1][blk];
+        if (el == SLOW && ep == SLOW)
+            continue; /* wave-uniform */
+        float lvl[FS_PER], pwr[FS_PER];
+        fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
+        if (el != SLOW) {
+            uint32_t f0, f1;
+            if (el >= 1 && fsum_block_total(lvl, el, f0))
+                f1 = f0;
+            else
+                fsum_block_function(lvl, el, lane, f0, f1);
+            if (lane == 0) {
+                blk_f0[0][blk] = f0;
+                blk_f1[0][blk] = f1;
+            }
+        }
+        if (ep != SLOW) {
+            uint32_t f0, f1;
+            if (ep >= 1 && fsum_block_total(pwr, ep, f0))
+                f1 = f0;
+            else
+                fsum_block_function(pwr, ep, lane, f0, f1);
+            if (lane == 0) {
+                blk_f0[1][blk] = f0;
+                blk_f1[1][blk] = f1;
+            }
+        }
+    }
+    __syncthreads();
+    /* apply: wavefront 0 the level sum, wavefront 1 the power sum */
+    if (wave < 2) {
+        float sum = 0.0f;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const int e = blk_e[wave][blk];
+            const uint32_t sb = __float_as_uint(sum);
+            bool fast = e != SLOW && (int)(sb >> 23) - 127 == e;
+            if (fast) {
+                const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+                const uint32_t S = S0 + ((S0 & 1u) ? blk_f1[wave][blk] : blk_f0[wave][blk]);
+                if (S < (1u << 24))
+                    sum = __uint_as_float((sb & 0xff800000u) | (S & 0x7fffffu));
+                else
+                    fast = false; /* left the binade after all */
+            }
+            if (!fast) { /* wave-uniform */
+                float lvl[FS_PER], pwr[FS_PER];
+                fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
+                sum = wave == 0 ? fsum_block(sum, lvl, lane) : fsum_block(sum, pwr, lane);
+            }
+        }
+        if (lane == 0)
+            out[2 * b + wave] = sum;
+    }
+}
+
 /* --dcfilter: the "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11).
  * Per channel z = f * dc_a + z * dc_b runs through the WHOLE stream (the converter state survives
  * the calls, convert.c:476-477), and a float recurrence cannot be re-associated bit-exactly, so this is
@@ -2019,6 +2256,21 @@ extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsa
 {
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
     const uint32_t grid = nbuffers; /* one workgroup per buffer */
+    static const bool v1 = getenv("MSD_FMEANS_V1") != nullptr; /* the one-wavefront-per-sum kernel, for comparison */
+    if (!v1 && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK) {
+        if (format == MSD_FMT_SC16)
+            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
+                               nsamples, buffer_len, nbuffers, d_out);
+        else if (format == MSD_FMT_SC16Q11)
+            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
+                               nsamples, buffer_len, nbuffers, d_out);
+        else if (format == MSD_FMT_MAGSQ) /* msd_launch_dc_sums */
+            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_MAGSQ>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
+                               nsamples, buffer_len, nbuffers, d_out);
+        else
+            return -22;
+        return hipGetLastError() == hipSuccess ? 0 : -5;
+    }
     if (format == MSD_FMT_SC16)
         hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
                            nsamples, buffer_len, nbuffers, d_out);
