@@ -127,3 +127,33 @@ def test_magbuf_entry_from_python(pkg, oracle, torch_cuda, fmt, mode_ac, nfix):
     for k in ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_modeac",
               "demod_preamblePhase", "demod_bestPhase"):
         assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
+
+
+@pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
+def test_sequential_float_sums_on_structured_inputs(pkg, oracle, torch_cuda, fmt):
+    """convert.c:228-252's sums are float and sequential; the kernel evaluates them block-parallel with
+    predicted binades and per-block functions.  Inputs chosen to sit on what that machinery has to get
+    right: constant blocks (every element the same, rounding ties in long runs), values that are exact
+    halves of the sum's unit, blocks of zeros between bursts, full scale (the sum races through the
+    binades), a ramp, and lengths that end inside a block."""
+    full = 32767 if fmt == "sc16" else 2047
+    rng = np.random.default_rng(11)
+    n = 131072
+    cases = {
+        "constant_small": np.full((n, 2), 3, dtype=np.int16),
+        "constant_mid": np.full((n, 2), full // 16, dtype=np.int16),
+        "full_scale": np.full((n, 2), full, dtype=np.int16),
+        "powers_of_two": np.stack([np.tile(np.array([1, 2, 4, 8, 16, 32, 64, 128], dtype=np.int16) * (full // 2048 + 1), n // 8),
+                                   np.zeros(n, dtype=np.int16)], axis=1),
+        "bursts": np.where((np.arange(n) // 3000 % 3 == 0)[:, None], rng.integers(-full, full, size=(n, 2)), 0).astype(np.int16),
+        "ramp": np.stack([(np.arange(n) % (2 * full) - full).astype(np.int16), np.zeros(n, dtype=np.int16)], axis=1),
+        "noise": rng.normal(0, full * 0.02, size=(n, 2)).round().astype(np.int16),
+    }
+    for name, iq16 in cases.items():
+        for length in (n, n - 1, 70000 + 513, 1025, 1023, 17):
+            iq = np.ascontiguousarray(iq16[:length]).view(np.uint8).reshape(-1)
+            out_g, out_o = convert_both(pkg, oracle, fmt, iq, length)
+            try:
+                assert_blocks_equal(out_g, out_o)
+            except AssertionError as e:
+                raise AssertionError(f"{name} length {length}: {e}")
