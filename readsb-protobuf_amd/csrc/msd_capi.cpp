@@ -181,7 +181,6 @@ struct msd_ctx {
     unsigned long long *d_timers = nullptr; /* MSD_KERNEL_TIMING experiments */
     /* GPU resolve stage: per-buffer reports, accepted-message records, filter snapshots, control arrays */
     bool gpu_resolve = false;
-    uint32_t *h_adds = nullptr; /* complete add lists, fetched only when a buffer needs them */
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
     uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
@@ -855,12 +854,11 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
                                         &s.resolve_ntodo);
-        if (rc == -2) { /* a flip, or very many new addresses in one buffer: the complete add lists are needed */
+        if (rc == -2) { /* a flip, or very many new addresses in one buffer: the complete add lists are needed.
+                           They are in pinned host memory already (the resolve kernel writes a buffer's ~60 addresses
+                           there itself; fetching the [buffer][1024] array cost a 2 MB copy per flip) */
             c->timing.resolve_long_lists++;
-            HIPCHK(c, hipMemcpyAsync(c->h_adds, s.d_adds, sizeof(uint32_t) * MSD_RB_MSG_CAP * n, hipMemcpyDeviceToHost,
-                                     c->aux_stream));
-            HIPCHK(c, hipStreamSynchronize(c->aux_stream));
-            rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, c->h_adds, c->inline_adds, pass, SNAP_CAP, c->h_pred,
+            rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, s.d_adds, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
                                         &s.resolve_ntodo);
         }
@@ -1296,7 +1294,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); (void)hipFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
+        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_wire) (void)hipHostFree(s.h_wire);
@@ -1322,7 +1320,6 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
     (void)hipFree(c->d_snaps);
-    if (c->h_adds) (void)hipHostFree(c->h_adds);
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
     if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
@@ -1552,7 +1549,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         for (Slot &s : c->slots) {
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_rbuf), sizeof(msd_rbuf) * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc), sizeof(msd_acc) * MSD_RB_MSG_CAP * c->max_buffers));
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
+            /* (page-locked host memory the kernels write into: see finish_gpu) */
+            CK(hipHostMalloc(reinterpret_cast<void **>(&s.d_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_nmsgs), sizeof(uint32_t) * c->max_buffers));
             if (cfg->mode_ac) {
                 CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc_ac), sizeof(uint32_t) * MSD_RB_AC_CAP * c->max_buffers));
@@ -1566,7 +1564,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipEventCreateWithFlags(&s.ev_records, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&s.ev_power, hipEventDisableTiming));
         }
-        CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_adds), sizeof(uint32_t) * MSD_RB_MSG_CAP * c->max_buffers));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming));
