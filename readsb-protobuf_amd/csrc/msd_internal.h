@@ -38,6 +38,9 @@ extern "C" {
                             0: a copy in LDS (needs MSD_TILE 1024) */
 #endif
 #ifndef MSD_TILE
+#ifndef MSD_SLICER_NG
+#define MSD_SLICER_NG 3 /* bit groups (of five bits) one lane slices per item of step B */
+#endif
 #define MSD_TILE 2048u /* scan positions per wavefront tile: 2048 (two runs of 16 per lane) or 1024 */
 #endif
 #define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */

@@ -419,42 +419,62 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     }
     wave_lds_sync();
 
-    /* ---- step B: item = (slot, four consecutive groups from 4 it + 1 on); a short message has 3 items
-     * (bits 5..55: the last one holds 11 bits), a long one 6 (bits 5..111: the last one holds 7) ---- */
+    /* ---- step B: item = (slot, NG consecutive groups from NG it + 1 on).  Groups 1..11 carry bits 5..55 of
+     * a short message (the last one one bit), groups 1..22 bits 5..111 of a long one (the last one two).
+     * NG groups = 24 NG bytes of samples per item: with NG = 3 the items of a try start 18 LDS banks apart,
+     * all on different banks (with four groups per item, 24 banks apart, every try collided with itself) ---- */
     if (!(P.debug_flags & 4)) {
-        const uint32_t short_items = 3u * ns, nitems = short_items + 6u * nl;
+        constexpr uint32_t NG = MSD_SLICER_NG, IS = (11 + NG - 1) / NG, IL = (22 + NG - 1) / NG;
+        constexpr uint32_t VB = 5 * NG; /* bits per item */
+        constexpr uint32_t LAST_S = 51 - VB * (IS - 1), LAST_L = 107 - VB * (IL - 1); /* bits of the last item */
+        constexpr uint32_t MASK_S = ((1u << LAST_S) - 1u) << (VB - LAST_S), MASK_L = ((1u << LAST_L) - 1u) << (VB - LAST_L);
+        const uint32_t short_items = IS * ns, nitems = short_items + IL * nl;
         for (uint32_t i0 = 0; i0 < nitems; i0 += 64) {
             const uint32_t i = i0 + (uint32_t)lane;
             const bool act = i < nitems;
             const bool lng = i >= short_items;
             const uint32_t j = act ? (lng ? i - short_items : i) : 0u;
-            const uint32_t t = (j * (lng ? 10923u : 21846u)) >> 16; /* j / 6 or j / 3 (j < 384) */
-            const uint32_t it = j - t * (lng ? 6u : 3u);
+            const uint32_t t = (j * (lng ? (65536u + IL - 1) / IL : (65536u + IS - 1) / IS)) >> 16; /* j / IL or j / IS (j < 1024) */
+            const uint32_t it = j - t * (lng ? IL : IS);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
             const uint32_t pos = me & (uint32_t)(WT_MAX - 1), q = (me >> 13) & 7u;
             const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
-            const uint32_t g1 = 4u * it + 1u;
+            const uint32_t g1 = NG * it + 1u;
             const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
             const unsigned char *a[5];
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 a[c] = base + ((qoff >> (6 * c)) & 63u);
             const uint8_t *pq = perm + q * 32u;
-            const uint32_t v0 = pq[group_verdicts<0>(a)], v1 = pq[group_verdicts<24>(a)];
-            const uint32_t v2 = pq[group_verdicts<48>(a)], v3 = pq[group_verdicts<72>(a)];
-            uint32_t val = (v0 << 15) | (v1 << 10) | (v2 << 5) | v3; /* message bits 5 g1 .. 5 g1 + 19 */
-            if (it == (lng ? 5u : 2u))
-                val &= lng ? 0xfe000u : 0xffe00u; /* bits past the end of the message */
+            uint32_t v[NG];
+            v[0] = pq[group_verdicts<0>(a)];
+            if (NG > 1) v[1 % NG] = pq[group_verdicts<24>(a)];
+            if (NG > 2) v[2 % NG] = pq[group_verdicts<48>(a)];
+            if (NG > 3) v[3 % NG] = pq[group_verdicts<72>(a)];
+            if (NG > 4) v[4 % NG] = pq[group_verdicts<96>(a)];
+            uint32_t val = 0; /* message bits 5 g1 .. 5 g1 + VB - 1 */
+#pragma unroll
+            for (uint32_t c = 0; c < NG; ++c)
+                val |= v[c] << (5u * (NG - 1u - c));
+            if (it == (lng ? IL - 1u : IS - 1u))
+                val &= lng ? MASK_L : MASK_S; /* bits past the end of the message */
             if (act) {
                 const uint32_t *gt = X.sl + (lng ? MSD_SL_GLONG : MSD_SL_GSHORT) + 32u * g1;
-                const uint32_t syn = gt[val >> 15] ^ gt[32u + ((val >> 10) & 31u)] ^ gt[64u + ((val >> 5) & 31u)] ^
-                                     gt[96u + (val & 31u)];
+                uint32_t syn = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < NG; ++c) {
+                    const uint32_t e = (val >> (5u * (NG - 1u - c))) & 31u;
+                    if (NG * IL <= 24u && NG * IS <= 12u)
+                        syn ^= gt[32u * c + e];
+                    else if (e) /* rows past the last group do not exist */
+                        syn ^= gt[32u * c + e];
+                }
                 atomicXor(&scrc[u], syn);
                 /* message bit n lives in bit 31 - (n & 31) of word n >> 5 until step C */
-                const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << 12;
+                const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << (32u - VB);
                 atomicOr(&smsg32[4u * u + (n0 >> 5)], top >> s);
-                if (s > 12u)
+                if (s > 32u - VB)
                     atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], __builtin_amdgcn_alignbit(top, 0u, s)); /* top << (32 - s) */
             }
         }

@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t out_short[MSD_RB_ADD_INLINE]; /* those the host must apply: not in the active table yet */
     __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
     __shared__ uint32_t okb[SEG / 32];  /* hits that would be accepted if nothing hides them */
-    __shared__ uint16_t ok_idx[SEG], ok_next[SEG], acc_k[SEG], add_first[SEG];
+    __shared__ uint16_t ok_idx[SEG], ok_next[SEG], acc_k[SEG];
+    uint16_t *const add_first = ok_next; /* per accepted message of a round; the chain walk is over by then */
     __shared__ uint32_t add_rank[ADDSET]; /* per address-set slot: rank of the first message of the round that adds it */
     __shared__ uint32_t ok_pos[SEG];
     __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
