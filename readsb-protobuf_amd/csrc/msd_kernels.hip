@@ -1484,17 +1484,21 @@ __device__ __forceinline__ void fsum_block_function(const float (&x)[FS_PER], in
  * function.  total is clamped so that 64 of them fit; anything >= 2^24 means "leaves the binade". */
 __device__ __forceinline__ bool fsum_block_total(const float (&x)[FS_PER], int e, uint32_t &total)
 {
-    const float A = __uint_as_float((uint32_t)(e + 127) << 23);        /* 2^e */
-    const float B = __uint_as_float(((uint32_t)(e + 127) << 23) | 1u); /* 2^e + u */
+    const float A = __uint_as_float((uint32_t)(e + 127) << 23);          /* 2^e */
+    const float half_u = __uint_as_float((uint32_t)(e - 24 + 127) << 23); /* u / 2 (e >= 1: normal) */
     const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23); /* 1 / u */
-    uint32_t mine = 0;
+    /* t = fl(2^e + x) - 2^e is x rounded to a multiple of u (ties to even = what an even sum does); x - t is
+     * exact, and the element is a tie exactly when it is +-u/2.  The t's are summed as floats: exact below
+     * 2^24 u, and a sum that reaches 2^24 u stays at or above it, which is all the caller needs to know. */
+    float acc = 0.0f;
     bool tie = false;
 #pragma unroll
     for (int k = 0; k < FS_PER; ++k) {
-        const float t0 = (A + x[k]) - A, t1 = (B + x[k]) - B;
-        tie |= t0 != t1;
-        mine += (uint32_t)(t0 * scale);
+        const float t = (A + x[k]) - A;
+        tie |= __builtin_fabsf(x[k] - t) == half_u;
+        acc += t;
     }
+    const uint32_t mine = (uint32_t)(acc * scale);
     if (__ballot(tie))
         return false;
     total = wave_last(wave_incl_scan(min(mine, 1u << 25)));
@@ -1509,6 +1513,12 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
+#ifdef MSD_FM_TIMERS
+__device__ unsigned long long msd_fm_cyc[8]; /* pass 1, prefix, pass 2, apply (100 MHz ticks, workgroup sums); slow blocks, blocks, workgroups */
+#define FM_T(k) if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&msd_fm_cyc[k], n_ - t_last); t_last = n_; }
+#else
+#define FM_T(k)
+#endif
 template <int FMT>
 __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
                                                                       uint64_t buffer_len, uint32_t nbuffers,
@@ -1531,16 +1541,46 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
     constexpr int NWV = FM_THREADS / 64;
     const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK; /* <= FB_MAX: buffer_len <= MSD_CHUNK_SAMPLES */
     constexpr int SLOW = -2147483647 - 1;
+#ifdef MSD_FM_TIMERS
+    unsigned long long t_last = wall_clock64();
+#endif
 
-    /* pass 1 */
+    /* pass 1: approximate totals.  I^2 + Q^2 is one v_dot2 on the packed sample (an exact integer; the float
+     * path rounds each square and the sum -- a relative 2^-23 that a prediction does not care about) */
     for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
-        float lvl[FS_PER], pwr[FS_PER];
-        fm_block_values<FMT, true>(src, n, blk, lane, inv, lvl, pwr);
         float sl = 0.0f, sp = 0.0f;
+        if (FMT == MSD_FMT_MAGSQ) {
+            float lvl[FS_PER], pwr[FS_PER];
+            fm_block_values<FMT, true>(src, n, blk, lane, inv, lvl, pwr);
 #pragma unroll
-        for (int k = 0; k < FS_PER; ++k) {
-            sl += lvl[k];
-            sp += pwr[k];
+            for (int k = 0; k < FS_PER; ++k) {
+                sl += lvl[k];
+                sp += pwr[k];
+            }
+        } else {
+            const uint32_t g0 = blk * FS_BLOCK + (uint32_t)lane * FS_PER;
+            uint32_t w[FS_PER];
+            if (g0 + FS_PER <= n) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(src + g0);
+#pragma unroll
+                for (int k = 0; k < FS_PER / 4; ++k) {
+                    const uint4 v = q[k];
+                    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < FS_PER; ++k)
+                    w[k] = g0 + k < n ? src[g0 + k] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < FS_PER; ++k) {
+                typedef short short2_t __attribute__((ext_vector_type(2)));
+                const short2_t v = __builtin_bit_cast(short2_t, w[k]);
+                const uint32_t d = (uint32_t)__builtin_amdgcn_sdot2(v, v, 0, false); /* <= 2^31 */
+                const float magsq = fminf((float)d * (inv * inv), 1.0f);
+                sl += __builtin_amdgcn_sqrtf(magsq);
+                sp += magsq;
+            }
         }
         sl = wave_sum_f32(sl);
         sp = wave_sum_f32(sp);
@@ -1550,22 +1590,36 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
         }
     }
     __syncthreads();
-    /* prefix: thread 0 level, thread 64 power (128 dependent adds: nothing next to the rest) */
-    if (lane == 0 && wave < 2) {
-        float run = 0.0f;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            const float tot = blk_tot[wave][blk], next = run + tot;
+    FM_T(0)
+    /* prefix (approximate, any order): wavefront 0 the levels, wavefront 1 the powers; lane L has blocks 2 L
+     * and 2 L + 1 */
+    if (wave < 2) {
+        const uint32_t b0 = 2u * (uint32_t)lane, b1 = b0 + 1u;
+        const float t0 = b0 < nblk ? blk_tot[wave][b0] : 0.0f, t1 = b1 < nblk ? blk_tot[wave][b1] : 0.0f;
+        float incl = t0 + t1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float up = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += up;
+        }
+        const float run0 = incl - (t0 + t1) < 0.0f ? 0.0f : incl - (t0 + t1);
+        const float runs[2] = {run0, run0 + t0}, tots[2] = {t0, t1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float run = runs[j], next = run + tots[j];
             const int e0 = (int)(__float_as_uint(run) >> 23) - 127, e1 = (int)(__float_as_uint(next) >> 23) - 127;
             /* a block inside which the sum changes its exponent, or whose sum is still tiny, is summed exactly;
              * so is a block that starts within 2^-12 of a power of two (the approximate prefix could be on the
              * wrong side of it -- and if it still is, the apply loop notices) */
             const uint32_t mant = __float_as_uint(run) & 0x7fffffu;
             const bool near_edge = mant < 0x800u || mant > 0x7ff800u;
-            blk_e[wave][blk] = (e0 != e1 || e0 < -7 || near_edge || tot == 0.0f) ? SLOW : e0;
-            run = next;
+            if (b0 + j < nblk)
+                blk_e[wave][b0 + j] = (e0 != e1 || e0 < -7 || near_edge || tots[j] == 0.0f) ? SLOW : e0;
         }
     }
     __syncthreads();
+    FM_T(1)
     /* pass 2 */
     for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
         const int el = blk_e[0][blk], ep = blk_e[1][blk];
@@ -1597,22 +1651,41 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
         }
     }
     __syncthreads();
+    FM_T(2)
     /* apply: wavefront 0 the level sum, wavefront 1 the power sum */
     if (wave < 2) {
+        /* the blocks' predictions and functions in registers, lane L: blocks L and L + 64; the walk then reads
+         * them with v_readlane instead of three dependent LDS loads per block */
+        int re[2];
+        uint32_t rf0[2], rf1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t blk = (uint32_t)lane + 64u * j;
+            re[j] = blk < nblk ? blk_e[wave][blk] : SLOW;
+            rf0[j] = blk < nblk ? blk_f0[wave][blk] : 0u;
+            rf1[j] = blk < nblk ? blk_f1[wave][blk] : 0u;
+        }
         float sum = 0.0f;
         for (uint32_t blk = 0; blk < nblk; ++blk) {
-            const int e = blk_e[wave][blk];
+            const int hi = blk >= 64u, l = (int)(blk & 63u);
+            const int e = __builtin_amdgcn_readlane(hi ? re[1] : re[0], l);
+            const uint32_t bf0 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf0[1] : rf0[0]), l);
+            const uint32_t bf1 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf1[1] : rf1[0]), l);
             const uint32_t sb = __float_as_uint(sum);
             bool fast = e != SLOW && (int)(sb >> 23) - 127 == e;
             if (fast) {
                 const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
-                const uint32_t S = S0 + ((S0 & 1u) ? blk_f1[wave][blk] : blk_f0[wave][blk]);
+                const uint32_t S = S0 + ((S0 & 1u) ? bf1 : bf0);
                 if (S < (1u << 24))
                     sum = __uint_as_float((sb & 0xff800000u) | (S & 0x7fffffu));
                 else
                     fast = false; /* left the binade after all */
             }
             if (!fast) { /* wave-uniform */
+#ifdef MSD_FM_TIMERS
+                if (lane == 0)
+                    atomicAdd(&msd_fm_cyc[4], 1ull);
+#endif
                 float lvl[FS_PER], pwr[FS_PER];
                 fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
                 sum = wave == 0 ? fsum_block(sum, lvl, lane) : fsum_block(sum, pwr, lane);
@@ -1621,7 +1694,27 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
         if (lane == 0)
             out[2 * b + wave] = sum;
     }
+#ifdef MSD_FM_TIMERS
+    __syncthreads();
+    FM_T(3)
+    if (tid == 0) {
+        atomicAdd(&msd_fm_cyc[5], 2ull * nblk);
+        atomicAdd(&msd_fm_cyc[6], 1ull);
+    }
+#endif
 }
+
+#ifdef MSD_FM_TIMERS
+extern "C" void msd_fm_report(void)
+{
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(msd_fm_cyc), sizeof h) != hipSuccess || !h[6])
+        return;
+    const double w = (double)h[6];
+    fprintf(stderr, "float means, mean us per workgroup: pass 1 %.1f, prefix %.1f, pass 2 %.1f, apply %.1f; slow blocks %.2f of %.0f per buffer\n",
+            h[0] / w / 100, h[1] / w / 100, h[2] / w / 100, h[3] / w / 100, h[4] / w, h[5] / w);
+}
+#endif
 
 /* --dcfilter: the "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11).
  * Per channel z = f * dc_a + z * dc_b runs through the WHOLE stream (the converter state survives
