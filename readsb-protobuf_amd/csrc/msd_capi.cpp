@@ -126,6 +126,8 @@ struct Slot {
     msd_hit *d_hits = nullptr;
     msd_try *d_tries = nullptr;
     uint64_t *d_totals = nullptr;
+    uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
+    bool buf_first_valid = false;
     uint64_t *d_sums = nullptr;
     float *d_fmeans = nullptr;
     /* pinned host */
@@ -375,8 +377,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
      * overwrites the totals. */
     const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || s.dc;
     const bool lean = nwg && !c->cfg.mode_ac && !fm; /* totals and sums are published by the offsets kernel */
-    if (!nwg)
+    if (!nwg) {
         HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
+        s.buf_first_valid = false;
+    }
     if (c->cfg.mode_ac)
         HIPCHK(c, hipMemsetAsync(s.d_ac_totals, 0, sizeof(uint64_t) * 4, c->stream));
     /* the three timing events cost about 5 us of stream time each (a barrier packet per record): they are
@@ -417,7 +421,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
                                s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0,
                                tail_here ? s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format) : nullptr,
                                tail_here ? s.tail_dst : nullptr, tail_here ? (uint32_t)(TAIL_SAMPLES * bps_of(format)) : 0,
-                               c->stream);
+                               tpw * tile, s.d_buf_first, c->stream);
+        s.buf_first_valid = true;
         if (tail_here)
             s.tail_dst = nullptr; /* done */
         if (rc)
@@ -668,6 +673,7 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     rp.hits = s.d_hits;
     rp.tries = s.d_tries;
     rp.totals = s.d_totals;
+    rp.buf_first = s.buf_first_valid ? s.d_buf_first : nullptr;
     /* the control arrays are read where they are, in pinned host memory: a few words per workgroup,
      * and an upload of 14 KiB would run as a blit kernel that fights the scan for compute units */
     rp.valid = g.h_valid;
@@ -687,6 +693,7 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     }
     rp.pred_key = s.d_pred;
     rp.pred_first = s.d_pred + MSD_PRED_SLOTS;
+    rp.pred_slots = s.d_pred + 2 * MSD_PRED_SLOTS;
 }
 
 uint32_t slot_valid(const Slot &s, uint32_t b)
@@ -956,8 +963,8 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         for (uint32_t b = 0; b < n; ++b)
             for (int k = 0; k < 8; ++k)
                 cyc[k] += s.h_rbuf[b].cyc[k];
-        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f stage %.1f eval %.1f walk %.1f count %.1f\n",
-                cyc[0] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100);
+        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f segment %.1f stage %.1f eval %.1f walk %.1f count %.1f\n",
+                cyc[0] / n / 100, cyc[5] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100);
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
                 "power stats %.3f ms (helper), then waited %.3f ms for it\n", npass, early ? " (first one queued early)" : "",
                 t_wait, t_replay, tms(e0, e1), t_power, tms(e1, tnow()));
@@ -1291,7 +1298,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(c->d_timers);
     }
     for (Slot &s : c->slots) {
-        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
+        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
         if (s.h_totals) (void)hipHostFree(s.h_totals);
         if (s.h_sums) (void)hipHostFree(s.h_sums);
         if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
@@ -1494,6 +1501,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_ragged), 64));
         CK(hipMemset(s.d_ragged, 0, 64));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));

@@ -43,6 +43,7 @@ typedef struct MsdResolveParams {
     const msd_hit *hits; /* the batch's ordered candidate lists, as the gather kernel left them */
     const msd_try *tries;
     const uint64_t *totals;   /* the batch's totals on the device: [0] hits, [2] arena overflow flag */
+    const uint32_t *buf_first; /* [buffer + 1] where each buffer's hits start in `hits` (the gather kernel), or NULL */
     const uint32_t *valid;    /* [buffer] new samples */
     const uint64_t *ts;       /* [buffer][2] sampleTimestamp, sysTimestamp */
     const uint32_t *snaps;    /* [snapshot][MSD_SNAP_WORDS] */
@@ -62,6 +63,7 @@ typedef struct MsdResolveParams {
     uint32_t *h_pred_count;
     const uint32_t *pred_key; /* [MSD_PRED_SLOTS] predicted adds: address ... */
     const uint32_t *pred_first; /* ... and the first buffer with a clean squitter of it */
+    const uint32_t *pred_slots; /* counter - 1, then the slots in use (what pred_list points at on the first pass) */
 } MsdResolveParams;
 
 #ifdef __cplusplus
@@ -104,13 +106,14 @@ int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipSt
  * workgroup leaves the totals in `totals` and, if h_totals / h_sums are not NULL, writes them and the
  * per-buffer level/power sums to those pinned host addresses and zeroes the device sums for the slot's
  * next batch.  wipe[0..wipe_bytes) (a multiple of 16) is set to all-ones, tail_bytes (a multiple of
- * 4) are copied from tail_src to tail_dst on the way. */
+ * 4) are copied from tail_src to tail_dst on the way.  buf_first[b], b = 0 .. nbuffers: index in the dense list
+ * of the first hit at or behind sample b * MSD_CHUNK_SAMPLES (a region is region_len scan positions). */
 int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_totals, uint32_t nwg, uint64_t *totals,
                       const msd_hit *hits,
                       const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,
                       msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
                       uint64_t *h_sums, void *wipe, uint32_t wipe_bytes, const void *tail_src, void *tail_dst,
-                      uint32_t tail_bytes, hipStream_t stream);
+                      uint32_t tail_bytes, uint32_t region_len, uint32_t *buf_first, hipStream_t stream);
 int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
                      unsigned long long *d_out, hipStream_t stream);
 /* Mode A/C candidate stage: noise levels (unless noise_ready), candidate kernel, ordered gather.

@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_region_counts
                                                          uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
                                                          uint64_t *h_sums, uint4 *wipe, uint32_t wipe_n,
                                                          const uint32_t *tail_src, uint32_t *tail_dst,
-                                                         uint32_t tail_words)
+                                                         uint32_t tail_words, uint32_t region_len, uint32_t *buf_first)
 {
     __shared__ unsigned long long ph[4], pt[4];
     __shared__ uint32_t povf[4];
@@ -978,6 +978,31 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_region_counts
     for (uint32_t i = w * blockDim.x + tid; i < wipe_n; i += nreg * blockDim.x)
         wipe[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     const msd_hit *hs = hits + (size_t)w * hcap;
+    if (buf_first && tid < 64) {
+        /* the buffers that start inside this region (the last region also answers for everything behind it, the
+         * end sentinel included): where their hits start in the dense list, so that the resolve workgroups need
+         * not search for it -- a 64-ary lower bound over the region's own hits */
+        const uint64_t p0 = (uint64_t)w * region_len, p1 = last ? ~0ull : p0 + region_len;
+        for (uint64_t bb = (p0 + MSD_CHUNK_SAMPLES - 1) / MSD_CHUNK_SAMPLES; bb <= nbuffers && bb * MSD_CHUNK_SAMPLES < p1; ++bb) {
+            const uint64_t want = bb * MSD_CHUNK_SAMPLES;
+            uint32_t lo = 0, hi = nh;
+            while (lo < hi) {
+                const uint32_t step = (hi - lo + 63) / 64, p = lo + tid * step;
+                const bool below = p < hi && MSD_HIT_POS(hs[p]) < want;
+                const uint32_t k = (uint32_t)__popcll(__ballot(below)); /* the first k probes are below: monotone */
+                if (k == 0) {
+                    hi = lo;
+                } else {
+                    const uint32_t nhi = lo + k * step;
+                    lo = lo + (k - 1) * step + 1;
+                    if (nhi < hi)
+                        hi = nhi;
+                }
+            }
+            if (tid == 0)
+                buf_first[bb] = (uint32_t)(ho + lo < 0xffffffffull ? ho + lo : 0xffffffffull);
+        }
+    }
     for (uint32_t i = tid; i < nh; i += blockDim.x) {
         msd_hit hr = hs[i];
         if (MSD_HIT_NLIVE(hr))
@@ -2192,12 +2217,13 @@ extern "C" int msd_launch_gather(const msd_region_counts *counts, const msd_wg_t
                                  const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits,
                                  uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums,
                                  uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums, void *wipe, uint32_t wipe_bytes,
-                                 const void *tail_src, void *tail_dst, uint32_t tail_bytes, hipStream_t stream)
+                                 const void *tail_src, void *tail_dst, uint32_t tail_bytes, uint32_t region_len,
+                                 uint32_t *buf_first, hipStream_t stream)
 {
     hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, wg_totals, hits, tries, hcap, tcap, dense_hits,
                        dense_hcap, dense_tries, dense_tcap, totals, sums, nbuffers, h_totals, h_sums,
                        static_cast<uint4 *>(wipe), wipe_bytes / 16, static_cast<const uint32_t *>(tail_src),
-                       static_cast<uint32_t *>(tail_dst), tail_bytes / 4);
+                       static_cast<uint32_t *>(tail_dst), tail_bytes / 4, region_len, buf_first);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -197,10 +197,15 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = wall_clock64();
 #define PHASE(k) { const uint64_t n_ = wall_clock64(); cyc[k] += (uint32_t)(n_ - tlast); tlast = n_; }
-    if (P.totals[2] || (P.ac && P.ac_totals[2]))
+    /* everything the set-up needs from global memory, in three rounds of independent loads */
+    const uint64_t ovf = P.totals[2], nhits = P.totals[0];
+    const uint64_t ac_ovf = P.ac ? P.ac_totals[2] : 0;
+    const uint32_t b = P.todo[blockIdx.x];
+    const uint32_t npred_raw = P.pred_slots[0] + 1u; /* the counter started at 0xffffffff */
+    if (ovf || ac_ovf)
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
     if (blockIdx.x == 0 && P.pred_list) { /* the prediction list of the batch, for the host's replay */
-        const uint32_t n = P.pred_list[0] + 1u; /* the counter started at 0xffffffff */
+        const uint32_t n = npred_raw;
         if (tid == 0)
             *P.h_pred_count = n <= MSD_PRED_LIST ? n : MSD_PRED_LIST + 1;
         for (uint32_t i = tid; i < n && i < MSD_PRED_LIST; i += RT) {
@@ -213,22 +218,22 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             P.h_pred[i] = e;
         }
     }
-    const uint64_t nhits = P.totals[0];
-    const uint32_t b = P.todo[blockIdx.x];
     const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * MSD_SNAP_WORDS;
-    const uint32_t snap_active = snap[2 * SLOTS] & 1u;
     const uint32_t mlen = P.valid[b];
     const uint64_t sys_ts = P.ts[2 * b + 1];
+    const uint32_t snap_active = snap[2 * SLOTS] & 1u;
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
     msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
     uint32_t *adds = P.adds + (size_t)b * MSD_RB_MSG_CAP;
     msd_rbuf *rb = P.rbuf + b;
-
     for (int i = tid; i < (int)ADDSET; i += RT)
         addset[i] = VACANT;
     if (tid < 16)
         sh_ctr[tid] = 0;
-    if (tid < 128) { /* range of this buffer's hits in the ordered list: a 64-ary search per wavefront */
+    if (P.buf_first) { /* the gather kernel left the range of this buffer's hits in the ordered list */
+        if (tid < 2)
+            sh_range[tid] = min((uint64_t)P.buf_first[b + tid], nhits);
+    } else if (tid < 128) { /* ... or a 64-ary search per wavefront */
         const int lane = tid & 63;
         const uint64_t want = base + ((tid >> 6) ? MSD_CHUNK_SAMPLES : 0);
         uint64_t lo = 0, hi = nhits; /* lower_bound lies in [lo, hi] */
@@ -318,12 +323,13 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         if (tid == RT - 1 && n == SEG)
             seg_toff[SEG] = (uint16_t)off;
         __syncthreads();
+        PHASE(5)
         for (uint32_t t = tid; t < seg_toff[n]; t += RT) { /* one try per thread: the loads of a round overlap */
             const uint32_t i = seg_thit[t];
             const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
             const uint32_t where = snap_probe(snap, v.addr);
             bool known = where != 0 || addset_has(addset, v.addr);
-            if (!known) /* added by an earlier buffer of this batch (predicted; the host verifies) */
+            if (!known && npred_raw) /* added by an earlier buffer of this batch (predicted; the host verifies) */
                 known = pred_lookup(P.pred_key, P.pred_first, v.addr) < b;
             seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
         }
@@ -555,31 +561,64 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 }
             }
             __syncthreads();
-            if (tid == 0) { /* append them in message order (the host applies them in this order) */
-                uint32_t nadds = sh_nadds, nshort = sh_nshort;
-                for (uint32_t j = 0; j < na; ++j) {
-                    const uint32_t f = add_first[j];
-                    if (!(f & 0x8000u))
-                        continue;
-                    const uint32_t hs = f & 0x7fffu;
-                    if (add_rank[hs] != j)
-                        continue;
-                    add_rank[hs] = 0xfffffffeu;
-                    const uint64_t r = seg_res[ok_idx[acc_k[j]]];
-                    const uint32_t addr = (uint32_t)(r >> 40);
-                    if (nadds < MSD_RB_MSG_CAP)
-                        out_adds[nadds] = addr;
-                    nadds++;
-                    if (!((r >> 37) & 1u)) { /* not in the active table yet: the host filter changes */
-                        if (nshort < MSD_RB_ADD_INLINE)
-                            out_short[nshort] = addr;
-                        nshort++;
+            { /* append them in message order (the host applies them in this order): thread t looks at
+                 * messages PERJ t .. PERJ t + PERJ - 1, a workgroup-wide exclusive count gives the places
+                 * (adds in the low half, those the host filter does not know yet in the high half) */
+                constexpr uint32_t PERJ = SEG / RT;
+                const uint32_t nadds0 = sh_nadds, nshort0 = sh_nshort;
+                uint32_t a_addr[PERJ], mine = 0;
+                bool a_is[PERJ], a_short[PERJ];
+#pragma unroll
+                for (uint32_t q = 0; q < PERJ; ++q) {
+                    const uint32_t j = (uint32_t)tid * PERJ + q;
+                    a_is[q] = a_short[q] = false;
+                    a_addr[q] = 0;
+                    if (j < na) {
+                        const uint32_t f = add_first[j];
+                        if ((f & 0x8000u) && add_rank[f & 0x7fffu] == j) {
+                            const uint64_t r = seg_res[ok_idx[acc_k[j]]];
+                            a_is[q] = true;
+                            a_short[q] = !((r >> 37) & 1u); /* not in the active table yet: the host filter changes */
+                            a_addr[q] = (uint32_t)(r >> 40);
+                            add_rank[f & 0x7fffu] = 0xfffffffeu; /* nobody else's j equals the old value */
+                        }
                     }
+                    mine += (a_is[q] ? 1u : 0u) + (a_short[q] ? 0x10000u : 0u);
                 }
-                sh_nadds = nadds;
-                sh_nshort = nshort;
-                sh_nacc = nacc0 + na;
-                sh_nmsgs = nmsgs0 + na;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d, 64);
+                    if ((tid & 63) >= d)
+                        incl += up;
+                }
+                if ((tid & 63) == 63)
+                    sh_wsum[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t off = incl - mine;
+                for (int w = 0; w < (tid >> 6); ++w)
+                    off += sh_wsum[w];
+                if (tid == RT - 1) { /* off + mine = the round's totals */
+                    const uint32_t tot = off + mine;
+                    sh_nadds = nadds0 + (tot & 0xffffu);
+                    sh_nshort = nshort0 + (tot >> 16);
+                    sh_nacc = nacc0 + na;
+                    sh_nmsgs = nmsgs0 + na;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < PERJ; ++q) {
+                    if (a_is[q]) {
+                        const uint32_t ia = nadds0 + (off & 0xffffu);
+                        if (ia < MSD_RB_MSG_CAP)
+                            out_adds[ia] = a_addr[q];
+                        if (a_short[q]) {
+                            const uint32_t is = nshort0 + (off >> 16);
+                            if (is < MSD_RB_ADD_INLINE)
+                                out_short[is] = a_addr[q];
+                        }
+                    }
+                    off += (a_is[q] ? 1u : 0u) + (a_short[q] ? 0x10000u : 0u);
+                }
             }
             __syncthreads();
             /* ---- phase C: the counters of every hit that no accepted message hides, in parallel ---- */
