@@ -48,6 +48,7 @@ struct Helper {
     std::condition_variable cv;
     std::function<void()> job;
     bool pending = false, stop = false;
+    bool delivered = false; /* the job has passed the point its poster waits for (mark_delivered); the rest is background */
     int device = 0;
     void loop()
     {
@@ -61,6 +62,7 @@ struct Helper {
             job();
             lk.lock();
             pending = false;
+            delivered = true;
             cv.notify_all();
         }
     }
@@ -69,9 +71,22 @@ struct Helper {
         std::unique_lock<std::mutex> lk(mu);
         if (!th.joinable())
             th = std::thread([this] { loop(); });
+        cv.wait(lk, [&] { return !pending; }); /* the background half of the previous job */
         job = std::move(f);
         pending = true;
+        delivered = false;
         cv.notify_all();
+    }
+    void mark_delivered() /* from the job */
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        delivered = true;
+        cv.notify_all();
+    }
+    void wait_delivered()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return delivered || !pending; });
     }
     void wait()
     {
@@ -98,6 +113,7 @@ struct Slot {
     bool resolve_inflight = false; /* its first resolve pass (and the speculative message records) are queued */
     int threshold = 0;             /* Modes.preambleThreshold when the batch was launched */
     bool timed = false;            /* ev_start / ev_scan / ev_kernels were recorded for this batch */
+    bool state_reset_done = false; /* ... and filter and clocks have been reset already (its chain was queued early) */
     bool reset_before = false;     /* msd_restart(): first batch of a new capture -- filter, clock and counters start
                                       over when its turn comes */
     bool dc = false;               /* --dcfilter: d_iq points at d_dcmag, the float sums come from d_magsq */
@@ -112,6 +128,7 @@ struct Slot {
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
+    unsigned long long *h_side = nullptr;          /* per record: power sum | signal_len << 48, for the statistics */
     msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr, ev_power = nullptr;
     /* batch description */
@@ -126,6 +143,7 @@ struct Slot {
     msd_hit *d_hits = nullptr;
     msd_try *d_tries = nullptr;
     uint64_t *d_totals = nullptr;
+    uint32_t *d_rec_off = nullptr;   /* [max_buffers + 2] records in front of each buffer's (power kernel) */
     uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
     bool buf_first_valid = false;
     uint64_t *d_sums = nullptr;
@@ -212,6 +230,14 @@ struct msd_ctx {
     /* experiment knobs, read from the environment once in msd_create */
     bool trace = false;      /* MSD_RESOLVE_TRACE */
     bool repass_aux = false; /* MSD_REPASS_AUX */
+    /* In-order layout without field decoding: the record kernel of a batch is not launched; the wavefronts of the
+     * next scan write the records on their way in (MsdScanParams.emit).  pending_emit: resolve chain and signal
+     * power queued, records not yet.  MSD_EMIT_FUSED=0 turns it off. */
+    std::vector<uint32_t> bg_valid, bg_buf; /* the statistics half of finishing a batch, on the helper thread */
+    std::vector<double> bg_means;
+    std::vector<uint64_t> bg_scaled; /* per message: power sum | signal_len << 48 (msd_emit_impl.h) */
+    bool emit_fused = false;
+    struct Slot *pending_emit = nullptr;
     bool emit_side_only = false; /* MSD_EMIT_SIDE_ONLY: everything in order on the scan stream but the record kernel */
     bool resolve_inline = false; /* MSD_RESOLVE_INLINE: predict + resolve in order on the scan stream, records on their own */
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
@@ -280,10 +306,12 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     if (s.h_req) (void)hipHostFree(s.h_req);
     if (s.h_pow) (void)hipHostFree(s.h_pow);
     if (s.h_wire) (void)hipHostFree(s.h_wire);
+    if (s.h_side) (void)hipHostFree(s.h_side);
     if (s.h_fields) (void)hipHostFree(s.h_fields);
     (void)hipFree(s.d_wire);
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
     s.h_wire = s.d_wire = nullptr;
+    s.h_side = nullptr;
     s.h_fields = nullptr;
     s.req_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_req), cap * sizeof(uint64_t)));
@@ -292,6 +320,7 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_pow), cap * sizeof(uint64_t)));
     if (c->gpu_resolve) {
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_wire), cap * sizeof(msd_wire)));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_side), cap * sizeof(unsigned long long)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_wire), cap * sizeof(msd_wire)));
         if (c->want_fields)
             HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_fields), cap * sizeof(msd_fields)));
@@ -355,6 +384,10 @@ size_t bps_of(int format)
 }
 
 /* Enqueue the GPU stage for `nsamples` samples at d_iq (absolute index batch_first). */
+int flush_pending_emit(msd_ctx *c);
+struct GpuCtl;
+void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp);
+
 int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
 {
     const uint64_t tile = msd_scan_tile(format);
@@ -408,11 +441,43 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.chunk_sums = s.d_sums;
         p.timers = c->d_timers;
         p.debug_flags = c->debug_flags;
+        Slot *carried = nullptr;
+        if (c->pending_emit && c->pending_emit != &s) {
+            Slot &a = *c->pending_emit;
+            if (nwg >= a.nbuffers && a.nbuffers) { /* this scan's wavefronts write that batch's records */
+                MsdResolveParams rp{};
+                gpu_params(c, a, rp);
+                p.emit.nbuffers = a.nbuffers;
+                p.emit.stride = nwg / a.nbuffers;
+                p.emit.cap = (uint32_t)a.req_cap;
+                p.emit.totals = rp.totals;
+                p.emit.nmsgs = rp.nmsgs;
+                p.emit.rec_off = a.d_rec_off;
+                p.emit.acc = rp.acc;
+                p.emit.tries = rp.tries;
+                p.emit.ts = rp.ts;
+                p.emit.power = reinterpret_cast<const unsigned long long *>(a.d_powr);
+                p.emit.dense = c->records_dma ? a.d_wire : a.h_wire;
+                p.emit.side = a.h_side;
+                p.emit.ac = rp.ac;
+                p.emit.ac_totals = rp.ac_totals;
+                p.emit.acc_ac = rp.acc_ac;
+                p.emit.nac = rp.nac;
+                carried = &a;
+                c->pending_emit = nullptr;
+            } else {
+                int rc = flush_pending_emit(c);
+                if (rc)
+                    return rc;
+            }
+        }
         int rc = msd_launch_scan(&p, format, nwg, c->stream);
         if (rc)
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         if (s.timed)
             HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
+        if (carried)
+            HIPCHK(c, hipEventRecord(carried->ev_records, c->stream));
         const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
                                (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
         rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
@@ -744,22 +809,27 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
 
 /* message records and signal power of every buffer on `ks` (device memory); ev_records marks the
  * end.  The host fetches them with one DMA once it knows how many there are (fetch_records). */
-int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t ks)
+int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t ks, bool do_power = true,
+                   bool do_emit = true)
 {
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
     MsdScanParams p{};
     fill_params(c, s, p);
     /* the signal power on `ps`, the records on `ks` behind it */
-    int rc = msd_launch_power_buffers(&p, format, s.d_acc, s.d_tries, s.d_nmsgs, s.nbuffers, s.d_totals,
-                                      reinterpret_cast<unsigned long long *>(s.d_powr), ps);
+    int rc = do_power ? msd_launch_power_buffers(&p, format, s.d_acc, s.d_tries, s.d_nmsgs, s.nbuffers, s.d_totals,
+                                                 reinterpret_cast<unsigned long long *>(s.d_powr),
+                                                 c->cfg.mode_ac ? s.d_nac : nullptr, s.d_rec_off, ps)
+                      : 0;
     if (rc)
         return fail(c, rc, "power kernel launch failed");
+    if (!do_emit)
+        return 0;
     if (ps != ks) {
         HIPCHK(c, hipEventRecord(s.ev_power, ps));
         HIPCHK(c, hipStreamWaitEvent(ks, s.ev_power, 0));
     }
-    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr),
+    rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.h_side,
                          c->records_dma ? s.d_wire : s.h_wire, c->want_fields ? s.h_fields : nullptr,
                          (uint32_t)s.req_cap, ks);
     if (rc)
@@ -783,6 +853,17 @@ int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     }
     return 0;
+}
+
+/* The records of the batch whose chain was queued last and whose records are still owed, by the stand-alone
+ * kernel on the scan stream (no scan came along to carry them). */
+int flush_pending_emit(msd_ctx *c)
+{
+    Slot *p = c->pending_emit;
+    if (!p)
+        return 0;
+    c->pending_emit = nullptr;
+    return gpu_queue_emit(c, *p, c->scan_format, c->stream, c->stream, false, true);
 }
 
 /* Clocks, snapshot 0 = the live filter, first pass over every buffer and the (speculative) message
@@ -819,9 +900,17 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
-        if (pws != ks)
-            HIPCHK(c, hipStreamWaitEvent(pws, s.ev_resolve, 0));
-        rc = gpu_queue_emit(c, s, format, pws, es);
+        if (c->emit_fused) {
+            rc = flush_pending_emit(c); /* an older one no scan came after */
+            if (!rc)
+                rc = gpu_queue_emit(c, s, format, ks, ks, true, false); /* signal power now, records with the next scan */
+            if (!rc)
+                c->pending_emit = &s;
+        } else {
+            if (pws != ks)
+                HIPCHK(c, hipStreamWaitEvent(pws, s.ev_resolve, 0));
+            rc = gpu_queue_emit(c, s, format, pws, es);
+        }
     }
     if (rc)
         return rc;
@@ -851,6 +940,11 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return rc;
     }
     s.resolve_inflight = false;
+    if (c->pending_emit == &s) { /* no scan was launched since */
+        int rc = flush_pending_emit(c);
+        if (rc)
+            return rc;
+    }
     hipEvent_t wait_for = s.ev_resolve;
     bool records_current = true; /* the message records in host memory belong to the latest pass */
     for (uint32_t pass = 0;; ++pass) {
@@ -916,13 +1010,18 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     int fetch_rc = 0;
     double t_power = 0;
     static_assert(sizeof(msd_wire) == sizeof(msd_message), "the records are msd_message arrays");
-    auto deliver = [&, total, n]() {
+    auto deliver = [&, total, n, cc = c]() {
         fetch_rc = fetch_records(c, s, total);
         if (fetch_rc)
             return;
         auto p0 = tnow();
-        msd_resolve_power(&c->resolver, n, c->valid.data(), c->means.data(), &s.h_wire[0].mm, sizeof(msd_wire), nullptr,
-                          c->out_buf.data(), &s.h_wire[0].mm.signalLevel, sizeof(msd_wire), total);
+        /* what the statistics half below needs, in the context's own storage: the caller's next batch reuses
+         * c->valid / c->means / c->out_buf and this batch's slot while it runs */
+        cc->bg_valid = cc->valid;
+        cc->bg_means = cc->means;
+        cc->bg_buf.swap(cc->out_buf);
+        cc->bg_scaled.resize(total ? total : 1);
+        memcpy(cc->bg_scaled.data(), s.h_side, (size_t)total * sizeof(uint64_t));
         t_power = tms(p0, tnow());
         /* the library's own array sinks take the whole batch with one copy instead of 35 000 calls */
         if (c->fsink == msd_array_fields_sink) {
@@ -937,6 +1036,13 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             memcpy(st->out + st->count, s.h_wire, k * sizeof(msd_message));
             st->count += total;
         }
+        /* ---- the caller has its messages; from here on nothing of finish_gpu's frame or of the slot is touched ---- */
+        msd_ctx *const ctx = cc;
+        const uint32_t nb = n;
+        const uint64_t nm = total;
+        ctx->helper.mark_delivered();
+        msd_resolve_power_stats(&ctx->resolver, nb, ctx->bg_valid.data(), ctx->bg_means.data(), ctx->bg_buf.data(),
+                                ctx->bg_scaled.data(), nm);
     };
     const bool threaded = !c->no_helper;
     if (threaded)
@@ -945,13 +1051,20 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     int begin_rc = 0;
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        /* (not across a capture boundary: the caller may still want this capture's counters) */
-        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && !nx.reset_before)
+        /* Across a capture boundary too: the filter and the clocks start over now (this batch was the old capture's
+         * last one), the counters when the new capture's first batch is collected -- the caller may still want
+         * the old ones.  (Not if samples were dropped in front of the new capture: they count on its counters.) */
+        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && (!nx.reset_before || nx.dropped_before == 0)) {
+            if (nx.reset_before) {
+                msd_resolver_reset_state(&c->resolver);
+                nx.state_reset_done = true;
+            }
             begin_rc = gpu_begin(c, nx, c->scan_format);
+        }
     }
     auto e1 = tnow();
     if (threaded)
-        c->helper.wait();
+        c->helper.wait_delivered();
     else
         deliver();
     if (begin_rc)
@@ -986,7 +1099,12 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
 {
     auto ta = std::chrono::steady_clock::now();
     if (s.reset_before) { /* msd_restart(): every batch of the previous capture has been delivered */
-        msd_resolver_reset(&c->resolver);
+        c->helper.wait(); /* ... and its statistics are complete */
+        if (s.state_reset_done)
+            msd_resolver_reset_stats(&c->resolver);
+        else
+            msd_resolver_reset(&c->resolver);
+        s.state_reset_done = false;
         memset(&c->timing, 0, sizeof c->timing);
         s.reset_before = false;
     }
@@ -1084,6 +1202,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
         c->timing.resolve_fallback++;
     }
+    c->helper.wait(); /* the statistics of the previous batch, if they are still being summed */
     c->timing.resolve_passes = 0;
     c->out_msgs.clear();
     c->out_req.clear();
@@ -1298,7 +1417,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(c->d_timers);
     }
     for (Slot &s : c->slots) {
-        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
+        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_rec_off); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
         if (s.h_totals) (void)hipHostFree(s.h_totals);
         if (s.h_sums) (void)hipHostFree(s.h_sums);
         if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
@@ -1311,6 +1430,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
+        if (s.h_side) (void)hipHostFree(s.h_side);
         if (s.h_wire) (void)hipHostFree(s.h_wire);
         if (s.h_fields) (void)hipHostFree(s.h_fields);
         (void)hipFree(s.d_dcmag); (void)hipFree(s.d_magsq);
@@ -1502,6 +1622,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
+        CK(hipMalloc(reinterpret_cast<void **>(&s.d_rec_off), (c->max_buffers + 2) * sizeof(uint32_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_ragged), 64));
         CK(hipMemset(s.d_ragged, 0, 64));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_sums), 2 * sizeof(uint64_t) * c->max_buffers));
@@ -1545,6 +1666,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             c->chain_inline = ci && *ci ? *ci != '0' : !follow_ups;
         }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
+        { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
         { const char *eo = getenv("MSD_EMIT_SIDE_ONLY"); c->emit_side_only = eo && *eo && *eo != '0'; }
         { const char *ri = getenv("MSD_RESOLVE_INLINE"); c->resolve_inline = ri && *ri && *ri != '0'; }
         c->helper.device = cfg->device;
@@ -1627,6 +1749,7 @@ int msd_reset(msd_ctx *c)
         }
         c->head = 0;
         c->outstanding = 0;
+        c->pending_emit = nullptr;
         c->failed = false;
     }
     c->next_sample = 0;
@@ -1635,6 +1758,7 @@ int msd_reset(msd_ctx *c)
     c->pending_dropped = 0;
     if (c->d_dcstate)
         HIPCHK(c, hipMemset(c->d_dcstate, 0, 2 * sizeof(float)));
+    c->helper.wait();
     msd_resolver_reset(&c->resolver);
     memset(&c->timing, 0, sizeof c->timing);
     return 0;
@@ -1846,6 +1970,7 @@ int msd_get_stats(const msd_ctx *c, msd_stats *st)
 {
     if (!c || !st)
         return -EINVAL;
+    const_cast<msd_ctx *>(c)->helper.wait(); /* the power statistics of the last batch are summed on the helper thread */
     *st = c->stats;
     return 0;
 }

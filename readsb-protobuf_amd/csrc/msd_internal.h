@@ -209,6 +209,8 @@ typedef void (*msd_emit_fn)(const struct msd_message *mm, const uint64_t *power_
                             uint32_t buffer, void *user);
 
 void msd_resolver_reset(msd_resolver *r);
+void msd_resolver_reset_state(msd_resolver *r); /* filter and clocks only */
+void msd_resolver_reset_stats(msd_resolver *r); /* the counters only */
 void msd_resolver_free(msd_resolver *r);
 /* Replays the buffers [first_chunk, first_chunk + nbuffers) of a batch.  hits/tries (Mode S) and
  * ac (Mode A/C) are the batch's ordered candidate lists; valid[i] is the i-th buffer's number of
@@ -223,6 +225,8 @@ void msd_resolve_batch(msd_resolver *r, uint64_t first_chunk, uint32_t nbuffers,
  * (demod_2400.c:386-408,422-427): fills signalLevel and the power statistics, in order.
  * msgs / power are arrays of msd_message / uint64_t with the given byte strides; power_req may be NULL
  * (the length then follows from msgbits, Mode A/C from msgtype). */
+void msd_resolve_power_stats(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
+                             const uint32_t *buffer, const uint64_t *side, uint64_t nmsgs);
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
                        void *msgs, size_t msg_stride, const uint64_t *power_req, const uint32_t *buffer,
                        const void *power, size_t power_stride, uint64_t nmsgs);

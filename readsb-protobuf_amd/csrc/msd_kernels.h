@@ -9,6 +9,30 @@
 #include "msd_internal.h"
 
 
+/* a record as the emit code writes it: the message, nothing else (the power sum travels in signalLevel) */
+typedef struct msd_wire {
+    msd_message mm;
+} msd_wire;
+
+/* The records of one batch (Mode S messages, then Mode A/C replies, per buffer) for the wavefronts of the NEXT
+ * batch's scan kernel to write on their way in: wavefront w * stride takes buffer w.  nbuffers == 0: nothing. */
+typedef struct MsdEmitJob {
+    uint32_t nbuffers, stride, cap;
+    const uint64_t *totals;    /* [2]: arena overflow flag of that batch */
+    const uint32_t *nmsgs;     /* [buffer] */
+    const uint32_t *rec_off;   /* [buffer] records in front of the buffer's (msd_power_buffers_kernel) */
+    const struct msd_acc *acc; /* [buffer][MSD_RB_MSG_CAP] */
+    const msd_try *tries;      /* that batch's dense try list */
+    const uint64_t *ts;        /* [buffer][2] */
+    const unsigned long long *power; /* [buffer][MSD_RB_MSG_CAP] signal power sums */
+    msd_wire *dense;           /* out: cap records, pinned host memory */
+    unsigned long long *side;  /* out: per record, power sum | signal_len << 48 (0: Mode A/C), pinned host memory */
+    const msd_ac_hit *ac;      /* NULL: Mode A/C off */
+    const uint64_t *ac_totals;
+    const uint32_t *acc_ac;
+    const uint32_t *nac;
+} MsdEmitJob;
+
 typedef struct MsdScanParams {
     const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */
     const uint8_t *prev_tail; /* the MSD_HALO_FRONT samples before it */
@@ -37,6 +61,7 @@ typedef struct MsdScanParams {
     unsigned long long *timers; /* MSD_KERNEL_TIMING builds only */
     int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
                              2 = stop after the conversion (results are then incomplete) */
+    MsdEmitJob emit;      /* the previous batch's records, or nbuffers == 0 */
 } MsdScanParams;
 
 typedef struct MsdResolveParams {
@@ -82,19 +107,17 @@ int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint3
 /* pred_first[patches[i].slot] = patches[i].first; patches is pinned host memory */
 int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
-/* signal power of the accepted messages of every buffer: out[buffer][MSD_RB_MSG_CAP] (device) */
+/* signal power of the accepted messages of every buffer: out[buffer][MSD_RB_MSG_CAP] (device); and, if rec_off is
+ * not NULL, rec_off[buffer] = messages and (nac not NULL) Mode A/C replies of the buffers in front of it */
 int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
                              const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals, unsigned long long *out,
-                             hipStream_t stream);
+                             const uint32_t *nac, uint32_t *rec_off, hipStream_t stream);
 /* one accepted message as the emit kernel leaves it: the record, with the 64-bit signal power sum
  * sitting in the bytes of signalLevel until the host has turned it into the level (it needs the sum
  * itself for the power statistics, and 8 bytes less per message cross PCIe) */
-typedef struct msd_wire {
-    msd_message mm;
-} msd_wire;
 /* the accepted messages as dense records, cap entries (what does not fit is dropped; the host notices
  * from the counts) */
-int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, msd_wire *dense,
+int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power, unsigned long long *side, msd_wire *dense,
                     msd_fields *fields /* NULL: no field decode */, uint32_t cap, hipStream_t stream);
 /* the field decoder of the emit kernel on its own: out[i] = fields of in[i] (device pointers) */
 int msd_launch_fields(const msd_message *d_in, msd_fields *d_out, uint32_t n, hipStream_t stream);

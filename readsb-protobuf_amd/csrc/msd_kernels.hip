@@ -34,6 +34,7 @@
 
 #include "msd_internal.h"
 #include "msd_kernels.h"
+#include "msd_emit_impl.h"
 
 /* The float converters must round like the reference's x86-64 build: separate multiply and add
  * (no FMA contraction) and a correctly rounded square root.  The file is compiled with
@@ -656,6 +657,12 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         }
     }
 
+    /* On the way: this wavefront's share of the previous batch's message records (its resolve and power kernels
+     * ran before this launch), written between two tiles from the candidate scratch -- a different tile for
+     * neighbouring wavefronts, so that the PCIe writes of the 2 MB spread over the whole launch instead of
+     * queueing up at its start (where every wavefront's next load would wait behind its own stores). */
+    const uint32_t emit_at = P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
+
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         const uint64_t tile_pos0 = (uint64_t)tile * WT; /* first scan position, batch-relative */
         const uint64_t a0 = P.batch_first + tile_pos0;
@@ -831,6 +838,8 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             cur[k] = nxt[k];
             cur_valid[k] = nxt_valid[k];
         }
+        if (tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
+            msd_emit_slice(P.emit, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
     }
     flush_sums();
     hits_total = hcur;
@@ -1142,10 +1151,39 @@ constexpr uint32_t PB_WGS = MSD_PB_WGS;  /* workgroups per buffer: a buffer rare
 template <int FMT>
 __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanParams P, const msd_acc *acc,
                                                                 const msd_try *tries, const uint32_t *nmsgs,
-                                                                const uint64_t *totals, unsigned long long *out)
+                                                                const uint64_t *totals, unsigned long long *out,
+                                                                const uint32_t *nac, uint32_t nbuffers, uint32_t *rec_off)
 {
     if (totals[2])
         return;
+    if (blockIdx.x == gridDim.x - 1 && rec_off) {
+        /* where each buffer's records start in the batch's record array (its Mode S messages, then its Mode A/C
+         * replies): an exclusive prefix over the buffers, for whoever writes the records */
+        __shared__ uint32_t wsum[4];
+        const uint32_t per = (nbuffers + 255u) / 256u, i0 = threadIdx.x * per;
+        uint32_t mine = 0;
+        for (uint32_t k = 0; k < per; ++k)
+            if (i0 + k < nbuffers)
+                mine += nmsgs[i0 + k] + (nac ? nac[i0 + k] : 0u);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d)
+                incl += up;
+        }
+        if ((threadIdx.x & 63) == 63)
+            wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t off = incl - mine;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w)
+            off += wsum[w];
+        for (uint32_t k = 0; k < per; ++k)
+            if (i0 + k < nbuffers) {
+                rec_off[i0 + k] = off;
+                off += nmsgs[i0 + k] + (nac ? nac[i0 + k] : 0u);
+            }
+    }
     const uint32_t b = blockIdx.x / PB_WGS, nm = nmsgs[b];
     const int lane = threadIdx.x & 63;
     /* six messages per trip, so that their record, sample and table loads overlap: the kernel is a chain
@@ -2254,23 +2292,24 @@ extern "C" int msd_launch_power(const MsdScanParams *p, int format, const uint64
 
 extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, const msd_acc *acc, const msd_try *tries,
                                         const uint32_t *nmsgs, uint32_t nbuffers, const uint64_t *totals,
-                                        unsigned long long *out, hipStream_t stream)
+                                        unsigned long long *out, const uint32_t *nac, uint32_t *rec_off,
+                                        hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
     const dim3 grid(nbuffers * PB_WGS), block(256);
     switch (format) {
     case MSD_FMT_UC8:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_UC8>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out, nac, nbuffers, rec_off);
         break;
     case MSD_FMT_SC16:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out, nac, nbuffers, rec_off);
         break;
     case MSD_FMT_SC16Q11:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_SC16Q11>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out, nac, nbuffers, rec_off);
         break;
     case MSD_FMT_MAG16:
-        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out);
+        hipLaunchKernelGGL(msd_power_buffers_kernel<MSD_FMT_MAG16>, grid, block, 0, stream, *p, acc, tries, nmsgs, totals, out, nac, nbuffers, rec_off);
         break;
     default:
         return -22;

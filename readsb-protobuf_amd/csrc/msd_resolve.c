@@ -599,13 +599,25 @@ static int default_threads(void)
     return (int)(n < 4 ? 4 : (n > 64 ? 64 : n));
 }
 
-void msd_resolver_reset(msd_resolver *r)
+/* a new capture: empty filter, clocks at zero ... */
+void msd_resolver_reset_state(msd_resolver *r)
 {
     filter_init(&r->filter);
     r->ifile_now = 0;
     r->sample_counter = 0;
+}
+
+/* ... and its counters */
+void msd_resolver_reset_stats(msd_resolver *r)
+{
     if (r->stats)
         memset(r->stats, 0, sizeof *r->stats);
+}
+
+void msd_resolver_reset(msd_resolver *r)
+{
+    msd_resolver_reset_state(r);
+    msd_resolver_reset_stats(r);
 }
 
 void msd_resolver_free(msd_resolver *r)
@@ -1098,6 +1110,42 @@ void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid
             if (mm->signalLevel > st->peak_signal_power)
                 st->peak_signal_power = mm->signalLevel;
             if (mm->signalLevel > 0.50119)
+                st->strong_signal_count++;
+        }
+        { /* demod_2400.c:422-427 */
+            const uint32_t mlen = valid[b];
+            const double sum_signal_power = sum_scaled_signal_power / 65535.0 / 65535.0;
+            st->noise_power_sum += (means[2 * b + 1] * mlen - sum_signal_power);
+            st->noise_power_count += mlen;
+        }
+    }
+}
+
+/* The statistics half alone, for the GPU resolve path (msd_capi.cpp): the record kernel has already written every
+ * message's signalLevel (msd_emit_impl.h, the same double arithmetic), and the order-sensitive sums (one
+ * dependent double add per message, demod_2400.c:398-408,422-427) follow from side[] = power sum | signal_len
+ * << 48 (0: a Mode A/C reply) while the caller already works on the next batch. */
+void msd_resolve_power_stats(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,
+                             const uint32_t *buffer, const uint64_t *side, uint64_t nmsgs)
+{
+    msd_stats *st = r->stats;
+    uint64_t i = 0;
+    for (uint32_t b = 0; b < nbuffers; ++b) {
+        uint64_t sum_scaled_signal_power = 0;
+        for (; i < nmsgs && buffer[i] == b; ++i) {
+            const int signal_len = (int)(side[i] >> 48);
+            if (!signal_len)
+                continue; /* Mode A/C */
+            const uint64_t scaled = side[i] & 0xffffffffffffull;
+            /* demod_2400.c:386-408 */
+            const double signal_power = scaled / 65535.0 / 65535.0;
+            const double level = signal_power / signal_len;
+            st->signal_power_sum += signal_power;
+            st->signal_power_count += (uint64_t)signal_len;
+            sum_scaled_signal_power += scaled;
+            if (level > st->peak_signal_power)
+                st->peak_signal_power = level;
+            if (level > 0.50119)
                 st->strong_signal_count++;
         }
         { /* demod_2400.c:422-427 */

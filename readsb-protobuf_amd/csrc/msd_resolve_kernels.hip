@@ -20,6 +20,7 @@
 #include "msd_internal.h"
 #include "msd_kernels.h"
 #include "msd_fields_impl.h"
+#include "msd_emit_impl.h"
 
 namespace {
 
@@ -823,7 +824,8 @@ __device__ inline void emit_rows(msd_wire *dense, msd_fields *fields, const msd_
  * next to a resident scan workgroup and the records leave while the next batch is scanned. */
 template <bool FIELDS>
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
-                                                       msd_wire *dense, msd_fields *fields_arg, uint32_t cap)
+                                                       unsigned long long *side, msd_wire *dense, msd_fields *fields_arg,
+                                                       uint32_t cap)
 {
     msd_fields *const fields = FIELDS ? fields_arg : nullptr;
     if (P.totals[2] || (P.ac && P.ac_totals[2]))
@@ -852,39 +854,13 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
     for (uint32_t m0 = 0; m0 < nm; m0 += 256) {
         const uint32_t m = m0 + threadIdx.x;
         if (m < nm) {
-            const msd_acc rec = acc[m];
-            const msd_try *t = P.tries + rec.try_index;
-            const uint4 lo = *reinterpret_cast<const uint4 *>(t);
-            const uint4 hi = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(t) + 16);
-            const uint32_t df = (lo.x & 0xffu) >> 3, tp = (lo.w >> 16) & 0xffu, errbit = lo.w >> 24;
-            const uint32_t errbit2 = hi.w & 0xffu;
-            const uint32_t msgbits = (df & 0x10u) ? 112u : 56u;
-            const uint32_t j = rec.pos - base;
-            msd_message mm;
-            mm.timestampMsg = sample_ts + (uint64_t)j * 5 + (8 + 56) * 12 + tp;
-            mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-            /* the power sum's bits, not a value */
-            mm.signalLevel = __longlong_as_double((long long)power[(size_t)b * MSD_RB_MSG_CAP + m]);
-            mm.addr = hi.x; /* CRC for AP formats; AA after the fix otherwise (mode_s.c:559-562) */
-            mm.crc = hi.y;
-            mm.score = rec.score;
-            mm.msgtype = (uint8_t)df;
-            mm.msgbits = (uint8_t)msgbits;
-            mm.correctedbits = errbit == 0xffu ? 0 : (errbit2 == 0xffu ? 1 : 2);
-            mm.bestphase = (uint8_t)tp;
-            uint32_t w[4] = {lo.x, lo.y, lo.z, lo.w & 0xffffu};
-            if (errbit != 0xffu)
-                w[errbit >> 5] ^= (0x80u >> (errbit & 7u)) << (8 * ((errbit >> 3) & 3u)); /* crc.c:417-425 */
-            if (errbit2 != 0xffu)
-                w[errbit2 >> 5] ^= (0x80u >> (errbit2 & 7u)) << (8 * ((errbit2 >> 3) & 3u));
-#pragma unroll
-            for (int k = 0; k < 14; ++k)
-                mm.msg[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-            mm.iid = df == 11 ? (uint8_t)(hi.y & 0x7fu) : 0;
-            mm.pad = 0;
+            unsigned long long sw;
+            const msd_message mm = msd_emit_mode_s(acc[m], P.tries, power[(size_t)b * MSD_RB_MSG_CAP + m], sample_ts, sys_ts, base, sw);
+            if (o + m < cap)
+                side[o + m] = sw;
             sh_rec[threadIdx.x].mm = mm;
             if (FIELDS) /* MSD_CFG_DECODE_FIELDS: the header fields, from the corrected bytes */
-                msd_fields_mode_s(mm.msg, df, mm.addr, &sh_f[threadIdx.x]);
+                msd_fields_mode_s(mm.msg, mm.msgtype, mm.addr, &sh_f[threadIdx.x]);
         }
         __syncthreads();
         /* what does not fit is dropped: the host notices (total > cap), grows the arrays and emits again */
@@ -910,24 +886,9 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
             const uint32_t m = m0 + threadIdx.x;
             if (m < na) {
                 const msd_ac_hit c = P.ac[acc_ac[m]];
-                msd_message mm;
-                mm.timestampMsg = sample_ts + c.f2_clock / 5; /* demod_2400.c:695 */
-                mm.sysTimestampMsg = sys_ts + (mm.timestampMsg - sample_ts) / 12000u;
-                mm.signalLevel = 0.0;
-                mm.addr = (c.modeac & 0x0000FF7Fu) | (1u << 24); /* mode_ac.c:168-202 */
-                mm.crc = 0;
-                mm.score = 0;
-                mm.msgtype = 32;
-                mm.msgbits = 16;
-                mm.correctedbits = 0;
-                mm.bestphase = 0;
-#pragma unroll
-                for (int k = 0; k < 14; ++k)
-                    mm.msg[k] = 0;
-                mm.msg[0] = (uint8_t)(c.modeac >> 8);
-                mm.msg[1] = (uint8_t)c.modeac;
-                mm.iid = 0;
-                mm.pad = 0;
+                const msd_message mm = msd_emit_mode_ac(c, sample_ts, sys_ts);
+                if (o + nm + m < cap)
+                    side[o + nm + m] = 0;
                 sh_rec[threadIdx.x].mm = mm;
                 if (FIELDS) {
                     /* the reference's one message record per buffer keeps the last decoded altitude
@@ -1081,13 +1042,14 @@ extern "C" int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hip
 }
 
 extern "C" int msd_launch_emit(const MsdResolveParams *p, uint32_t nbuffers, const unsigned long long *power,
-                               msd_wire *dense, msd_fields *fields, uint32_t cap, hipStream_t stream)
+                               unsigned long long *side, msd_wire *dense, msd_fields *fields, uint32_t cap,
+                               hipStream_t stream)
 {
     if (nbuffers == 0)
         return 0;
     if (fields)
-        hipLaunchKernelGGL(msd_emit_kernel<true>, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
+        hipLaunchKernelGGL(msd_emit_kernel<true>, dim3(nbuffers), dim3(256), 0, stream, *p, power, side, dense, fields, cap);
     else
-        hipLaunchKernelGGL(msd_emit_kernel<false>, dim3(nbuffers), dim3(256), 0, stream, *p, power, dense, fields, cap);
+        hipLaunchKernelGGL(msd_emit_kernel<false>, dim3(nbuffers), dim3(256), 0, stream, *p, power, side, dense, fields, cap);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
