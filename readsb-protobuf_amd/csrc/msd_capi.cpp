@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -43,61 +44,64 @@ constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
  * statistics, the copy into the caller's arrays), so that it overlaps with the calling thread queueing
  * the next batch's resolve.  At most one job at a time; run() returns at once, wait() joins it. */
 struct Helper {
+    /* one worker thread, jobs in order.  A job may call mark_delivered() when the part its poster waits for is
+     * done; what it does after that is background work that the next job queues up behind. */
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<void()> job;
-    bool pending = false, stop = false;
-    bool delivered = false; /* the job has passed the point its poster waits for (mark_delivered); the rest is background */
+    std::deque<std::function<void()>> jobs;
+    uint64_t posted = 0, delivered = 0, finished = 0; /* jobs posted / past their delivery point / complete */
+    bool stop = false;
     int device = 0;
     void loop()
     {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv.wait(lk, [&] { return pending || stop; });
-            if (stop)
-                return;
+            cv.wait(lk, [&] { return !jobs.empty() || stop; });
+            if (jobs.empty())
+                return; /* stop, and nothing left to do */
+            std::function<void()> job = std::move(jobs.front());
+            jobs.pop_front();
             lk.unlock();
             job();
             lk.lock();
-            pending = false;
-            delivered = true;
+            ++finished;
+            if (delivered < finished)
+                delivered = finished;
             cv.notify_all();
         }
     }
-    void run(std::function<void()> f)
+    void run(std::function<void()> f) /* does not wait: the job starts when the ones before it are complete */
     {
         std::unique_lock<std::mutex> lk(mu);
         if (!th.joinable())
             th = std::thread([this] { loop(); });
-        cv.wait(lk, [&] { return !pending; }); /* the background half of the previous job */
-        job = std::move(f);
-        pending = true;
-        delivered = false;
+        jobs.push_back(std::move(f));
+        ++posted;
         cv.notify_all();
     }
-    void mark_delivered() /* from the job */
+    void mark_delivered() /* from the running job */
     {
         std::unique_lock<std::mutex> lk(mu);
-        delivered = true;
+        delivered = finished + 1;
         cv.notify_all();
     }
-    void wait_delivered()
+    void wait_delivered() /* the last job posted has passed its delivery point */
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return delivered || !pending; });
+        cv.wait(lk, [&] { return delivered >= posted; });
     }
-    void wait()
+    void wait() /* everything posted is complete */
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !pending; });
+        cv.wait(lk, [&] { return finished >= posted; });
     }
     void shutdown()
     {
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !pending; });
+            cv.wait(lk, [&] { return finished >= posted; });
             stop = true;
             cv.notify_all();
         }
@@ -131,6 +135,8 @@ struct Slot {
     unsigned long long *h_side = nullptr;          /* per record: power sum | signal_len << 48, for the statistics */
     msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr, ev_power = nullptr;
+    hipEvent_t ev_scanned = nullptr; /* side-stream layout: this batch's scan + gather are done (its float sums / Mode A/C kernels follow) */
+    uint64_t launch_seq = 0;         /* running number of the launch that filled the slot */
     /* batch description */
     const uint8_t *d_iq = nullptr;
     const uint8_t *d_prev = nullptr;
@@ -243,6 +249,7 @@ struct msd_ctx {
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
+    uint64_t launch_count = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
     float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
@@ -492,6 +499,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
             s.tail_dst = nullptr; /* done */
         if (rc)
             return fail(c, rc, "gather kernel launch failed");
+        if (!c->chain_inline && s.ev_scanned) /* the previous batch's chain is queued to start here, beside what follows */
+            HIPCHK(c, hipEventRecord(s.ev_scanned, c->stream));
     } else if (s.timed) {
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
@@ -895,8 +904,15 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (rc)
         return rc;
-    if (ks != c->stream)
+    if (ks != c->stream) {
         HIPCHK(c, hipStreamWaitEvent(ks, s.ev_totals, 0));
+        /* Side streams: a scan workgroup fills its compute unit (all registers, all LDS), so a chain kernel that
+         * meets a scan waits for it; the latency-bound kernels behind the scan (float sums, Mode A/C) leave
+         * room.  If the next batch is queued already, the chain starts when that batch's scan has retired. */
+        Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
+        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES)
+            HIPCHK(c, hipStreamWaitEvent(ks, nx.ev_scanned, 0));
+    }
     rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
@@ -1299,6 +1315,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         return fail(c, -EBUSY, "pipeline full: call msd_collect() first");
     Slot &s = c->slots[(c->head + c->outstanding) % MSD_PIPELINE_DEPTH];
     s.busy = true;
+    s.launch_seq = ++c->launch_count;
     s.d_iq = static_cast<const uint8_t *>(d_iq);
     s.d_prev = c->d_tail[c->tail_cur];
     s.have_prev = c->have_prev ? 1 : 0;
@@ -1437,6 +1454,7 @@ void destroy(msd_ctx *c)
         if (s.ev_resolve) (void)hipEventDestroy(s.ev_resolve);
         if (s.ev_records) (void)hipEventDestroy(s.ev_records);
         if (s.ev_power) (void)hipEventDestroy(s.ev_power);
+        if (s.ev_scanned) (void)hipEventDestroy(s.ev_scanned);
         if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
         (void)hipFree(s.d_upload);
         (void)hipFree(s.d_wire);
@@ -1700,6 +1718,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipEventCreateWithFlags(&s.ev_resolve, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&s.ev_records, hipEventDisableTiming));
             CK(hipEventCreateWithFlags(&s.ev_power, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&s.ev_scanned, hipEventDisableTiming));
         }
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
         CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_snaps), sizeof(uint32_t) * MSD_SNAP_WORDS * (SNAP_CAP + 1)));
