@@ -244,8 +244,6 @@ struct msd_ctx {
     std::vector<uint64_t> bg_scaled; /* per message: power sum | signal_len << 48 (msd_emit_impl.h) */
     bool emit_fused = false;
     struct Slot *pending_emit = nullptr;
-    bool emit_side_only = false; /* MSD_EMIT_SIDE_ONLY: everything in order on the scan stream but the record kernel */
-    bool resolve_inline = false; /* MSD_RESOLVE_INLINE: predict + resolve in order on the scan stream, records on their own */
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
@@ -898,9 +896,9 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     /* The scan stream carries scans (and their gathers) only, back to back.  Prediction + resolve run on
      * the high-priority chain stream behind the batch's own scan (ev_totals), power + records on a third
      * one behind the resolve: they share the GPU with the next batch's scan instead of delaying it. */
-    hipStream_t ks = (c->chain_inline || c->resolve_inline || c->emit_side_only) ? c->stream : c->aux_stream;
+    hipStream_t ks = c->chain_inline ? c->stream : c->aux_stream;
     hipStream_t es = c->chain_inline ? c->stream : c->emit_stream;
-    hipStream_t pws = c->emit_side_only ? c->stream : es; /* the signal power kernel */
+    hipStream_t pws = es; /* the signal power kernel */
     int rc = ensure_req(c, s, (size_t)s.nbuffers * 96 + 4096);
     if (rc)
         return rc;
@@ -986,7 +984,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
-        hipStream_t ps = (c->repass_aux || !(c->chain_inline || c->resolve_inline || c->emit_side_only)) ? c->aux_stream : c->stream;
+        hipStream_t ps = (c->repass_aux || !c->chain_inline) ? c->aux_stream : c->stream;
         rc = gpu_queue_pass(c, s, ps, false);
         if (rc)
             return rc;
@@ -1564,10 +1562,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
-        /* MSD_EMIT_PRIORITY (experiment): 0 = lowest, 1 = default, 2 = highest (default) */
-        const char *ep = getenv("MSD_EMIT_PRIORITY");
-        const int eprio = ep && *ep == '0' ? least : (ep && *ep == '1' ? (least + greatest) / 2 : greatest);
-        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, eprio));
+        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, greatest));
     }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
@@ -1685,8 +1680,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
         { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
-        { const char *eo = getenv("MSD_EMIT_SIDE_ONLY"); c->emit_side_only = eo && *eo && *eo != '0'; }
-        { const char *ri = getenv("MSD_RESOLVE_INLINE"); c->resolve_inline = ri && *ri && *ri != '0'; }
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);

@@ -658,7 +658,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
     }
 
     /* On the way: this wavefront's share of the previous batch's message records (its resolve and power kernels
-     * ran before this launch), written between two tiles from the candidate scratch -- a different tile for
+     * ran before this launch), written inside one of its tiles from the candidate scratch -- a different tile for
      * neighbouring wavefronts, so that the PCIe writes of the 2 MB spread over the whole launch instead of
      * queueing up at its start (where every wavefront's next load would wait behind its own stores). */
     const uint32_t emit_at = P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
@@ -716,6 +716,11 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             }
         }
         wave_lds_sync();
+
+        /* the record slice goes here, behind the tile's last global loads: tests and candidate rounds need none,
+         * so nothing waits for the PCIe stores until the next tile's table loads, 15 us on */
+        if (tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
+            msd_emit_slice(P.emit, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
 
         if (!(P.debug_flags & 2)) {
             /* ---- stage 2: preamble tests for my NH runs of 16 consecutive positions (demod_2400.c:257-335) ---- */
@@ -838,8 +843,6 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             cur[k] = nxt[k];
             cur_valid[k] = nxt_valid[k];
         }
-        if (tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
-            msd_emit_slice(P.emit, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
     }
     flush_sums();
     hits_total = hcur;

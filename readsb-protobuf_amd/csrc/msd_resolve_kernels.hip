@@ -818,10 +818,12 @@ __device__ inline void emit_rows(msd_wire *dense, msd_fields *fields, const msd_
     }
 }
 
-/* The accepted messages of buffer b as 64-byte records (msd_message + signal power sum), dense over
- * the batch; one DMA then takes them to the host while the next scan runs. */
-/* FIELDS = false (no MSD_CFG_DECODE_FIELDS): 14 KB of LDS and few registers, so that the workgroups fit
- * next to a resident scan workgroup and the records leave while the next batch is scanned. */
+/* The accepted messages of buffer b as 56-byte msd_message records, dense over the batch, written straight to
+ * page-locked host memory (msd_emit_impl.h builds them; `side` gets the power sum and length per record, for the
+ * host's statistics).  This kernel is the record writer with MSD_CFG_DECODE_FIELDS (FIELDS = true: the header
+ * fields, 140 bytes more per message), in the side-stream layout, for the last batch of a run and after a
+ * second resolve pass; in the in-order layout the wavefronts of the next scan write the records
+ * (msd_emit_slice, MsdScanParams.emit). */
 template <bool FIELDS>
 __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P, const unsigned long long *power,
                                                        unsigned long long *side, msd_wire *dense, msd_fields *fields_arg,
