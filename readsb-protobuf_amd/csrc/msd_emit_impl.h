@@ -97,10 +97,10 @@ __device__ inline void msd_emit_slice(const MsdEmitJob &J, uint32_t w, int lane,
         __builtin_amdgcn_wave_barrier();
         if (first < J.cap && !dbg_no_store) {
             n = min(n, J.cap - first);
-            uint2 *d = reinterpret_cast<uint2 *>(J.dense + first);
-            const uint2 *r = reinterpret_cast<const uint2 *>(rec);
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(J.dense + first);
+            const unsigned long long *r = reinterpret_cast<const unsigned long long *>(rec);
             for (uint32_t i = (uint32_t)lane; i < n * (uint32_t)(sizeof(msd_wire) / 8); i += 64)
-                d[i] = r[i];
+                __builtin_nontemporal_store(r[i], &d[i]); /* streaming: nothing on the device reads it again */
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
