@@ -35,3 +35,51 @@ def test_bounded_slice_of_the_randomised_sweep():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "24", "5000"], capture_output=True,
                          text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "failures: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{"MSD_CHAIN_INLINE": "0"}, {"MSD_CHAIN_INLINE": "1"}, {"MSD_EMIT_FUSED": "0"},
+                                 {"MSD_NO_HELPER": "1"}],
+                         ids=["side-streams", "in-order", "record-kernel", "no-helper"])
+@pytest.mark.parametrize("mode", ["uc8", "uc8-ac-fix", "sc16"])
+def test_every_stream_layout_gives_the_same_messages(pkg, oracle, torch_cuda, monkeypatch, env, mode):
+    """The stream layouts of DESIGN.md 4.6 (chain in order with the records written by the next scan, chain on
+    side streams, a record kernel of its own, no helper thread) are scheduling only: each of them, forced through
+    its environment switch, must deliver the oracle's messages and counters -- two captures back to back on one
+    context (msd_restart), so that the early start across a capture boundary is on the path too."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fmt, ofmt, fix, ac = {"uc8": (pkg.FMT_UC8, oracle.FMT_UC8, 0, 0), "uc8-ac-fix": (pkg.FMT_UC8, oracle.FMT_UC8, 1, 1),
+                          "sc16": (pkg.FMT_SC16, oracle.FMT_SC16, 1, 0)}[mode]
+    n, batch = 36 * pkg.CHUNK + 4321, 8 * pkg.CHUNK
+    dem = pkg.Demodulator(fmt=fmt, nfix_crc=fix, mode_ac=ac, max_batch_samples=batch, message_capacity=1 << 18)
+    bps = dem.bytes_per_sample
+    caps, dev = [], []
+    for seed in (4711, 4712):
+        iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=seed, fmt=fmt, ac_per_sec=600 if ac else 0), n)
+        caps.append(iq)
+        dev.append(torch_cuda.from_numpy(iq).to("cuda:0"))
+    got, stats, inflight = {0: [], 1: []}, {}, []
+
+    def collect_one():
+        cap, last = inflight.pop(0)
+        got[cap].append(dem.collect())
+        if last:
+            stats[cap] = dem.stats() # the capture's own counters: the next capture's first batch is still out
+
+    for cap in (0, 1):
+        if cap == 1:
+            dem.restart() # the first capture's last batches are still in flight
+        off = 0
+        while off < n:
+            if len(inflight) == pkg.capi.PIPELINE_DEPTH:
+                collect_one()
+            m = min(batch, n - off)
+            dem.launch_device(dev[cap].data_ptr() + off * bps, m, off + m >= n)
+            inflight.append((cap, off + m >= n))
+            off += m
+    while inflight:
+        collect_one()
+    for cap in (0, 1):
+        want, wstats = oracle.Oracle(ofmt, 58, fix, ac).replay(caps[cap], cap=1 << 18)
+        assert len(want) > 500
+        assert_same(np.concatenate(got[cap]), stats[cap], want, wstats)
