@@ -180,6 +180,12 @@ def main():
                 "algorithmic_bytes_per_launch": launch_samples * bps, "kernel": "msd_scan_kernel",
                 "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
                 "algorithmic_bytes_per_sample": bps, "launches_timed": len(scan_ms), "launches": len(timings)}
+    # in the in-order layout without field decoding the scan's wavefronts also write the previous batch's message
+    # records; MSD_EMIT_FUSED=0 gives them a kernel of their own and times the scan alone
+    fused = (os.environ.get("MSD_EMIT_FUSED", "1") != "0" and not args.fields and
+             os.environ.get("MSD_CHAIN_INLINE", "0" if (args.mode_ac or args.format != "uc8" or args.dcfilter) else "1") != "0")
+    roofline["launch_includes"] = ("the previous batch's message records (35 000 x 56 B to host memory); "
+                                   "MSD_EMIT_FUSED=0 times the scan alone") if fused else "the scan only"
 
     out = {
         "metric": "IQ Msamples/s, 2.4 MSPS %s, Mode S demodulation (CRC-valid msgs/s alongside)" % args.format.upper(),
