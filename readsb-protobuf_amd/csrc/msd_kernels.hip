@@ -1999,6 +1999,71 @@ __device__ __forceinline__ bool ac_eval(const uint16_t *mags, int p, uint32_t j0
     return true;
 }
 
+/* The same reply in pieces, for positions that are known to pass the F1 and F2 pulse tests (ac_eval<1>):
+ * ac_head gives the clock of the first bit and the two thresholds of the bit windows (demod_2400.c:591-640),
+ * ac_bit looks at one of the twenty windows (:642-668), ac_code turns the twenty bits into the reply
+ * (:669-685).  Same arithmetic, operation for operation, as ac_eval<2>. */
+__device__ __forceinline__ void ac_head(const uint16_t *mags, int p, uint32_t j0, uint32_t noise_level, uint32_t &f1_clock,
+                                        uint32_t &signal_threshold, uint32_t &noise_threshold)
+{
+    const uint32_t f1_sample = j0 + (uint32_t)p;
+#define ACM(x) ((uint32_t)mags[p + 2 + (int)((x) - f1_sample)])
+    const uint32_t m0 = ACM(f1_sample), m1 = ACM(f1_sample + 1);
+    const uint32_t f1_level = (m0 + m1) / 2;
+    const float f1a_power = (float)m0 * (float)m0;
+    const float f1b_power = (float)m1 * (float)m1;
+    const float fsum = f1a_power + f1b_power;
+    const float fraction = f1b_power / fsum;
+    const float frac2 = fraction * fraction;
+    const float fpos = (float)f1_sample + frac2;
+    const float fclk = 25.0f * fpos;
+    f1_clock = (uint32_t)((double)fclk + 0.5);
+    const uint32_t f2_sample = (f1_clock + (87 * 14)) / 25;
+    const uint32_t n0 = ACM(f2_sample), n1 = ACM(f2_sample + 1);
+    const uint32_t f2_level = (n0 + n1) / 2;
+    const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
+    const float midpoint = __builtin_sqrtf((float)(noise_level * f1f2_level)); /* u32 product */
+    const double up = (double)midpoint * 1.41421356237309504880;
+    const double down = (double)midpoint / 1.41421356237309504880;
+    signal_threshold = (uint32_t)(up + 0.5);
+    noise_threshold = (uint32_t)(down + 0.5);
+#undef ACM
+}
+
+/* window `bit` (0 = first) of the reply whose F1 position is p: bit 19 - bit set = a pulse, bit 31 = the window
+ * spoils the reply (noisy quiet period or uncertain bit) */
+__device__ __forceinline__ uint32_t ac_bit(const uint16_t *mags, int p, uint32_t j0, uint32_t f1_clock, uint32_t bit,
+                                           uint32_t signal_threshold, uint32_t noise_threshold)
+{
+    const uint32_t f1_sample = j0 + (uint32_t)p;
+    const uint32_t s = (f1_clock + 87u * bit) / 25u;
+    const uint16_t *w = mags + p + 2 + (int)(s - f1_sample);
+    const uint32_t x0 = w[0], x1 = w[1], x2 = w[2];
+    uint32_t r = 0;
+    if (x2 >= signal_threshold)
+        r |= 1u << 31;
+    if (x0 >= signal_threshold || x1 >= signal_threshold)
+        r |= 1u << (19u - bit);
+    else if (x0 > noise_threshold && x1 > noise_threshold)
+        r |= 1u << 31;
+    return r;
+}
+
+__device__ __forceinline__ bool ac_code(uint32_t bits /* with bit 31 = spoiled */, uint32_t &modeac)
+{
+    if (!((bits & 0x80020u) == 0x80020u && (bits & 0x0101Bu) == 0 && !(bits >> 31)))
+        return false;
+    /* demod_2400.c:672-685: 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 */
+    modeac = ((bits & 0x40000u) ? 0x0010u : 0) | ((bits & 0x20000u) ? 0x1000u : 0) |
+             ((bits & 0x10000u) ? 0x0020u : 0) | ((bits & 0x08000u) ? 0x2000u : 0) |
+             ((bits & 0x04000u) ? 0x0040u : 0) | ((bits & 0x02000u) ? 0x4000u : 0) |
+             ((bits & 0x00800u) ? 0x0100u : 0) | ((bits & 0x00400u) ? 0x0001u : 0) |
+             ((bits & 0x00200u) ? 0x0200u : 0) | ((bits & 0x00100u) ? 0x0002u : 0) |
+             ((bits & 0x00080u) ? 0x0400u : 0) | ((bits & 0x00040u) ? 0x0004u : 0) |
+             ((bits & 0x00004u) ? 0x0080u : 0);
+    return true;
+}
+
 /* Ordered compaction inside a workgroup: dst[] = the entries i of [0, n) (or src[i]) for which pred(i)
  * holds, in order; returns how many.  Entry i = r * ACNT + tid is looked at by thread tid in round r. */
 template <typename Pred>
@@ -2161,20 +2226,60 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
             uint32_t a, c;
             return ac_eval<1>(mags, (int)p, j0, mlen, noise_level, a, c);
         });
-        const uint32_t n3 = ac_compact(n2, surv2, surv, kcount, tid, [&](uint32_t p) {
-            uint32_t a, c;
-            return ac_eval<2>(mags, (int)p, j0, mlen, noise_level, a, c);
-        });
-        for (uint32_t i = (uint32_t)tid; i < n3; i += ACNT) { /* the records, decoded once more */
-            const int p = surv[i];
-            uint32_t f2c = 0, code = 0;
-            (void)ac_eval<2>(mags, p, j0, mlen, noise_level, f2c, code);
-            if (cur + i < cap) {
-                msd_ac_hit h;
-                h.pos = pos0 + (uint64_t)p;
-                h.f2_clock = f2c;
-                h.modeac = code;
-                mine[cur + i] = h;
+        /* The twenty bit windows of the n2 positions that are left (about one in a hundred), 256 of them at a
+         * time: one thread per position for the clock and the thresholds, then one thread per (position, window)
+         * -- a thread per position walking its twenty windows kept one wavefront in four busy with a fifth of
+         * its lanes -- then the survivors' records straight to the region, in position order.  The scratch
+         * lives in surv[], which the second compaction has left. */
+        uint32_t n3 = 0;
+        {
+            uint32_t *h_clk = reinterpret_cast<uint32_t *>(surv), *h_sig = h_clk + ACNT, *h_noise = h_sig + ACNT,
+                     *h_bits = h_noise + ACNT;
+            static_assert(sizeof(uint16_t) * ACT >= 4 * sizeof(uint32_t) * ACNT, "scratch fits in surv[]");
+            for (uint32_t c0 = 0; c0 < n2; c0 += ACNT) { /* workgroup-uniform */
+                const uint32_t nc = min((uint32_t)ACNT, n2 - c0);
+                if ((uint32_t)tid < nc) {
+                    uint32_t clk, sg, nz;
+                    ac_head(mags, (int)surv2[c0 + tid], j0, noise_level, clk, sg, nz);
+                    h_clk[tid] = clk;
+                    h_sig[tid] = sg;
+                    h_noise[tid] = nz;
+                    h_bits[tid] = 0;
+                }
+                __syncthreads();
+                for (uint32_t t = (uint32_t)tid; t < nc * 20u; t += ACNT) {
+                    const uint32_t i = t / 20u, bit = t - i * 20u;
+                    const uint32_t r = ac_bit(mags, (int)surv2[c0 + i], j0, h_clk[i], bit, h_sig[i], h_noise[i]);
+                    if (r)
+                        atomicOr(&h_bits[i], r);
+                }
+                __syncthreads();
+                uint32_t code = 0;
+                const bool keep = (uint32_t)tid < nc && ac_code(h_bits[tid], code);
+                const unsigned long long bal = __ballot(keep);
+                if (lane == 0)
+                    kcount32[wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < ACNT / 64; ++w) {
+                    const uint32_t c = kcount32[w];
+                    if (w < wave)
+                        before += c;
+                    total += c;
+                }
+                if (keep) {
+                    const uint32_t k = cur + n3 + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (k < cap) {
+                        msd_ac_hit h;
+                        h.pos = pos0 + (uint64_t)surv2[c0 + tid];
+                        h.f2_clock = h_clk[tid] + (87 * 14);
+                        h.modeac = code;
+                        mine[k] = h;
+                    }
+                }
+                n3 += total;
+                __syncthreads(); /* the scratch and kcount32 are rewritten by the next chunk / tile */
             }
         }
         cur += n3;
