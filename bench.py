@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1 << 29, help="samples per capture (1 GiB UC8 = 2^29)")
     ap.add_argument("--batch", type=int, default=1 << 26, help="samples per GPU batch")
     ap.add_argument("--format", default="uc8", choices=["uc8", "sc16", "sc16q11"])

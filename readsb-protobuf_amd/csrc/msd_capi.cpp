@@ -13,6 +13,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <chrono>
@@ -45,30 +46,55 @@ constexpr int TAIL_SAMPLES = MSD_HALO_FRONT;
  * the next batch's resolve.  At most one job at a time; run() returns at once, wait() joins it. */
 struct Helper {
     /* one worker thread, jobs in order.  A job may call mark_delivered() when the part its poster waits for is
-     * done; what it does after that is background work that the next job queues up behind. */
+     * done; what it does after that is background work that the next job queues up behind.  Both sides spin for
+     * a few hundred microseconds before they sleep: in a running stream the next event is never further away,
+     * and a sleeping thread on a busy host comes back late. */
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> jobs;
-    uint64_t posted = 0, delivered = 0, finished = 0; /* jobs posted / past their delivery point / complete */
+    std::atomic<uint64_t> posted{0}, delivered{0}, finished{0}; /* jobs posted / past their delivery point / complete */
     bool stop = false;
     int device = 0;
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    template <typename Pred>
+    static bool spin_for(Pred pred, int microseconds)
+    {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(microseconds);
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (pred())
+                    return true;
+                relax();
+            }
+            if (std::chrono::steady_clock::now() >= until)
+                return false;
+        }
+    }
     void loop()
     {
         (void)hipSetDevice(device);
-        std::unique_lock<std::mutex> lk(mu);
+        uint64_t taken = 0;
         for (;;) {
+            (void)spin_for([&] { return posted.load(std::memory_order_acquire) > taken; }, 500);
+            std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !jobs.empty() || stop; });
             if (jobs.empty())
                 return; /* stop, and nothing left to do */
             std::function<void()> job = std::move(jobs.front());
             jobs.pop_front();
+            ++taken;
             lk.unlock();
             job();
             lk.lock();
-            ++finished;
-            if (delivered < finished)
-                delivered = finished;
+            finished.store(taken, std::memory_order_release);
+            if (delivered.load(std::memory_order_relaxed) < taken)
+                delivered.store(taken, std::memory_order_release);
             cv.notify_all();
         }
     }
@@ -78,30 +104,36 @@ struct Helper {
         if (!th.joinable())
             th = std::thread([this] { loop(); });
         jobs.push_back(std::move(f));
-        ++posted;
+        posted.fetch_add(1, std::memory_order_release);
         cv.notify_all();
     }
     void mark_delivered() /* from the running job */
     {
         std::unique_lock<std::mutex> lk(mu);
-        delivered = finished + 1;
+        delivered.store(finished.load(std::memory_order_relaxed) + 1, std::memory_order_release);
         cv.notify_all();
     }
     void wait_delivered() /* the last job posted has passed its delivery point */
     {
+        const uint64_t want = posted.load(std::memory_order_acquire);
+        if (spin_for([&] { return delivered.load(std::memory_order_acquire) >= want; }, 400))
+            return;
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return delivered >= posted; });
+        cv.wait(lk, [&] { return delivered.load(std::memory_order_acquire) >= want; });
     }
     void wait() /* everything posted is complete */
     {
+        const uint64_t want = posted.load(std::memory_order_acquire);
+        if (spin_for([&] { return finished.load(std::memory_order_acquire) >= want; }, 200))
+            return;
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return finished >= posted; });
+        cv.wait(lk, [&] { return finished.load(std::memory_order_acquire) >= want; });
     }
     void shutdown()
     {
+        wait();
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return finished >= posted; });
             stop = true;
             cv.notify_all();
         }
