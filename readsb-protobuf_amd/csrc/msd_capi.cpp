@@ -142,6 +142,21 @@ struct Helper {
     }
 };
 
+/* hipEventSynchronize for events that are about to fire: poll for a few hundred microseconds first (the runtime's
+ * wait may put the thread to sleep, and on a busy host it then comes back late) */
+static hipError_t event_wait(hipEvent_t ev)
+{
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady)
+            return e;
+        if (std::chrono::steady_clock::now() >= until)
+            return hipEventSynchronize(ev);
+        Helper::relax();
+    }
+}
+
 struct Slot {
     bool busy = false;
     bool download_started = false;
@@ -702,7 +717,7 @@ int start_download(msd_ctx *c, Slot &s, int format)
         return 0;
     const bool trace = c->trace;
     auto td0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipEventSynchronize(s.ev_totals));
+    HIPCHK(c, event_wait(s.ev_totals));
     if (trace && s.timed) {
         float a = 0, b = 0;
         (void)hipEventElapsedTime(&a, s.ev_start, s.ev_scan);
@@ -885,7 +900,7 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t 
  * runtime picks a blit kernel instead, that copy takes compute units from the scan. */
 int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
 {
-    HIPCHK(c, hipEventSynchronize(s.ev_records));
+    HIPCHK(c, event_wait(s.ev_records));
     if (total && c->records_dma) {
         HIPCHK(c, hipMemcpyAsync(s.h_wire, s.d_wire, (size_t)total * sizeof(msd_wire), hipMemcpyDeviceToHost,
                                  c->copy_stream));
@@ -996,7 +1011,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     for (uint32_t pass = 0;; ++pass) {
         auto k0 = tnow();
         ++npass;
-        HIPCHK(c, hipEventSynchronize(wait_for));
+        HIPCHK(c, event_wait(wait_for));
         auto k1 = tnow();
         int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
