@@ -196,6 +196,7 @@ struct Slot {
     msd_hit *d_hits = nullptr;
     msd_try *d_tries = nullptr;
     uint64_t *d_totals = nullptr;
+    float *d_tile_sums = nullptr;    /* SC16 / SC16Q11: the scan's per-tile float sums, for the float-sum kernel's predictions */
     uint32_t *d_rec_off = nullptr;   /* [max_buffers + 2] records in front of each buffer's (power kernel) */
     uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
     bool buf_first_valid = false;
@@ -491,6 +492,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         p.counts = c->d_counts;
         p.wg_totals = c->d_wg_totals;
         p.chunk_sums = s.d_sums;
+        p.tile_sums = (fm && !s.dc && tile == 1024) ? s.d_tile_sums : nullptr;
         p.timers = c->d_timers;
         p.debug_flags = c->debug_flags;
         Slot *carried = nullptr;
@@ -552,6 +554,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     if (fm && s.nbuffers) {
         int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, c->stream)
                       : msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
+                                               nwg && msd_scan_tile(format) == 1024 ? s.d_tile_sums : nullptr,
                                                c->stream);
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
@@ -1479,7 +1482,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(c->d_timers);
     }
     for (Slot &s : c->slots) {
-        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_rec_off); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
+        (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_rec_off); (void)hipFree(s.d_tile_sums); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
         if (s.h_totals) (void)hipHostFree(s.h_totals);
         if (s.h_sums) (void)hipHostFree(s.h_sums);
         if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
@@ -1682,6 +1685,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
+        if (cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11)
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_tile_sums), ((size_t)c->max_buffers * (MSD_CHUNK_SAMPLES / 1024) + 2) * 2 * sizeof(float)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_rec_off), (c->max_buffers + 2) * sizeof(uint32_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_ragged), 64));
         CK(hipMemset(s.d_ragged, 0, 64));
@@ -2079,7 +2084,7 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
         if (rc)
             return fail(c, rc, "convert kernel launch failed");
         if (c->cfg.format != MSD_FMT_UC8) {
-            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, c->stream);
+            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->stream);
             if (rc)
                 return fail(c, rc, "float means kernel launch failed");
         }

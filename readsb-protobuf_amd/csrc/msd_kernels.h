@@ -58,6 +58,8 @@ typedef struct MsdScanParams {
     msd_region_counts *counts; /* [scan workgroups * MSD_SCAN_WAVES] */
     msd_wg_totals *wg_totals;  /* [scan workgroups] */
     uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
+    float *tile_sums;     /* SC16 / SC16Q11: [tile][2] approximate float sums of a tile's magnitudes and squares (what the
+                             float-sum kernel predicts its binades from), or NULL */
     unsigned long long *timers; /* MSD_KERNEL_TIMING builds only */
     int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
                              2 = stop after the conversion (results are then incomplete) */
@@ -153,8 +155,9 @@ int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float d
                         uint16_t *d_mag, float *d_magsq, hipStream_t stream);
 int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
                        hipStream_t stream);
+/* tile_sums: the scan kernel's per-1024-sample approximate sums of the same batch (buffer_len a multiple of 1024), or NULL */
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                           uint32_t nbuffers, float *d_out, hipStream_t stream);
+                           uint32_t nbuffers, float *d_out, const float *tile_sums, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -613,10 +613,29 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
      * wraps), pw_top = the sum of (m >> 5)^2, which fits (2047^2 * 256 < 2^32) and brackets the true
      * sum: 1024 * pw_top <= sum < 1024 * pw_top + 256 * (64 * 2047 * 31 + 31^2) < 1024 * pw_top + 2^31.
      * power_sum() puts the two together when the buffer changes or after 256 samples per lane. */
-    uint32_t pw_mod = 0, pw_top = 0, sum_tiles = 0;
+    uint32_t pw_mod = 0, pw_top = 0, sum_tiles = 0, sum_tile0 = tile_lo; /* sum_tile0: first tile in the running sums */
     uint64_t sum_chunk = (uint64_t)tile_lo * WT / MSD_CHUNK_SAMPLES;
+    /* 16-bit IQ (P.tile_sums): the sums of every single tile as floats (magnitude / 65535, its square) -- what
+     * the float-sum kernel needs to predict the binade of its sequential sums at every 1024-sample block.  A
+     * lane then holds 16 samples: its sums fit 20 and 36 bits, the wavefront's are three DPP scans, and the
+     * buffer's exact sums wait in scalar registers until the buffer changes. */
+    unsigned long long acc_level = 0, acc_power = 0;
     auto flush_sums = [&]() {
-        if (P.chunk_sums) {
+        if (P.chunk_sums && P.tile_sums) {
+            if (sum_tiles) {
+                const unsigned long long sp = power_sum(pw_mod, pw_top);
+                const uint32_t tl = wave_last(wave_incl_scan((uint32_t)sum_level));
+                const uint32_t tlo = wave_last(wave_incl_scan((uint32_t)sp & 0xffffffu));
+                const uint32_t thi = wave_last(wave_incl_scan((uint32_t)(sp >> 24)));
+                const unsigned long long tp = ((unsigned long long)thi << 24) + tlo;
+                acc_level += tl;
+                acc_power += tp;
+                if (lane == 0) {
+                    P.tile_sums[2 * sum_tile0] = (float)tl * (1.0f / 65535.0f);
+                    P.tile_sums[2 * sum_tile0 + 1] = (float)tp * (1.0f / (65535.0f * 65535.0f));
+                }
+            }
+        } else if (P.chunk_sums) {
             unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -632,6 +651,14 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         pw_mod = 0;
         pw_top = 0;
         sum_tiles = 0;
+    };
+    auto flush_chunk = [&]() { /* tile mode: the buffer's exact sums, once per buffer and wavefront */
+        if (P.chunk_sums && P.tile_sums && lane == 0 && (acc_level | acc_power)) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), acc_level);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), acc_power);
+        }
+        acc_level = 0;
+        acc_power = 0;
     };
 
     /* look-behind of the first tile: samples [a0 - 328, a0) */
@@ -670,9 +697,12 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
         {
             const uint64_t c = tile_pos0 / MSD_CHUNK_SAMPLES;
-            if (c != sum_chunk || sum_tiles == 16 / NH) { /* wave-uniform */
+            if (c != sum_chunk || sum_tiles == (P.tile_sums ? 1u : 16u / NH)) { /* wave-uniform */
                 flush_sums();
+                if (c != sum_chunk)
+                    flush_chunk();
                 sum_chunk = c;
+                sum_tile0 = tile;
             }
             ++sum_tiles;
         }
@@ -845,6 +875,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         }
     }
     flush_sums();
+    flush_chunk();
     hits_total = hcur;
     tries_total = tcur;
 }
@@ -1588,7 +1619,8 @@ __device__ unsigned long long msd_fm_cyc[8]; /* pass 1, prefix, pass 2, apply (1
 template <int FMT>
 __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
                                                                       uint64_t buffer_len, uint32_t nbuffers,
-                                                                      float *out /* [nbuffers][2] */)
+                                                                      float *out /* [nbuffers][2] */,
+                                                                      const float *tile_sums /* or NULL */)
 {
     __shared__ float blk_tot[2][FB_MAX];    /* approximate totals, then approximate prefix at the block's start */
     __shared__ uint32_t blk_f0[2][FB_MAX], blk_f1[2][FB_MAX];
@@ -1613,6 +1645,13 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
 
     /* pass 1: approximate totals.  I^2 + Q^2 is one v_dot2 on the packed sample (an exact integer; the float
      * path rounds each square and the sum -- a relative 2^-23 that a prediction does not care about) */
+    if (tile_sums) { /* the scan kernel of the same batch left them: one load per block instead of a pass over the samples */
+        const float *ts = tile_sums + 2 * (first / FS_BLOCK);
+        for (uint32_t blk = (uint32_t)tid; blk < nblk; blk += FM_THREADS) {
+            blk_tot[0][blk] = ts[2 * blk];
+            blk_tot[1][blk] = ts[2 * blk + 1];
+        }
+    } else
     for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
         float sl = 0.0f, sp = 0.0f;
         if (FMT == MSD_FMT_MAGSQ) {
@@ -2534,25 +2573,27 @@ extern "C" int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsampl
 extern "C" int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers,
                                   float *d_out, hipStream_t stream)
 {
-    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, stream);
+    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, nullptr, stream);
 }
 
 extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                                      uint32_t nbuffers, float *d_out, hipStream_t stream)
+                                      uint32_t nbuffers, float *d_out, const float *tile_sums, hipStream_t stream)
 {
+    if (buffer_len % FS_BLOCK)
+        tile_sums = nullptr;
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
     const uint32_t grid = nbuffers; /* one workgroup per buffer */
     static const bool v1 = getenv("MSD_FMEANS_V1") != nullptr; /* the one-wavefront-per-sum kernel, for comparison */
     if (!v1 && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK) {
         if (format == MSD_FMT_SC16)
             hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out);
+                               nsamples, buffer_len, nbuffers, d_out, tile_sums);
         else if (format == MSD_FMT_SC16Q11)
             hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out);
+                               nsamples, buffer_len, nbuffers, d_out, tile_sums);
         else if (format == MSD_FMT_MAGSQ) /* msd_launch_dc_sums */
             hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_MAGSQ>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out);
+                               nsamples, buffer_len, nbuffers, d_out, static_cast<const float *>(nullptr));
         else
             return -22;
         return hipGetLastError() == hipSuccess ? 0 : -5;
