@@ -157,3 +157,37 @@ def test_sequential_float_sums_on_structured_inputs(pkg, oracle, torch_cuda, fmt
                 assert_blocks_equal(out_g, out_o)
             except AssertionError as e:
                 raise AssertionError(f"{name} length {length}: {e}")
+
+
+@pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
+def test_stream_float_sums_on_structured_buffers(pkg, oracle, torch_cuda, fmt):
+    """The same structured inputs through the stream path, one pattern per 131072-sample buffer: there the
+    float-sum kernel predicts the binades of its sums from the per-tile sums the scan kernel leaves (16-bit
+    magnitudes, not the floats themselves), so what is tested is that a prediction which is off -- tiny sums,
+    block totals on a power of two, bursts after silence -- only ever costs time.  The per-buffer means reach
+    the statistics (noise power) that the comparison with the oracle covers."""
+    from test_gpu_parity import assert_same
+    full = 32767 if fmt == "sc16" else 2047
+    rng = np.random.default_rng(12)
+    n = 131072
+    bufs = [
+        np.full((n, 2), 3, dtype=np.int16),
+        np.full((n, 2), full // 16, dtype=np.int16),
+        np.full((n, 2), full, dtype=np.int16),
+        np.stack([np.tile(np.array([1, 2, 4, 8, 16, 32, 64, 128], dtype=np.int16) * (full // 2048 + 1), n // 8),
+                  np.zeros(n, dtype=np.int16)], axis=1),
+        np.where((np.arange(n) // 3000 % 3 == 0)[:, None], rng.integers(-full, full, size=(n, 2)), 0).astype(np.int16),
+        np.stack([(np.arange(n) % (2 * full) - full).astype(np.int16), np.zeros(n, dtype=np.int16)], axis=1),
+        rng.normal(0, full * 0.02, size=(n, 2)).round().astype(np.int16),
+        np.zeros((n, 2), dtype=np.int16),
+        np.where((np.arange(n) % 1024 == 1023)[:, None], np.full((n, 2), full), 0).astype(np.int16),  # one full-scale sample per block
+        rng.normal(0, full * 0.3, size=(n // 2 + 77, 2)).round().astype(np.int16),   # a ragged last buffer
+    ]
+    iq = np.ascontiguousarray(np.concatenate(bufs)).view(np.uint8).reshape(-1)
+    nsamples = iq.size // 4
+    pfmt, ofmt = (pkg.FMT_SC16, oracle.FMT_SC16) if fmt == "sc16" else (pkg.FMT_SC16Q11, oracle.FMT_SC16Q11)
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=pfmt, nfix_crc=1, max_batch_samples=4 * pkg.CHUNK, message_capacity=1 << 16)
+    got = pkg.replay_device(dem, d.data_ptr(), nsamples, 4 * pkg.CHUNK)
+    want, wstats = oracle.Oracle(ofmt, 58, 1, 0).replay(iq, cap=1 << 16)
+    assert_same(got, dem.stats(), want, wstats)
