@@ -311,6 +311,8 @@ int msd_launch_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last)
 int msd_host_alloc(msd_ctx *ctx, size_t bytes, void **out); /* page-locked host memory */
 void msd_host_free(msd_ctx *ctx, void *p);
 
+/* The counters of everything collected so far (the order-sensitive power statistics of the last batch are summed on
+ * a helper thread after msd_collect() has returned: this call waits for them). */
 int msd_get_stats(const msd_ctx *ctx, msd_stats *st);
 int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
 /* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
