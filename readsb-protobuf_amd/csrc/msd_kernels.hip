@@ -591,7 +591,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
 }
 
 /* One wavefront's share of the batch: the tiles [tile_lo, tile_hi) of 1024 * tile_runs(FMT) scan positions each. */
-template <int FMT, bool FIX2>
+template <int FMT, bool FIX2, bool EMIT>
 __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCtx &X, const uint16_t *lut,
                                             uint32_t region, uint32_t tile_lo, uint32_t tile_hi, uint32_t &hits_total,
                                             uint32_t &tries_total)
@@ -688,7 +688,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
      * ran before this launch), written inside one of its tiles from the candidate scratch -- a different tile for
      * neighbouring wavefronts, so that the PCIe writes of the 2 MB spread over the whole launch instead of
      * queueing up at its start (where every wavefront's next load would wait behind its own stores). */
-    const uint32_t emit_at = P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
+    const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
 
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         const uint64_t tile_pos0 = (uint64_t)tile * WT; /* first scan position, batch-relative */
@@ -749,7 +749,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 
         /* the record slice goes here, behind the tile's last global loads: tests and candidate rounds need none,
          * so nothing waits for the PCIe stores until the next tile's table loads, 15 us on */
-        if (tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
+        if (EMIT && tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
             msd_emit_slice(P.emit, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
 
         if (!(P.debug_flags & 2)) {
@@ -880,7 +880,9 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
     tries_total = tcur;
 }
 
-template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */>
+template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */,
+          bool EMIT /* the wavefronts also write the previous batch's message records (P.emit): an instantiation of its
+                       own, because the call alone costs the tile loop 7 us per launch in spills */>
 __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3) / 4) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -919,7 +921,7 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
         X.syn = syn;
         X.sl = sl;
         X.lane = lane;
-        scan_region<FMT, FIX2>(P, X, lut, region, tile_lo, tile_hi, nhits, ntries);
+        scan_region<FMT, FIX2, EMIT>(P, X, lut, region, tile_lo, tile_hi, nhits, ntries);
     }
     if (lane == 0) {
         wgc[4 * wave] = nhits;
@@ -2366,24 +2368,27 @@ extern "C" size_t msd_scan_lds_bytes(int format)
     return format == MSD_FMT_UC8 ? (size_t)LDS_UC8 : (size_t)LDS_COMMON;
 }
 
-template <int FMT, bool FIX2>
+template <int FMT, bool FIX2, bool EMIT>
 static int launch_scan_fix(const MsdScanParams *p, uint32_t nregions, hipStream_t stream)
 {
     const size_t lds = msd_scan_lds_bytes(FMT);
     const uint32_t nwg = (nregions + WAVES - 1) / WAVES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT, FIX2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT, FIX2, EMIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return -5;
-    hipLaunchKernelGGL((msd_scan_kernel<FMT, FIX2>), dim3(nwg), dim3(NT), lds, stream, *p);
+    hipLaunchKernelGGL((msd_scan_kernel<FMT, FIX2, EMIT>), dim3(nwg), dim3(NT), lds, stream, *p);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 template <int FMT>
 static int launch_scan_fmt(const MsdScanParams *p, uint32_t nregions, hipStream_t stream)
 {
-    return p->fix2_112 ? launch_scan_fix<FMT, true>(p, nregions, stream)
-                       : launch_scan_fix<FMT, false>(p, nregions, stream);
+    if (p->emit.nbuffers)
+        return p->fix2_112 ? launch_scan_fix<FMT, true, true>(p, nregions, stream)
+                           : launch_scan_fix<FMT, false, true>(p, nregions, stream);
+    return p->fix2_112 ? launch_scan_fix<FMT, true, false>(p, nregions, stream)
+                       : launch_scan_fix<FMT, false, false>(p, nregions, stream);
 }
 
 extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipStream_t stream)
