@@ -149,6 +149,28 @@ typedef struct msd_fields { /* 140 bytes */
     uint8_t commb_valid;         /* MSD_COMMB_* */
     uint8_t pad2[3];
 } msd_fields;
+/* The float-valued members of struct modesMessage (readsb.h:423-438,533-534) that decodeModesMessage derives from
+ * the integers above, with the reference's own expressions evaluated on the host (msd_fields_to_float):
+ *   gs.v0 / gs.v2 / gs.selected   sqrtf(ns^2 + ew^2 + 0.5) (mode_s.c:831), the surface movement tables
+ *                                 (mode_s.c:216-259,913-915), BDS 5,0 ground speed (comm_b.c:577)
+ *   heading                       atan2 ground track (mode_s.c:835-839), raw * 360/1024 (:853), * 360/128 (:922),
+ *                                 BDS 5,0 track / BDS 6,0 heading (comm_b.c:485-490,623-628)
+ *   roll, track_rate, mach        comm_b.c:469-474,513-518,649-651
+ *   nav.qnh, nav.heading          mode_s.c:1131,1212,1219; comm_b.c:323-326
+ * A *_valid of 0 leaves the value 0.  The GPU delivers the integers (a float square root or atan2 evaluated
+ * there would not be the host libm's); this is the last step to a complete struct modesMessage. */
+typedef struct msd_fields_float {
+    float gs_v0, gs_v2, gs_selected;
+    float heading;     /* with heading_type from msd_fields, or HEADING_GROUND_TRACK (1) when derived from ew/ns */
+    float track_rate;
+    float roll;
+    float nav_qnh;
+    float nav_heading;
+    double mach;
+    uint8_t gs_valid, heading_valid, heading_type, track_rate_valid, roll_valid, mach_valid, nav_qnh_valid,
+        nav_heading_valid;
+} msd_fields_float;
+
 #define MSD_COMMB_ROLL 1u
 #define MSD_COMMB_GS 2u
 #define MSD_COMMB_TRACK_RATE 4u
@@ -282,7 +304,7 @@ int msd_set_timing_interval(msd_ctx *ctx, uint32_t every);
 /* Modes.preambleThreshold for the batches launched from now on.  The reference raises it to
  * max(PREAMBLE_THRESHOLD_PIZERO = 75, threshold) while its 15-minute statistics hold dropped samples
  * (demod_2400.c:285-290); that statistics window belongs to the host program, which calls this when
- * it opens and closes.  -EINVAL outside 1..255. */
+ * it opens and closes.  -EINVAL outside 1..MSD_MAX_PREAMBLE_THRESHOLD (400). */
 #define MSD_MAX_PREAMBLE_THRESHOLD 400 /* --preamble-threshold is clamped to 40..400, readsb.c:503-505 */
 int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
 
@@ -318,6 +340,9 @@ int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
 /* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
  * fifo.h:70-71): 2 doubles per buffer, up to cap buffers; returns the number of buffers. */
 int msd_get_buffer_means(const msd_ctx *ctx, double *means, size_t cap);
+
+/* msd_fields -> the float-valued members of struct modesMessage, on the host (see msd_fields_float). */
+void msd_fields_to_float(const msd_fields *fields, msd_fields_float *out);
 
 /* ---- iq_convert_fn-shaped converter (convert.h:33-38): host buffers in, host buffers out,
  * bit-identical u16 magnitudes and means for UC8 / SC16 / SC16Q11 without DC filter.

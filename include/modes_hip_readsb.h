@@ -93,6 +93,21 @@ void msd_fifo_release(struct msd_mag_buf *buf);                                 
 /* ------------------------------------------------------------------------------------------ */
 /* "ifile" SDR front-end (sdr.c:41-50,78-98; sdr_ifile.c)                                     */
 /* ------------------------------------------------------------------------------------------ */
+/* demodulators (demod_2400.h:37-38)                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* `void demodulate2400(struct mag_buf *)` / `void demodulate2400AC(struct mag_buf *)` for the consumer loop of
+ * readsb.c:820-855.  What the reference's functions take from the global `Modes` is bound once: the GPU context
+ * (created with the receiver's options, e.g. msd_converter_context() or msd_create) and the message sink that
+ * stands for useModesMessage().  msd_demodulate2400 runs the buffer through the GPU (Mode S, Mode A/C if the
+ * context has it, icaoFilterExpire) and delivers the Mode S messages; msd_demodulate2400AC on the SAME buffer
+ * then delivers its Mode A/C replies -- the reference's order.  void like the reference's: after a device
+ * failure nothing is delivered and msd_demod_error() says why.  ctx == NULL unbinds. */
+int msd_demod_bind(msd_ctx *ctx, int mode_ac, msd_message_fn sink, void *user);
+void msd_demodulate2400(struct msd_mag_buf *mag);   /* demod_2400.h:37 */
+void msd_demodulate2400AC(struct msd_mag_buf *mag); /* demod_2400.h:38 */
+const char *msd_demod_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Shaped like the reference's handler so it can be registered in sdr_handlers[]:
  *     { msd_ifileInitConfig, msd_ifileHandleOption, msd_ifileOpen, msd_ifileRun, msd_ifileClose,
  *       "ifile", SDR_IFILE, 0 }

@@ -806,6 +806,38 @@ static void es_ident(const uint8_t *me, orc_fields *f) /* mode_s.c:736-766 */
     f->category_valid = 1;
 }
 
+/* The float-valued members decodeModesMessage assigns (readsb.h:423-438,533-534), written where the reference
+ * writes them, with its expressions and its variable types; orc_fields_float_of points this at its output. */
+enum { HT_INVALID, HT_GROUND_TRACK, HT_TRUE, HT_MAGNETIC, HT_MAGNETIC_OR_TRUE, HT_TRACK_OR_HEADING }; /* readsb.h:158-165 */
+static __thread orc_fields_float *cur_ff;
+
+static float movement_field_v2(unsigned movement) /* mode_s.c:216-234 */
+{
+    if (movement >= 125) return 0;
+    else if (movement == 124) return 180;
+    else if (movement >= 109) return 100 + (movement - 109 + 0.5) * 5;
+    else if (movement >= 94) return 70 + (movement - 94 + 0.5) * 2;
+    else if (movement >= 39) return 15 + (movement - 39 + 0.5) * 1;
+    else if (movement >= 13) return 2 + (movement - 13 + 0.5) * 0.50;
+    else if (movement >= 9) return 1 + (movement - 9 + 0.5) * 0.25;
+    else if (movement >= 3) return 0.125 + (movement - 3 + 0.5) * 0.875 / 6;
+    else if (movement >= 2) return 0.125 / 2;
+    else return 0;
+}
+
+static float movement_field_v0(unsigned movement) /* mode_s.c:242-259 */
+{
+    if (movement >= 125) return 0;
+    else if (movement == 124) return 180;
+    else if (movement >= 109) return 100 + (movement - 109 + 0.5) * 5;
+    else if (movement >= 94) return 70 + (movement - 94 + 0.5) * 2;
+    else if (movement >= 39) return 15 + (movement - 39 + 0.5) * 1;
+    else if (movement >= 13) return 2 + (movement - 13 + 0.5) * 0.50;
+    else if (movement >= 9) return 1 + (movement - 9 + 0.5) * 0.25;
+    else if (movement >= 2) return 0.125 + (movement - 2 + 0.5) * 0.125;
+    else return 0;
+}
+
 static void es_velocity(const uint8_t *me, orc_fields *f, int check_imf) /* mode_s.c:794-900 */
 {
     f->mesub = (uint8_t)getbits(me, 6, 8);
@@ -824,6 +856,18 @@ static void es_velocity(const uint8_t *me, orc_fields *f, int check_imf) /* mode
             f->ew_vel = (int16_t)ew_vel; /* gs = sqrtf(ns^2 + ew^2 + 0.5), track = atan2(ew, ns): left to the caller */
             f->ns_vel = (int16_t)ns_vel;
             f->velocity_valid = 1;
+            if (cur_ff) { /* mode_s.c:830-843 */
+                cur_ff->gs_v0 = cur_ff->gs_v2 = cur_ff->gs_selected = sqrtf((ns_vel * ns_vel) + (ew_vel * ew_vel) + 0.5);
+                cur_ff->gs_valid = 1;
+                if (cur_ff->gs_selected > 0) {
+                    float ground_track = atan2(ew_vel, ns_vel) * 180.0 / M_PI;
+                    if (ground_track < 0)
+                        ground_track += 360;
+                    cur_ff->heading = ground_track;
+                    cur_ff->heading_type = HT_GROUND_TRACK;
+                    cur_ff->heading_valid = 1;
+                }
+            }
         }
         break;
     }
@@ -832,6 +876,11 @@ static void es_velocity(const uint8_t *me, orc_fields *f, int check_imf) /* mode
             f->heading_valid = 1;
             f->heading_raw = (uint16_t)getbits(me, 15, 24); /* x 360 / 1024 */
             f->heading_type = 4;
+            if (cur_ff) { /* mode_s.c:851-855 */
+                cur_ff->heading_valid = 1;
+                cur_ff->heading = getbits(me, 15, 24) * 360.0 / 1024.0;
+                cur_ff->heading_type = 4;
+            }
         }
         const unsigned airspeed = getbits(me, 26, 35);
         if (airspeed) {
@@ -872,11 +921,21 @@ static void es_surface(const uint8_t *me, orc_fields *f, int check_imf) /* mode_
     f->cpr_type = 0; /* CPR_SURFACE */
     const unsigned movement = getbits(me, 6, 12);
     if (movement > 0 && movement < 125)
-        f->movement = (uint8_t)movement; /* gs via decodeMovementFieldV0/V2: left to the caller */
+        f->movement = (uint8_t)movement;
+    if (cur_ff && movement > 0 && movement < 125) { /* mode_s.c:911-916 */
+        cur_ff->gs_valid = 1;
+        cur_ff->gs_selected = cur_ff->gs_v0 = movement_field_v0(movement);
+        cur_ff->gs_v2 = movement_field_v2(movement);
+    }
     if (getbits(me, 13, 13)) {
         f->heading_valid = 1;
         f->heading_raw = (uint16_t)getbits(me, 14, 20); /* x 360 / 128 */
         f->heading_type = 5;
+        if (cur_ff) { /* mode_s.c:920-924 */
+            cur_ff->heading_valid = 1;
+            cur_ff->heading = getbits(me, 14, 20) * 360.0 / 128.0;
+            cur_ff->heading_type = 5;
+        }
     }
     if (check_imf && getbits(me, 21, 21))
         set_imf(f);
@@ -940,7 +999,6 @@ static void es_airborne(const uint8_t *me, orc_fields *f, int check_imf) /* mode
 /* ---- ME type 29: decodeESTargetStatus, mode_s.c:1058-1249 ---- */
 enum { NAVALT_INVALID, NAVALT_UNKNOWN, NAVALT_AIRCRAFT, NAVALT_MCP, NAVALT_FMS };            /* readsb.h:189-195 */
 enum { NM_AUTOPILOT = 1, NM_VNAV = 2, NM_ALT_HOLD = 4, NM_APPROACH = 8, NM_LNAV = 16, NM_TCAS = 32 }; /* readsb.h:180-187 */
-enum { HT_INVALID, HT_GROUND_TRACK, HT_TRUE, HT_MAGNETIC, HT_MAGNETIC_OR_TRUE, HT_TRACK_OR_HEADING }; /* readsb.h:158-165 */
 enum { SILT_INVALID, SILT_UNKNOWN, SILT_PER_SAMPLE, SILT_PER_HOUR };                         /* readsb.pb-c.h:101-106 */
 enum { NAVV_MODES = 1, NAVV_HEADING = 2, NAVV_MCP = 4, NAVV_FMS = 8, NAVV_QNH = 16, NAVV_HEADING_V2 = 32 };
 enum { ACCV_NAC_P = 1, ACCV_NIC_BARO = 2, ACCV_NIC_A = 4, ACCV_NIC_C = 8, ACCV_GVA = 16, ACCV_SDA = 32 };
@@ -987,6 +1045,10 @@ static void es_target_status(const uint8_t *me, orc_fields *f, int check_imf)
         if (h_source != 0) {
             f->nav_valid |= NAVV_HEADING;
             f->nav_heading_raw = (uint16_t)getbits(me, 28, 36);
+            if (cur_ff) { /* mode_s.c:1130-1131 */
+                cur_ff->nav_heading_valid = 1;
+                cur_ff->nav_heading = getbits(me, 28, 36);
+            }
             f->nav_heading_type = getbits(me, 37, 37) ? HT_GROUND_TRACK : HT_MAGNETIC_OR_TRUE;
         }
         switch (getbits(me, 38, 39)) {
@@ -1024,11 +1086,19 @@ static void es_target_status(const uint8_t *me, orc_fields *f, int check_imf)
         unsigned baro_bits = getbits(me, 21, 29);
         if (baro_bits != 0) {
             f->nav_valid |= NAVV_QNH;
-            f->nav_qnh_raw = (uint16_t)baro_bits; /* 800.0 + (baro_bits - 1) * 0.8 */
+            f->nav_qnh_raw = (uint16_t)baro_bits;
+            if (cur_ff) { /* mode_s.c:1211-1212 */
+                cur_ff->nav_qnh_valid = 1;
+                cur_ff->nav_qnh = 800.0 + (baro_bits - 1) * 0.8;
+            }
         }
         if (getbits(me, 30, 30)) {
             f->nav_valid |= NAVV_HEADING | NAVV_HEADING_V2;
-            f->nav_heading_raw = (uint16_t)getbits(me, 31, 39); /* x 180.0 / 256.0 */
+            f->nav_heading_raw = (uint16_t)getbits(me, 31, 39);
+            if (cur_ff) { /* mode_s.c:1216-1219 */
+                cur_ff->nav_heading_valid = 1;
+                cur_ff->nav_heading = getbits(me, 31, 39) * 180.0 / 256.0;
+            }
             f->nav_heading_type = HT_MAGNETIC_OR_TRUE;
         }
         f->acc_valid |= ACCV_NAC_P;
@@ -1366,7 +1436,11 @@ static int cb_bds40(const uint8_t *msg, orc_fields *f, int store) /* :272-434 */
         }
         if (qnh_on) {
             f->nav_valid |= NAVV_QNH | NAVV_QNH_COMMB;
-            f->nav_qnh_raw = (uint16_t)qnh; /* nav.qnh = 800 + raw * 0.1 */
+            f->nav_qnh_raw = (uint16_t)qnh;
+            if (cur_ff) { /* comm_b.c:397-400 */
+                cur_ff->nav_qnh_valid = 1;
+                cur_ff->nav_qnh = baro_setting;
+            }
         }
         if (mode_on) {
             f->nav_valid |= NAVV_MODES;
@@ -1392,6 +1466,9 @@ static int cb_bds50(const uint8_t *msg, orc_fields *f, int store) /* :438-592 */
     float track_rate = rate_raw * 8.0 / 256.0;
     if (rate_neg)
         track_rate -= 16;
+    float track = trk_raw * 90.0 / 512.0; /* comm_b.c:485-490 */
+    if (trk_west)
+        track += 180.0;
     const unsigned gs = gs_raw * 2, tas = tas_raw * 2;
     int score = 0;
     if (!cb_field(roll_on, roll_raw | roll_neg, roll_raw, 0, roll >= -40 && roll < 40, 11, &score) ||
@@ -1423,6 +1500,19 @@ static int cb_bds50(const uint8_t *msg, orc_fields *f, int store) /* :438-592 */
         }
         f->tas_valid = 1;
         f->tas = (uint16_t)tas;
+        if (cur_ff) { /* comm_b.c:561-584 */
+            cur_ff->roll_valid = 1;
+            cur_ff->roll = roll;
+            cur_ff->heading_valid = 1;
+            cur_ff->heading = track;
+            cur_ff->heading_type = HT_GROUND_TRACK;
+            cur_ff->gs_valid = 1;
+            cur_ff->gs_v0 = cur_ff->gs_v2 = cur_ff->gs_selected = gs;
+            if (rate_on) {
+                cur_ff->track_rate_valid = 1;
+                cur_ff->track_rate = track_rate;
+            }
+        }
     }
     return score;
 }
@@ -1437,6 +1527,9 @@ static int cb_bds60(const uint8_t *msg, orc_fields *f, int store) /* :596-744 */
     if (!hdg_on || !ias_on || !mach_on || (!baro_on && !ins_on))
         return 0;
     const float mach = mach_raw * 2.048 / 512;
+    float heading = hdg_raw * 90.0 / 512.0; /* comm_b.c:623-628 */
+    if (hdg_west)
+        heading += 180.0;
     const int baro_rate = (int)baro_raw * 32 - (baro_neg ? 16384 : 0), inertial_rate = (int)ins_raw * 32 - (ins_neg ? 16384 : 0);
     int score = 0;
     if (!cb_field(hdg_on, hdg_raw | hdg_west, hdg_raw, 0, 1, 12, &score) ||
@@ -1455,7 +1548,14 @@ static int cb_bds60(const uint8_t *msg, orc_fields *f, int store) /* :596-744 */
         f->ias_valid = 1;
         f->ias = (uint16_t)ias;
         f->commb_valid |= CBV_MACH;
-        f->mach_raw = (uint16_t)mach_raw; /* mach = mach_raw * 2.048 / 512 */
+        f->mach_raw = (uint16_t)mach_raw;
+        if (cur_ff) { /* comm_b.c:714-728 */
+            cur_ff->heading_valid = 1;
+            cur_ff->heading = heading;
+            cur_ff->heading_type = HT_MAGNETIC;
+            cur_ff->mach_valid = 1;
+            cur_ff->mach = mach;
+        }
         if (baro_on) {
             f->baro_rate_valid = 1;
             f->baro_rate = (int16_t)baro_rate;
@@ -1586,6 +1686,16 @@ static void fields_mode_ac(orc_fields *mm, unsigned ModeA)
 void orc_fields_of(const orc_message *mm, orc_fields *out)
 {
     fields_mode_s(mm, out);
+}
+
+/* the float-valued members for one accepted Mode S message, straight from its bytes */
+void orc_fields_float_of(const orc_message *mm, orc_fields_float *out)
+{
+    orc_fields scratch;
+    memset(out, 0, sizeof *out);
+    cur_ff = out;
+    fields_mode_s(mm, &scratch);
+    cur_ff = NULL;
 }
 
 void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap)

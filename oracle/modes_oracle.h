@@ -163,6 +163,22 @@ typedef struct orc_fields {
 void orc_set_fields_out(orc_ctx *ctx, orc_fields *fields, size_t cap);
 /* the fields of one accepted Mode S message (msgtype 0..31) */
 void orc_fields_of(const orc_message *mm, orc_fields *out);
+/* The float-valued members of struct modesMessage (readsb.h:423-438,533-534: gs.v0/v2/selected, heading,
+ * track_rate, roll, mach, nav.qnh, nav.heading), computed where and how the reference computes them
+ * (mode_s.c:831-843,853,913-922,1131,1212,1219; comm_b.c:323-326,469-518,623-651).  Same layout as
+ * msd_fields_float. */
+typedef struct orc_fields_float {
+    float gs_v0, gs_v2, gs_selected;
+    float heading;
+    float track_rate;
+    float roll;
+    float nav_qnh;
+    float nav_heading;
+    double mach;
+    uint8_t gs_valid, heading_valid, heading_type, track_rate_valid, roll_valid, mach_valid, nav_qnh_valid,
+        nav_heading_valid;
+} orc_fields_float;
+void orc_fields_float_of(const orc_message *mm, orc_fields_float *out);
 /* single pieces, for known-answer tests */
 int orc_decode_ac13(unsigned ac13, int *unit);
 unsigned orc_decode_id13(unsigned id13);

@@ -276,6 +276,25 @@ def fields_of(message):
     return out[0]
 
 
+FIELDS_FLOAT_DTYPE = np.dtype(
+    [("gs_v0", "<f4"), ("gs_v2", "<f4"), ("gs_selected", "<f4"), ("heading", "<f4"), ("track_rate", "<f4"),
+     ("roll", "<f4"), ("nav_qnh", "<f4"), ("nav_heading", "<f4"), ("mach", "<f8"), ("gs_valid", "u1"),
+     ("heading_valid", "u1"), ("heading_type", "u1"), ("track_rate_valid", "u1"), ("roll_valid", "u1"),
+     ("mach_valid", "u1"), ("nav_qnh_valid", "u1"), ("nav_heading_valid", "u1")], align=True)
+
+
+def fields_float_of(message):
+    """orc_fields_float_of: the float-valued members of struct modesMessage, computed from the message bytes where
+    and how the reference computes them."""
+    rec = np.zeros(1, dtype=MESSAGE_DTYPE)
+    rec[0] = message
+    out = np.zeros(1, dtype=FIELDS_FLOAT_DTYPE)
+    lib().orc_fields_float_of.restype = None
+    lib().orc_fields_float_of.argtypes = [C.c_void_p, C.c_void_p]
+    lib().orc_fields_float_of(rec.ctypes.data, out.ctypes.data)
+    return out[0]
+
+
 def checksum(msg: bytes) -> int:
     lib().orc_create(0, 58, 0, 0)  # makes sure the static tables exist (leaks one tiny ctx once)
     return lib().orc_checksum(bytes(msg), len(msg) * 8)

@@ -139,7 +139,7 @@ EXPORTS = [
     "msd_create", "msd_destroy", "msd_last_error", "msd_submit_device", "msd_submit_host", "msd_reset",
     "msd_launch_device", "msd_launch_host", "msd_host_alloc", "msd_host_free", "msd_collect", "msd_get_stats",
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
-    "msd_collect_fields", "msd_decode_fields", "msd_array_fields_sink",
+    "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
 ]
 
@@ -400,6 +400,25 @@ def replay_device(demod, dptr, nsamples, batch_samples):
         out.append(demod.collect())
         inflight -= 1
     return np.concatenate(out) if out else np.zeros(0, dtype=MESSAGE_DTYPE)
+
+
+FIELDS_FLOAT_DTYPE = np.dtype(
+    [("gs_v0", "<f4"), ("gs_v2", "<f4"), ("gs_selected", "<f4"), ("heading", "<f4"), ("track_rate", "<f4"),
+     ("roll", "<f4"), ("nav_qnh", "<f4"), ("nav_heading", "<f4"), ("mach", "<f8"), ("gs_valid", "u1"),
+     ("heading_valid", "u1"), ("heading_type", "u1"), ("track_rate_valid", "u1"), ("roll_valid", "u1"),
+     ("mach_valid", "u1"), ("nav_qnh_valid", "u1"), ("nav_heading_valid", "u1")], align=True)
+assert FIELDS_FLOAT_DTYPE.itemsize == 48
+
+
+def fields_to_float(fields):
+    """msd_fields_to_float: the float-valued members of struct modesMessage for one msd_fields record."""
+    rec = np.zeros(1, dtype=FIELDS_DTYPE)
+    rec[0] = fields
+    out = np.zeros(1, dtype=FIELDS_FLOAT_DTYPE)
+    lib().msd_fields_to_float.restype = None
+    lib().msd_fields_to_float.argtypes = [C.c_void_p, C.c_void_p]
+    lib().msd_fields_to_float(rec.ctypes.data, out.ctypes.data)
+    return out[0]
 
 
 def decode_fields(message, carry=None):

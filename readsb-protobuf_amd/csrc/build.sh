@@ -14,7 +14,8 @@ gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_fifo.c -o host/m
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_sdr_ifile.c -o host/msd_sdr_ifile.o
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_wire.c -o host/msd_wire.o
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_converter.c -o host/msd_converter.o
-gcc -shared -fPIC -o libmsd_host.so host/msd_fifo.o host/msd_sdr_ifile.o host/msd_wire.o host/msd_converter.o -L. -lmodes_hip -Wl,-rpath,'$ORIGIN' -lpthread -lm
+gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_demod.c -o host/msd_demod.o
+gcc -shared -fPIC -o libmsd_host.so host/msd_fifo.o host/msd_sdr_ifile.o host/msd_wire.o host/msd_converter.o host/msd_demod.o -L. -lmodes_hip -Wl,-rpath,'$ORIGIN' -lpthread -lm
 gcc -std=c11 -O2 -g -Wall -Wextra $INC -Ihost host/msd_replay_main.c host/msd_sdr_ifile.o host/msd_fifo.o host/msd_wire.o host/msd_converter.o -o msd_replay \
     -L. -lmodes_hip -Wl,-rpath,'$ORIGIN' -lpthread -lm
 gcc -std=c11 -O2 -Wall -Wextra -fPIC -shared -o libmsd_siggen.so msd_siggen.c -lpthread

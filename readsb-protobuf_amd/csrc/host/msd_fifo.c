@@ -12,7 +12,7 @@
  * another one.
  */
 #define _POSIX_C_SOURCE 200809L
-#include "msd_fifo.h"
+#include "modes_hip_readsb.h"
 
 #include <errno.h>
 #include <pthread.h>
@@ -56,6 +56,30 @@ static void wait_for(const bool *stop, const unsigned *len, uint32_t ms)
     while (!*stop && !*len)
         if (pthread_cond_timedwait(&Q.changed, &Q.mu, &until) == ETIMEDOUT)
             break;
+}
+
+/* A buffer index back onto the unused stack (mutex held).  A buffer that is already there, or that is still
+ * queued, is a caller bug (double release / release of a queued buffer): ignored instead of growing the stack
+ * past its allocation. */
+static void push_unused(unsigned idx)
+{
+    if (!Q.ready || idx >= Q.count || Q.unused_len >= Q.count)
+        return;
+    for (unsigned i = 0; i < Q.unused_len; ++i)
+        if (Q.unused[i] == idx)
+            return;
+    for (unsigned i = 0; i < Q.ring_len; ++i)
+        if (Q.ring[(Q.ring_first + i) % Q.count] == idx)
+            return;
+    Q.unused[Q.unused_len++] = idx;
+}
+
+/* the record a caller handed back -> its index, or Q.count if it is not one of ours (mutex held) */
+static unsigned index_of(const struct msd_mag_buf *buf)
+{
+    if (!Q.ready || buf < Q.rec || buf >= Q.rec + Q.count)
+        return Q.count;
+    return (unsigned)(buf - Q.rec);
 }
 
 bool msd_fifo_create(unsigned buffer_count, unsigned buffer_size, unsigned overlap)
@@ -110,10 +134,11 @@ void msd_fifo_halt(void)
 {
     pthread_mutex_lock(&Q.mu);
     Q.halted = true;
-    while (Q.ring_len) { /* what was queued is unused again */
-        Q.unused[Q.unused_len++] = Q.ring[Q.ring_first];
+    while (Q.ready && Q.ring_len) { /* what was queued is unused again */
+        const unsigned idx = Q.ring[Q.ring_first];
         Q.ring_first = (Q.ring_first + 1) % Q.count;
         Q.ring_len--;
+        push_unused(idx);
     }
     pthread_cond_broadcast(&Q.changed);
     pthread_mutex_unlock(&Q.mu);
@@ -144,10 +169,14 @@ void msd_fifo_enqueue(struct msd_mag_buf *buf)
 {
     if (!buf)
         return;
-    const unsigned idx = (unsigned)(buf - Q.rec);
     pthread_mutex_lock(&Q.mu);
-    if (Q.halted) { /* fifo.h:92: produced buffers go straight back */
-        Q.unused[Q.unused_len++] = idx;
+    const unsigned idx = index_of(buf);
+    if (idx == Q.count || buf->validLength > buf->totalLength || Q.ring_len >= Q.count) {
+        /* not one of this FIFO's buffers (or the FIFO is gone), or filled past its end (fifo.c:172 asserts it): dropped */
+        if (idx != Q.count)
+            push_unused(idx);
+    } else if (Q.halted) { /* fifo.h:92: produced buffers go straight back */
+        push_unused(idx);
     } else {
         /* the region in front of the new samples: the previous buffer's tail, or silence at the start
          * of the stream and behind a gap (fifo.h:34-55, MAGBUF_DISCONTINUOUS) */
@@ -188,7 +217,7 @@ void msd_fifo_release(struct msd_mag_buf *buf)
     if (!buf)
         return;
     pthread_mutex_lock(&Q.mu);
-    Q.unused[Q.unused_len++] = (unsigned)(buf - Q.rec);
+    push_unused(index_of(buf));
     pthread_cond_broadcast(&Q.changed);
     pthread_mutex_unlock(&Q.mu);
 }

@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "msd_sdr_ifile.h"
+#include "modes_hip_readsb.h"
 #include "msd_wire.h"
 
 static int g_mlat;

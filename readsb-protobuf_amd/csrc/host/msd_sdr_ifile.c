@@ -1,7 +1,7 @@
-/* msd_sdr_ifile.c -- see msd_sdr_ifile.h.  Host C, like the reference's sdr_ifile.c; all the
+/* msd_sdr_ifile.c -- see include/modes_hip_readsb.h.  Host C, like the reference's sdr_ifile.c; all the
  * signal processing happens behind the C-ABI of modes_hip.h. */
 #define _GNU_SOURCE
-#include "msd_sdr_ifile.h"
+#include "modes_hip_readsb.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -12,7 +12,7 @@
 #include <strings.h>
 #include <unistd.h>
 
-#include "msd_fifo.h"
+#include "modes_hip_readsb.h"
 
 static struct {
     char *filename;
@@ -30,7 +30,7 @@ static struct {
     /* magbuf mode: the converter of msd_init_converter (convert.h:40-43) and its state, like sdr_ifile.c:58-68 */
     msd_iq_convert_fn converter;
     struct converter_state *converter_state;
-    /* buffers handed to the consumer and not yet demodulated (the GPU context is shared) */
+    /* buffers handed to the consumer and not yet demodulated */
     pthread_mutex_t mu;
     pthread_cond_t idle;
     int in_flight;
@@ -253,13 +253,11 @@ static void run_magbuf(void)
         F.in_flight++;
         pthread_mutex_unlock(&F.mu);
         msd_fifo_enqueue(out);
-        /* the GPU context is shared by msd_convert (here) and msd_demodulate_magbuf (consumer):
-         * wait until the consumer is done with the buffer before converting the next one, which
-         * is also the lossless, depth-one feed of SURVEY.md 8(b) */
-        pthread_mutex_lock(&F.mu);
-        while (F.in_flight)
-            pthread_cond_wait(&F.idle, &F.mu);
-        pthread_mutex_unlock(&F.mu);
+        /* The converter owns a GPU context of its own (msd_init_converter), the consumer demodulates on F.ctx:
+         * the next block is read and converted while this one is demodulated, as the reference's reader and
+         * main threads overlap (readsb.c:271-285,820-855).  The FIFO is lossless at any depth (msd_fifo.c), so
+         * the messages do not depend on how far the reader gets ahead; msd_fifo_acquire() holds it back once
+         * all twelve buffers are in use. */
         sample_counter += samples;
     }
     msd_fifo_drain();

@@ -312,6 +312,7 @@ struct msd_ctx {
     int cu_count = 256;
     Helper helper;
     bool failed = false;    /* a batch could not be finished: only msd_reset() / msd_destroy() are accepted */
+    bool scan_queued = false; /* enqueue(): its scan kernel is on the stream (a later failure cannot be undone) */
     bool no_helper = false; /* MSD_NO_HELPER: everything on the calling thread */
     char err[256] = {0};
 };
@@ -525,13 +526,27 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
                     return rc;
             }
         }
+        c->scan_queued = false;
         int rc = msd_launch_scan(&p, format, nwg, c->stream);
-        if (rc)
+        if (rc) {
+            /* nothing was queued: the older batch's records are still owed (finish_gpu / flush_pending_emit write
+             * them), as the header promises for a failed launch */
+            if (carried)
+                c->pending_emit = carried;
             return fail(c, rc, "scan kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        c->scan_queued = true;
         if (s.timed)
             HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
-        if (carried)
-            HIPCHK(c, hipEventRecord(carried->ev_records, c->stream));
+        if (carried) {
+            /* the records are on their way with this scan; without the event nobody could tell when they are
+             * complete, so a failure here poisons the context instead of delivering stale records */
+            const hipError_t e = hipEventRecord(carried->ev_records, c->stream);
+            if (e != hipSuccess) {
+                c->failed = true;
+                return fail(c, -EIO, "hipEventRecord(ev_records) failed: %s", hipGetErrorString(e));
+            }
+        }
         const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
                                (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
         rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
@@ -1391,8 +1406,12 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     const int tail_nxt = (c->tail_cur + 1) % (MSD_PIPELINE_DEPTH + 1);
     s.tail_dst = nsamples >= (uint64_t)TAIL_SAMPLES ? c->d_tail[tail_nxt] : nullptr;
     auto tl0 = std::chrono::steady_clock::now();
+    c->scan_queued = false;
     rc = enqueue(c, s, c->scan_format, nullptr);
     if (rc) { /* nothing was consumed: the dropped samples and a pending restart wait for the next launch */
+        if (c->scan_queued) /* ... unless kernels of this batch are on the stream already: their follow-ups are missing,
+                               the slot's lists and sums are half written -- only msd_reset() starts over */
+            c->failed = true;
         s.busy = false;
         c->pending_dropped += s.dropped_before;
         c->restart_pending = c->restart_pending || s.reset_before;
@@ -1569,7 +1588,10 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     g_create_err[0] = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
-        return -ENODEV; /* no GPU: there is deliberately no CPU fallback */
+    {   /* no GPU: there is deliberately no CPU fallback */
+        snprintf(g_create_err, sizeof g_create_err, "no usable HIP device (found %d, asked for device %d): this library has no CPU path", ndev, cfg->device);
+        return -ENODEV;
+    }
     msd_ctx *c = new (std::nothrow) msd_ctx;
     if (!c)
         return -ENOMEM;
@@ -1731,7 +1753,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             c->chain_inline = ci && *ci ? *ci != '0' : !follow_ups;
         }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
-        { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
+        { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !c->repass_aux /* a re-pass on another stream would race the scan that carries the records */ && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);

@@ -62,6 +62,24 @@ int main(int argc, char **argv)
     cleanup(state);
     cleanup(NULL);
 
+    /* the demodulators with the reference's shape (demod_2400.h:37-38): void f(struct mag_buf *) */
+    {
+        void (*demod)(struct msd_mag_buf *) = msd_demodulate2400;
+        void (*demod_ac)(struct msd_mag_buf *) = msd_demodulate2400AC;
+        static uint16_t silence[326 + 1024];
+        struct msd_mag_buf buf;
+        memset(&buf, 0, sizeof buf);
+        buf.data = silence;
+        buf.totalLength = buf.validLength = 326 + 1024;
+        buf.overlap = 326;
+        CHECK(msd_demod_bind(NULL, 0, NULL, NULL) == 0);
+        demod(&buf); /* nothing bound: says so, delivers nothing */
+        CHECK(strstr(msd_demod_error(), "no receiver bound") != NULL);
+        demod_ac(&buf);
+        demod(NULL);
+        demod_ac(NULL);
+    }
+
     /* the handler, driven the way sdr.c drives the one it replaces */
     msd_ifile_hooks hooks = {on_should_exit, on_monitor, on_eof, on_selected};
     msd_ifileSetOptionKeys(OptIfileName, OptIfileFormat, OptIfileThrottle, -1);

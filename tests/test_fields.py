@@ -440,3 +440,112 @@ def test_comm_b_against_the_oracle(pkg, oracle):
             assert got[f] == want[f], (f, m["msg"].tobytes().hex(), int(got[f]), int(want[f]))
         seen[want["commb_format"]] += 1
     assert (seen[2:] > 50).all() and seen[1] > 10, seen  # every format, and ambiguity, occurred
+
+
+FLOAT_NAMES = ("gs_v0", "gs_v2", "gs_selected", "heading", "track_rate", "roll", "nav_qnh", "nav_heading", "mach",
+               "gs_valid", "heading_valid", "heading_type", "track_rate_valid", "roll_valid", "mach_valid",
+               "nav_qnh_valid", "nav_heading_valid")
+
+
+def assert_floats_equal(pkg, oracle, m):
+    """msd_fields -> msd_fields_to_float (product, from the delivered integers) against the oracle's values, which
+    are computed from the message bytes at the places the reference computes them: bit for bit."""
+    got = pkg.capi.fields_to_float(pkg.capi.decode_fields(m))
+    want = oracle.fields_float_of(m)
+    for f in FLOAT_NAMES:
+        a, b = got[f], want[f]
+        assert a.tobytes() == b.tobytes(), (f, m["msg"].tobytes().hex(), float(a), float(b))
+    return want
+
+
+def test_float_fields_published_examples(pkg, oracle):
+    """The float-valued members of struct modesMessage (readsb.h:423-438,533-534) on the published examples:
+    159.20 kt on track 182.88 deg, heading 243.98 deg, BDS 5,0 / 6,0 / 4,0 values, QNH 1012.8 hPa."""
+    v = assert_floats_equal(pkg, oracle, es_record(pkg, "8D485020994409940838175B284F"))
+    assert (v["gs_valid"], v["heading_valid"], v["heading_type"]) == (1, 1, 1)
+    assert abs(v["gs_selected"] - 159.20) < 0.01 and abs(v["heading"] - 182.88) < 0.01 and v["gs_v0"] == v["gs_v2"] == v["gs_selected"]
+    a = assert_floats_equal(pkg, oracle, es_record(pkg, "8DA05F219B06B6AF189400CBC33F"))
+    assert (a["gs_valid"], a["heading_valid"], a["heading_type"]) == (0, 1, 4) and abs(a["heading"] - 243.98) < 0.01
+    t = assert_floats_equal(pkg, oracle, es_record(pkg, "A000139381951536E024D4CCF6B5"))  # BDS 5,0
+    assert (t["roll_valid"], t["track_rate_valid"], t["gs_valid"], t["heading_type"]) == (1, 1, 1, 1)
+    assert (round(float(t["roll"]), 1), float(t["heading"]), float(t["gs_selected"]), float(t["track_rate"])) == (2.1, 114.2578125, 438.0, 0.125)
+    h = assert_floats_equal(pkg, oracle, es_record(pkg, "A00004128F39F91A7E27C46ADC21"))  # BDS 6,0
+    assert (h["mach_valid"], h["heading_type"], float(h["heading"])) == (1, 3, 42.71484375)
+    assert round(float(h["mach"]), 3) == 0.42 and h["mach"] == np.float32(h["mach"])  # a float, widened
+    q = assert_floats_equal(pkg, oracle, es_record(pkg, "A000029C85E42F313000007047D3"))  # BDS 4,0
+    assert q["nav_qnh_valid"] == 1 and q["nav_qnh"] == np.float32(800 + 2200 * 0.1)
+    s = assert_floats_equal(pkg, oracle, es_record(pkg, "8DA05629EA21485CBF3F8CADAEEB"))  # target state (DO-260B example)
+    assert s["nav_qnh_valid"] == 1 and abs(s["nav_qnh"] - 1012.8) < 0.01
+    assert s["nav_heading_valid"] == 1 and abs(s["nav_heading"] - 66.8) < 0.1
+
+
+def test_float_fields_every_velocity_and_movement_code(pkg, oracle):
+    """sqrtf / atan2 ground speed and track for all four quadrants and both subtypes on a lattice of the 1023 x 1023
+    speed components (incl. the largest, where ns^2 + ew^2 + 0.5 no longer fits a float), the heading scale of
+    subtypes 3 and 4, and every surface movement code with both tables (mode_s.c:216-259,826-855,911-924)."""
+    def me_record(df, me):
+        raw = bytes([(df << 3) | 5, 0x48, 0x40, 0xD6]) + me.to_bytes(7, "big") + bytes(3)
+        return es_record(pkg, raw.hex())
+    rng = np.random.default_rng(19)
+    comps = sorted(set([1, 2, 3, 512, 1022, 1023] + [int(x) for x in rng.integers(1, 1024, 40)]))
+    n = 0
+    for sub in (1, 2):
+        for ew in comps:
+            for ns in comps[:: 3 if sub == 2 else 1]:
+                for signs in range(4):
+                    me = (19 << 51) | (sub << 48) | ((signs & 1) << 42) | (ew << 32) | ((signs >> 1) << 31) | (ns << 21) | (1 << 10) | 5
+                    w = assert_floats_equal(pkg, oracle, me_record(17, me))
+                    assert w["gs_valid"] == 1 and (w["heading_valid"] == 1) == (w["gs_selected"] > 0)
+                    n += 1
+    for sub in (3, 4):
+        for hdg in list(range(0, 1024, 7)) + [1023]:
+            me = (19 << 51) | (sub << 48) | (1 << 42) | (hdg << 32) | (1 << 31) | (300 << 21)
+            w = assert_floats_equal(pkg, oracle, me_record(17, me))
+            assert w["heading"] == np.float32(hdg * 360.0 / 1024.0) and w["gs_valid"] == 0
+    for movement in range(128):
+        for trk in (0, 1, 77, 127):
+            me = (6 << 51) | (movement << 44) | (1 << 43) | (trk << 36) | 12345
+            w = assert_floats_equal(pkg, oracle, me_record(17, me))
+            assert w["gs_valid"] == (1 if 0 < movement < 125 else 0) and w["heading"] == np.float32(trk * 360.0 / 128.0)
+    assert n > 5000
+
+
+def test_float_fields_against_the_oracle_on_random_payloads(pkg, oracle):
+    """Random ME type 29 payloads (both layouts: QNH and selected heading) and crafted Comm-B registers 4,0 / 5,0 /
+    6,0 (roll, track, track rate, Mach, QNH): product floats from the integers equal the oracle's from the bytes."""
+    rng = np.random.default_rng(2950)
+    seen = dict(qnh=0, nav_heading=0, roll=0, mach=0, track_rate=0)
+    for k in range(4000):
+        raw = bytearray(rng.integers(0, 256, 14, dtype=np.uint8).tobytes())
+        raw[0] = (17 << 3) | 5
+        raw[4] = (29 << 3) | (int(rng.integers(0, 2)) << 1) | (raw[4] & 1)
+        w = assert_floats_equal(pkg, oracle, es_record(pkg, bytes(raw).hex()))
+        seen["qnh"] += int(w["nav_qnh_valid"])
+        seen["nav_heading"] += int(w["nav_heading_valid"])
+    for k in range(6000):
+        kind = (40, 50, 60)[k % 3]
+        head = bytes([((20 if k % 2 else 21) << 3) | int(rng.integers(0, 8)), 0, int(rng.integers(0, 256)), int(rng.integers(0, 256))])
+        w = assert_floats_equal(pkg, oracle, es_record(pkg, (head + make_commb(rng, kind) + bytes(3)).hex()))
+        seen["roll"] += int(w["roll_valid"])
+        seen["mach"] += int(w["mach_valid"])
+        seen["track_rate"] += int(w["track_rate_valid"])
+        seen["qnh"] += int(w["nav_qnh_valid"])
+    assert all(v > 300 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("name", ["uc8_fix_modeac", "sc16q11_fix_modeac"])
+def test_float_fields_on_replayed_captures(pkg, oracle, name):
+    """... and on every Mode S message of two golden captures (regenerated from their seeds, replayed by the oracle)."""
+    meta, z = load_golden(name)
+    fmt = {"uc8": pkg.FMT_UC8, "sc16": pkg.FMT_SC16, "sc16q11": pkg.FMT_SC16Q11}[meta["format"]]
+    ofmt = {"uc8": oracle.FMT_UC8, "sc16": oracle.FMT_SC16, "sc16q11": oracle.FMT_SC16Q11}[meta["format"]]
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=meta["seed"], fmt=fmt, **meta["gen"]), meta["nsamples"])
+    msgs, _, _ = oracle.Oracle(ofmt, 58, meta["nfix_crc"], meta["mode_ac"]).replay_fields(iq, cap=1 << 17)
+    assert len(msgs) == len(z["timestampMsg"])
+    n = 0
+    for m in msgs:
+        if m["msgtype"] == 32:
+            continue
+        w = assert_floats_equal(pkg, oracle, m)
+        n += int(w["gs_valid"]) + int(w["heading_valid"])
+    assert n > 0
