@@ -175,7 +175,17 @@ struct Slot {
     msd_rbuf *h_rbuf = nullptr;    /* pinned; the resolve kernel reports straight into it */
     msd_acc *d_acc = nullptr;
     uint32_t *d_adds = nullptr, *d_nmsgs = nullptr, *d_acc_ac = nullptr, *d_nac = nullptr;
-    uint32_t *d_pred = nullptr; /* key[SLOTS] | first[SLOTS] | counter | slot list[LIST]; wiped by the gather kernel */
+    uint32_t *d_pred = nullptr; /* the batch's prediction table (msd_internal.h: MSD_PRED_WORDS), filled by its scan */
+    uint32_t pred_gen = 0, pred_uses = 0; /* its generation for the batch in the slot; batches it has served */
+    /* lean layout (UC8 / magnitudes, Mode S only, chain in order, resolve on the GPU): no gather kernel -- the
+     * candidate lists stay in this slot's own region arenas until the batch's records are out, the resolve
+     * workgroups read their buffer's region slices, the first resolve pass publishes sums and totals */
+    bool lean = false;
+    msd_hit *d_rhits = nullptr;
+    msd_try *d_rtries = nullptr;
+    msd_region_counts *d_rcounts = nullptr;
+    msd_wg_totals *d_rwgt = nullptr;
+    uint32_t lean_k = 0, lean_hcap = 0, lean_tcap = 0, lean_nreg = 0; /* regions per buffer, slice capacities, regions */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
@@ -293,6 +303,7 @@ struct msd_ctx {
     bool emit_fused = false;
     struct Slot *pending_emit = nullptr;
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
+    bool lean_ok = false;     /* the configuration allows the lean layout (Slot::lean; MSD_LEAN=0 turns it off) */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
     uint64_t launch_count = 0;
@@ -442,7 +453,9 @@ int flush_pending_emit(msd_ctx *c);
 struct GpuCtl;
 void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp);
 
-int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
+bool gpu_eligible(const msd_ctx *c, const Slot &s);
+
+int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pipelined = false)
 {
     const uint64_t tile = msd_scan_tile(format);
     const uint64_t ntiles64 = (s.nsamples + tile - 1) / tile;
@@ -453,6 +466,23 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     if (tpw == 0)
         tpw = 1;
     uint32_t nwg = ntiles ? (ntiles + tpw - 1) / tpw : 0;
+    /* Lean layout: k regions per buffer, none across a buffer boundary.  Only for batches that come through
+     * msd_launch_* and will be resolved on the GPU in order on this stream. */
+    const uint32_t tiles_per_buffer = (uint32_t)(MSD_CHUNK_SAMPLES / tile);
+    uint32_t lean_k = 0, lean_tpr = 0;
+    s.lean = false;
+    if (pipelined && c->lean_ok && nwg && gpu_eligible(c, s) && s.nbuffers <= c->max_wg && !(c->debug_flags & 0x1f)) {
+        uint32_t k = c->max_wg / s.nbuffers;
+        if (k > 64)
+            k = 64;
+        if (k > tiles_per_buffer)
+            k = tiles_per_buffer;
+        lean_tpr = (tiles_per_buffer + k - 1) / k;
+        lean_k = (tiles_per_buffer + lean_tpr - 1) / lean_tpr; /* no empty pieces */
+        nwg = s.nbuffers * lean_k;
+        tpw = lean_tpr;
+        s.lean = true;
+    }
 
     if (s.nsamples & 7u) { /* the last, partially filled 8-sample group: a zero-padded private copy */
         const size_t bps = (format == MSD_FMT_UC8 || format == MSD_FMT_MAG16) ? 2 : 4;
@@ -463,7 +493,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
     /* d_sums is zero: whoever published the slot's previous batch left it so.  The offsets kernel
      * overwrites the totals. */
     const bool fm = format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || s.dc;
-    const bool lean = nwg && !c->cfg.mode_ac && !fm; /* totals and sums are published by the offsets kernel */
+    const bool gather_publishes = nwg && !c->cfg.mode_ac && !fm; /* totals and sums are published by the gather kernel */
     if (!nwg) {
         HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
         s.buf_first_valid = false;
@@ -480,8 +510,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         fill_params(c, s, p);
         p.ntiles = ntiles;
         p.tiles_per_wg = tpw;
-        p.hits = c->d_region_hits;
-        p.tries = c->d_region_tries;
+        p.hits = s.lean ? s.d_rhits : c->d_region_hits;
+        p.tries = s.lean ? s.d_rtries : c->d_region_tries;
         /* a tile can never produce more than one hit per position and five tries per hit */
         uint64_t hcap = c->hit_arena / nwg, tcap = c->try_arena / nwg;
         if (hcap > (uint64_t)tpw * tile)
@@ -490,8 +520,32 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
             tcap = (uint64_t)tpw * tile * 5;
         p.hcap = (uint32_t)hcap;
         p.tcap = (uint32_t)tcap;
-        p.counts = c->d_counts;
-        p.wg_totals = c->d_wg_totals;
+        s.lean_hcap = p.hcap;
+        s.lean_tcap = p.tcap;
+        p.counts = s.lean ? s.d_rcounts : c->d_counts;
+        p.wg_totals = s.lean ? s.d_rwgt : c->d_wg_totals;
+        if (s.d_pred && s.gpu_resolve) { /* the batch's prediction table: a generation of its own, no wipe */
+            s.pred_gen = s.pred_uses % MSD_PRED_GENS;
+            if (s.pred_uses && s.pred_gen == 0) /* the 8-bit generations have come round: old entries must go */
+                HIPCHK(c, hipMemsetAsync(s.d_pred, 0xFF, sizeof(uint32_t) * MSD_PRED_WORDS, c->stream));
+            s.pred_uses++;
+            p.pred = reinterpret_cast<unsigned long long *>(s.d_pred);
+            p.pred_gen = s.pred_gen;
+        }
+        const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
+                               (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
+        if (s.lean) {
+            p.regions_per_buffer = lean_k;
+            p.tiles_per_region = lean_tpr;
+            p.overflow = reinterpret_cast<unsigned long long *>(s.d_totals + 2);
+            if (tail_here) {
+                p.tail_src = reinterpret_cast<const uint32_t *>(s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format));
+                p.tail_dst = reinterpret_cast<uint32_t *>(s.tail_dst);
+                p.tail_words = (uint32_t)(TAIL_SAMPLES * bps_of(format) / 4);
+            }
+            s.lean_k = lean_k;
+            s.lean_nreg = nwg;
+        }
         p.chunk_sums = s.d_sums;
         p.tile_sums = (fm && !s.dc && tile == 1024) ? s.d_tile_sums : nullptr;
         p.timers = c->d_timers;
@@ -547,20 +601,24 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
                 return fail(c, -EIO, "hipEventRecord(ev_records) failed: %s", hipGetErrorString(e));
             }
         }
-        const bool tail_here = s.tail_dst && s.nsamples >= (uint64_t)TAIL_SAMPLES &&
-                               (((s.nsamples - TAIL_SAMPLES) * bps_of(format)) & 3u) == 0; /* copied as dwords */
-        rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
-                               s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers,
-                               lean ? s.h_totals : nullptr, lean ? s.h_sums : nullptr, s.d_pred,
-                               s.d_pred ? 4 * (2 * MSD_PRED_SLOTS + 4) : 0,
-                               tail_here ? s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format) : nullptr,
-                               tail_here ? s.tail_dst : nullptr, tail_here ? (uint32_t)(TAIL_SAMPLES * bps_of(format)) : 0,
-                               tpw * tile, s.d_buf_first, c->stream);
-        s.buf_first_valid = true;
-        if (tail_here)
-            s.tail_dst = nullptr; /* done */
-        if (rc)
-            return fail(c, rc, "gather kernel launch failed");
+        if (s.lean) {
+            /* no gather: the resolve workgroups read the region slices, the first resolve pass publishes */
+            s.buf_first_valid = false;
+            if (tail_here)
+                s.tail_dst = nullptr; /* the scan's first wavefront copies it */
+        } else {
+            rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
+                                   s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers,
+                                   gather_publishes ? s.h_totals : nullptr, gather_publishes ? s.h_sums : nullptr, nullptr, 0,
+                                   tail_here ? s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format) : nullptr,
+                                   tail_here ? s.tail_dst : nullptr, tail_here ? (uint32_t)(TAIL_SAMPLES * bps_of(format)) : 0,
+                                   tpw * tile, s.d_buf_first, 0, c->stream);
+            s.buf_first_valid = true;
+            if (tail_here)
+                s.tail_dst = nullptr; /* done */
+            if (rc)
+                return fail(c, rc, "gather kernel launch failed");
+        }
         if (!c->chain_inline && s.ev_scanned) /* the previous batch's chain is queued to start here, beside what follows */
             HIPCHK(c, hipEventRecord(s.ev_scanned, c->stream));
     } else if (s.timed) {
@@ -592,14 +650,15 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise)
         HIPCHK(c, hipEventRecord(s.ev_kernels, c->stream));
 
     /* totals and per-buffer sums go to pinned host memory from this stream, right behind the kernels */
-    if (!lean) {
+    if (!gather_publishes && !s.lean) {
         int rc = msd_launch_publish(s.d_totals, c->cfg.mode_ac ? s.d_ac_totals : nullptr, s.d_sums,
                                     fm ? s.d_fmeans : nullptr, s.nbuffers, s.h_totals, s.h_ac_totals, s.h_sums,
                                     s.h_fmeans, c->stream);
         if (rc)
             return fail(c, rc, "publish kernel launch failed");
     }
-    HIPCHK(c, hipEventRecord(s.ev_totals, c->stream));
+    if (!s.lean) /* a lean batch's totals and sums come with its first resolve pass (ev_resolve) */
+        HIPCHK(c, hipEventRecord(s.ev_totals, c->stream));
     return 0;
 }
 
@@ -620,8 +679,6 @@ int ensure_ac_host(msd_ctx *c, Slot &s, size_t nac)
     s.h_ac_cap = cap;
     return 0;
 }
-
-int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise);
 
 /* A batch whose candidate lists did not fit its arenas (an interference storm: a large share of
  * all positions look like preambles) is scanned again in pieces -- halves, quarters, ... down to
@@ -733,6 +790,12 @@ int start_download(msd_ctx *c, Slot &s, int format)
 {
     if (s.download_started)
         return 0;
+    if (s.lean) { /* totals, sums and the overflow flag arrive with the first resolve pass (finish_gpu) */
+        HIPCHK(c, hipEventRecord(s.ev_copy0, c->copy_stream));
+        HIPCHK(c, hipEventRecord(s.ev_copy1, c->copy_stream));
+        s.download_started = true;
+        return 0;
+    }
     const bool trace = c->trace;
     auto td0 = std::chrono::steady_clock::now();
     HIPCHK(c, event_wait(s.ev_totals));
@@ -828,9 +891,21 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
         rp.acc_ac = s.d_acc_ac;
         rp.nac = s.d_nac;
     }
-    rp.pred_key = s.d_pred;
-    rp.pred_first = s.d_pred + MSD_PRED_SLOTS;
-    rp.pred_slots = s.d_pred + 2 * MSD_PRED_SLOTS;
+    rp.pred = reinterpret_cast<const unsigned long long *>(s.d_pred);
+    rp.pred_gen = s.pred_gen;
+    if (s.lean) {
+        rp.hits = s.d_rhits;
+        rp.tries = s.d_rtries;
+        rp.buf_first = nullptr;
+        rp.region_counts = s.d_rcounts;
+        rp.wg_totals = s.d_rwgt;
+        rp.regions_per_buffer = s.lean_k;
+        rp.hcap = s.lean_hcap;
+        rp.nscan_wg = (s.lean_nreg + MSD_SCAN_WAVES - 1) / MSD_SCAN_WAVES;
+        rp.sums = s.d_sums;
+        rp.h_sums = s.h_sums;
+        rp.h_totals = s.h_totals;
+    }
 }
 
 uint32_t slot_valid(const Slot &s, uint32_t b)
@@ -863,16 +938,13 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
     int rc = 0;
-    if (first_pass) { /* which new addresses will this batch add, and where first */
-        rc = msd_launch_predict(s.d_tries, s.d_totals, c->d_snaps, s.d_pred, ks);
-        rp.pred_list = s.d_pred + 2 * MSD_PRED_SLOTS;
-        rp.h_pred = c->h_pred;
-        rp.h_pred_count = c->h_pred_count;
-    } else {
-        rc = msd_launch_pred_patch(s.d_pred + MSD_PRED_SLOTS, c->h_patches, c->npatches, ks);
-    }
+    rp.first_pass = first_pass ? 1 : 0;
+    rp.h_pred = c->h_pred;
+    rp.h_pred_count = c->h_pred_count;
+    if (!first_pass) /* (the first pass finds the table as the batch's scan kernel left it) */
+        rc = msd_launch_pred_patch(reinterpret_cast<unsigned long long *>(s.d_pred), c->h_patches, c->npatches, ks);
     if (rc)
-        return fail(c, rc, "prediction kernel launch failed");
+        return fail(c, rc, "prediction patch kernel launch failed");
     rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
     if (rc)
         return fail(c, rc, "resolve kernel launch failed");
@@ -1002,7 +1074,35 @@ bool gpu_eligible(const msd_ctx *c, const Slot &s)
     return c->gpu_resolve && s.nbuffers >= 4;
 }
 
-/* Returns 1 when the batch has to go through the host resolver instead (nothing committed). */
+/* per-buffer sample counts and means (mag_buf.validLength - overlap, .mean_level, .mean_power) of an integer format */
+void means_from_sums(msd_ctx *c, const Slot &s)
+{
+    c->valid.assign(s.nbuffers, 0);
+    c->means.assign(2 * (size_t)s.nbuffers, 0.0);
+    for (uint32_t b = 0; b < s.nbuffers; ++b) {
+        const uint32_t n = slot_valid(s, b);
+        c->valid[b] = n;
+        /* convert.c:104-110 (note 65536 for the level, 65535^2 for the power) */
+        c->means[2 * b] = (double)s.h_sums[2 * b] / 65536.0 / (double)n;
+        c->means[2 * b + 1] = (double)s.h_sums[2 * b + 1] / 65535.0 / 65535.0 / (double)n;
+    }
+}
+
+/* Lean layout: the dense, ordered candidate lists after all (somebody on the host wants them): the gather kernel
+ * over the slot's region slices, synchronously.  Totals land in h_totals; the sums were published already. */
+int lean_gather_now(msd_ctx *c, Slot &s)
+{
+    int rc = msd_launch_gather(s.d_rcounts, s.d_rwgt, s.lean_nreg, s.d_totals, s.d_rhits, s.d_rtries, s.lean_hcap, s.lean_tcap,
+                               s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers, s.h_totals, nullptr,
+                               nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 1, c->stream);
+    if (rc)
+        return fail(c, rc, "gather kernel launch failed");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* Returns 1 when the batch has to go through the host resolver instead (nothing committed); 2 when its candidate
+ * arenas overflowed (lean layout: only the first resolve pass tells). */
 int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
 {
     const uint32_t n = s.nbuffers;
@@ -1031,6 +1131,11 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         ++npass;
         HIPCHK(c, event_wait(wait_for));
         auto k1 = tnow();
+        if (s.lean && pass == 0) { /* what the gather kernel's totals used to say */
+            if (s.h_totals[2])
+                return 2;
+            means_from_sums(c, s);
+        }
         int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
                                         &s.resolve_ntodo);
@@ -1190,24 +1295,25 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     int rc = start_download(c, s, format);
     if (rc)
         return rc;
-    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
+    uint64_t H = s.lean ? 0 : s.h_totals[0], Tn = s.lean ? 0 : s.h_totals[1];
     HIPCHK(c, hipEventSynchronize(s.ev_copy1));
     auto tb = std::chrono::steady_clock::now();
     s.download_started = false;
     /* the following batch's lists can come down while this one is resolved on the host */
     if (c->outstanding > 1) {
         Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy && hipEventQuery(nx.ev_totals) == hipSuccess) {
+        if (&nx != &s && nx.busy && !nx.lean && hipEventQuery(nx.ev_totals) == hipSuccess) {
             rc = start_download(c, nx, c->scan_format); /* its kernels are done: does not block */
             if (rc)
                 return rc;
         }
     }
 
-    /* per-buffer sample counts and means (mag_buf.validLength-overlap, .mean_level, .mean_power) */
+    /* per-buffer sample counts and means (mag_buf.validLength-overlap, .mean_level, .mean_power); a lean batch's
+     * sums arrive with its first resolve pass (finish_gpu) */
     c->valid.assign(s.nbuffers, 0);
     c->means.assign(2 * (size_t)s.nbuffers, 0.0);
-    for (uint32_t b = 0; b < s.nbuffers; ++b) {
+    for (uint32_t b = 0; b < s.nbuffers && !s.lean; ++b) {
         const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
         uint64_t n = s.nsamples > first ? s.nsamples - first : 0;
         if (n > MSD_CHUNK_SAMPLES)
@@ -1234,6 +1340,10 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         s.resolve_inflight = false;
         if (rc < 0)
             return rc;
+        if (s.lean) {
+            H = s.h_totals[0];
+            Tn = s.h_totals[1];
+        }
         if (rc == 0) {
             auto t1 = std::chrono::steady_clock::now();
             if (c->outstanding > 1) {
@@ -1263,12 +1373,35 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             return 0;
         }
         /* the host resolver takes the batch: it needs the lists after all */
-        rc = ensure_host(c, s, H, Tn);
+        const bool overflowed = rc == 2;
+        if (overflowed) { /* lean layout, arenas overflowed: scanned again in pieces, stitched on the host */
+            if (c->pending_emit == &s)
+                c->pending_emit = nullptr; /* its speculative records are void */
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            s.lean = false;
+            rc = rerun_in_pieces(c, s, format);
+            if (rc)
+                return rc;
+            for (uint32_t b = 0; b < s.nbuffers; ++b) { /* the pieces' gather kernels published the sums again */
+                const uint32_t n = slot_valid(s, b);
+                c->valid[b] = n;
+                c->means[2 * b] = (double)s.h_sums[2 * b] / 65536.0 / (double)n;
+                c->means[2 * b + 1] = (double)s.h_sums[2 * b + 1] / 65535.0 / 65535.0 / (double)n;
+            }
+            s.gpu_resolve = false;
+        } else if (s.lean) {
+            rc = lean_gather_now(c, s);
+            if (rc)
+                return rc;
+        }
+        H = s.h_totals[0];
+        Tn = s.h_totals[1];
+        rc = overflowed ? 0 : ensure_host(c, s, H, Tn);
         if (rc)
             return rc;
-        if (H)
+        if (H && !overflowed)
             HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->aux_stream));
-        if (Tn)
+        if (Tn && !overflowed)
             HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->aux_stream));
         if (c->cfg.mode_ac) {
             const uint64_t nac = s.h_ac_totals[0];
@@ -1407,7 +1540,8 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.tail_dst = nsamples >= (uint64_t)TAIL_SAMPLES ? c->d_tail[tail_nxt] : nullptr;
     auto tl0 = std::chrono::steady_clock::now();
     c->scan_queued = false;
-    rc = enqueue(c, s, c->scan_format, nullptr);
+    s.gpu_resolve = gpu_eligible(c, s);
+    rc = enqueue(c, s, c->scan_format, nullptr, true);
     if (rc) { /* nothing was consumed: the dropped samples and a pending restart wait for the next launch */
         if (c->scan_queued) /* ... unless kernels of this batch are on the stream already: their follow-ups are missing,
                                the slot's lists and sums are half written -- only msd_reset() starts over */
@@ -1425,7 +1559,6 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
                 std::chrono::duration<double, std::milli>(tl0 - t_origin).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     }
-    s.gpu_resolve = gpu_eligible(c, s);
     s.resolve_inflight = false;
     if (s.gpu_resolve && c->outstanding == 0) { /* no earlier batch to wait for: resolve right behind the scan */
         rc = gpu_begin(c, s, c->scan_format);
@@ -1511,7 +1644,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
+        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_side) (void)hipHostFree(s.h_side);
@@ -1766,6 +1899,19 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         if (ia && atoi(ia) >= 0 && (uint32_t)atoi(ia) < MSD_RB_ADD_INLINE)
             c->inline_adds = (uint32_t)atoi(ia);
     }
+    {
+        const char *le = getenv("MSD_LEAN"); /* 0: keep the gather kernel and the dense lists everywhere */
+        const bool fm = cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11 || c->dc;
+        c->lean_ok = c->gpu_resolve && c->chain_inline && !cfg->mode_ac && !fm && !(le && *le == '0');
+    }
+    if (c->lean_ok)
+        for (Slot &s : c->slots) {
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rhits), c->hit_arena * sizeof(msd_hit)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rtries), c->try_arena * sizeof(msd_try)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rcounts), c->max_wg * sizeof(msd_region_counts)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rwgt), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
+            CK(hipMemset(s.d_totals, 0, 4 * sizeof(uint64_t)));
+        }
     if (c->gpu_resolve) {
         const size_t ctl_bytes = (size_t)28 * c->max_buffers;
         for (Slot &s : c->slots) {
@@ -1778,7 +1924,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
                 CK(hipMalloc(reinterpret_cast<void **>(&s.d_acc_ac), sizeof(uint32_t) * MSD_RB_AC_CAP * c->max_buffers));
                 CK(hipMalloc(reinterpret_cast<void **>(&s.d_nac), sizeof(uint32_t) * c->max_buffers));
             }
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * (2 * MSD_PRED_SLOTS + 4 + MSD_PRED_LIST)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * MSD_PRED_WORDS));
+            CK(hipMemset(s.d_pred, 0xFF, sizeof(uint32_t) * MSD_PRED_WORDS)); /* every slot vacant (generation 0xff) */
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
             memset(s.h_ctl, 0, ctl_bytes);

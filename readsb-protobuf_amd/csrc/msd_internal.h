@@ -102,14 +102,23 @@ typedef struct msd_wg_totals {
 #define MSD_RB_ADD_INLINE 224u /* icaoFilterAdd addresses of one buffer reported inline: those that are not in the
                                   snapshot's active table already (the others cannot change the filter) */
 #define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[2][8192], then the index of the active table */
-/* Predicted adds of a batch: every address that is not in the filter when the batch starts but has
- * a CRC-clean DF17 / DF11(II=0) try somewhere in it, with the first buffer holding such a try.  The
- * resolve kernel treats the address as known in all later buffers, so a batch in which new aircraft
- * show up still converges in one pass; the host checks every prediction against the adds that
- * really happened (a predicted message can be hidden behind another one) and corrects the table. */
-#define MSD_PRED_SLOTS 16384u
-#define MSD_PRED_LIST 8192u /* at most this many predicted addresses; more: the host resolver takes the batch */
+/* Predicted adds of a batch: every address that has a CRC-clean DF17 / DF11(II=0) try somewhere in it, with the
+ * first buffer holding such a try (the scan kernel notes them as it finds them; it does not know the filter).  The
+ * resolve kernel treats the address as known in all later buffers, so a batch in which new aircraft show up still
+ * converges in one pass; the host ignores the entries whose address the filter held when the batch began, checks
+ * every other prediction against the adds that really happened (a predicted message can be hidden behind another
+ * one) and corrects the table. */
+#define MSD_PRED_SLOTS 65536u
+#define MSD_PRED_LIST 32768u /* at most this many predicted addresses; more: the host resolver takes the batch */
 #define MSD_PRED_NEVER 0xFFFFFFFFu
+/* The device table: MSD_PRED_SLOTS 64-bit entries (generation << 56 | address << 32 | first buffer), then a 32-bit
+ * cell (generation << 24 | number of entries) and MSD_PRED_LIST slot indices.  An entry of another generation is a
+ * vacant slot: the table of a pipeline slot is never wiped between batches (the scan kernel fills it while it runs,
+ * so nothing could wipe it in time); the host moves to the next generation with every batch and clears the memory
+ * when the 8-bit count comes round.  Open addressing, linear probing from MSD_PRED_HASH. */
+#define MSD_PRED_WORDS (2u * MSD_PRED_SLOTS + 2u + MSD_PRED_LIST) /* 32-bit words */
+#define MSD_PRED_GENS 255u /* generations 0..254; 0xff never */
+#define MSD_PRED_HASH(addr) (((addr) * 2654435761u) >> 16)
 typedef struct msd_pred_entry {
     uint32_t addr;
     uint32_t first; /* buffer of the first clean squitter */

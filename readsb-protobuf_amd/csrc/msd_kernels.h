@@ -60,6 +60,21 @@ typedef struct MsdScanParams {
     uint64_t *chunk_sums; /* [buffers in batch][2]: sum of mag, sum of mag^2 */
     float *tile_sums;     /* SC16 / SC16Q11: [tile][2] approximate float sums of a tile's magnitudes and squares (what the
                              float-sum kernel predicts its binades from), or NULL */
+    /* ---- lean layout (msd_capi.cpp): no gather kernel behind the scan ----
+     * regions_per_buffer != 0: region r is piece r % k of buffer r / k (tiles_per_region tiles, never across a buffer
+     * boundary), so that the resolve workgroup of a buffer reads its k region slices where they are; the try index
+     * in a hit record is then arena-absolute (region * tcap + index). */
+    uint32_t regions_per_buffer, tiles_per_region;
+    unsigned long long *overflow; /* the batch's totals[2]: set by any region whose slice overflowed */
+    /* predicted adds, written as the tries are found: every CRC-clean DF17 / DF11(II=0) address with the first buffer
+     * holding one (msd_internal.h); NULL: nobody wants them */
+    unsigned long long *pred;
+    uint32_t pred_gen;
+    /* the batch's last MSD_HALO_FRONT samples, kept for the look-behind of its successor (lean layout: the first
+     * wavefront copies them on its way in; otherwise the gather kernel does) */
+    const uint32_t *tail_src;
+    uint32_t *tail_dst;
+    uint32_t tail_words;
     unsigned long long *timers; /* MSD_KERNEL_TIMING builds only */
     int debug_flags;      /* MSD_DEBUG_FLAGS env, perf experiments only: 1 = stop after the scan,
                              2 = stop after the conversion (results are then incomplete) */
@@ -85,12 +100,19 @@ typedef struct MsdResolveParams {
     uint32_t *acc_ac;         /* [buffer][MSD_RB_AC_CAP] indices of the accepted ones */
     uint32_t *nac;            /* [buffer] how many */
     /* first pass only: its first workgroup publishes the prediction list the predict kernel built */
-    const uint32_t *pred_list; /* counter - 1, then the used slots; NULL on later passes */
+    int first_pass;            /* publish the prediction list (and, lean layout, the sums and totals) */
     msd_pred_entry *h_pred;    /* pinned host memory */
     uint32_t *h_pred_count;
-    const uint32_t *pred_key; /* [MSD_PRED_SLOTS] predicted adds: address ... */
-    const uint32_t *pred_first; /* ... and the first buffer with a clean squitter of it */
-    const uint32_t *pred_slots; /* counter - 1, then the slots in use (what pred_list points at on the first pass) */
+    const unsigned long long *pred; /* the batch's prediction table (msd_internal.h: MSD_PRED_*), written by its scan */
+    uint32_t pred_gen;
+    /* lean layout: the candidate lists stay in the scan's region slices.  hits / tries above are then the arenas,
+     * region r's hits are hits[r * hcap .. + region_counts[r].nhits), buffer b owns regions [b * k, (b + 1) * k);
+     * the first pass also publishes what the gather kernel used to: the buffer's level / power sums and, from its
+     * first workgroup, the batch's totals and overflow flag. */
+    const msd_region_counts *region_counts; /* NULL: dense lists */
+    const msd_wg_totals *wg_totals;
+    uint32_t regions_per_buffer, hcap, nscan_wg;
+    uint64_t *sums, *h_sums, *h_totals;
 } MsdResolveParams;
 
 #ifdef __cplusplus
@@ -100,14 +122,10 @@ extern "C" {
 int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_totals, uint64_t *sums, const float *fmeans,
                        uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_ac_totals, uint64_t *h_sums, float *h_fmeans,
                        hipStream_t stream);
-/* Builds the prediction table of a batch from its try list (against snapshot 0).
- * pred (device): key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | counter | slot list[MSD_PRED_LIST], wiped to
- * all-ones beforehand.  The list of entries is published by the first resolve pass: h_pred[0..*h_pred_count)
- * in pinned host memory, *h_pred_count = MSD_PRED_LIST + 1 on overflow. */
-int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
-                       hipStream_t stream);
-/* pred_first[patches[i].slot] = patches[i].first; patches is pinned host memory */
-int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream);
+/* The prediction table of a batch (msd_internal.h) is filled by its scan kernel (MsdScanParams.pred); the list of
+ * entries is published by the first resolve pass: h_pred[0..*h_pred_count) in pinned host memory, *h_pred_count =
+ * MSD_PRED_LIST + 1 on overflow.  table[patches[i].slot].first = patches[i].first; patches is pinned host memory. */
+int msd_launch_pred_patch(unsigned long long *table, const msd_pred_patch *patches, uint32_t n, hipStream_t stream);
 int msd_launch_resolve(const MsdResolveParams *p, uint32_t ntodo, hipStream_t stream);
 /* signal power of the accepted messages of every buffer: out[buffer][MSD_RB_MSG_CAP] (device); and, if rec_off is
  * not NULL, rec_off[buffer] = messages and (nac not NULL) Mode A/C replies of the buffers in front of it */
@@ -138,7 +156,7 @@ int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_t
                       const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,
                       msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
                       uint64_t *h_sums, void *wipe, uint32_t wipe_bytes, const void *tail_src, void *tail_dst,
-                      uint32_t tail_bytes, uint32_t region_len, uint32_t *buf_first, hipStream_t stream);
+                      uint32_t tail_bytes, uint32_t region_len, uint32_t *buf_first, uint32_t try_abs, hipStream_t stream);
 int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
                      unsigned long long *d_out, hipStream_t stream);
 /* Mode A/C candidate stage: noise levels (unless noise_ready), candidate kernel, ordered gather.

@@ -35,6 +35,7 @@
 #include "msd_internal.h"
 #include "msd_kernels.h"
 #include "msd_emit_impl.h"
+#include "msd_pred_impl.h"
 
 /* The float converters must round like the reference's x86-64 build: separate multiply and add
  * (no FMA contraction) and a correctly rounded square root.  The file is compiled with
@@ -343,7 +344,7 @@ struct WaveCtx {
 template <bool FIX2>
 __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const WaveCtx &X, uint32_t nh, uint64_t tile_pos0,
                                                 msd_hit *hit_out, uint32_t hits_room, msd_try *my_tries,
-                                                uint32_t &tcur)
+                                                uint32_t &tcur, uint32_t try_base /* of my_tries[0] in the hit records */)
 {
     const int lane = X.lane;
     const unsigned char *mbytes = X.w + W_MAGS;
@@ -541,6 +542,9 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             }
         }
         const uint32_t q = (me >> 13) & 7u, h = me >> 20;
+        if (alive && crc == 0 && (df == 17 || df == 11) && P.pred) /* a clean DF17 / DF11 with II = 0: it will reach
+                                                                     icaoFilterAdd if it is accepted (mode_s.c:717-726) */
+            msd_pred_note(P.pred, P.pred_gen, aa, (uint32_t)(tile_pos0 / MSD_CHUNK_SAMPLES));
         if (alive) {
             /* the record holds the message as bytes, first byte first */
             *reinterpret_cast<uint4 *>(smsg32 + 4u * u) =
@@ -568,7 +572,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
         if ((uint32_t)lane < hits_room) {
             msd_hit rec = (tile_pos0 + pos) | ((msd_hit)my_m << 28) | ((msd_hit)nlive << 31);
             if (nlive)
-                rec |= (msd_hit)idx << 34;
+                rec |= (msd_hit)(try_base + idx) << 34;
             hit_out[lane] = rec;
         }
 #pragma unroll
@@ -604,6 +608,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
     const uint64_t batch_end = P.batch_first + P.nsamples; /* one past the last scan position */
     msd_hit *const my_hits = P.hits + (size_t)region * P.hcap;
     msd_try *const my_tries = P.tries + (size_t)region * P.tcap;
+    const uint32_t try_base = P.regions_per_buffer ? region * P.tcap : 0u; /* lean layout: arena-absolute try indices */
     uint32_t hcur = 0, tcur = 0; /* wave-uniform cursors into the region's slices of the arenas */
 
     /* running buffer sums (convert.c:78-110), flushed when the wavefront moves to another buffer */
@@ -847,7 +852,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     }
                     const uint32_t out0 = hcur + r0;
                     const uint32_t room = out0 < P.hcap ? P.hcap - out0 : 0u;
-                    if (!candidate_round<FIX2>(P, X, nh, tile_pos0, my_hits + out0, room, my_tries, tcur)) {
+                    if (!candidate_round<FIX2>(P, X, nh, tile_pos0, my_hits + out0, room, my_tries, tcur, try_base)) {
                         nh = (nh + 1) / 2; /* too many tries with a known DF: halve the round */
                         fill = false;
                         wave_lds_sync();
@@ -910,8 +915,23 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
 
     /* from here to the end of the batch the wavefronts do not meet again */
     const uint32_t region = blockIdx.x * WAVES + (uint32_t)wave;
-    const uint32_t tile_lo = region * P.tiles_per_wg;
-    uint32_t tile_hi = tile_lo + P.tiles_per_wg;
+    uint32_t tile_lo, tile_hi;
+    if (P.regions_per_buffer) { /* lean layout: piece region % k of buffer region / k, never across a buffer boundary */
+        constexpr uint32_t TPB = MSD_CHUNK_SAMPLES / (1024u * tile_runs(FMT)); /* tiles per buffer */
+        const uint32_t b = region / P.regions_per_buffer, piece = region - b * P.regions_per_buffer;
+        tile_lo = b * TPB + piece * P.tiles_per_region;
+        tile_hi = tile_lo + P.tiles_per_region;
+        if (tile_hi > (b + 1) * TPB)
+            tile_hi = (b + 1) * TPB;
+        if (tile_lo > tile_hi)
+            tile_lo = tile_hi;
+        if (region == 0 && P.tail_words) /* the batch's last samples, for the look-behind of its successor */
+            for (uint32_t i = (uint32_t)lane; i < P.tail_words; i += 64)
+                P.tail_dst[i] = P.tail_src[i];
+    } else {
+        tile_lo = region * P.tiles_per_wg;
+        tile_hi = tile_lo + P.tiles_per_wg;
+    }
     if (tile_hi > P.ntiles)
         tile_hi = P.ntiles;
     uint32_t nhits = 0, ntries = 0;
@@ -922,6 +942,10 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
         X.sl = sl;
         X.lane = lane;
         scan_region<FMT, FIX2, EMIT>(P, X, lut, region, tile_lo, tile_hi, nhits, ntries);
+    } else if (EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers && !(P.debug_flags & 128)) {
+        /* a region without tiles (lean layout: the pieces of a short last buffer) still owes its share of the
+         * previous batch's records */
+        msd_emit_slice(P.emit, region, lane, smem + OFF_WAVE + wave * W_BYTES + W_HITS, (P.debug_flags & 64) != 0);
     }
     if (lane == 0) {
         wgc[4 * wave] = nhits;
@@ -948,6 +972,8 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
         if (tid == 0) {
             msd_wg_totals t = {hb, tb, ovf, 0};
             P.wg_totals[blockIdx.x] = t;
+            if (ovf && P.overflow)
+                atomicOr(P.overflow, 1ull);
         }
     }
 }
@@ -962,7 +988,8 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_region_counts
                                                          uint64_t *sums, uint32_t nbuffers, uint64_t *h_totals,
                                                          uint64_t *h_sums, uint4 *wipe, uint32_t wipe_n,
                                                          const uint32_t *tail_src, uint32_t *tail_dst,
-                                                         uint32_t tail_words, uint32_t region_len, uint32_t *buf_first)
+                                                         uint32_t tail_words, uint32_t region_len, uint32_t *buf_first,
+                                                         uint32_t try_abs /* lean layout: the hits hold arena-absolute try indices */)
 {
     __shared__ unsigned long long ph[4], pt[4];
     __shared__ uint32_t povf[4];
@@ -1051,7 +1078,7 @@ __global__ void __launch_bounds__(256) msd_gather_kernel(const msd_region_counts
     for (uint32_t i = tid; i < nh; i += blockDim.x) {
         msd_hit hr = hs[i];
         if (MSD_HIT_NLIVE(hr))
-            hr += (msd_hit)to << 34;
+            hr = (hr & ((1ull << 34) - 1)) | ((MSD_HIT_TRY(hr) - (try_abs ? (uint64_t)w * tcap : 0ull) + to) << 34);
         if (ho + i < dense_hcap)
             dense_hits[ho + i] = hr;
     }
@@ -2408,12 +2435,12 @@ extern "C" int msd_launch_gather(const msd_region_counts *counts, const msd_wg_t
                                  uint64_t dense_hcap, msd_try *dense_tries, uint64_t dense_tcap, uint64_t *sums,
                                  uint32_t nbuffers, uint64_t *h_totals, uint64_t *h_sums, void *wipe, uint32_t wipe_bytes,
                                  const void *tail_src, void *tail_dst, uint32_t tail_bytes, uint32_t region_len,
-                                 uint32_t *buf_first, hipStream_t stream)
+                                 uint32_t *buf_first, uint32_t try_abs, hipStream_t stream)
 {
     hipLaunchKernelGGL(msd_gather_kernel, dim3(nwg), dim3(256), 0, stream, counts, wg_totals, hits, tries, hcap, tcap, dense_hits,
                        dense_hcap, dense_tries, dense_tcap, totals, sums, nbuffers, h_totals, h_sums,
                        static_cast<uint4 *>(wipe), wipe_bytes / 16, static_cast<const uint32_t *>(tail_src),
-                       static_cast<uint32_t *>(tail_dst), tail_bytes / 4, region_len, buf_first);
+                       static_cast<uint32_t *>(tail_dst), tail_bytes / 4, region_len, buf_first, try_abs);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

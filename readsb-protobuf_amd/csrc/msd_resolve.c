@@ -960,6 +960,12 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
             while (bs->pmap[h])
                 h = (h + 1) & (cap - 1);
             bs->pmap[h] = i + 1;
+            /* The scan kernel notes every address with a clean squitter, not only new ones (it does not know the
+             * filter).  An address the filter holds as the batch begins needs no confirmation: its squitters add
+             * nothing new, and "known from its first buffer on" is true as long as it stays a member -- if a flip
+             * drops it first, the flip below takes the entry back like a confirmed one's. */
+            if (pred[i].first != MSD_PRED_NEVER && filter_test(&bs->work, pred[i].addr))
+                bs->pconf[i] = 2;
         }
         if (nbuffers > bs->stale_cap) {
             bs->stale = realloc(bs->stale, nbuffers);

@@ -21,6 +21,7 @@
 #include "msd_kernels.h"
 #include "msd_fields_impl.h"
 #include "msd_emit_impl.h"
+#include "msd_pred_impl.h"
 
 namespace {
 
@@ -140,20 +141,6 @@ __device__ __forceinline__ uint32_t res_len(uint64_t r) /* samples hidden by the
     return (((uint32_t)(r >> 20) & 0x10u) ? 112u : 56u) * 12u / 5u;
 }
 
-/* predicted adds (msd_internal.h): the first buffer with a clean squitter of addr, or NEVER */
-__device__ __forceinline__ uint32_t pred_lookup(const uint32_t *key, const uint32_t *first, uint32_t addr)
-{
-    uint32_t h = (addr * 2654435761u) >> 18; /* 16384 slots */
-    for (;;) {
-        const uint32_t k = key[h];
-        if (k == addr)
-            return first[h];
-        if (k == VACANT)
-            return MSD_PRED_NEVER;
-        h = (h + 1) & (MSD_PRED_SLOTS - 1);
-    }
-}
-
 constexpr uint32_t TCAP = 2 * SEG; /* tries staged per segment; a segment is cut short where they would not fit */
 constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
@@ -190,6 +177,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     __shared__ uint32_t sh_ctr[16];
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ uint64_t sh_range[2];
+    __shared__ uint32_t sh_rpre[64]; /* lean layout: hits of the buffer in front of each of its regions */
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
     __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_nfit, sh_nok, sh_na, sh_last, sh_nf;
     __shared__ uint32_t f_addr[FCAP], f_resume[FCAP], f_idx[FCAP]; /* new aircraft of the round: address, end and hit of the adding message */
@@ -202,18 +190,45 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     const uint64_t ovf = P.totals[2], nhits = P.totals[0];
     const uint64_t ac_ovf = P.ac ? P.ac_totals[2] : 0;
     const uint32_t b = P.todo[blockIdx.x];
-    const uint32_t npred_raw = P.pred_slots[0] + 1u; /* the counter started at 0xffffffff */
+    const uint32_t npred_raw = msd_pred_count(P.pred, P.pred_gen);
+    if (P.first_pass && P.region_counts) {
+        /* lean layout: what the gather kernel used to leave for the host -- the buffer's level / power sums (the
+         * device cells are zeroed for the slot's next batch) and, from the first workgroup, the batch's totals */
+        if (tid < 2) {
+            P.h_sums[2 * b + tid] = P.sums[2 * b + tid];
+            P.sums[2 * b + tid] = 0;
+        }
+        if (blockIdx.x == 0 && tid < 64) {
+            unsigned long long h = 0, t = 0;
+            for (uint32_t i = tid; i < P.nscan_wg; i += 64) {
+                h += P.wg_totals[i].nhits;
+                t += P.wg_totals[i].ntries;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                h += __shfl_down(h, d, 64);
+                t += __shfl_down(t, d, 64);
+            }
+            if (tid == 0) {
+                P.h_totals[0] = h;
+                P.h_totals[1] = t;
+                P.h_totals[2] = ovf;
+            }
+        }
+    }
     if (ovf || ac_ovf)
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
-    if (blockIdx.x == 0 && P.pred_list) { /* the prediction list of the batch, for the host's replay */
+    if (blockIdx.x == 0 && P.first_pass) { /* the prediction list of the batch, for the host's replay */
         const uint32_t n = npred_raw;
+        const uint32_t *list = reinterpret_cast<const uint32_t *>(P.pred + MSD_PRED_SLOTS) + 2;
         if (tid == 0)
             *P.h_pred_count = n <= MSD_PRED_LIST ? n : MSD_PRED_LIST + 1;
         for (uint32_t i = tid; i < n && i < MSD_PRED_LIST; i += RT) {
-            const uint32_t h = P.pred_list[1 + i];
+            const uint32_t h = list[i];
+            const unsigned long long en = P.pred[h];
             msd_pred_entry e;
-            e.addr = P.pred_key[h];
-            e.first = P.pred_first[h];
+            e.addr = (uint32_t)(en >> 32) & 0xffffffu;
+            e.first = (uint32_t)en;
             e.slot = h;
             e.pad = 0;
             P.h_pred[i] = e;
@@ -231,7 +246,26 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         addset[i] = VACANT;
     if (tid < 16)
         sh_ctr[tid] = 0;
-    if (P.buf_first) { /* the gather kernel left the range of this buffer's hits in the ordered list */
+    if (P.region_counts) { /* lean layout: the buffer's hits are the slices of its k regions, one after the other */
+        if (tid < 64) {
+            const uint32_t k = P.regions_per_buffer;
+            uint32_t c = 0;
+            if ((uint32_t)tid < k)
+                c = min(P.region_counts[(size_t)b * k + tid].nhits, P.hcap);
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (tid >= d)
+                    incl += up;
+            }
+            sh_rpre[tid] = incl - c; /* hits in the buffer's earlier regions */
+            if (tid == 63) {
+                sh_range[0] = 0;
+                sh_range[1] = incl;
+            }
+        }
+    } else if (P.buf_first) { /* the gather kernel left the range of this buffer's hits in the ordered list */
         if (tid < 2)
             sh_range[tid] = min((uint64_t)P.buf_first[b + tid], nhits);
     } else if (tid < 128) { /* ... or a 64-ary search per wavefront */
@@ -267,8 +301,19 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     uint32_t n = 0;
     for (uint64_t s0 = hb; s0 < he; s0 += n) {
         n = (he - s0 < (uint64_t)SEG) ? (uint32_t)(he - s0) : (uint32_t)SEG;
-        for (uint32_t i = tid; i < n; i += RT)
-            seg_hits[i] = P.hits[s0 + i];
+        if (P.region_counts) {
+            const uint32_t k = P.regions_per_buffer;
+            for (uint32_t i = tid; i < n; i += RT) {
+                const uint32_t v = (uint32_t)s0 + i;
+                uint32_t j = 0; /* the last region that starts at or before v (k is a handful) */
+                for (uint32_t q = 1; q < k; ++q)
+                    j = sh_rpre[q] <= v ? q : j;
+                seg_hits[i] = P.hits[((size_t)b * k + j) * P.hcap + (v - sh_rpre[j])];
+            }
+        } else {
+            for (uint32_t i = tid; i < n; i += RT)
+                seg_hits[i] = P.hits[s0 + i];
+        }
         if (tid == 0) {
             sh_seg_resume = sh_resume;
             sh_nacc = 0;
@@ -331,7 +376,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             const uint32_t where = snap_probe(snap, v.addr);
             bool known = where != 0 || addset_has(addset, v.addr);
             if (!known && npred_raw) /* added by an earlier buffer of this batch (predicted; the host verifies) */
-                known = pred_lookup(P.pred_key, P.pred_first, v.addr) < b;
+                known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
             seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
         }
         __syncthreads();
@@ -916,48 +961,11 @@ __global__ void __launch_bounds__(256) msd_emit_kernel(const MsdResolveParams P,
     }
 }
 
-/* Prediction table of a batch: one thread per try; a clean DF17 / DF11(II=0) try whose address the
- * filter does not hold yet claims a slot and lowers its first-buffer value. */
-__global__ void __launch_bounds__(256) msd_predict_kernel(const msd_try *tries, const uint64_t *totals,
-                                                          const uint32_t *snap0, uint32_t *pred_key,
-                                                          uint32_t *pred_first, uint32_t *count, uint32_t *list)
+__global__ void __launch_bounds__(64) msd_pred_patch_kernel(unsigned long long *table, const msd_pred_patch *patches, uint32_t n)
 {
-    if (totals[2])
-        return;
-    const uint64_t ntries = totals[1];
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntries; t += (uint64_t)gridDim.x * blockDim.x) {
-        const TryView v = load_try(tries + t);
-        const uint32_t df = (v.w0 & 0xffu) >> 3;
-        if ((v.w3 >> 24) != 0xffu || !(df == 17 || (df == 11 && (v.crc & 0x7fu) == 0)))
-            continue; /* mode_s.c:717-726: only these reach icaoFilterAdd */
-        if (snap_probe(snap0, v.addr))
-            continue;
-        const uint32_t buffer = tries[t].pos / MSD_CHUNK_SAMPLES;
-        uint32_t h = (v.addr * 2654435761u) >> 18;
-        for (;;) {
-            uint32_t old = __atomic_load_n(&pred_key[h], __ATOMIC_RELAXED); /* most tries find their aircraft's slot */
-            if (old == VACANT) {
-                old = atomicCAS(&pred_key[h], VACANT, v.addr);
-                if (old == VACANT) {
-                    const uint32_t k = atomicAdd(count, 1u) + 1u; /* the counter starts at 0xffffffff */
-                    if (k < MSD_PRED_LIST)
-                        list[k] = h;
-                }
-            }
-            if (old == VACANT || old == v.addr) {
-                if (__atomic_load_n(&pred_first[h], __ATOMIC_RELAXED) > buffer)
-                    atomicMin(&pred_first[h], buffer);
-                break;
-            }
-            h = (h + 1) & (MSD_PRED_SLOTS - 1);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(64) msd_pred_patch_kernel(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n)
-{
+    /* the first buffer is the low half of the entry */
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-        pred_first[patches[i].slot] = patches[i].first;
+        reinterpret_cast<uint32_t *>(table + patches[i].slot)[0] = patches[i].first;
 }
 
 /* The small per-batch results the host waits for -- list totals and per-buffer level/power sums --
@@ -993,22 +1001,11 @@ extern "C" int msd_launch_publish(const uint64_t *totals, const uint64_t *ac_tot
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int msd_launch_predict(const msd_try *tries, const uint64_t *totals, const uint32_t *snap0, uint32_t *pred,
-                                  hipStream_t stream)
-{
-    /* pred: key[MSD_PRED_SLOTS] | first[MSD_PRED_SLOTS] | count - 1 | slot list[MSD_PRED_LIST];
-     * key, first and the counter are all-ones here: the slot's gather kernel wiped them */
-    uint32_t *key = pred, *first = pred + MSD_PRED_SLOTS, *count = pred + 2 * MSD_PRED_SLOTS;
-    hipLaunchKernelGGL(msd_predict_kernel, dim3(1024), dim3(256), 0, stream, tries, totals, snap0, key, first, count,
-                       count + 1);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
-}
-
-extern "C" int msd_launch_pred_patch(uint32_t *pred_first, const msd_pred_patch *patches, uint32_t n, hipStream_t stream)
+extern "C" int msd_launch_pred_patch(unsigned long long *table, const msd_pred_patch *patches, uint32_t n, hipStream_t stream)
 {
     if (n == 0)
         return 0;
-    hipLaunchKernelGGL(msd_pred_patch_kernel, dim3(1), dim3(64), 0, stream, pred_first, patches, n);
+    hipLaunchKernelGGL(msd_pred_patch_kernel, dim3(1), dim3(64), 0, stream, table, patches, n);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
