@@ -181,6 +181,13 @@ struct Slot {
      * candidate lists stay in this slot's own region arenas until the batch's records are out, the resolve
      * workgroups read their buffer's region slices, the first resolve pass publishes sums and totals */
     bool lean = false;
+    bool power_done = false; /* the batch's signal power kernel has been queued (d_powr, d_rec_off) */
+    bool ahead_done = false; /* its resolve passes are through and its filter changes committed (by the msd_collect of
+                                the batch before it); counters and delivery wait for its own msd_collect */
+    int ahead_verdict = 0;   /* 1 / 2: the msd_collect before this batch's already found that the host resolver has to take
+                                it / that its arenas overflowed (resolve_passes); nothing was committed */
+    bool records_current = true; /* no further resolve pass ran after the one whose records were written */
+    uint32_t npass = 0;
     msd_hit *d_rhits = nullptr;
     msd_try *d_rtries = nullptr;
     msd_region_counts *d_rcounts = nullptr;
@@ -301,9 +308,12 @@ struct msd_ctx {
     std::vector<double> bg_means;
     std::vector<uint64_t> bg_scaled; /* per message: power sum | signal_len << 48 (msd_emit_impl.h) */
     bool emit_fused = false;
+    bool power_fused = true; /* no signal power kernel: the resolve workgroups sum it (MSD_POWER_FUSED=0 keeps the kernel) */
     struct Slot *pending_emit = nullptr;
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
     bool lean_ok = false;     /* the configuration allows the lean layout (Slot::lean; MSD_LEAN=0 turns it off) */
+    bool wait_inputs_on_stream = false; /* MSD_WAIT_INPUTS_ON_STREAM=1: the resolve kernel's stream waits for the snapshot upload */
+    bool resolve_ahead = true; /* msd_collect also takes the next batch through its resolve passes (MSD_RESOLVE_AHEAD=0: no) */
     int debug_flags = 0;     /* MSD_DEBUG_FLAGS */
     uint64_t enqueue_seq = 0;
     uint64_t launch_count = 0;
@@ -561,7 +571,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
                 p.emit.cap = (uint32_t)a.req_cap;
                 p.emit.totals = rp.totals;
                 p.emit.nmsgs = rp.nmsgs;
-                p.emit.rec_off = a.d_rec_off;
+                p.emit.rec_off = a.power_done ? a.d_rec_off : nullptr;
                 p.emit.acc = rp.acc;
                 p.emit.tries = rp.tries;
                 p.emit.ts = rp.ts;
@@ -893,6 +903,18 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
     }
     rp.pred = reinterpret_cast<const unsigned long long *>(s.d_pred);
     rp.pred_gen = s.pred_gen;
+    if (c->power_fused) { /* the signal power of the accepted messages at the end of every resolve workgroup */
+        MsdScanParams sp{};
+        fill_params(c, s, sp);
+        rp.power = reinterpret_cast<unsigned long long *>(s.d_powr);
+        rp.iq = sp.iq;
+        rp.prev_tail = sp.prev_tail;
+        rp.have_prev = sp.have_prev;
+        rp.batch_first = sp.batch_first;
+        rp.nsamples = sp.nsamples;
+        rp.lut = sp.lut;
+        rp.format = c->scan_format;
+    }
     if (s.lean) {
         rp.hits = s.d_rhits;
         rp.tries = s.d_rtries;
@@ -933,7 +955,14 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     c->snaps_uploaded = nsn;
     if (ks != c->aux_stream) {
         HIPCHK(c, hipEventRecord(c->ev_inputs, c->aux_stream));
-        HIPCHK(c, hipStreamWaitEvent(ks, c->ev_inputs, 0));
+        if (ks == c->stream && c->chain_inline && !c->wait_inputs_on_stream) {
+            /* In order on the scan stream: the caller waits the few microseconds the 64 KB take (the copy engine is
+             * idle) instead of the stream -- a wait packet in front of the resolve kernel holds the stream for 10 us
+             * behind every scan, however long ago the event fired. */
+            HIPCHK(c, event_wait(c->ev_inputs));
+        } else {
+            HIPCHK(c, hipStreamWaitEvent(ks, c->ev_inputs, 0));
+        }
     }
     MsdResolveParams rp{};
     gpu_params(c, s, rp);
@@ -961,12 +990,18 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t 
     MsdScanParams p{};
     fill_params(c, s, p);
     /* the signal power on `ps`, the records on `ks` behind it */
+    if (c->power_fused && do_power) { /* the resolve workgroups left the sums; the emit kernel adds up its own offsets */
+        do_power = false;
+        s.power_done = false;
+    }
     int rc = do_power ? msd_launch_power_buffers(&p, format, s.d_acc, s.d_tries, s.d_nmsgs, s.nbuffers, s.d_totals,
                                                  reinterpret_cast<unsigned long long *>(s.d_powr),
                                                  c->cfg.mode_ac ? s.d_nac : nullptr, s.d_rec_off, ps)
                       : 0;
     if (rc)
         return fail(c, rc, "power kernel launch failed");
+    if (do_power)
+        s.power_done = true;
     if (!do_emit)
         return 0;
     if (ps != ks) {
@@ -1007,7 +1042,7 @@ int flush_pending_emit(msd_ctx *c)
     if (!p)
         return 0;
     c->pending_emit = nullptr;
-    return gpu_queue_emit(c, *p, c->scan_format, c->stream, c->stream, false, true);
+    return gpu_queue_emit(c, *p, c->scan_format, c->stream, c->stream, !p->power_done, true);
 }
 
 /* Clocks, snapshot 0 = the live filter, first pass over every buffer and the (speculative) message
@@ -1025,6 +1060,7 @@ void apply_dropped(msd_ctx *c, Slot &s)
 int gpu_begin(msd_ctx *c, Slot &s, int format)
 {
     apply_dropped(c, s);
+    s.power_done = false;
     const GpuCtl g = gpu_ctl(c, s);
     for (uint32_t b = 0; b < s.nbuffers; ++b)
         g.h_valid[b] = slot_valid(s, b);
@@ -1053,10 +1089,10 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
         if (c->emit_fused) {
             rc = flush_pending_emit(c); /* an older one no scan came after */
-            if (!rc)
+            if (!rc && !c->power_fused)
                 rc = gpu_queue_emit(c, s, format, ks, ks, true, false); /* signal power now, records with the next scan */
             if (!rc)
-                c->pending_emit = &s;
+                c->pending_emit = &s; /* (power_fused: the next scan's wavefronts sum the signal power as well) */
         } else {
             if (pws != ks)
                 HIPCHK(c, hipStreamWaitEvent(pws, s.ev_resolve, 0));
@@ -1103,39 +1139,26 @@ int lean_gather_now(msd_ctx *c, Slot &s)
 
 /* Returns 1 when the batch has to go through the host resolver instead (nothing committed); 2 when its candidate
  * arenas overflowed (lean layout: only the first resolve pass tells). */
-int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
+/* The resolve passes of a batch whose first pass is queued: wait, replay the filter changes on the host, run the
+ * buffers that saw the wrong filter again, until the replay agrees with what every buffer assumed.  0: done (nothing
+ * is committed yet); 1: the host resolver has to take the batch; 2: its candidate arenas overflowed (lean layout:
+ * only the first pass tells); < 0: error. */
+int resolve_passes(msd_ctx *c, Slot &s, double &t_wait, double &t_replay)
 {
     const uint32_t n = s.nbuffers;
     const GpuCtl g = gpu_ctl(c, s);
-    const bool trace = c->trace;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    double t_wait = 0, t_replay = 0;
-    uint32_t npass = 0;
-    const bool early = s.resolve_inflight;
-    if (!s.resolve_inflight) {
-        int rc = gpu_begin(c, s, format);
-        if (rc)
-            return rc;
-    }
-    s.resolve_inflight = false;
-    if (c->pending_emit == &s) { /* no scan was launched since */
-        int rc = flush_pending_emit(c);
-        if (rc)
-            return rc;
-    }
     hipEvent_t wait_for = s.ev_resolve;
-    bool records_current = true; /* the message records in host memory belong to the latest pass */
+    s.records_current = true; /* the message records in host memory belong to the latest pass */
+    s.npass = 0;
     for (uint32_t pass = 0;; ++pass) {
         auto k0 = tnow();
-        ++npass;
+        ++s.npass;
         HIPCHK(c, event_wait(wait_for));
         auto k1 = tnow();
-        if (s.lean && pass == 0) { /* what the gather kernel's totals used to say */
-            if (s.h_totals[2])
-                return 2;
-            means_from_sums(c, s);
-        }
+        if (s.lean && pass == 0 && s.h_totals[2]) /* what the gather kernel's totals used to say */
+            return 2;
         int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
                                         &s.resolve_ntodo);
@@ -1150,7 +1173,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         t_wait += tms(k0, k1);
         t_replay += tms(k1, tnow());
         if (rc == 0)
-            break;
+            return 0;
         if (rc < 0)
             return 1;
         /* some buffers saw the wrong filter: once more for those, ahead of the queued scans */
@@ -1160,11 +1183,83 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
             return rc;
         HIPCHK(c, hipEventRecord(c->ev_aux, ps));
         wait_for = c->ev_aux;
-        records_current = false;
+        s.records_current = false;
     }
+}
+
+/* The successor of a batch whose filter changes have just been committed: its first resolve pass can be queued. */
+int begin_successor(msd_ctx *c, Slot &s)
+{
+    Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
+    /* Across a capture boundary too: the filter and the clocks start over now (this batch was the old capture's
+     * last one), the counters when the new capture's first batch is collected -- the caller may still want
+     * the old ones.  (Not if samples were dropped in front of the new capture: they count on its counters.) */
+    if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.gpu_resolve && !nx.resolve_inflight && !nx.ahead_done &&
+        (!nx.reset_before || nx.dropped_before == 0)) {
+        if (nx.reset_before) {
+            msd_resolver_reset_state(&c->resolver);
+            nx.state_reset_done = true;
+        }
+        return gpu_begin(c, nx, c->scan_format);
+    }
+    return 0;
+}
+
+/* Returns 1 when the batch has to go through the host resolver instead (nothing committed); 2 when its candidate
+ * arenas overflowed (lean layout: only the first resolve pass tells). */
+int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
+{
+    const uint32_t n = s.nbuffers;
+    const GpuCtl g = gpu_ctl(c, s);
+    const bool trace = c->trace;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double t_wait = 0, t_replay = 0;
+    const bool early = s.resolve_inflight || s.ahead_done;
+    int begin_rc = 0;
+    if (s.ahead_verdict) { /* the msd_collect before this one has been through the passes already */
+        const int v = s.ahead_verdict;
+        s.ahead_verdict = 0;
+        s.resolve_inflight = false;
+        if (c->pending_emit == &s)
+            c->pending_emit = nullptr; /* its speculative records are void */
+        return v;
+    }
+    if (!s.ahead_done) { /* (an earlier msd_collect may have done this half already: see below) */
+        if (!s.resolve_inflight) {
+            int rc = gpu_begin(c, s, format);
+            if (rc)
+                return rc;
+        }
+        s.resolve_inflight = false;
+        if (c->pending_emit == &s) { /* no scan was launched since */
+            int rc = flush_pending_emit(c);
+            if (rc)
+                return rc;
+        }
+        int rc = resolve_passes(c, s, t_wait, t_replay);
+        if (rc)
+            return rc;
+        msd_gpu_resolve_commit_state(&c->resolver, n, g.h_valid, s.h_rbuf);
+        /* the filter is final for this batch: its successor can start */
+        if (c->outstanding > 1)
+            begin_rc = begin_successor(c, s);
+    }
+    s.ahead_done = false;
+    s.resolve_inflight = false;
+    if (c->pending_emit == &s) { /* no scan was launched since its chain was queued: nobody carries its records */
+        int rc = flush_pending_emit(c);
+        if (rc)
+            return rc;
+    }
+    const uint32_t npass = s.npass;
+    bool records_current = s.records_current;
+    hipEvent_t wait_for = c->ev_aux; /* (only looked at after a further pass, which recorded it) */
     c->timing.resolve_passes = npass;
     auto e0 = tnow();
-    msd_gpu_resolve_commit(&c->resolver, n, g.h_valid, s.h_rbuf);
+    if (s.lean)
+        means_from_sums(c, s);
+    msd_gpu_resolve_commit_stats(&c->resolver, n, g.h_valid, s.h_rbuf);
 
     uint32_t total = 0;
     c->out_buf.clear();
@@ -1231,19 +1326,32 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     const bool threaded = !c->no_helper;
     if (threaded)
         c->helper.run(deliver);
-    /* the filter is final for this batch: its successor can start */
-    int begin_rc = 0;
-    if (c->outstanding > 1) {
-        Slot &nx = c->slots[(c->head + 1) % MSD_PIPELINE_DEPTH];
-        /* Across a capture boundary too: the filter and the clocks start over now (this batch was the old capture's
-         * last one), the counters when the new capture's first batch is collected -- the caller may still want
-         * the old ones.  (Not if samples were dropped in front of the new capture: they count on its counters.) */
-        if (&nx != &s && nx.busy && nx.gpu_resolve && !nx.resolve_inflight && (!nx.reset_before || nx.dropped_before == 0)) {
-            if (nx.reset_before) {
-                msd_resolver_reset_state(&c->resolver);
-                nx.state_reset_done = true;
+    /* While this batch's records are on their way: the resolve half of the NEXT batch -- wait for its first pass
+     * (queued when this batch's filter changes were committed, possibly by the msd_collect before this one), replay,
+     * commit its filter changes and queue the first pass of the batch behind it.  The chain of resolve passes then
+     * runs one batch ahead of the delivery: the caller, who can only launch the next scan once this call returns,
+     * never finds the GPU waiting for a resolve pass it has not been able to queue yet.  The counters of the next
+     * batch are added when it is collected, as before. */
+    if (c->outstanding > 1 && !begin_rc && c->resolve_ahead) {
+        Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
+        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.gpu_resolve && nx.resolve_inflight && !nx.ahead_done &&
+            !nx.reset_before) {
+            double tw = 0, tr = 0;
+            const int arc = resolve_passes(c, nx, tw, tr);
+            if (trace)
+                fprintf(stderr, "ahead: next batch's passes: waits %.3f ms, replay %.3f ms, verdict %d\n", tw, tr, arc);
+            if (arc < 0) {
+                begin_rc = arc;
+            } else if (arc == 0) {
+                const GpuCtl gn = gpu_ctl(c, nx);
+                msd_gpu_resolve_commit_state(&c->resolver, nx.nbuffers, gn.h_valid, nx.h_rbuf);
+                nx.ahead_done = true;
+                nx.resolve_inflight = false;
+                if (c->outstanding > 2)
+                    begin_rc = begin_successor(c, nx);
+            } else { /* the host resolver's case or an overflow: nothing is committed, that batch's msd_collect acts on it */
+                nx.ahead_verdict = arc;
             }
-            begin_rc = gpu_begin(c, nx, c->scan_format);
         }
     }
     auto e1 = tnow();
@@ -1260,8 +1368,8 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         for (uint32_t b = 0; b < n; ++b)
             for (int k = 0; k < 8; ++k)
                 cyc[k] += s.h_rbuf[b].cyc[k];
-        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f segment %.1f stage %.1f eval %.1f walk %.1f count %.1f\n",
-                cyc[0] / n / 100, cyc[5] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100);
+        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f segment %.1f stage %.1f eval %.1f walk %.1f count %.1f power %.1f\n",
+                cyc[0] / n / 100, cyc[5] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100, cyc[6] / n / 100);
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
                 "power stats %.3f ms (helper), then waited %.3f ms for it\n", npass, early ? " (first one queued early)" : "",
                 t_wait, t_replay, tms(e0, e1), t_power, tms(e1, tnow()));
@@ -1390,6 +1498,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             }
             s.gpu_resolve = false;
         } else if (s.lean) {
+            means_from_sums(c, s); /* (published by the first resolve pass, which did run) */
             rc = lean_gather_now(c, s);
             if (rc)
                 return rc;
@@ -1560,6 +1669,8 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     }
     s.resolve_inflight = false;
+    s.ahead_done = false;
+    s.ahead_verdict = 0;
     if (s.gpu_resolve && c->outstanding == 0) { /* no earlier batch to wait for: resolve right behind the scan */
         rc = gpu_begin(c, s, c->scan_format);
         if (rc) {
@@ -1887,6 +1998,9 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
         { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !c->repass_aux /* a re-pass on another stream would race the scan that carries the records */ && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
+        { const char *pf = getenv("MSD_POWER_FUSED"); c->power_fused = !(pf && *pf == '0'); }
+        { const char *ra = getenv("MSD_RESOLVE_AHEAD"); c->resolve_ahead = !(ra && *ra == '0'); }
+        c->wait_inputs_on_stream = getenv("MSD_WAIT_INPUTS_ON_STREAM") != nullptr;
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);
@@ -1979,6 +2093,8 @@ int msd_reset(msd_ctx *c)
         for (Slot &s : c->slots) {
             s.busy = false;
             s.resolve_inflight = false;
+            s.ahead_done = false;
+            s.ahead_verdict = 0;
         }
         c->head = 0;
         c->outstanding = 0;

@@ -75,63 +75,4 @@ __device__ __forceinline__ msd_message msd_emit_mode_ac(const msd_ac_hit c, uint
     return mm;
 }
 
-/* One wavefront writes its share of job J: wavefront w of the scan takes slice w % stride of buffer w / stride,
- * a run of consecutive records, between two of its tiles.  Up to 64 records at a time are put together in `lds` (3.5 KB of the wavefront's own) and leave as
- * consecutive dwords -- the destination is host memory, where a lane-strided struct store costs a PCIe write
- * per piece. */
-__device__ inline void msd_emit_slice(const MsdEmitJob &J, uint32_t w, int lane, unsigned char *lds, bool dbg_no_store = false)
-{
-    const uint32_t b = w / J.stride, slice = w % J.stride;
-    /* one round of loads: flags, the buffer's place in the record array (the power kernel's prefix), its counts, its clocks */
-    const uint64_t ovf = J.totals[2], ac_ovf = J.ac ? J.ac_totals[2] : 0;
-    const uint32_t o = J.rec_off[b], nm = J.nmsgs[b], na_all = J.ac ? J.nac[b] : 0u;
-    if (ovf || ac_ovf)
-        return; /* arenas overflowed: the host rescans the batch */
-    const uint64_t sample_ts = J.ts[2 * b], sys_ts = J.ts[2 * b + 1];
-    const uint32_t base = b * MSD_CHUNK_SAMPLES;
-    const msd_acc *acc = J.acc + (size_t)b * MSD_RB_MSG_CAP;
-    msd_wire *rec = reinterpret_cast<msd_wire *>(lds);
-    static_assert(sizeof(msd_wire) % 8 == 0, "record size");
-    auto flush = [&](uint32_t first, uint32_t n) { /* rows [first, first + n) from the LDS image, clipped to cap */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (first < J.cap && !dbg_no_store) {
-            n = min(n, J.cap - first);
-            unsigned long long *d = reinterpret_cast<unsigned long long *>(J.dense + first);
-            const unsigned long long *r = reinterpret_cast<const unsigned long long *>(rec);
-            for (uint32_t i = (uint32_t)lane; i < n * (uint32_t)(sizeof(msd_wire) / 8); i += 64)
-                __builtin_nontemporal_store(r[i], &d[i]); /* streaming: nothing on the device reads it again */
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    {
-        const uint32_t run = (nm + J.stride - 1) / J.stride, lo = min(nm, slice * run), hi = min(nm, lo + run);
-        for (uint32_t m0 = lo; m0 < hi; m0 += 64) {
-            const uint32_t m = m0 + (uint32_t)lane;
-            if (m < hi) {
-                unsigned long long side;
-                rec[lane].mm = msd_emit_mode_s(acc[m], J.tries, J.power[(size_t)b * MSD_RB_MSG_CAP + m], sample_ts, sys_ts, base, side);
-                if (o + m < J.cap)
-                    J.side[o + m] = side;
-            }
-            flush(o + m0, min(64u, hi - m0));
-        }
-    }
-    if (J.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
-        const uint32_t na = na_all;
-        const uint32_t *acc_ac = J.acc_ac + (size_t)b * MSD_RB_AC_CAP;
-        const uint32_t run = (na + J.stride - 1) / J.stride, lo = min(na, slice * run), hi = min(na, lo + run);
-        for (uint32_t m0 = lo; m0 < hi; m0 += 64) {
-            const uint32_t m = m0 + (uint32_t)lane;
-            if (m < hi) {
-                rec[lane].mm = msd_emit_mode_ac(J.ac[acc_ac[m]], sample_ts, sys_ts);
-                if (o + nm + m < J.cap)
-                    J.side[o + nm + m] = 0;
-            }
-            flush(o + nm + m0, min(64u, hi - m0));
-        }
-    }
-}
-
 #endif

@@ -264,7 +264,8 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
                            uint32_t inline_adds, uint32_t pass, uint32_t max_snaps, msd_pred_entry *pred, uint32_t npred,
                            msd_pred_patch *patches, uint32_t *npatches, uint32_t *snap_idx, uint32_t *todo,
                            uint32_t *ntodo);
-void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
+void msd_gpu_resolve_commit_state(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
+void msd_gpu_resolve_commit_stats(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ typedef struct MsdEmitJob {
     uint32_t nbuffers, stride, cap;
     const uint64_t *totals;    /* [2]: arena overflow flag of that batch */
     const uint32_t *nmsgs;     /* [buffer] */
-    const uint32_t *rec_off;   /* [buffer] records in front of the buffer's (msd_power_buffers_kernel) */
+    const uint32_t *rec_off;   /* [buffer] records in front of the buffer's (msd_power_buffers_kernel), or NULL: the
+                                  wavefronts add up nmsgs / nac themselves */
     const struct msd_acc *acc; /* [buffer][MSD_RB_MSG_CAP] */
     const msd_try *tries;      /* that batch's dense try list */
     const uint64_t *ts;        /* [buffer][2] */
@@ -113,6 +114,13 @@ typedef struct MsdResolveParams {
     const msd_wg_totals *wg_totals;
     uint32_t regions_per_buffer, hcap, nscan_wg;
     uint64_t *sums, *h_sums, *h_totals;
+    /* power != NULL: every workgroup finishes with the signal power of its buffer's accepted messages
+     * (demod_2400.c:386-399), power[buffer][MSD_RB_MSG_CAP], from the batch's samples -- no kernel of its own */
+    unsigned long long *power;
+    const uint8_t *iq, *prev_tail;
+    int have_prev, format;
+    uint64_t batch_first, nsamples;
+    const uint16_t *lut;
 } MsdResolveParams;
 
 #ifdef __cplusplus

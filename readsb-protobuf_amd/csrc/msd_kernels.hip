@@ -36,6 +36,7 @@
 #include "msd_kernels.h"
 #include "msd_emit_impl.h"
 #include "msd_pred_impl.h"
+#include "msd_mag_impl.h"
 
 /* The float converters must round like the reference's x86-64 build: separate multiply and add
  * (no FMA contraction) and a correctly rounded square root.  The file is compiled with
@@ -100,26 +101,6 @@ static_assert(OFF_WAVE % 16 == 0 && W_SMSG % 16 == 0 && W_BYTES % 16 == 0 && OFF
               "LDS carve offsets must stay aligned");
 static_assert(LDS_UC8 <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
 
-
-/* (b - 127.5)^2 only depends on k = b-128 (b >= 128) or 127-b (b < 128) */
-__device__ __forceinline__ uint32_t fold8(uint32_t b)
-{
-    return (b ^ ((b >> 7) - 1u)) & 0x7fu;
-}
-
-/* convert.c:215-253 / :332-370 float path */
-__device__ __forceinline__ uint32_t mag_from_s16(int I, int Q, float inv_scale)
-{
-    const float fi = (float)I * inv_scale; /* division by a power of two is exact */
-    const float fq = (float)Q * inv_scale;
-    const float sq_i = fi * fi, sq_q = fq * fq;
-    float magsq = sq_i + sq_q;
-    if (magsq > 1.0f)
-        magsq = 1.0f;
-    const float m = __builtin_sqrtf(magsq);
-    const float scaled = m * 65535.0f;
-    return (uint32_t)(uint16_t)(scaled + 0.5f);
-}
 
 template <int FMT>
 struct RawGroup { /* the raw bytes of 8 consecutive samples */
@@ -594,6 +575,10 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     return true;
 }
 
+template <int FMT>
+__device__ inline void msd_emit_slice(const MsdEmitJob &J, const uint16_t *lut_g, uint32_t w, int lane, unsigned char *lds,
+                                      bool dbg_no_store = false);
+
 /* One wavefront's share of the batch: the tiles [tile_lo, tile_hi) of 1024 * tile_runs(FMT) scan positions each. */
 template <int FMT, bool FIX2, bool EMIT>
 __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCtx &X, const uint16_t *lut,
@@ -755,7 +740,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         /* the record slice goes here, behind the tile's last global loads: tests and candidate rounds need none,
          * so nothing waits for the PCIe stores until the next tile's table loads, 15 us on */
         if (EMIT && tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
-            msd_emit_slice(P.emit, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
+            msd_emit_slice<FMT>(P.emit, P.lut, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
 
         if (!(P.debug_flags & 2)) {
             /* ---- stage 2: preamble tests for my NH runs of 16 consecutive positions (demod_2400.c:257-335) ---- */
@@ -945,7 +930,7 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
     } else if (EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers && !(P.debug_flags & 128)) {
         /* a region without tiles (lean layout: the pieces of a short last buffer) still owes its share of the
          * previous batch's records */
-        msd_emit_slice(P.emit, region, lane, smem + OFF_WAVE + wave * W_BYTES + W_HITS, (P.debug_flags & 64) != 0);
+        msd_emit_slice<FMT>(P.emit, P.lut, region, lane, smem + OFF_WAVE + wave * W_BYTES + W_HITS, (P.debug_flags & 64) != 0);
     }
     if (lane == 0) {
         wgc[4 * wave] = nhits;
@@ -1153,27 +1138,89 @@ __global__ void __launch_bounds__(256) msd_offsets_kernel(const msd_wg_counts *c
 template <int FMT>
 __device__ __forceinline__ uint32_t stream_mag(const MsdScanParams &P, int64_t n, const uint16_t *lut_g)
 {
-    constexpr int BPS = RawGroup<FMT>::WORDS / 2;
-    const int64_t rel = n - (int64_t)P.batch_first;
-    const uint8_t *src;
-    if (rel < 0) {
-        if (!P.have_prev || rel < -(int64_t)FRONT)
-            return 0;
-        src = P.prev_tail + (rel + FRONT) * BPS;
+    MsdSampleSource S;
+    S.iq = P.iq;
+    S.prev_tail = P.prev_tail;
+    S.have_prev = P.have_prev;
+    S.batch_first = P.batch_first;
+    S.nsamples = P.nsamples;
+    return msd_stream_mag<FMT>(S, n, lut_g);
+}
+
+/* One wavefront writes its share of job J (the previous batch's message records): wavefront w of the scan takes
+ * slice w % stride of buffer w / stride, a run of consecutive records, between two of its tiles.  Up to 32 records at
+ * a time are put together in `lds` (the wavefront's candidate scratch) and leave as consecutive dwords -- the
+ * destination is host memory, where a lane-strided struct store costs a PCIe write per piece.  Without J.rec_off the
+ * place of the buffer's records in the batch's array is added up from the per-buffer counts.  (Summing the signal
+ * power here as well -- three messages' samples in flight per wavefront -- was measured: the code alone costs the
+ * tile loop 56 more bytes of spills and the launch 11 us, in use 32 us; the resolve workgroups do it instead.) */
+template <int FMT>
+__device__ inline void msd_emit_slice(const MsdEmitJob &J, const uint16_t *lut_g, uint32_t w, int lane, unsigned char *lds,
+                                      bool dbg_no_store)
+{
+    const uint32_t b = w / J.stride, slice = w % J.stride;
+    /* one round of loads: flags, the buffer's counts and clocks, the counts in front of it */
+    const uint64_t ovf = J.totals[2], ac_ovf = J.ac ? J.ac_totals[2] : 0;
+    const uint32_t nm = J.nmsgs[b], na_all = J.ac ? J.nac[b] : 0u;
+    uint32_t o;
+    if (J.rec_off) {
+        o = J.rec_off[b];
     } else {
-        if (rel >= (int64_t)P.nsamples)
-            return 0;
-        src = P.iq + rel * BPS;
+        uint32_t mine = 0;
+        for (uint32_t i = (uint32_t)lane; i < b; i += 64)
+            mine += J.nmsgs[i] + (J.ac ? J.nac[i] : 0u);
+        o = wave_last(wave_incl_scan(mine));
     }
-    if (FMT == MSD_FMT_UC8) {
-        const uint32_t pair = *reinterpret_cast<const uint16_t *>(src);
-        return lut_g[fold8(pair >> 8) * LUT_STRIDE + fold8(pair & 0xffu)];
-    } else if (FMT == MSD_FMT_MAG16) {
-        return *reinterpret_cast<const uint16_t *>(src);
-    } else {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(src);
-        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-        return mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
+    if (ovf || ac_ovf)
+        return; /* arenas overflowed: the host rescans the batch */
+    const uint64_t sample_ts = J.ts[2 * b], sys_ts = J.ts[2 * b + 1];
+    const uint32_t base = b * MSD_CHUNK_SAMPLES;
+    const msd_acc *acc = J.acc + (size_t)b * MSD_RB_MSG_CAP;
+    constexpr uint32_t ROUND = 32;
+    msd_wire *rec = reinterpret_cast<msd_wire *>(lds);
+    static_assert(sizeof(msd_wire) % 8 == 0 && ROUND * sizeof(msd_wire) <= W_BYTES - W_HITS, "the records of a round fit the candidate scratch");
+    auto flush = [&](uint32_t first, uint32_t n) { /* rows [first, first + n) from the LDS image, clipped to cap */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (first < J.cap && !dbg_no_store) {
+            n = min(n, J.cap - first);
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(J.dense + first);
+            const unsigned long long *r = reinterpret_cast<const unsigned long long *>(rec);
+            for (uint32_t i = (uint32_t)lane; i < n * (uint32_t)(sizeof(msd_wire) / 8); i += 64)
+                __builtin_nontemporal_store(r[i], &d[i]); /* streaming: nothing on the device reads it again */
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    {
+        const uint32_t run = (nm + J.stride - 1) / J.stride, lo = min(nm, slice * run), hi = min(nm, lo + run);
+        for (uint32_t m0 = lo; m0 < hi; m0 += ROUND) {
+            const uint32_t m = m0 + (uint32_t)lane, cnt = min(ROUND, hi - m0);
+            const bool mine = (uint32_t)lane < cnt;
+            msd_acc a = acc[mine ? m : m0];
+            const unsigned long long psum = J.power[(size_t)b * MSD_RB_MSG_CAP + (mine ? m : m0)];
+            if (mine) {
+                unsigned long long side;
+                rec[lane].mm = msd_emit_mode_s(a, J.tries, psum, sample_ts, sys_ts, base, side);
+                if (o + m < J.cap)
+                    J.side[o + m] = side;
+            }
+            flush(o + m0, cnt);
+        }
+    }
+    if (J.ac) { /* the buffer's Mode A/C replies follow its Mode S messages (readsb.c:826-829) */
+        const uint32_t na = na_all;
+        const uint32_t *acc_ac = J.acc_ac + (size_t)b * MSD_RB_AC_CAP;
+        const uint32_t run = (na + J.stride - 1) / J.stride, lo = min(na, slice * run), hi = min(na, lo + run);
+        for (uint32_t m0 = lo; m0 < hi; m0 += ROUND) {
+            const uint32_t m = m0 + (uint32_t)lane, cnt = min(ROUND, hi - m0);
+            if ((uint32_t)lane < cnt) {
+                rec[lane].mm = msd_emit_mode_ac(J.ac[acc_ac[m]], sample_ts, sys_ts);
+                if (o + nm + m < J.cap)
+                    J.side[o + nm + m] = 0;
+            }
+            flush(o + nm + m0, cnt);
+        }
     }
 }
 
@@ -1270,7 +1317,8 @@ __global__ void __launch_bounds__(256) msd_power_buffers_kernel(const MsdScanPar
 #pragma unroll
             for (int v = 0; v < 5; ++v) {
                 const int k = lane + 64 * v;
-                x[u][v] = k < (int)rec[u].len ? stream_mag<FMT>(P, n0 + k, P.lut) : 0u;
+                const uint32_t mg = stream_mag<FMT>(P, n0 + (k < (int)rec[u].len ? k : 0), P.lut); /* unconditional load */
+                x[u][v] = k < (int)rec[u].len ? mg : 0u;
             }
         }
 #pragma unroll

@@ -1069,7 +1069,18 @@ int msd_gpu_resolve_replay(msd_resolver *r, uint32_t nbuffers, const msd_rbuf *r
     return pass >= MAX_SPECULATIVE_PASSES ? -1 : 1;
 }
 
-void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb)
+/* What the next batch's resolve needs of a batch that went through: the filter as its last buffer left it, the
+ * sample clock, Modes.ifile_now. */
+void msd_gpu_resolve_commit_state(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb)
+{
+    for (uint32_t b = 0; b < nbuffers; ++b)
+        r->sample_counter += valid[b];
+    r->filter = r->batch->work;
+    r->ifile_now = rb[nbuffers - 1].end_now;
+}
+
+/* ... and what only the statistics want (stats.h:61-80), added when the batch is delivered */
+void msd_gpu_resolve_commit_stats(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const msd_rbuf *rb)
 {
     msd_stats *st = r->stats;
     for (uint32_t b = 0; b < nbuffers; ++b) {
@@ -1086,10 +1097,7 @@ void msd_gpu_resolve_commit(msd_resolver *r, uint32_t nbuffers, const uint32_t *
         st->demod_modeac += br->nac;
         st->samples_processed += (uint64_t)valid[b] + MSD_OVERLAP; /* readsb.c:835 */
         st->buffers++;
-        r->sample_counter += valid[b];
     }
-    r->filter = r->batch->work;
-    r->ifile_now = rb[nbuffers - 1].end_now;
 }
 
 void msd_resolve_power(msd_resolver *r, uint32_t nbuffers, const uint32_t *valid, const double *means,

@@ -22,6 +22,7 @@
 #include "msd_fields_impl.h"
 #include "msd_emit_impl.h"
 #include "msd_pred_impl.h"
+#include "msd_mag_impl.h"
 
 namespace {
 
@@ -155,6 +156,51 @@ __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr
         if (v == VACANT)
             return false;
         hs = (hs + 1) & (ADDSET - 1);
+    }
+}
+
+/* Signal power of the accepted messages acc[0..nm) of one buffer, by the workgroup that accepted them: a wavefront
+ * per message, five messages' samples in flight per wavefront (the step is a chain of dependent loads -- record, IQ
+ * bytes, magnitude table -- and nothing else). */
+template <int FMT>
+__device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_acc *acc, uint32_t nm, unsigned long long *out,
+                                         int tid)
+{
+    MsdSampleSource S;
+    S.iq = P.iq;
+    S.prev_tail = P.prev_tail;
+    S.have_prev = P.have_prev;
+    S.batch_first = P.batch_first;
+    S.nsamples = P.nsamples;
+    constexpr uint32_t PER = 5, NW = RT / 64;
+    const int lane = tid & 63;
+    for (uint32_t m0 = (uint32_t)(tid >> 6); m0 < nm; m0 += PER * NW) { /* wave-uniform */
+        uint32_t x[PER][5];
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) {
+            const uint32_t m = m0 + u * NW;
+            const msd_acc rec = acc[m < nm ? m : m0];
+            msd_power_loads<FMT>(S, P.lut, rec.pos, m < nm ? rec.len : 0u, lane, x[u]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) {
+            /* at most 320 squares < 2^32 each: two 32-bit sums (low and high halves of the squares) */
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const uint32_t sq = x[u][v] * x[u][v];
+                lo += sq & 0xffffu;
+                hi += sq >> 16;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                lo += __shfl_down(lo, d, 64);
+                hi += __shfl_down(hi, d, 64);
+            }
+            const uint32_t m = m0 + u * NW;
+            if (lane == 0 && m < nm)
+                out[m] = (unsigned long long)lo + ((unsigned long long)hi << 16);
+        }
     }
 }
 
@@ -736,6 +782,19 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             }
             PHASE(4)
         }
+    }
+
+    if (P.power) { /* the signal power of the buffer's messages (the records in acc[] are this workgroup's own) */
+        __syncthreads();
+        const uint32_t nm = sh_nmsgs < MSD_RB_MSG_CAP ? sh_nmsgs : MSD_RB_MSG_CAP;
+        unsigned long long *out = P.power + (size_t)b * MSD_RB_MSG_CAP;
+        switch (P.format) {
+        case MSD_FMT_UC8: power_of_accepted<MSD_FMT_UC8>(P, acc, nm, out, tid); break;
+        case MSD_FMT_SC16: power_of_accepted<MSD_FMT_SC16>(P, acc, nm, out, tid); break;
+        case MSD_FMT_SC16Q11: power_of_accepted<MSD_FMT_SC16Q11>(P, acc, nm, out, tid); break;
+        default: power_of_accepted<MSD_FMT_MAG16>(P, acc, nm, out, tid); break;
+        }
+        PHASE(6)
     }
 
     /* ---- Mode A/C (demod_2400.c:522-708): every test is done, only the 69-sample skip-ahead of an
