@@ -51,9 +51,62 @@ def parse():
                     help="MSD_CFG_DECODE_FIELDS: also decode header and extended squitter fields of every message")
     ap.add_argument("--dcfilter", action="store_true",
                     help="MSD_CFG_DC_FILTER: the DC-blocking converters (sequential by nature, ~0.1 GS/s); use a small --samples")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the post-clock runs of BASELINE configs[2] and [4] that the default N=1 run appends ('also')")
+    ap.add_argument("--no-pin", action="store_true", help="leave the process's CPU affinity alone")
     ap.add_argument("--timing-interval", type=int, default=4,
                     help="record the kernel timing events on one launch in N (msd_set_timing_interval)")
     return ap.parse_args()
+
+
+def pin_to_gpu_local_cpus(torch, local_rank, world):
+    """The rank's threads (this one, the context's helper thread, the host resolver's pool) onto CPUs of the NUMA
+    node its GPU hangs off, a disjoint slice per rank -- the reference pins its reader and demodulator threads too
+    (readsb.c:275,749).  Every rank runs a calling thread that polls for events and a helper thread that copies the
+    records: eight ranks on one node must not end up on each other's cores.  Returns a description,
+    or None where sysfs does not tell (nothing is changed then)."""
+    try:
+        def cpulist(i):
+            p = torch.cuda.get_device_properties(i)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            txt = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+            cpus = []
+            for part in txt.split(","):
+                a, _, b = part.partition("-")
+                cpus.extend(range(int(a), int(b or a) + 1))
+            return bdf, cpus
+        bdf, cpus = cpulist(local_rank)
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        ngpu = torch.cuda.device_count()
+        mates = [i for i in range(min(ngpu, max(world, 1))) if cpulist(i)[1] == cpus]  # ranks whose GPU shares these CPUs
+        k, j = max(1, len(mates)), (mates.index(local_rank) if local_rank in mates else 0)
+        per = max(2, len(allowed) // k)
+        mine = allowed[j * per:(j + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        return {"gpu": bdf, "cpus": "%d-%d (%d of the %d local to the GPU, slice %d of %d)" % (mine[0], mine[-1], len(mine), len(allowed), j, k)}
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+def run_also(extra):
+    """One of the other BASELINE workloads through this same script in a process of its own, after the clock stopped:
+    its bench line, cut down to what the `also` block reports."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--check", "--no-also"] + extra
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        d = json.loads(res.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+        return {"workload": " ".join(extra), "error": repr(e)[:200]}
+    pm = d.get("pipeline_ms") or {}
+    scan, rest = pm.get("scan_kernel_ms"), pm.get("other_kernels_ms")
+    return {"workload": d["config"]["workload"], "options": " ".join(extra), "value": d["value"], "unit": d["unit"],
+            "ms_per_step": d["ms_per_step"], "dominant_kernel": "msd_scan_kernel" if (scan or 0) >= (rest or 0) else "kernels behind the scan",
+            "kernel_ms": scan, "kernels_behind_the_scan_ms": rest, "frac": d["roofline"]["frac"],
+            "traffic": d["roofline"]["traffic"], "messages_per_step": d["messages_per_step"],
+            "message_set_diff_vs_oracle": d.get("message_set_diff_vs_oracle"), "resolve_stage": d.get("resolve_stage")}
 
 
 def main():
@@ -71,6 +124,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pinned = None if args.no_pin else pin_to_gpu_local_cpus(torch, local_rank, world)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -147,6 +201,12 @@ def main():
     nmsg = run_steps(args.steps, timings)
     barrier()
     elapsed = time.perf_counter() - t0
+    my_ms_per_step = elapsed * 1e3 / max(1, args.steps)
+    per_rank_ms = [my_ms_per_step]
+    if world > 1:  # every rank's own time, beside the MAX the contract asks for
+        gathered = [None] * world
+        dist.all_gather_object(gathered, my_ms_per_step)
+        per_rank_ms = [float(x) for x in gathered]
     elapsed, nmsg_total, total_samples = pkg.sharding.reduce_job(elapsed, nmsg, n, device=dev)
 
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -180,6 +240,11 @@ def main():
                 "algorithmic_bytes_per_launch": launch_samples * bps, "kernel": "msd_scan_kernel",
                 "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
                 "algorithmic_bytes_per_sample": bps, "launches_timed": len(scan_ms), "launches": len(timings)}
+    # what the kernel is really bound by (it is not HBM): from the latest profiles/*_binding.json, a summary of SQ counter
+    # passes of this same command (scripts/r3_profiles.sh) and of the issue-rate microbenchmark
+    bfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_binding.json"))
+    if bfiles and args.format == "uc8" and not args.mode_ac:
+        roofline["binding"] = json.load(open(os.path.join(ROOT, "profiles", bfiles[-1])))
     # in the in-order layout without field decoding the scan's wavefronts also write the previous batch's message
     # records; MSD_EMIT_FUSED=0 gives them a kernel of their own and times the scan alone
     fused = (os.environ.get("MSD_EMIT_FUSED", "1") != "0" and not args.fields and
@@ -207,6 +272,10 @@ def main():
                          **{k: round(float(np.mean([t[k] for t in timings])), 4) for k in
                             ("d2h_ms", "resolve_ms", "hits", "tries")}} if timings and measured else None),
         "capture_generation_s": round(gen_s, 2),
+        "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3)},
+        "host_placement": pinned or "process affinity left as found",
+        "host_threads_per_rank": "2 busy (caller: polls events, replays filter changes, queues kernels; helper: copies the "
+                                 "records, power statistics) + an idle pool for the host resolver",
         "resolve_stage": ("gpu, %.2f passes per batch, %d batches handed to the host resolver"
                           % (float(np.mean([t["resolve_passes"] for t in timings])), int(timings[-1]["resolve_fallback"]))
                           if timings and any(t["resolve_passes"] for t in timings)
@@ -300,6 +369,12 @@ def main():
         out["messages_checked"] = int(len(want))
         if ndiff:
             raise SystemExit("bench: GPU messages differ from the oracle: " + json.dumps(out))
+    if rank == 0 and world == 1 and not args.no_also and not args.no_cpu_baseline and args.format == "uc8" and \
+            not (args.mode_ac or args.fields or args.dcfilter or args.fix) and n == 1 << 29:
+        # BASELINE configs[2] and configs[4] at full size, after the clock stopped, each against the oracle
+        for d in dems:
+            d.close() if hasattr(d, "close") else None
+        out["also"] = [run_also(["--format", "sc16", "--samples", str(1 << 28)]), run_also(["--mode-ac", "--fix", "1"])]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -1998,7 +1998,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         }
         c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
         { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !c->repass_aux /* a re-pass on another stream would race the scan that carries the records */ && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
-        { const char *pf = getenv("MSD_POWER_FUSED"); c->power_fused = !(pf && *pf == '0'); }
+        /* the signal power in the resolve workgroups (no kernel of its own): in the in-order layout it takes a kernel
+         * and a gap off the stream; on side streams, where the resolve kernel shares the GPU with a scan, a longer
+         * resolve kernel costs more than the small power kernel behind it (measured: SC16 121 -> 124.5, Mode A/C 149 ->
+         * 156 GS/s with the kernel) */
+        { const char *pf = getenv("MSD_POWER_FUSED"); c->power_fused = pf && *pf ? *pf != '0' : c->chain_inline; }
         { const char *ra = getenv("MSD_RESOLVE_AHEAD"); c->resolve_ahead = !(ra && *ra == '0'); }
         c->wait_inputs_on_stream = getenv("MSD_WAIT_INPUTS_ON_STREAM") != nullptr;
         c->helper.device = cfg->device;

@@ -758,6 +758,44 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                         v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
                     }
                 }
+#if MSD_TESTS_V2
+                /* All 38 samples this run's 16 positions touch, unpacked once -- through opaque instructions, so that
+                 * the compiler cannot fold the unpacking back into SDWA operands: on gfx950 a wave64 instruction with
+                 * an SDWA / DPP / SGPR operand, a compare, a carry, a multiply or any three-operand integer form
+                 * issues in 4 cycles, plain v_add / v_sub / v_and / v_or / v_lshrrev / v_ashrrev in 2
+                 * (scripts/micro/valu_issue.hip) -- and every sample is an operand of a dozen of them. */
+                int sm[40];
+#pragma unroll
+                for (int k = 0; k < 20; ++k) {
+                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(sm[2 * k]) : "v"(v[k]));
+                    asm("v_lshrrev_b32 %0, 16, %1" : "=v"(sm[2 * k + 1]) : "v"(v[k]));
+                }
+                uint32_t p0 = 0, p1 = 0, p2 = 0;
+                const int thr = P.threshold, m32 = -32;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    /* pa[d] = mags[p + 2 + d].  Branch-free, and compare-free: every verdict is the sign bit of a
+                     * difference (all values stay below 2^28), the pre-check the AND of three of them
+                     * (demod_2400.c:276-282), one v_alignbit shifts a verdict into its plane.
+                     *   ref - 1 = (base_noise * threshold - 32) >> 5 (arithmetic), common = sum_1_4 - diff_2_3 + pa9 + pa12,
+                     *   test 0: common - diff_10_11 >= ref  <=>  (ref - 1) - common + diff_10_11 < 0, and so on. */
+#define PA(d) (sm[q + 2 + (d)])
+                    const int pre = (PA(7) - PA(1)) & (PA(14) - PA(12)) & (PA(15) - PA(12));
+                    const int base_noise = PA(5) + PA(8) + PA(16) + PA(17) + PA(18);
+                    int refm;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(refm) : "v"(base_noise), "v"(thr), "v"(m32));
+                    refm >>= 5;
+                    const int diff_2_3 = PA(2) - PA(3), diff_10_11 = PA(10) - PA(11);
+                    const int b = refm - (PA(1) + PA(4) + PA(12));
+                    const int r1 = b + diff_2_3 - PA(9);
+                    const int g0 = pre & (r1 + diff_10_11), g1 = pre & (r1 - diff_10_11);
+                    const int g2 = pre & (b - diff_2_3 - diff_2_3 - diff_10_11);
+#undef PA
+                    p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)g0, 31); /* plane = 2 * plane + verdict */
+                    p1 = __builtin_amdgcn_alignbit(p1, (uint32_t)g1, 31);
+                    p2 = __builtin_amdgcn_alignbit(p2, (uint32_t)g2, 31);
+                }
+#else
                 /* all 36 samples this run's 16 positions touch, unpacked once */
                 int sm[40];
 #pragma unroll
@@ -786,6 +824,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     MSD_PUSH(p1, f1);
                     MSD_PUSH(p2, f2);
                 }
+#endif
                 /* positions past the last one the reference scans */
                 {
                     const uint64_t first = a0 + 1024ull * h + 16ull * lane;

@@ -29,6 +29,9 @@ namespace {
 #ifndef MSD_RESOLVE_WG
 #define MSD_RESOLVE_WG 512
 #endif
+#ifndef MSD_POWER_PER
+#define MSD_POWER_PER 5 /* messages whose samples a wavefront has in flight in the signal power step */
+#endif
 #ifndef MSD_RESOLVE_SEG
 #define MSD_RESOLVE_SEG 1024
 #endif
@@ -172,7 +175,7 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
     S.have_prev = P.have_prev;
     S.batch_first = P.batch_first;
     S.nsamples = P.nsamples;
-    constexpr uint32_t PER = 5, NW = RT / 64;
+    constexpr uint32_t PER = MSD_POWER_PER, NW = RT / 64;
     const int lane = tid & 63;
     for (uint32_t m0 = (uint32_t)(tid >> 6); m0 < nm; m0 += PER * NW) { /* wave-uniform */
         uint32_t x[PER][5];
@@ -419,10 +422,19 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         for (uint32_t t = tid; t < seg_toff[n]; t += RT) { /* one try per thread: the loads of a round overlap */
             const uint32_t i = seg_thit[t];
             const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
+            /* the prediction table's first slot is fetched beside the snapshot's two (three independent loads, one
+             * round trip); only a collision walks on */
+            const uint32_t hp = MSD_PRED_HASH(v.addr) & (MSD_PRED_SLOTS - 1);
+            const unsigned long long pe = npred_raw ? P.pred[hp] : ~0ull;
             const uint32_t where = snap_probe(snap, v.addr);
             bool known = where != 0 || addset_has(addset, v.addr);
-            if (!known && npred_raw) /* added by an earlier buffer of this batch (predicted; the host verifies) */
-                known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
+            if (!known && npred_raw) { /* added by an earlier buffer of this batch (predicted; the host verifies) */
+                const unsigned long long key = msd_pred_key(P.pred_gen, v.addr);
+                if ((pe & 0xffffffff00000000ull) == key)
+                    known = (uint32_t)pe < b;
+                else if ((uint32_t)(pe >> 56) == P.pred_gen)
+                    known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
+            }
             seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
         }
         __syncthreads();
