@@ -1335,7 +1335,7 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
     if (c->outstanding > 1 && !begin_rc && c->resolve_ahead) {
         Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
         if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.gpu_resolve && nx.resolve_inflight && !nx.ahead_done &&
-            !nx.reset_before) {
+            (!nx.reset_before || nx.state_reset_done)) { /* (a new capture's first batch: only once filter and clocks have started over) */
             double tw = 0, tr = 0;
             const int arc = resolve_passes(c, nx, tw, tr);
             if (trace)
