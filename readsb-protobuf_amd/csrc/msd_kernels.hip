@@ -711,6 +711,16 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                 pw_top = dot2u(top, top, pw_top);
             }
         }
+        wave_lds_sync();
+
+        /* the record slice goes here, behind the tile's table loads and in front of the next tile's prefetch: tests
+         * and candidate rounds need no global data, so nothing waits for the PCIe stores until the next tile's
+         * conversion, 15 us on */
+        if (EMIT && tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
+            msd_emit_slice<FMT>(P.emit, P.lut, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
+
+        /* ---- prefetch the next tile's IQ (behind the record slice: at that point neither this tile's raw groups nor
+         * the next one's are live, which is what keeps the slice out of the loop's register budget) ---- */
         if (tile + 1 < tile_hi) {
             /* one unconditional load per group from a selected address (see fetch_group); tiles that lie
              * wholly inside the batch -- all but the last -- take the short way */
@@ -735,12 +745,6 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + WT + 8 * (lane + 64 * k), nxt[k]);
             }
         }
-        wave_lds_sync();
-
-        /* the record slice goes here, behind the tile's last global loads: tests and candidate rounds need none,
-         * so nothing waits for the PCIe stores until the next tile's table loads, 15 us on */
-        if (EMIT && tile == emit_at && !(P.debug_flags & 128)) /* wave-uniform */
-            msd_emit_slice<FMT>(P.emit, P.lut, region, lane, X.w + W_HITS, (P.debug_flags & 64) != 0);
 
         if (!(P.debug_flags & 2)) {
             /* ---- stage 2: preamble tests for my NH runs of 16 consecutive positions (demod_2400.c:257-335) ---- */
