@@ -190,6 +190,7 @@ struct Slot {
                                 it / that its arenas overflowed (resolve_passes); nothing was committed */
     bool records_current = true; /* no further resolve pass ran after the one whose records were written */
     uint32_t npass = 0;
+    uint64_t sample_counter0 = 0; /* the sample clock at the batch's first sample (gpu_begin) */
     msd_hit *d_rhits = nullptr;
     msd_try *d_rtries = nullptr;
     msd_region_counts *d_rcounts = nullptr;
@@ -976,6 +977,9 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     gpu_params(c, s, rp);
     int rc = 0;
     rp.first_pass = first_pass ? 1 : 0;
+    rp.ctl_implicit = 1;
+    rp.sample_counter0 = s.sample_counter0;
+    rp.batch_samples = s.nsamples;
     rp.h_pred = c->h_pred;
     rp.h_pred_count = c->h_pred_count;
     Slot *carried = nullptr;
@@ -1093,6 +1097,7 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
     const GpuCtl g = gpu_ctl(c, s);
     for (uint32_t b = 0; b < s.nbuffers; ++b)
         g.h_valid[b] = slot_valid(s, b);
+    s.sample_counter0 = c->resolver.sample_counter;
     msd_gpu_resolve_begin(&c->resolver, s.nbuffers, g.h_valid, g.h_ts, g.h_snap, g.h_todo, &s.resolve_ntodo);
     c->snaps_uploaded = 0;
     /* The scan stream carries scans (and their gathers) only, back to back.  Prediction + resolve run on

@@ -102,6 +102,8 @@ typedef struct MsdResolveParams {
     uint32_t *nac;            /* [buffer] how many */
     /* first pass only: its first workgroup publishes the prediction list the predict kernel built */
     int first_pass;            /* publish the prediction list (and, lean layout, the sums and totals) */
+    int ctl_implicit;          /* first pass: todo[i] = i, snap_idx = 0, valid / ts follow from the two values below */
+    uint64_t sample_counter0, batch_samples; /* sample clock at the batch's first sample; its samples */
     msd_pred_entry *h_pred;    /* pinned host memory */
     uint32_t *h_pred_count;
     const unsigned long long *pred; /* the batch's prediction table (msd_internal.h: MSD_PRED_*), written by its scan */

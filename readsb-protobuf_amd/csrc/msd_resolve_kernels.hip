@@ -238,7 +238,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     /* everything the set-up needs from global memory, in three rounds of independent loads */
     const uint64_t ovf = P.totals[2], nhits = P.totals[0];
     const uint64_t ac_ovf = P.ac ? P.ac_totals[2] : 0;
-    const uint32_t b = P.todo[blockIdx.x];
+    /* First pass: every buffer in turn against snapshot 0, the clocks a linear function of the buffer index
+     * (sdr_ifile.c:187-190) -- worked out here instead of read from the control arrays, which live in host memory
+     * (two dependent reads over PCIe before the workgroup knows which buffer it has). */
+    const bool implicit = P.first_pass && P.ctl_implicit;
+    const uint32_t b = implicit ? blockIdx.x : P.todo[blockIdx.x];
     const uint32_t npred_raw = msd_pred_count(P.pred, P.pred_gen);
     if (P.first_pass && P.region_counts) {
         /* lean layout: what the gather kernel used to leave for the host -- the buffer's level / power sums (the
@@ -314,9 +318,23 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             P.h_pred[i] = e;
         }
     }
-    const uint32_t *snap = P.snaps + (size_t)P.snap_idx[b] * MSD_SNAP_WORDS;
-    const uint32_t mlen = P.valid[b];
-    const uint64_t sys_ts = P.ts[2 * b + 1];
+    const uint32_t snap_index = implicit ? 0u : P.snap_idx[b];
+    const uint32_t *snap = P.snaps + (size_t)snap_index * MSD_SNAP_WORDS;
+    uint32_t mlen;
+    uint64_t sample_ts_b, sys_ts;
+    if (implicit) {
+        const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
+        const uint64_t left = P.batch_samples > first ? P.batch_samples - first : 0;
+        mlen = (uint32_t)(left > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : left);
+        /* the host's own expression, in doubles like sdr_ifile.c:187 (beyond 7.5e8 samples the product is no longer
+         * exact, and the truncation must fall the same way) */
+        sample_ts_b = (uint64_t)((double)(P.sample_counter0 + first) * 12e6 / 2400000.0);
+        sys_ts = sample_ts_b / 12000u;
+    } else {
+        mlen = P.valid[b];
+        sample_ts_b = P.ts[2 * b];
+        sys_ts = P.ts[2 * b + 1];
+    }
     const uint32_t snap_active = snap[2 * SLOTS] & 1u;
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
     msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
@@ -839,7 +857,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         }
         if (P.stage_rec) { /* ... and the buffer's message records, for the next batch's first pass to send home */
             __syncthreads();
-            const uint64_t sample_ts = P.ts[2 * b];
+            const uint64_t sample_ts = sample_ts_b;
             for (uint32_t m = tid; m < nm; m += RT) {
                 unsigned long long side;
                 msd_wire w;
@@ -945,7 +963,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         rb->nadds = sh_nadds;
         rb->nshort = sh_nshort;
         rb->nac = nac_total;
-        rb->version_used = P.snap_idx[b];
+        rb->version_used = snap_index;
         rb->fallback = (sh_nmsgs > MSD_RB_MSG_CAP || sh_nadds > MSD_RB_MSG_CAP || nac_total > MSD_RB_AC_CAP) ? 1u : 0u;
         rb->end_now = sh_now;
         for (int k = 0; k < 8; ++k)
