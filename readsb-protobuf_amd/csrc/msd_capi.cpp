@@ -672,7 +672,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         if (rc)
             return fail(c, rc, "publish kernel launch failed");
     }
-    if (!s.lean) /* a lean batch's totals and sums come with its first resolve pass (ev_resolve) */
+    if (!s.lean || !c->chain_inline) /* in order, a lean batch's totals and sums come with its first resolve pass (ev_resolve)
+                                        and nobody waits for this event; on side streams the chain does */
         HIPCHK(c, hipEventRecord(s.ev_totals, c->stream));
     return 0;
 }
@@ -936,6 +937,11 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
         rp.sums = s.d_sums;
         rp.h_sums = s.h_sums;
         rp.h_totals = s.h_totals;
+        if (c->scan_format == MSD_FMT_SC16 || c->scan_format == MSD_FMT_SC16Q11) {
+            rp.fmeans = s.d_fmeans;
+            rp.h_fmeans = s.h_fmeans;
+        }
+        rp.h_ac_totals = s.h_ac_totals;
     }
 }
 
@@ -1149,9 +1155,15 @@ void means_from_sums(msd_ctx *c, const Slot &s)
 {
     c->valid.assign(s.nbuffers, 0);
     c->means.assign(2 * (size_t)s.nbuffers, 0.0);
+    const bool fm = c->scan_format == MSD_FMT_SC16 || c->scan_format == MSD_FMT_SC16Q11;
     for (uint32_t b = 0; b < s.nbuffers; ++b) {
         const uint32_t n = slot_valid(s, b);
         c->valid[b] = n;
+        if (fm) { /* convert.c:245-251: float sum / unsigned -> float division, widened to double */
+            c->means[2 * b] = (double)(s.h_fmeans[2 * b] / (float)n);
+            c->means[2 * b + 1] = (double)(s.h_fmeans[2 * b + 1] / (float)n);
+            continue;
+        }
         /* convert.c:104-110 (note 65536 for the level, 65535^2 for the power) */
         c->means[2 * b] = (double)s.h_sums[2 * b] / 65536.0 / (double)n;
         c->means[2 * b + 1] = (double)s.h_sums[2 * b + 1] / 65535.0 / 65535.0 / (double)n;
@@ -1191,7 +1203,8 @@ int resolve_passes(msd_ctx *c, Slot &s, double &t_wait, double &t_replay)
         ++s.npass;
         HIPCHK(c, event_wait(wait_for));
         auto k1 = tnow();
-        if (s.lean && pass == 0 && s.h_totals[2]) /* what the gather kernel's totals used to say */
+        if (s.lean && pass == 0 && (s.h_totals[2] || (c->cfg.mode_ac && s.h_ac_totals[2]))) /* what the gather
+                                                                                                   kernels' totals used to say */
             return 2;
         int rc = msd_gpu_resolve_replay(&c->resolver, n, s.h_rbuf, nullptr, c->inline_adds, pass, SNAP_CAP, c->h_pred,
                                         *c->h_pred_count, c->h_patches, &c->npatches, g.h_snap, g.h_todo,
@@ -1524,12 +1537,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             rc = rerun_in_pieces(c, s, format);
             if (rc)
                 return rc;
-            for (uint32_t b = 0; b < s.nbuffers; ++b) { /* the pieces' gather kernels published the sums again */
-                const uint32_t n = slot_valid(s, b);
-                c->valid[b] = n;
-                c->means[2 * b] = (double)s.h_sums[2 * b] / 65536.0 / (double)n;
-                c->means[2 * b + 1] = (double)s.h_sums[2 * b + 1] / 65535.0 / 65535.0 / (double)n;
-            }
+            means_from_sums(c, s); /* the pieces' gather / publish kernels published the sums again */
             s.gpu_resolve = false;
         } else if (s.lean) {
             means_from_sums(c, s); /* (published by the first resolve pass, which did run) */
@@ -2059,7 +2067,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     {
         const char *le = getenv("MSD_LEAN"); /* 0: keep the gather kernel and the dense lists everywhere */
         const bool fm = cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11 || c->dc;
-        c->lean_ok = c->gpu_resolve && c->chain_inline && !cfg->mode_ac && !fm && !(le && *le == '0');
+        (void)fm; /* every layout: UC8 / magnitudes in order, 16-bit IQ and Mode A/C with the chain on side streams */
+        c->lean_ok = c->gpu_resolve && !c->dc && !(le && *le == '0');
     }
     if (c->lean_ok)
         for (Slot &s : c->slots) {

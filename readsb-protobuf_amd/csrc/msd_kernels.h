@@ -116,6 +116,9 @@ typedef struct MsdResolveParams {
     const msd_wg_totals *wg_totals;
     uint32_t regions_per_buffer, hcap, nscan_wg;
     uint64_t *sums, *h_sums, *h_totals;
+    const float *fmeans; /* 16-bit IQ: the buffers' float sums (msd_float_means kernels), published like the integer ones */
+    float *h_fmeans;
+    uint64_t *h_ac_totals; /* Mode A/C: the candidate totals and overflow flag, likewise */
     /* power != NULL: every workgroup finishes with the signal power of its buffer's accepted messages
      * (demod_2400.c:386-399), power[buffer][MSD_RB_MSG_CAP], from the batch's samples -- no kernel of its own */
     unsigned long long *power;

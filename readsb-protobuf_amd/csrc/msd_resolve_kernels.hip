@@ -250,7 +250,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         if (tid < 2) {
             P.h_sums[2 * b + tid] = P.sums[2 * b + tid];
             P.sums[2 * b + tid] = 0;
+            if (P.fmeans)
+                P.h_fmeans[2 * b + tid] = P.fmeans[2 * b + tid];
         }
+        if (blockIdx.x == 0 && tid >= 64 && tid < 68 && P.ac)
+            P.h_ac_totals[tid - 64] = P.ac_totals[tid - 64];
         if (blockIdx.x == 0 && tid < 64) {
             unsigned long long h = 0, t = 0;
             for (uint32_t i = tid; i < P.nscan_wg; i += 64) {

@@ -1,0 +1,82 @@
+#!/bin/bash
+# Round-3 evidence set -> gpurun_out/r03/ (copied to profiles/r03_* afterwards).  One gpurun call.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r03; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+
+kstats() { # <name> <bench args...>: rocprofv3 --kernel-trace --stats summary + the scan kernel's first dispatches
+  local name=$1; shift
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $O/${name}_bench_under_profiler.json 2> $O/${name}_rocprof.log)
+  for f in $(find $O/trace_$name -name "*kernel_stats.csv"); do cp $f $O/${name}_kernel_stats.csv; done
+  for f in $(find $O/trace_$name -name "*kernel_trace.csv"); do head -1 $f > $O/${name}_scan_kernel_trace_head.csv; grep msd_scan $f | head -12 >> $O/${name}_scan_kernel_trace_head.csv; done
+  rm -rf $O/trace_$name $O/${name}_rocprof.log
+}
+kstats uc8
+kstats sc16 --format sc16 --samples 268435456
+kstats modeac --mode-ac --fix 1
+
+traffic() { # <name> <bench args...>: FETCH_SIZE / WRITE_SIZE of the scan kernel, separate --pmc passes, no trace domains
+  local name=$1; shift
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-check --batch $((1<<26)) "$@" > $O/pmc_$name/$ctr.log 2>&1)
+  done
+  python3 - $O/pmc_$name $O/${name}_traffic.json "$*" <<'PY'
+import csv, glob, json, sys, collections
+src, dst, args = sys.argv[1], sys.argv[2], sys.argv[3]
+res = {"bench_args": args}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{src}/{ctr}/**/*counter_collection.csv", recursive=True)
+    rows = list(csv.DictReader(open(f[0])))
+    vals = {"with_records": collections.defaultdict(float), "scan_only": collections.defaultdict(float)}
+    other = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        if r["Counter_Name"] != ctr:
+            continue
+        name = r["Kernel_Name"]
+        if "msd_scan_kernel" in name:
+            targs = name[name.index("msd_scan_kernel<"):].split(">")[0]
+            vals["with_records" if targs.endswith("true") else "scan_only"][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        elif "msd_" in name:
+            short = name[name.index("msd_"):].split("(")[0].split("<")[0]
+            other[short][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for kind, d in vals.items():
+        v = sorted(d.values())
+        if v:
+            suffix = "" if kind == "with_records" else "_scan_only"
+            res[ctr + "_KB_per_launch" + suffix] = v[len(v) // 2]
+            res[ctr + "_launches" + suffix] = len(v)
+    res[ctr + "_KB_per_launch_other_kernels"] = {k: sorted(d.values())[len(d) // 2] for k, d in other.items()}
+res["samples_per_launch"] = 1 << 26
+res["note"] = ("rocprofv3 --pmc, median over launches of msd_scan_kernel with the record slice (_scan_only: the launches without); "
+               "gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (MI355X_MICROARCH.md), so fetch bytes = 2 * FETCH_SIZE * 1024")
+json.dump(res, open(dst, "w"), indent=1)
+print(json.dumps(res))
+PY
+  rm -rf $O/pmc_$name
+}
+mkdir -p $O/pmc_uc8 $O/pmc_sc16
+traffic uc8
+traffic sc16 --format sc16 --samples 268435456
+
+# SQ counters of the scan kernel: the full kernel and ablated variants (MSD_DEBUG_FLAGS 4: no step B, 1: stop after the tests, 2: conversion only)
+FLAGS="0 4 1 2" bash scripts/pmc_quick.sh > $O/pmc_counters.txt 2>&1
+timeout 120 scripts/micro/valu_issue $O/valu_issue.csv > $O/valu_issue.txt 2>&1
+
+for cfg in "uc8:" "sc16:--format sc16 --samples 268435456" "modeac:--mode-ac --fix 1"; do
+  name=${cfg%%:*}; args=${cfg#*:}
+  BACK=6 ROWS=40 bash scripts/r3_timeline.sh r03_tl_$name $args > /dev/null 2>&1; cp gpurun_out/r03_tl_$name/timeline.txt $O/${name}_timeline.txt
+done
+MSD_RESOLVE_TRACE=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2> $O/host_trace.txt > /dev/null
+
+: > $O/configs.txt
+for f in "" "--fix 1" "--fix 2" "--fields" "--mode-ac --fix 1" "--format sc16 --samples 268435456" "--format sc16q11 --samples 268435456" "--format sc16 --samples 268435456 --mode-ac --fix 1"; do
+  echo -n "bench.py $f : " >> $O/configs.txt
+  python bench.py --no-cpu-baseline --check $f 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'msgs', d['messages_per_step'], 'diff', d.get('message_set_diff_vs_oracle'))" >> $O/configs.txt
+done
+for e in "MSD_EMIT_FUSED=0" "MSD_LEAN=0" "MSD_RESOLVE_AHEAD=0" "MSD_POWER_FUSED=0" "MSD_EMIT_VIA_RESOLVE=1" "MSD_WAIT_INPUTS_ON_STREAM=1" "MSD_CHAIN_INLINE=0" "MSD_LEAN=0 MSD_RESOLVE_AHEAD=0 MSD_POWER_FUSED=0 MSD_WAIT_INPUTS_ON_STREAM=1"; do
+  echo -n "$e : " >> $O/configs.txt; env $e python bench.py --no-cpu-baseline --no-check 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'])" >> $O/configs.txt
+done
+python scripts/pcie_rate.py >> $O/configs.txt 2>&1
+cat $O/configs.txt
+tail -1 $O/bench_default.json | cut -c1-300
