@@ -228,12 +228,19 @@ def main():
     # scripts/pmc_traffic.sh; the summary is committed under profiles/).  FETCH_SIZE is doubled as
     # MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; WRITE_SIZE is taken as is.
     traffic = None
-    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-    tfile = os.path.join(ROOT, "profiles", tfiles[-1]) if tfiles else ""  # the latest round's measurement
-    if tfile and args.format == "uc8":
+    # the latest round's measurement for this sample format; the launches of the in-order layout also carry the
+    # previous batch's message records (fused), the others are the scan alone (_scan_only)
+    fused = (os.environ.get("MSD_EMIT_FUSED", "1") != "0" and not args.fields and
+             os.environ.get("MSD_CHAIN_INLINE", "0" if (args.mode_ac or args.format != "uc8" or args.dcfilter) else "1") != "0")
+    tag = "_traffic.json" if args.format == "uc8" else "_sc16_traffic.json" if args.format == "sc16" else None
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                    if tag and f.endswith(tag) and (args.format != "uc8" or "sc16" not in f))
+    tfile = os.path.join(ROOT, "profiles", tfiles[-1]) if tfiles else ""
+    if tfile and not args.dcfilter:
         t = json.load(open(tfile))
-        if t.get("samples_per_launch") == launch_samples:
-            traffic = int((2 * t["FETCH_SIZE_KB_per_launch"] + t["WRITE_SIZE_KB_per_launch"]) * 1024)
+        sfx = "" if fused else "_scan_only"
+        if t.get("samples_per_launch") == launch_samples and ("FETCH_SIZE_KB_per_launch" + sfx) in t:
+            traffic = int((2 * t["FETCH_SIZE_KB_per_launch" + sfx] + t["WRITE_SIZE_KB_per_launch" + sfx]) * 1024)
     roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC, %s)" % (os.path.basename(tfile) if traffic else "not measured for this workload"),
@@ -247,8 +254,6 @@ def main():
         roofline["binding"] = json.load(open(os.path.join(ROOT, "profiles", bfiles[-1])))
     # in the in-order layout without field decoding the scan's wavefronts also write the previous batch's message
     # records; MSD_EMIT_FUSED=0 gives them a kernel of their own and times the scan alone
-    fused = (os.environ.get("MSD_EMIT_FUSED", "1") != "0" and not args.fields and
-             os.environ.get("MSD_CHAIN_INLINE", "0" if (args.mode_ac or args.format != "uc8" or args.dcfilter) else "1") != "0")
     roofline["launch_includes"] = ("the previous batch's message records (35 000 x 56 B to host memory); "
                                    "MSD_EMIT_FUSED=0 times the scan alone") if fused else "the scan only"
 
