@@ -487,14 +487,17 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
     uint32_t lean_k = 0, lean_tpr = 0;
     s.lean = false;
     if (pipelined && c->lean_ok && nwg && gpu_eligible(c, s) && s.nbuffers <= c->max_wg && !(c->debug_flags & 0x1f)) {
-        uint32_t k = c->max_wg / s.nbuffers;
+        /* (the buffers that hold samples: a capture's last batch ends with one more, empty or short, buffer --
+         * counting it would cost a full batch of 512 buffers an eighth of its regions, 4096 / 513 = 7) */
+        const uint32_t nb_data = (uint32_t)((s.nsamples + MSD_CHUNK_SAMPLES - 1) / MSD_CHUNK_SAMPLES);
+        uint32_t k = c->max_wg / (nb_data ? nb_data : 1);
         if (k > 64)
             k = 64;
         if (k > tiles_per_buffer)
             k = tiles_per_buffer;
         lean_tpr = (tiles_per_buffer + k - 1) / k;
         lean_k = (tiles_per_buffer + lean_tpr - 1) / lean_tpr; /* no empty pieces */
-        nwg = s.nbuffers * lean_k;
+        nwg = (nb_data ? nb_data : 1) * lean_k;
         tpw = lean_tpr;
         s.lean = true;
     }
@@ -934,6 +937,7 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
         rp.regions_per_buffer = s.lean_k;
         rp.hcap = s.lean_hcap;
         rp.nscan_wg = (s.lean_nreg + MSD_SCAN_WAVES - 1) / MSD_SCAN_WAVES;
+        rp.nregions = s.lean_nreg;
         rp.sums = s.d_sums;
         rp.h_sums = s.h_sums;
         rp.h_totals = s.h_totals;

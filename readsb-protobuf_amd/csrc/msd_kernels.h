@@ -114,7 +114,7 @@ typedef struct MsdResolveParams {
      * first workgroup, the batch's totals and overflow flag. */
     const msd_region_counts *region_counts; /* NULL: dense lists */
     const msd_wg_totals *wg_totals;
-    uint32_t regions_per_buffer, hcap, nscan_wg;
+    uint32_t regions_per_buffer, hcap, nscan_wg, nregions; /* (a trailing buffer without samples has no regions) */
     uint64_t *sums, *h_sums, *h_totals;
     const float *fmeans; /* 16-bit IQ: the buffers' float sums (msd_float_means kernels), published like the integer ones */
     float *h_fmeans;

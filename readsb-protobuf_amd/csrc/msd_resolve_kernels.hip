@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         if (tid < 64) {
             const uint32_t k = P.regions_per_buffer;
             uint32_t c = 0;
-            if ((uint32_t)tid < k)
+            if ((uint32_t)tid < k && b * k + (uint32_t)tid < P.nregions)
                 c = min(P.region_counts[(size_t)b * k + tid].nhits, P.hcap);
             uint32_t incl = c;
 #pragma unroll
