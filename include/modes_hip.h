@@ -310,7 +310,16 @@ int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
 
 /* ---- pipelined form: launch the GPU stage for a batch and return; msd_collect() waits for the
  * oldest outstanding batch, runs the ordered resolve and delivers its messages.  At most
- * MSD_PIPELINE_DEPTH batches may be outstanding. ---- */
+ * MSD_PIPELINE_DEPTH batches may be outstanding.
+ * msd_collect(n) also takes batch n + 1 through its resolve passes (it waits for them: they were queued when batch
+ * n's filter changes were committed) and queues those of batch n + 2, so that the resolve chain runs one batch
+ * ahead of the delivery and the GPU never waits for the caller between two scans; counters and messages of a batch
+ * still appear with its own msd_collect.  Host cost per context while batches are in flight: the calling thread
+ * polls for events for up to a few hundred microseconds at a time before it sleeps, and one helper thread per
+ * context (started by the first batch) does the same while it copies the message records and keeps the
+ * order-sensitive power statistics -- two busy threads per receiver, plus a pool that only works when a batch has to
+ * be resolved on the host.  Several receivers on one host should be pinned to disjoint cores near their GPU
+ * (bench.py: pin_to_gpu_local_cpus). ---- */
 #define MSD_PIPELINE_DEPTH 4
 int msd_launch_device(msd_ctx *ctx, const void *d_iq, uint64_t nsamples, int last);
 int msd_collect(msd_ctx *ctx, msd_message_fn sink, void *user);
