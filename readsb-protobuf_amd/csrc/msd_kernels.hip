@@ -146,7 +146,7 @@ __device__ __forceinline__ uint32_t fetch_group(const MsdScanParams &P, int64_t 
     return valid;
 }
 
-template <int FMT>
+template <int FMT, bool MASK = true /* false: the caller masks (mask_group) once all its groups' loads are out */>
 __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t valid, const uint16_t *lut,
                                               uint32_t (&mg)[8])
 {
@@ -174,6 +174,17 @@ __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t v
             mg[k] = mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
         }
     }
+    if (MASK && valid != 0xffu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (!((valid >> k) & 1u))
+                mg[k] = 0;
+    }
+}
+
+/* samples of the group that do not exist (before the stream, behind a gap, past the end) are silence (fifo.c:179-182) */
+__device__ __forceinline__ void mask_group(uint32_t valid, uint32_t (&mg)[8])
+{
     if (valid != 0xffu) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -696,10 +707,16 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             }
             ++sum_tiles;
         }
+        /* all of the tile's table loads first (8 per group, GPT groups), then their uses: the compiler keeps the
+         * order it is given, and one round trip to the table instead of GPT is 3 us per tile */
+        uint32_t mgs[GPT][8];
+#pragma unroll
+        for (int k = 0; k < GPT; ++k)
+            convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
-            uint32_t mg[8];
-            convert_group<FMT>(cur[k], cur_valid[k], lut, mg);
+            uint32_t(&mg)[8] = mgs[k];
+            mask_group(cur_valid[k], mg);
             const uint4 packed = pack8(mg);
             *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) = packed;
             const uint32_t pk[4] = {packed.x, packed.y, packed.z, packed.w};
