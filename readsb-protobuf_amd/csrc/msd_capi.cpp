@@ -516,7 +516,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         HIPCHK(c, hipMemsetAsync(s.d_totals, 0, sizeof(uint64_t) * 4, c->stream));
         s.buf_first_valid = false;
     }
-    if (c->cfg.mode_ac)
+    if (c->cfg.mode_ac && !(s.nbuffers && s.nsamples)) /* (msd_launch_ac's offsets kernel writes them otherwise) */
         HIPCHK(c, hipMemsetAsync(s.d_ac_totals, 0, sizeof(uint64_t) * 4, c->stream));
     /* the three timing events cost about 5 us of stream time each (a barrier packet per record): they are
      * recorded for one batch in every c->timing_interval */

@@ -2078,12 +2078,8 @@ __global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t 
  *   UC8 / MAG16: integer sums -> mean_level = sum/65536/n, mean_power = sum/65535^2/n (convert.c:104-110)
  *   SC16 / SC16Q11: the sequential float sums of msd_float_means_kernel, float division by n.
  * All arithmetic is IEEE double (division and sqrt are correctly rounded on gfx950). */
-__global__ void __launch_bounds__(64) msd_ac_noise_kernel(const uint64_t *sums, const float *fmeans, int use_float,
-                                                           uint64_t nsamples, uint32_t nbuffers, uint32_t *noise_level)
+__device__ inline uint32_t ac_noise_level_of(const uint64_t *sums, const float *fmeans, int use_float, uint64_t nsamples, uint32_t b)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuffers)
-        return;
     const uint64_t first = (uint64_t)b * MSD_CHUNK_SAMPLES;
     uint64_t n = nsamples > first ? nsamples - first : 0;
     if (n > MSD_CHUNK_SAMPLES)
@@ -2099,7 +2095,7 @@ __global__ void __launch_bounds__(64) msd_ac_noise_kernel(const uint64_t *sums, 
     const double level_sq = mean_level * mean_level;
     const double noise_stddev = sqrt(mean_power - level_sq);
     const double scaled = (mean_power + noise_stddev) * 65535;
-    noise_level[b] = n ? (uint32_t)(scaled + 0.5) : 0u;
+    return n ? (uint32_t)(scaled + 0.5) : 0u;
 }
 
 constexpr int ACNT = 256;                    /* threads per workgroup */
@@ -2286,7 +2282,8 @@ __device__ __forceinline__ uint32_t ac_compact(uint32_t n, const uint16_t *src, 
 
 template <int FMT>
 __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                      const uint32_t *noise_levels, msd_ac_hit *out,
+                                                      const uint32_t *noise_levels /* or NULL: from the sums */,
+                                                      const uint64_t *sums, const float *fmeans, int use_float, msd_ac_hit *out,
                                                       uint32_t cap, msd_wg_counts *counts)
 {
     __shared__ __attribute__((aligned(16))) uint16_t mags[AC_LOAD + 8];
@@ -2305,6 +2302,8 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
         tile_hi = ntiles;
     uint32_t cur = 0; /* workgroup-uniform output cursor */
     msd_ac_hit *const mine = out + (size_t)wg * cap;
+    uint32_t noise_b = 0xffffffffu, noise_of_b = 0; /* the buffer whose noise level is known (every thread works it out:
+                                                       a dozen double operations once per buffer and workgroup) */
 
     /* the raw samples of a tile are fetched into registers one tile ahead */
     constexpr int GPT_AC = (AC_LOAD / 8 + ACNT - 1) / ACNT;
@@ -2340,7 +2339,11 @@ __global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uin
         const uint64_t bfirst = (uint64_t)b * MSD_CHUNK_SAMPLES;
         uint64_t mlen64 = P.nsamples > bfirst ? P.nsamples - bfirst : 0;
         const uint32_t mlen = mlen64 > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : (uint32_t)mlen64;
-        const uint32_t noise_level = noise_levels[b];
+        if (b != noise_b) { /* workgroup-uniform */
+            noise_of_b = noise_levels ? noise_levels[b] : ac_noise_level_of(sums, fmeans, use_float, P.nsamples, b);
+            noise_b = b;
+        }
+        const uint32_t noise_level = noise_of_b;
 
         /* Three ordered compactions: positions that pass the F1 pulse test (a few percent: every strong
          * pulse edge, a tenth of pure noise) -> those that also pass the F2 test 20.3 us later -> those
@@ -2612,11 +2615,11 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
 {
     if (nbuffers == 0)
         return 0;
-    if (noise_ready != 1) { /* 2: from the float sums whatever the format (magnitudes behind the DC filter) */
-        const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || noise_ready == 2);
-        hipLaunchKernelGGL(msd_ac_noise_kernel, dim3((nbuffers + 63) / 64), dim3(64), 0, stream, d_sums, d_fmeans,
-                           use_float, p->nsamples, nbuffers, d_noise);
-    }
+    /* noise_ready 1: the caller's levels (d_noise); else the candidate kernel works them out from the buffers' sums
+     * (2: from the float sums whatever the format -- magnitudes behind the DC filter) */
+    const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || noise_ready == 2);
+    const uint32_t *levels = noise_ready == 1 ? d_noise : nullptr;
+    (void)nbuffers;
     const uint32_t ntiles = (uint32_t)((p->nsamples + ACT - 1) / ACT);
     if (ntiles == 0) {
         (void)hipMemsetAsync(d_totals, 0, 4 * sizeof(uint64_t), stream);
@@ -2631,20 +2634,20 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
         cap = (uint64_t)tpw * ACT;
     switch (format) {
     case MSD_FMT_UC8:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_UC8>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
-                           d_regions, (uint32_t)cap, d_counts);
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_UC8>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
+                           use_float, d_regions, (uint32_t)cap, d_counts);
         break;
     case MSD_FMT_SC16:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
-                           d_regions, (uint32_t)cap, d_counts);
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
+                           use_float, d_regions, (uint32_t)cap, d_counts);
         break;
     case MSD_FMT_SC16Q11:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16Q11>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
-                           d_regions, (uint32_t)cap, d_counts);
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16Q11>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
+                           use_float, d_regions, (uint32_t)cap, d_counts);
         break;
     case MSD_FMT_MAG16:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_MAG16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, d_noise,
-                           d_regions, (uint32_t)cap, d_counts);
+        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_MAG16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
+                           use_float, d_regions, (uint32_t)cap, d_counts);
         break;
     default:
         return -22;
