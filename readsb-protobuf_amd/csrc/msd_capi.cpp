@@ -717,6 +717,8 @@ int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
         bool again = false;
         for (uint64_t off = 0; off < s.nsamples || (off == 0 && s.nsamples == 0); off += piece) {
             Slot t = s; /* shares the device buffers and events of s */
+            t.gpu_resolve = false; /* the host resolver takes the pieces: no predictions wanted (they would land in the
+                                      slot's table under a generation its next batch uses) */
             const uint64_t n = s.nsamples - off < piece ? s.nsamples - off : piece;
             const bool is_last = off + n >= s.nsamples;
             const uint64_t b0 = off / MSD_CHUNK_SAMPLES;

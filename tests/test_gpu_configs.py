@@ -87,3 +87,27 @@ def test_every_stream_layout_gives_the_same_messages(pkg, oracle, torch_cuda, mo
         want, wstats = oracle.Oracle(ofmt, 58, fix, ac).replay(caps[cap], cap=1 << 18)
         assert len(want) > 500
         assert_same(np.concatenate(got[cap]), stats[cap], want, wstats)
+
+
+def test_overflowing_batch_in_the_middle_of_a_pipelined_stream(pkg, oracle, torch_cuda, monkeypatch):
+    """Four batches in flight, the third one an interference storm that overflows its candidate arenas (lean layout:
+    only its first resolve pass tells, possibly a msd_collect early -- the resolve passes run one batch ahead).  It is
+    rescanned in pieces and resolved on the host; the batches around it stay on the GPU, and what the pieces' scans
+    note must not leak into the slot's next prediction table."""
+    C, nb = pkg.CHUNK, 96
+    n = 5 * nb * C + 4321
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=777, msgs_per_sec=5000, n_aircraft=400), n).copy()
+    rng = np.random.default_rng(6)
+    lo, hi = 2 * nb * C, 3 * nb * C
+    on = rng.random(hi - lo) < 0.3
+    iq[2 * lo:2 * hi:2] = np.where(on, 128 + 100 * rng.choice([-1, 1], hi - lo), 128 + rng.integers(-2, 3, hi - lo)).clip(0, 255).astype(np.uint8)
+    iq[2 * lo + 1:2 * hi:2] = (128 + rng.integers(-3, 4, hi - lo)).clip(0, 255).astype(np.uint8)
+    monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "200")
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=pkg.FMT_UC8, nfix_crc=1, max_batch_samples=nb * C, message_capacity=1 << 18)
+    got = pkg.replay_device(dem, d.data_ptr(), n, nb * C)
+    t = dem.timing()
+    assert t["reruns"] >= 1 and t["resolve_fallback"] >= 1, t
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 18)
+    assert len(want) > 1000
+    assert_same(got, dem.stats(), want, wstats)
