@@ -968,7 +968,11 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     for (uint32_t i = c->snaps_uploaded; i < nsn; ++i) {
         uint32_t *stage = c->h_snaps + (size_t)i * MSD_SNAP_WORDS;
         uint32_t active = 0;
-        memcpy(stage, msd_gpu_resolve_snapshot(&c->resolver, i, &active), sizeof(uint32_t) * 16384);
+        const uint32_t *two = msd_gpu_resolve_snapshot(&c->resolver, i, &active); /* slot[2][8192] */
+        for (uint32_t h = 0; h < 8192; ++h) { /* interleaved on the device: a probe's two first slots are one load */
+            stage[2 * h] = two[h];
+            stage[2 * h + 1] = two[8192 + h];
+        }
         stage[16384] = active;
         HIPCHK(c, hipMemcpyAsync(c->d_snaps + (size_t)i * MSD_SNAP_WORDS, stage, sizeof(uint32_t) * MSD_SNAP_WORDS,
                                  hipMemcpyHostToDevice, c->aux_stream));
@@ -1421,8 +1425,10 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
         for (uint32_t b = 0; b < n; ++b)
             for (int k = 0; k < 8; ++k)
                 cyc[k] += s.h_rbuf[b].cyc[k];
-        fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f segment %.1f stage %.1f eval %.1f walk %.1f count %.1f power %.1f\n",
-                cyc[0] / n / 100, cyc[5] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100, cyc[6] / n / 100);
+        if (cyc[0] > 0) /* built with -DMSD_RESOLVE_TIMING=1 */
+            fprintf(stderr, "resolve kernel, mean us per buffer: setup %.1f segment %.1f stage %.1f eval %.1f walk %.1f count %.1f no-try hits %.1f power %.1f\n",
+                    cyc[0] / n / 100, cyc[5] / n / 100, cyc[1] / n / 100, cyc[2] / n / 100, cyc[3] / n / 100, cyc[4] / n / 100, cyc[7] / n / 100,
+                    cyc[6] / n / 100);
         fprintf(stderr, "gpu resolve: %u passes%s, waits %.3f ms, replay %.3f ms, commit + next batch's first pass %.3f ms, "
                 "power stats %.3f ms (helper), then waited %.3f ms for it\n", npass, early ? " (first one queued early)" : "",
                 t_wait, t_replay, tms(e0, e1), t_power, tms(e1, tnow()));

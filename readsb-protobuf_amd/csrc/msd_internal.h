@@ -72,7 +72,7 @@ typedef struct msd_try {
     uint32_t crc;    /* modesChecksum of the uncorrected message */
     uint32_t pos;    /* batch-relative scan position (same as the owning hit's) */
     uint8_t errbit2; /* second corrected bit (--aggressive only), 0xff = none; errbit < errbit2 */
-    uint8_t pad[3];
+    uint8_t again[3]; /* msg[0], tp, errbit once more: everything a score needs is in the record's second half */
 } msd_try;
 
 /* Mode A/C candidate: every f1_sample that passes all tests of demod_2400.c:581-668; only the
@@ -108,7 +108,7 @@ typedef struct msd_wg_totals {
 #define MSD_RB_AC_CAP 2048u    /* accepted Mode A/C replies of one buffer: at most 131072/70 = 1872 */
 #define MSD_RB_ADD_INLINE 224u /* icaoFilterAdd addresses of one buffer reported inline: those that are not in the
                                   snapshot's active table already (the others cannot change the filter) */
-#define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[2][8192], then the index of the active table */
+#define MSD_SNAP_WORDS 16400u  /* a filter snapshot on the device: slot[8192][2] (the two tables interleaved), then the index of the active table */
 /* Predicted adds of a batch: every address that has a CRC-clean DF17 / DF11(II=0) try somewhere in it, with the
  * first buffer holding such a try (the scan kernel notes them as it finds them; it does not know the filter).  The
  * resolve kernel treats the address as known in all later buffers, so a batch in which new aircraft show up still

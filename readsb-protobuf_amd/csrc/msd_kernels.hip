@@ -573,9 +573,13 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             if (u != 0xffffu) {
                 if (idx < P.tcap) {
                     uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
-                    dst[0] = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
+                    const uint4 m16 = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
+                    dst[0] = m16;
                     const uint32_t cw = sres[2 * u + 1];
-                    dst[1] = make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos), cw >> 24);
+                    /* the last word repeats the first byte (DF), the trial phase and the first corrected bit beside the
+                     * second one: the resolve kernel reads this half of the record only */
+                    dst[1] = make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos),
+                                        (cw >> 24) | ((m16.x & 0xffu) << 8) | (m16.w & 0xffff0000u));
                 }
                 ++idx;
             }

@@ -32,12 +32,26 @@ namespace {
 #ifndef MSD_POWER_PER
 #define MSD_POWER_PER 5 /* messages whose samples a wavefront has in flight in the signal power step */
 #endif
+#ifndef MSD_RESOLVE_TIMING
+#define MSD_RESOLVE_TIMING 0 /* 1: per-phase clocks of every workgroup in msd_rbuf.cyc (MSD_TRACE prints their means) */
+#endif
 #ifndef MSD_RESOLVE_SEG
-#define MSD_RESOLVE_SEG 1024
+#define MSD_RESOLVE_SEG 1280
 #endif
 constexpr int RT = MSD_RESOLVE_WG;   /* threads per workgroup (one workgroup per buffer) */
 constexpr int SEG = MSD_RESOLVE_SEG; /* hits staged per segment */
 constexpr uint32_t VACANT = 0xFFFFFFFFu;
+
+/* A value every lane of the wavefront holds alike (read from one address): into scalar registers, so that it does not
+ * occupy a vector register for as long as it lives and the branches on it are scalar. */
+__device__ __forceinline__ uint32_t uni(uint32_t x)
+{
+    return __builtin_amdgcn_readfirstlane(x);
+}
+__device__ __forceinline__ uint64_t uni(uint64_t x)
+{
+    return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32);
+}
 constexpr uint32_t SLOTS = 8192u;
 
 __device__ __forceinline__ uint32_t hash24(uint32_t a) /* icao_filter.c:44-65 */
@@ -52,11 +66,13 @@ __device__ __forceinline__ uint32_t hash24(uint32_t a) /* icao_filter.c:44-65 */
     return h & (SLOTS - 1);
 }
 
-/* linear probing from slot h; `stop` is the slot the probe started at (a full circle ends it) */
+/* linear probing from slot h; `stop` is the slot the probe started at (a full circle ends it).  The two tables of a
+ * snapshot are interleaved (slot h of table k at word 2 h + k: one 8-byte load fetches both first slots); t points
+ * at word k. */
 __device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint32_t h, uint32_t stop)
 {
     while (h != stop) {
-        const uint32_t v = t[h];
+        const uint32_t v = t[2 * h];
         if (v == addr)
             return true;
         if (v == VACANT)
@@ -69,10 +85,9 @@ __device__ __forceinline__ bool table_has(const uint32_t *t, uint32_t addr, uint
 /* icaoFilterTest (icao_filter.c:99-119) against a snapshot: two tables of 8192 slots.
  * bit 0: in table 0, bit 1: in table 1.  The first slot of both tables is fetched at once (at the
  * usual load that already decides both probes); only a collision walks on. */
-__device__ __forceinline__ uint32_t snap_probe(const uint32_t *snap, uint32_t addr)
+__device__ __forceinline__ uint32_t snap_probe_from(const uint32_t *snap, uint32_t addr, uint32_t a, uint32_t b)
 {
-    const uint32_t start = hash24(addr);
-    const uint32_t a = snap[start], b = snap[SLOTS + start];
+    const uint32_t start = hash24(addr); /* a, b: the first slot of the two tables, fetched by the caller */
     uint32_t where = 0;
     if (a == addr)
         where |= 1u;
@@ -80,7 +95,7 @@ __device__ __forceinline__ uint32_t snap_probe(const uint32_t *snap, uint32_t ad
         where |= 1u;
     if (b == addr)
         where |= 2u;
-    else if (b != VACANT && table_has(snap + SLOTS, addr, (start + 1) & (SLOTS - 1), start))
+    else if (b != VACANT && table_has(snap + 1, addr, (start + 1) & (SLOTS - 1), start))
         where |= 2u;
     return where;
 }
@@ -93,11 +108,11 @@ struct TryView {
 
 __device__ __forceinline__ TryView load_try(const msd_try *t)
 {
-    const uint4 lo = *reinterpret_cast<const uint4 *>(t);
+    /* the second half of the record: addr, crc, pos, { errbit2, msg[0], tp, errbit } */
     const uint4 hi = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(t) + 16);
     TryView v;
-    v.w0 = lo.x;
-    v.w3 = lo.w;
+    v.w0 = (hi.w >> 8) & 0xffu;
+    v.w3 = hi.w; /* tp and errbit sit where they do in the message's last word */
     v.addr = hi.x;
     v.crc = hi.y;
     v.errbit2 = hi.w & 0xffu;
@@ -145,7 +160,8 @@ __device__ __forceinline__ uint32_t res_len(uint64_t r) /* samples hidden by the
     return (((uint32_t)(r >> 20) & 0x10u) ? 112u : 56u) * 12u / 5u;
 }
 
-constexpr uint32_t TCAP = 2 * SEG; /* tries staged per segment; a segment is cut short where they would not fit */
+constexpr uint32_t TCAP = SEG + 3 * SEG / 10; /* tries staged per segment; a segment is cut short where they would not fit */
+constexpr int MAXC = 5; /* a segment is made from at most MAXC x RT hits of the list */
 constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
 
@@ -162,9 +178,12 @@ __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr
     }
 }
 
-/* Signal power of the accepted messages acc[0..nm) of one buffer, by the workgroup that accepted them: a wavefront
- * per message, five messages' samples in flight per wavefront (the step is a chain of dependent loads -- record, IQ
- * bytes, magnitude table -- and nothing else). */
+/* Signal power of the accepted messages of one buffer, by the workgroup that accepted them: a wavefront per message,
+ * MSD_POWER_PER messages' samples in flight per wavefront (the step is a chain of dependent loads -- IQ bytes,
+ * magnitude table -- and nothing else).  The wavefront's records (message w, w + 8, w + 16, ...) are fetched once, two
+ * per lane, and handed round by v_readlane.  Written in stages -- every address, every IQ load, every table load, then the sums -- so that the loads
+ * of a round are in flight together whatever the register allocator makes of the rest of the kernel; a round whose
+ * messages lie wholly inside the batch (all but those in its first 300 samples) addresses the IQ array directly. */
 template <int FMT>
 __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_acc *acc, uint32_t nm, unsigned long long *out,
                                          int tid)
@@ -176,14 +195,71 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
     S.batch_first = P.batch_first;
     S.nsamples = P.nsamples;
     constexpr uint32_t PER = MSD_POWER_PER, NW = RT / 64;
+    constexpr uint32_t BPS = (FMT == MSD_FMT_SC16 || FMT == MSD_FMT_SC16Q11) ? 4 : 2;
+    static_assert(MSD_RB_MSG_CAP <= 128 * NW, "two records per lane");
     const int lane = tid & 63;
-    for (uint32_t m0 = (uint32_t)(tid >> 6); m0 < nm; m0 += PER * NW) { /* wave-uniform */
-        uint32_t x[PER][5];
+    const uint32_t wave = (uint32_t)(tid >> 6);
+    if (wave >= nm)
+        return;
+    uint32_t rpos[2], rlen[2];
+#pragma unroll
+    for (uint32_t q = 0; q < 2; ++q) {
+        const uint32_t m = wave + ((uint32_t)lane + 64u * q) * NW;
+        const msd_acc rec = acc[m < nm ? m : wave];
+        rpos[q] = rec.pos;
+        rlen[q] = m < nm ? rec.len : 0u;
+    }
+    for (uint32_t q0 = 0; wave + q0 * NW < nm; q0 += PER) { /* wave-uniform */
+        const uint32_t m0 = wave + q0 * NW;
+        uint32_t x[PER][5], pos[PER], len[PER];
+        bool inside = true;
 #pragma unroll
         for (uint32_t u = 0; u < PER; ++u) {
-            const uint32_t m = m0 + u * NW;
-            const msd_acc rec = acc[m < nm ? m : m0];
-            msd_power_loads<FMT>(S, P.lut, rec.pos, m < nm ? rec.len : 0u, lane, x[u]);
+            const uint32_t q = q0 + u; /* < 128 + PER: past the last record the lengths are zero */
+            const uint32_t p0 = __builtin_amdgcn_readlane(rpos[0], q & 63u), p1 = __builtin_amdgcn_readlane(rpos[1], q & 63u);
+            const uint32_t l0 = __builtin_amdgcn_readlane(rlen[0], q & 63u), l1 = __builtin_amdgcn_readlane(rlen[1], q & 63u);
+            pos[u] = q < 64u ? p0 : p1;
+            len[u] = q < 64u ? l0 : (q < 128u ? l1 : 0u);
+            const int64_t rel0 = (int64_t)pos[u] - (int64_t)MSD_OVERLAP + 19;
+            inside = inside && rel0 >= 0 && rel0 + (int64_t)len[u] <= (int64_t)S.nsamples;
+        }
+        if (inside) {
+#pragma unroll
+            for (uint32_t u = 0; u < PER; ++u) {
+                const uint32_t rel0 = pos[u] - MSD_OVERLAP + 19u;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const uint32_t k = (uint32_t)lane + 64u * v;
+                    const uint32_t off = (rel0 + (k < len[u] ? k : 0u)) * BPS;
+                    if (BPS == 2)
+                        x[u][v] = *reinterpret_cast<const uint16_t *>(S.iq + off);
+                    else
+                        x[u][v] = *reinterpret_cast<const uint32_t *>(S.iq + off);
+                }
+            }
+            if (FMT == MSD_FMT_UC8) {
+#pragma unroll
+                for (uint32_t u = 0; u < PER; ++u)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v)
+                        x[u][v] = P.lut[fold8(x[u][v] >> 8) * MSD_LUT_STRIDE + fold8(x[u][v] & 0xffu)];
+            } else if (FMT != MSD_FMT_MAG16) {
+                const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+#pragma unroll
+                for (uint32_t u = 0; u < PER; ++u)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v)
+                        x[u][v] = mag_from_s16((int)(int16_t)(x[u][v] & 0xffffu), (int)(int16_t)(x[u][v] >> 16), inv);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PER; ++u)
+#pragma unroll
+                for (int v = 0; v < 5; ++v)
+                    x[u][v] = ((uint32_t)lane + 64u * v) < len[u] ? x[u][v] : 0u;
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < PER; ++u)
+                msd_power_loads<FMT>(S, P.lut, pos[u], len[u], lane, x[u]);
         }
 #pragma unroll
         for (uint32_t u = 0; u < PER; ++u) {
@@ -207,7 +283,7 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
     }
 }
 
-__global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams P)
+__global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolveParams P)
 {
     __shared__ msd_hit seg_hits[SEG];
     __shared__ uint64_t seg_res[SEG];
@@ -222,28 +298,34 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
     uint16_t *const add_first = ok_next; /* per accepted message of a round; the chain walk is over by then */
     __shared__ uint32_t add_rank[ADDSET]; /* per address-set slot: rank of the first message of the round that adds it */
     __shared__ uint32_t ok_pos[SEG];
-    __shared__ uint16_t accidx[SEG];    /* accepted hits of the segment, ascending */
+    __shared__ uint32_t front[SEG];     /* where the scan resumes once it is past hit i (relative to the buffer) */
     __shared__ uint32_t sh_ctr[16];
     __shared__ uint32_t sh_wsum[RT / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_cw[MAXC][RT / 64]; /* per chunk and wavefront: hits with tries | tries << 16 */
     __shared__ uint64_t sh_range[2];
-    __shared__ uint32_t sh_rpre[64]; /* lean layout: hits of the buffer in front of each of its regions */
+    __shared__ __attribute__((aligned(16))) uint32_t sh_rpre[64]; /* lean layout: hits of the buffer in front of each of its regions */
     __shared__ uint64_t sh_resume, sh_seg_resume, sh_now;
-    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nacc, sh_nfit, sh_nok, sh_na, sh_last, sh_nf;
+    __shared__ uint32_t sh_nmsgs, sh_nadds, sh_nshort, sh_next, sh_nfit, sh_nok, sh_na, sh_last, sh_nf;
     __shared__ uint32_t f_addr[FCAP], f_resume[FCAP], f_idx[FCAP]; /* new aircraft of the round: address, end and hit of the adding message */
 
     const int tid = threadIdx.x;
+    const uint32_t wave = uni((uint32_t)tid >> 6);
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = wall_clock64();
+#if MSD_RESOLVE_TIMING
 #define PHASE(k) { const uint64_t n_ = wall_clock64(); cyc[k] += (uint32_t)(n_ - tlast); tlast = n_; }
+#else
+#define PHASE(k) { (void)tlast; }
+#endif
     /* everything the set-up needs from global memory, in three rounds of independent loads */
-    const uint64_t ovf = P.totals[2], nhits = P.totals[0];
-    const uint64_t ac_ovf = P.ac ? P.ac_totals[2] : 0;
+    const uint64_t ovf = uni((uint64_t)P.totals[2]), nhits = uni((uint64_t)P.totals[0]);
+    const uint64_t ac_ovf = P.ac ? uni((uint64_t)P.ac_totals[2]) : 0;
     /* First pass: every buffer in turn against snapshot 0, the clocks a linear function of the buffer index
      * (sdr_ifile.c:187-190) -- worked out here instead of read from the control arrays, which live in host memory
      * (two dependent reads over PCIe before the workgroup knows which buffer it has). */
     const bool implicit = P.first_pass && P.ctl_implicit;
-    const uint32_t b = implicit ? blockIdx.x : P.todo[blockIdx.x];
-    const uint32_t npred_raw = msd_pred_count(P.pred, P.pred_gen);
+    const uint32_t b = implicit ? blockIdx.x : uni(P.todo[blockIdx.x]);
+    const uint32_t npred_raw = uni(msd_pred_count(P.pred, P.pred_gen));
     if (P.first_pass && P.region_counts) {
         /* lean layout: what the gather kernel used to leave for the host -- the buffer's level / power sums (the
          * device cells are zeroed for the slot's next batch) and, from the first workgroup, the batch's totals */
@@ -322,7 +404,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             P.h_pred[i] = e;
         }
     }
-    const uint32_t snap_index = implicit ? 0u : P.snap_idx[b];
+    const uint32_t snap_index = implicit ? 0u : uni(P.snap_idx[b]);
     const uint32_t *snap = P.snaps + (size_t)snap_index * MSD_SNAP_WORDS;
     uint32_t mlen;
     uint64_t sample_ts_b, sys_ts;
@@ -335,11 +417,11 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         sample_ts_b = (uint64_t)((double)(P.sample_counter0 + first) * 12e6 / 2400000.0);
         sys_ts = sample_ts_b / 12000u;
     } else {
-        mlen = P.valid[b];
-        sample_ts_b = P.ts[2 * b];
-        sys_ts = P.ts[2 * b + 1];
+        mlen = uni(P.valid[b]);
+        sample_ts_b = uni((uint64_t)P.ts[2 * b]);
+        sys_ts = uni((uint64_t)P.ts[2 * b + 1]);
     }
-    const uint32_t snap_active = snap[2 * SLOTS] & 1u;
+    const uint32_t snap_active = uni(snap[2 * SLOTS]) & 1u;
     const uint64_t base = (uint64_t)b * MSD_CHUNK_SAMPLES, end = base + mlen;
     msd_acc *acc = P.acc + (size_t)b * MSD_RB_MSG_CAP;
     uint32_t *adds = P.adds + (size_t)b * MSD_RB_MSG_CAP;
@@ -397,101 +479,177 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
         sh_nmsgs = sh_nadds = sh_nshort = 0;
     }
     __syncthreads();
-    const uint64_t hb = sh_range[0], he = sh_range[1];
+    const uint64_t hb = uni(sh_range[0]), he = uni(sh_range[1]);
     PHASE(0)
 
-    uint32_t n = 0;
-    for (uint64_t s0 = hb; s0 < he; s0 += n) {
-        n = (he - s0 < (uint64_t)SEG) ? (uint32_t)(he - s0) : (uint32_t)SEG;
+    /* hit v of the buffer's ordered list */
+    uint32_t rp[8]; /* lean layout, up to eight regions per buffer: their places in the list, in scalar registers */
+    {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(&sh_rpre[0]), r1 = *reinterpret_cast<const uint4 *>(&sh_rpre[4]);
+        const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}; /* two LDS reads, then the lot */
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q)
+            rp[q] = (P.region_counts && q < P.regions_per_buffer) ? uni(r[q]) : ~0u;
+    }
+    auto hit_at = [&](uint64_t v) -> msd_hit {
         if (P.region_counts) {
             const uint32_t k = P.regions_per_buffer;
-            for (uint32_t i = tid; i < n; i += RT) {
-                const uint32_t v = (uint32_t)s0 + i;
-                uint32_t j = 0; /* the last region that starts at or before v (k is a handful) */
+            uint32_t j = 0, first = 0; /* the last region that starts at or before v, and where it starts */
+            if (k <= 8) {
+#pragma unroll
+                for (uint32_t q = 1; q < 8; ++q) {
+                    const bool le = rp[q] <= (uint32_t)v; /* ascending: true for a prefix of the regions */
+                    j = le ? q : j;
+                    first = le ? rp[q] : first;
+                }
+            } else {
                 for (uint32_t q = 1; q < k; ++q)
-                    j = sh_rpre[q] <= v ? q : j;
-                seg_hits[i] = P.hits[((size_t)b * k + j) * P.hcap + (v - sh_rpre[j])];
+                    j = sh_rpre[q] <= (uint32_t)v ? q : j;
+                first = sh_rpre[j];
             }
-        } else {
-            for (uint32_t i = tid; i < n; i += RT)
-                seg_hits[i] = P.hits[s0 + i];
+            return P.hits[((size_t)b * k + j) * P.hcap + ((uint32_t)v - first)];
+        }
+        return P.hits[v];
+    };
+    /* A segment holds the hits that have tries, in order.  A hit without one (no phase of the preamble got past the
+     * DF / CRC tests) scores -2 whatever the filter holds: it only counts, unless a message hides it -- the thread that
+     * loaded it keeps it in a register with the number of segment hits in front of it, and looks at the resume
+     * frontier front[] once the segment is done. */
+    uint32_t nraw = 0;
+    for (uint64_t s0 = hb; s0 < he; s0 += nraw) {
+        msd_hit keep[MAXC];
+        uint32_t keep_d[MAXC], place[MAXC]; /* keep_d: position (17 bits) | phases (3) | segment hits in front (12) */
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { /* up to MAXC x RT hits of the list, all loads first: one round trip */
+            const uint64_t v = s0 + (uint64_t)c * RT + tid;
+            keep[c] = hit_at(v < he ? v : he - 1);
+        }
+        /* place of every hit among those with tries, and of its tries among the segment's: inside the wavefront here,
+         * the wavefronts' sums through LDS */
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const uint64_t v = s0 + (uint64_t)c * RT + tid;
+            const uint32_t nl = v < he ? MSD_HIT_NLIVE(keep[c]) : 0u;
+            const uint64_t bal = __ballot(nl != 0);
+            const uint32_t lrank = (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            uint32_t incl = nl;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d)
+                    incl += up;
+            }
+            place[c] = lrank | ((incl - nl) << 8); /* rank among the wavefront's hits with tries | its earlier lanes' tries */
+            if ((tid & 63) == 63)
+                sh_cw[c][tid >> 6] = (uint32_t)__popcll(bal) | (incl << 16);
         }
         if (tid == 0) {
             sh_seg_resume = sh_resume;
-            sh_nacc = 0;
-            sh_nfit = n;
+            sh_nfit = ~0u;
         }
         __syncthreads();
-        /* ---- phase P: stage every try of the segment in LDS with its filter verdict ---- */
-        constexpr uint32_t PER = SEG / RT; /* consecutive hits per thread */
-        uint32_t nl[PER], mine = 0;
+        /* the sums of the wavefronts in front of mine, chunk by chunk: every wavefront runs the same 40-entry scan in
+         * its lanes (eight lanes a chunk; both counts in one word, neither reaches 2^16) and picks its two numbers per
+         * chunk out with v_readlane */
+        static_assert(RT / 64 == 8 && MAXC * 8 <= 64, "one lane per chunk and wavefront");
+        uint32_t cw_incl, cw_excl;
+        {
+            const uint32_t x = (tid & 63) < MAXC * 8 ? (&sh_cw[0][0])[tid & 63] : 0u;
+            uint32_t incl = x;
 #pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t i = tid * PER + k;
-            nl[k] = i < n ? MSD_HIT_NLIVE(seg_hits[i]) : 0u;
-            mine += nl[k];
+            for (int d = 1; d < 8; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 8);
+                if ((tid & 7) >= d)
+                    incl += up;
+            }
+            cw_incl = incl;
+            cw_excl = incl - x;
         }
-        uint32_t incl = mine; /* block-wide exclusive prefix of the try counts */
+        uint32_t n = 0, ntr = 0;
+        nraw = 0;
+        bool open = true; /* uniform */
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d)
-                incl += up;
+        for (int c = 0; c < MAXC; ++c) {
+            keep_d[c] = ~0u;
+            const uint32_t tot = __builtin_amdgcn_readlane(cw_incl, 8 * c + 7), mine = __builtin_amdgcn_readlane(cw_excl, 8 * c + wave);
+            const uint32_t ch = tot & 0xffffu, ct = tot >> 16; /* hits with tries / tries of the chunk ... */
+            const uint32_t bh = mine & 0xffffu, bt = mine >> 16; /* ... and of the wavefronts in front of mine */
+            const uint64_t v = s0 + (uint64_t)c * RT + tid;
+            open = open && s0 + (uint64_t)c * RT < he && n + ch <= (uint32_t)SEG; /* the first chunk always fits: RT <= SEG */
+            if (open) {
+                const msd_hit h = keep[c];
+                const uint32_t nl = v < he ? MSD_HIT_NLIVE(h) : 0u;
+                const uint32_t d = n + bh + (place[c] & 0xffu), toff = ntr + bt + (place[c] >> 8);
+                if (nl) {
+                    seg_hits[d] = h;
+                    ok_idx[d] = (uint16_t)(c * RT + tid); /* place in the list, should the segment be cut short below */
+                    seg_toff[d] = (uint16_t)toff;
+                    if (toff + nl > TCAP) /* cut the segment in front of the first hit whose tries do not fit */
+                        atomicMin(&sh_nfit, d);
+                    else
+                        for (uint32_t q = 0; q < nl; ++q)
+                            seg_thit[toff + q] = (uint16_t)d;
+                } else if (v < he && MSD_HIT_POS(h) < end) {
+                    keep_d[c] = (uint32_t)(MSD_HIT_POS(h) - base) | (MSD_HIT_MASK(h) << 17) | (d << 20);
+                }
+                n += ch;
+                ntr += ct;
+                nraw += (he - (s0 + (uint64_t)c * RT) < (uint64_t)RT) ? (uint32_t)(he - (s0 + (uint64_t)c * RT)) : (uint32_t)RT;
+            }
         }
-        if ((tid & 63) == 63)
-            sh_wsum[tid >> 6] = incl;
+        if (tid == 0)
+            seg_toff[n] = (uint16_t)ntr; /* entry n = all tries of the segment (nobody's hit: d < n) */
         __syncthreads();
-        uint32_t off = incl - mine;
-        for (int w = 0; w < (tid >> 6); ++w)
-            off += sh_wsum[w];
-        { /* cut the segment in front of the first hit whose tries do not fit (at least one hit always fits) */
-            uint32_t o = off;
+        if (uni(sh_nfit) < n) {
+            n = uni(sh_nfit); /* >= 1: a hit's tries always fit; entry n of seg_toff is that hit's own */
+            nraw = uni((uint32_t)ok_idx[n]); /* the next segment starts with the hit that did not fit */
+        }
+        const uint32_t ntries = uni((uint32_t)seg_toff[n]);
+        PHASE(5)
+        /* ---- phase P: stage every try of the segment in LDS with its filter verdict: up to NT tries per thread, in
+         * stages -- the tries, then the first slots of the tables (the prediction table's beside the snapshot's two),
+         * then the verdicts -- so that a stage's loads are one round trip ---- */
+        {
+            constexpr uint32_t NT = 3; /* per round */
+            for (uint32_t t0 = 0; t0 < ntries; t0 += NT * RT) {
+                TryView tv[NT];
+                uint32_t sa[NT], sb[NT];
+                unsigned long long pe[NT];
 #pragma unroll
-            for (uint32_t k = 0; k < PER; ++k) {
-                o += nl[k];
-                if (o > TCAP) {
-                    atomicMin(&sh_nfit, tid * PER + k);
-                    break;
+                for (uint32_t q = 0; q < NT; ++q) {
+                    const uint32_t t = t0 + (uint32_t)tid + q * RT;
+                    const uint32_t tt = t < ntries ? t : t0;
+                    const uint32_t i = seg_thit[tt];
+                    tv[q] = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (tt - seg_toff[i]));
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < NT; ++q) {
+                    const uint32_t start = hash24(tv[q].addr);
+                    const uint2 ab = *reinterpret_cast<const uint2 *>(snap + 2 * start);
+                    sa[q] = ab.x;
+                    sb[q] = ab.y;
+                    pe[q] = npred_raw ? P.pred[MSD_PRED_HASH(tv[q].addr) & (MSD_PRED_SLOTS - 1)] : ~0ull;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < NT; ++q) {
+                    const uint32_t t = t0 + (uint32_t)tid + q * RT;
+                    if (t < ntries) {
+                        const TryView &v = tv[q];
+                        const uint32_t where = snap_probe_from(snap, v.addr, sa[q], sb[q]);
+                        bool known = where != 0 || addset_has(addset, v.addr);
+                        if (!known && npred_raw) { /* added by an earlier buffer of this batch (predicted; the host verifies) */
+                            const unsigned long long key = msd_pred_key(P.pred_gen, v.addr);
+                            if ((pe[q] & 0xffffffff00000000ull) == key)
+                                known = (uint32_t)pe[q] < b;
+                            else if ((uint32_t)(pe[q] >> 56) == P.pred_gen)
+                                known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
+                        }
+                        seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
+                    }
                 }
             }
         }
         __syncthreads();
-        n = sh_nfit;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t i = tid * PER + k;
-            if (i >= n)
-                nl[k] = 0;
-            if (i <= n)
-                seg_toff[i] = (uint16_t)off; /* entry n = all tries of the segment */
-            for (uint32_t q = 0; q < nl[k]; ++q)
-                seg_thit[off + q] = (uint16_t)i;
-            off += nl[k];
-        }
-        if (tid == RT - 1 && n == SEG)
-            seg_toff[SEG] = (uint16_t)off;
-        __syncthreads();
-        PHASE(5)
-        for (uint32_t t = tid; t < seg_toff[n]; t += RT) { /* one try per thread: the loads of a round overlap */
-            const uint32_t i = seg_thit[t];
-            const TryView v = load_try(P.tries + MSD_HIT_TRY(seg_hits[i]) + (t - seg_toff[i]));
-            /* the prediction table's first slot is fetched beside the snapshot's two (three independent loads, one
-             * round trip); only a collision walks on */
-            const uint32_t hp = MSD_PRED_HASH(v.addr) & (MSD_PRED_SLOTS - 1);
-            const unsigned long long pe = npred_raw ? P.pred[hp] : ~0ull;
-            const uint32_t where = snap_probe(snap, v.addr);
-            bool known = where != 0 || addset_has(addset, v.addr);
-            if (!known && npred_raw) { /* added by an earlier buffer of this batch (predicted; the host verifies) */
-                const unsigned long long key = msd_pred_key(P.pred_gen, v.addr);
-                if ((pe & 0xffffffff00000000ull) == key)
-                    known = (uint32_t)pe < b;
-                else if ((uint32_t)(pe >> 56) == P.pred_gen)
-                    known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
-            }
-            seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
-        }
-        __syncthreads();
-        const uint32_t ntries = seg_toff[n];
         PHASE(1)
 
         uint32_t start = 0;
@@ -508,6 +666,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             for (uint32_t i = start + tid; i < n; i += RT) {
                 const msd_hit h = seg_hits[i];
                 const uint32_t nlive = MSD_HIT_NLIVE(h), o = seg_toff[i];
+                front[i] = 0;
                 int bestscore = -2;
                 uint64_t best = 0;
                 for (uint32_t q = 0; q < nlive; ++q) {
@@ -567,7 +726,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     sh_nok = incl;
             }
             __syncthreads();
-            const uint32_t nok = sh_nok;
+            const uint32_t nok = uni(sh_nok);
             /* ... for each, the first acceptable hit behind its message (bit 15: it adds an address the
              * filter does not know yet, so the hits behind it have to be looked at again) ... */
             for (uint32_t k = tid; k < nok; k += RT) {
@@ -590,44 +749,65 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             /* ... and the chain of accepted ones, the only sequential bit.  A message that adds an
              * address the filter does not know yet (a new aircraft) may change how later hits score;
              * the chain runs on and the check below finds the first hit that really is affected. */
-            if (tid == 0) {
-                const uint32_t from = (uint32_t)(sh_resume - base);
+            if (tid < 64) {
+                /* One wavefront: a window of 64 chain pointers per LDS read, walked by v_readlane (a few cycles a step
+                 * instead of an LDS round trip); the lanes of the messages passed write them out together. */
+                const uint32_t from = uni((uint32_t)(sh_resume - base));
                 uint32_t lo = 0, hi = nok;
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (ok_pos[mid] < from)
+                    if (uni(ok_pos[mid]) < from)
                         lo = mid + 1;
                     else
                         hi = mid;
                 }
                 uint32_t k = lo, na = 0, next = n, nf = 0;
-                while (k < nok) {
-                    const uint32_t nx = ok_next[k];
-                    acc_k[na++] = (uint16_t)k;
-                    if (nx & 0x8000u) {
-                        const uint32_t i = ok_idx[k];
-                        if (nf == FCAP) { /* more new aircraft than the check handles at once: stop behind this one */
+                bool full = false;
+                while (k < nok && !full) {
+                    const uint32_t w0 = k;
+                    const uint32_t mine = w0 + (uint32_t)tid < nok ? (uint32_t)ok_next[w0 + tid] : 0x7fffu;
+                    const uint64_t fresh = __ballot((mine & 0x8000u) != 0); /* messages that add a new aircraft */
+                    const uint32_t nxt = mine & 0x7fffu;
+                    const uint32_t lim = nok - w0 < 64u ? nok - w0 : 64u; /* >= 1 */
+                    uint64_t passed = 0;
+                    uint32_t off = 0; /* the walk proper: one v_readlane and a handful of scalar instructions a message */
+                    do {
+                        passed |= 1ull << off;
+                        off = __builtin_amdgcn_readlane(nxt, off) - w0;
+                    } while (off < lim); /* past the window or the list */
+                    k = w0 + off;
+                    for (uint64_t fp = passed & fresh; fp; fp &= fp - 1) { /* in order */
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(fp), kk = w0 + bit;
+                        const uint32_t i = uni((uint32_t)ok_idx[kk]);
+                        if (nf == FCAP) { /* more new aircraft than the check handles at once: stop in front of this one */
                             next = i;
-                            --na;
+                            passed &= (1ull << bit) - 1ull;
+                            full = true;
                             break;
                         }
-                        const uint64_t r = seg_res[i];
-                        f_addr[nf] = (uint32_t)(r >> 40);
-                        f_resume[nf] = ok_pos[k] + res_len(r) + 1;
-                        f_idx[nf] = i;
+                        if (tid == 0) {
+                            const uint64_t r = seg_res[i];
+                            f_addr[nf] = (uint32_t)(r >> 40);
+                            f_resume[nf] = ok_pos[kk] + res_len(r) + 1;
+                            f_idx[nf] = i;
+                        }
                         ++nf;
                     }
-                    k = nx & 0x7fffu;
+                    if ((passed >> tid) & 1ull)
+                        acc_k[na + (uint32_t)__popcll(passed & ((1ull << tid) - 1ull))] = (uint16_t)(w0 + tid);
+                    na += (uint32_t)__popcll(passed);
                 }
-                sh_na = na;
-                sh_next = next;
-                sh_nf = nf;
+                if (tid == 0) {
+                    sh_na = na;
+                    sh_next = next;
+                    sh_nf = nf;
+                }
             }
             __syncthreads();
             if (sh_nf) { /* uniform */
                 /* first hit with a not yet known try of one of the new addresses behind the message that adds it */
-                const uint32_t nf = sh_nf;
-                uint32_t first = sh_next;
+                const uint32_t nf = uni(sh_nf);
+                uint32_t first = uni(sh_next);
                 for (uint32_t t = tid; t < ntries; t += RT) {
                     const uint64_t v = seg_try[t];
                     if ((v >> 19) & 1u)
@@ -645,7 +825,7 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 if (first < sh_next)
                     atomicMin(&sh_next, first);
                 __syncthreads();
-                const uint32_t cut = sh_next;
+                const uint32_t cut = uni(sh_next);
                 /* the new addresses whose messages stay accepted are known from here on */
                 for (uint32_t t = tid; t < ntries; t += RT) {
                     const uint64_t v = seg_try[t];
@@ -673,14 +853,14 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             __syncthreads();
             PHASE(3)
             /* the accepted messages of this round, in parallel: records, counters, addresses to add */
-            const uint32_t na = sh_na, nacc0 = sh_nacc, nmsgs0 = sh_nmsgs;
+            const uint32_t na = uni(sh_na), nmsgs0 = uni(sh_nmsgs);
             for (uint32_t j = tid; j < na; j += RT) {
                 const uint32_t i = ok_idx[acc_k[j]];
                 const msd_hit h = seg_hits[i];
                 const uint64_t r = seg_res[i];
                 const uint32_t df = (uint32_t)(r >> 20) & 31u, nerr = (uint32_t)(r >> 28) & 3u;
                 const uint32_t addr = (uint32_t)(r >> 40);
-                accidx[nacc0 + j] = (uint16_t)i;
+                front[i] = ok_pos[acc_k[j]] + res_len(r) + 1u; /* j += len, then the loop's ++ */
                 if (nmsgs0 + j < MSD_RB_MSG_CAP) {
                     msd_acc rec;
                     rec.pos = (uint32_t)MSD_HIT_POS(h);
@@ -721,8 +901,8 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             { /* append them in message order (the host applies them in this order): thread t looks at
                  * messages PERJ t .. PERJ t + PERJ - 1, a workgroup-wide exclusive count gives the places
                  * (adds in the low half, those the host filter does not know yet in the high half) */
-                constexpr uint32_t PERJ = SEG / RT;
-                const uint32_t nadds0 = sh_nadds, nshort0 = sh_nshort;
+                constexpr uint32_t PERJ = (SEG + RT - 1) / RT;
+                const uint32_t nadds0 = uni(sh_nadds), nshort0 = uni(sh_nshort);
                 uint32_t a_addr[PERJ], mine = 0;
                 bool a_is[PERJ], a_short[PERJ];
 #pragma unroll
@@ -759,7 +939,6 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                     const uint32_t tot = off + mine;
                     sh_nadds = nadds0 + (tot & 0xffffu);
                     sh_nshort = nshort0 + (tot >> 16);
-                    sh_nacc = nacc0 + na;
                     sh_nmsgs = nmsgs0 + na;
                 }
 #pragma unroll
@@ -778,29 +957,54 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
                 }
             }
             __syncthreads();
+            { /* the resume frontier: an inclusive running maximum over the segment (the entries of this round's messages
+               * were set above, those of earlier rounds are final, the rest is zero) */
+                constexpr uint32_t PERF = (SEG + RT - 1) / RT;
+                uint32_t f[PERF], run = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < PERF; ++k) {
+                    const uint32_t i = (uint32_t)tid * PERF + k;
+                    const uint32_t x = i < n ? front[i] : 0u;
+                    run = x > run ? x : run;
+                    f[k] = run;
+                }
+                uint32_t incl = run;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d, 64);
+                    if ((tid & 63) >= d)
+                        incl = up > incl ? up : incl;
+                }
+                if ((tid & 63) == 63)
+                    sh_wsum[tid >> 6] = incl;
+                uint32_t pre = __shfl_up(incl, 1, 64);
+                if ((tid & 63) == 0)
+                    pre = 0;
+                __syncthreads();
+                for (int w = 0; w < (tid >> 6); ++w) {
+                    const uint32_t x = sh_wsum[w];
+                    pre = x > pre ? x : pre;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < PERF; ++k) {
+                    const uint32_t i = (uint32_t)tid * PERF + k;
+                    if (i < n)
+                        front[i] = f[k] > pre ? f[k] : pre;
+                }
+                __syncthreads();
+            }
             /* ---- phase C: the counters of every hit that no accepted message hides, in parallel ---- */
-            const uint32_t stop_at = sh_next, nacc = sh_nacc;
-            const uint64_t seg_resume = sh_seg_resume;
+            const uint32_t stop_at = uni(sh_next);
+            const uint32_t segres = uni((uint32_t)(sh_seg_resume - base));
             uint32_t c_pre = 0, c_bad = 0, c_unk = 0, c_p01 = 0, c_p23 = 0, c_p4 = 0, last = 0;
             for (uint32_t i = start + tid; i < stop_at; i += RT) {
                 const msd_hit h = seg_hits[i];
                 const uint64_t a = MSD_HIT_POS(h);
                 if (a >= end)
                     continue;
-                uint32_t lo = 0, hi = nacc; /* number of accepted hits in front of i */
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (accidx[mid] < i)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                uint64_t resume = seg_resume;
-                if (lo) {
-                    const uint32_t k = accidx[lo - 1];
-                    resume = MSD_HIT_POS(seg_hits[k]) + res_len(seg_res[k]) + 1;
-                }
-                if (a < resume)
+                uint32_t resume = i ? front[i - 1] : 0u;
+                resume = resume > segres ? resume : segres;
+                if ((uint32_t)(a - base) < resume)
                     continue;
                 const uint32_t mask = MSD_HIT_MASK(h);
                 c_pre++;
@@ -847,11 +1051,50 @@ __global__ void __launch_bounds__(RT) msd_resolve_kernel(const MsdResolveParams 
             }
             PHASE(4)
         }
+        { /* the segment's hits without a try: counted unless a message hides them (the scan resumes behind a message,
+           * demod_2400.c:404-410); front[] is complete for the segment now */
+            const uint32_t segres = uni((uint32_t)(sh_seg_resume - base));
+            uint32_t d_pre = 0, d_p01 = 0, d_p23 = 0, d_p4 = 0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const uint32_t kd = keep_d[c], d = kd >> 20;
+                if (kd == ~0u || (uint32_t)(c * RT + tid) >= nraw || d > n)
+                    continue;
+                uint32_t resume = d ? front[d - 1] : 0u;
+                resume = resume > segres ? resume : segres;
+                if ((kd & 0x1ffffu) < resume)
+                    continue;
+                const uint32_t mask = (kd >> 17) & 7u;
+                d_pre++;
+                d_p01 += mask & 1u;
+                d_p23 += (mask >> 1) & 1u;
+                d_p4 += (mask >> 2) & 1u;
+            }
+            /* every hit without a try that counted is a "bad" rejection (score -2) */
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                d_pre += __shfl_down(d_pre, o, 64);
+                d_p01 += __shfl_down(d_p01, o, 64);
+                d_p23 += __shfl_down(d_p23, o, 64);
+                d_p4 += __shfl_down(d_p4, o, 64);
+            }
+            if ((tid & 63) == 0 && d_pre) {
+                atomicAdd(&sh_ctr[0], d_pre);
+                atomicAdd(&sh_ctr[1], d_pre);
+                atomicAdd(&sh_ctr[6], d_p01);
+                atomicAdd(&sh_ctr[7], d_p01);
+                atomicAdd(&sh_ctr[8], d_p23);
+                atomicAdd(&sh_ctr[9], d_p23);
+                atomicAdd(&sh_ctr[10], d_p4);
+            }
+            __syncthreads(); /* front[] and the segment arrays are rewritten by the next segment */
+        }
+        PHASE(7)
     }
 
     if (P.power) { /* the signal power of the buffer's messages (the records in acc[] are this workgroup's own) */
         __syncthreads();
-        const uint32_t nm = sh_nmsgs < MSD_RB_MSG_CAP ? sh_nmsgs : MSD_RB_MSG_CAP;
+        const uint32_t nm = uni(sh_nmsgs) < MSD_RB_MSG_CAP ? uni(sh_nmsgs) : MSD_RB_MSG_CAP;
         unsigned long long *out = P.power + (size_t)b * MSD_RB_MSG_CAP;
         switch (P.format) {
         case MSD_FMT_UC8: power_of_accepted<MSD_FMT_UC8>(P, acc, nm, out, tid); break;
