@@ -164,6 +164,7 @@ constexpr uint32_t TCAP = SEG + 3 * SEG / 10; /* tries staged per segment; a seg
 constexpr int MAXC = 5; /* a segment is made from at most MAXC x RT hits of the list */
 constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
+constexpr uint32_t SPEC = 256;    /* new aircraft of one buffer followed speculatively (the rest go the slow way) */
 
 __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr)
 {
@@ -176,6 +177,20 @@ __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr
             return false;
         hs = (hs + 1) & (ADDSET - 1);
     }
+}
+
+__device__ __forceinline__ int spec_find(const uint32_t *key, uint32_t addr)
+{
+    uint32_t h = (addr * 2654435761u) >> 24;
+    for (uint32_t probes = 0; probes < SPEC; ++probes) {
+        const uint32_t k = key[h];
+        if (k == addr)
+            return (int)h;
+        if (k == VACANT)
+            return -1;
+        h = (h + 1) & (SPEC - 1);
+    }
+    return -1;
 }
 
 /* Signal power of the accepted messages of one buffer, by the workgroup that accepted them: a wavefront per message,
@@ -290,7 +305,6 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
     __shared__ uint64_t seg_try[TCAP];
     __shared__ uint16_t seg_toff[SEG + 1];
     __shared__ uint16_t seg_thit[TCAP];       /* owner of each staged try */
-    __shared__ uint32_t out_adds[ADDSET / 2]; /* this buffer's adds, flushed at the end */
     __shared__ uint32_t out_short[MSD_RB_ADD_INLINE]; /* those the host must apply: not in the active table yet */
     __shared__ uint32_t addset[ADDSET]; /* addresses this buffer has passed to icaoFilterAdd */
     __shared__ uint32_t okb[SEG / 32];  /* hits that would be accepted if nothing hides them */
@@ -300,6 +314,14 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
     __shared__ uint32_t ok_pos[SEG];
     __shared__ uint32_t front[SEG];     /* where the scan resumes once it is past hit i (relative to the buffer) */
     __shared__ uint32_t sh_ctr[16];
+    /* New aircraft inside the buffer: address -> position (<< 1 | long message) of the buffer's first CRC-clean DF17 /
+     * DF11 (IID 0) candidate with an address no filter knows.  Tries of that address behind that message are staged as
+     * known right away -- the message will add the address if it is accepted, and a clean one nearly always is --
+     * instead of being found out round by round; every round checks the assumption against the messages it accepted
+     * (spec_conf: 1 the message was accepted and adds the address, 2 it was not: the tries go back to unknown). */
+    __shared__ uint32_t spec_key[SPEC], spec_val[SPEC];
+    __shared__ uint8_t spec_conf[SPEC];
+    __shared__ uint32_t sh_nspec, sh_nuse, sh_specfail;
     __shared__ uint32_t sh_wsum[RT / 64];
     __shared__ __attribute__((aligned(16))) uint32_t sh_cw[MAXC][RT / 64]; /* per chunk and wavefront: hits with tries | tries << 16 */
     __shared__ uint64_t sh_range[2];
@@ -430,6 +452,13 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
         addset[i] = VACANT;
     if (tid < 16)
         sh_ctr[tid] = 0;
+    if (tid < (int)SPEC) {
+        spec_key[tid] = VACANT;
+        spec_val[tid] = ~0u;
+        spec_conf[tid] = 0;
+    }
+    if (tid == 0)
+        sh_nspec = 0;
     if (P.region_counts) { /* lean layout: the buffer's hits are the slices of its k regions, one after the other */
         if (tid < 64) {
             const uint32_t k = P.regions_per_buffer;
@@ -645,7 +674,42 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                                 known = msd_pred_lookup(P.pred, P.pred_gen, v.addr) < b;
                         }
                         seg_try[t] = pack_try(v, known, (where >> snap_active) & 1u);
+                        const uint32_t df = (v.w0 & 0xffu) >> 3;
+                        if (!known && (v.w3 >> 24) == 0xffu && (df == 17 || (df == 11 && (v.crc & 0x7fu) == 0))) {
+                            /* this message would add the address (mode_s.c:717-726): note the first one per address */
+                            const uint32_t at = (uint32_t)(MSD_HIT_POS(seg_hits[seg_thit[t]]) - base);
+                            uint32_t h = (v.addr * 2654435761u) >> 24;
+                            for (uint32_t probes = 0; probes < SPEC; ++probes) {
+                                const uint32_t old = atomicCAS(&spec_key[h], VACANT, v.addr);
+                                if (old == VACANT || old == v.addr) {
+                                    atomicMin(&spec_val[h], (at << 1) | (df == 17 ? 1u : 0u));
+                                    if (old == VACANT)
+                                        atomicAdd(&sh_nspec, 1u);
+                                    break;
+                                }
+                                h = (h + 1) & (SPEC - 1);
+                            }
+                        }
                     }
+                }
+            }
+        }
+        if (tid == 0)
+            sh_nuse = 0;
+        __syncthreads();
+        if (uni(sh_nspec)) { /* tries of those addresses behind the message that will add them: known, on probation */
+            for (uint32_t t = tid; t < ntries; t += RT) {
+                const uint64_t v = seg_try[t];
+                if ((v >> 19) & 1u)
+                    continue;
+                const int e = spec_find(spec_key, (uint32_t)(v >> 40));
+                if (e < 0)
+                    continue;
+                const uint32_t val = spec_val[e];
+                const uint32_t resume = (val >> 1) + ((val & 1u) ? 268u : 134u) + 1u;
+                if ((uint32_t)(MSD_HIT_POS(seg_hits[seg_thit[t]]) - base) >= resume) {
+                    seg_try[t] = v | (1ull << 19) | (1ull << 39);
+                    sh_nuse = 1; /* benign race: everybody writes 1 */
                 }
             }
         }
@@ -804,39 +868,95 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                 }
             }
             __syncthreads();
-            if (sh_nf) { /* uniform */
-                /* first hit with a not yet known try of one of the new addresses behind the message that adds it */
-                const uint32_t nf = uni(sh_nf);
-                uint32_t first = uni(sh_next);
-                for (uint32_t t = tid; t < ntries; t += RT) {
-                    const uint64_t v = seg_try[t];
-                    if ((v >> 19) & 1u)
-                        continue;
-                    const uint32_t i = seg_thit[t];
-                    if (i < start || i >= first)
-                        continue;
-                    const uint32_t addr = (uint32_t)(v >> 40), pos = (uint32_t)(MSD_HIT_POS(seg_hits[i]) - base);
-                    for (uint32_t f = 0; f < nf; ++f)
-                        if (f_addr[f] == addr && pos >= f_resume[f]) {
-                            first = i;
-                            break;
-                        }
+            const uint32_t nf = uni(sh_nf), nuse = uni(sh_nuse);
+            if (nf | nuse) { /* uniform */
+                if (nf) {
+                    /* first hit with a not yet known try of one of the new addresses behind the message that adds it */
+                    uint32_t first = uni(sh_next);
+                    for (uint32_t t = tid; t < ntries; t += RT) {
+                        const uint64_t v = seg_try[t];
+                        if ((v >> 19) & 1u)
+                            continue;
+                        const uint32_t i = seg_thit[t];
+                        if (i < start || i >= first)
+                            continue;
+                        const uint32_t addr = (uint32_t)(v >> 40), pos = (uint32_t)(MSD_HIT_POS(seg_hits[i]) - base);
+                        for (uint32_t f = 0; f < nf; ++f)
+                            if (f_addr[f] == addr && pos >= f_resume[f]) {
+                                first = i;
+                                break;
+                            }
+                    }
+                    if (first < sh_next)
+                        atomicMin(&sh_next, first);
                 }
-                if (first < sh_next)
-                    atomicMin(&sh_next, first);
+                if (tid == 0)
+                    sh_specfail = 0;
                 __syncthreads();
+                if (nuse) {
+                    /* the tries on probation: the messages of this round (in front of the cut so far) that add their
+                     * address confirm the table's entries ... */
+                    const uint32_t cut1 = uni(sh_next), na1 = uni(sh_na);
+                    for (uint32_t j = tid; j < na1; j += RT) {
+                        const uint32_t k = acc_k[j], i = ok_idx[k];
+                        if (i >= cut1)
+                            continue;
+                        const uint64_t r = seg_res[i];
+                        const uint32_t df = (uint32_t)(r >> 20) & 31u, nerr = (uint32_t)(r >> 28) & 3u;
+                        if (nerr == 0 && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) {
+                            const int e = spec_find(spec_key, (uint32_t)(r >> 40));
+                            if (e >= 0 && (spec_val[e] >> 1) == ok_pos[k])
+                                spec_conf[e] = 1;
+                        }
+                    }
+                    __syncthreads();
+                    /* ... a try in front of the cut whose entry is not confirmed (the message was looked at and is not
+                     * among the accepted ones) was staged wrongly: the round ends in front of the first such hit ... */
+                    uint32_t first = cut1;
+                    for (uint32_t t = tid; t < ntries; t += RT) {
+                        const uint64_t v = seg_try[t];
+                        if (!((v >> 39) & 1u))
+                            continue;
+                        const uint32_t i = seg_thit[t];
+                        if (i < start || i >= cut1)
+                            continue;
+                        const int e = spec_find(spec_key, (uint32_t)(v >> 40));
+                        if (e >= 0 && spec_conf[e] == 1)
+                            continue;
+                        if (e >= 0)
+                            spec_conf[e] = 2;
+                        first = i < first ? i : first;
+                        sh_specfail = 1; /* benign race */
+                    }
+                    if (first < cut1)
+                        atomicMin(&sh_next, first);
+                    __syncthreads();
+                    if (uni(sh_specfail)) { /* ... and all tries of such an address go back to unknown */
+                        for (uint32_t t = tid; t < ntries; t += RT) {
+                            const uint64_t v = seg_try[t];
+                            if (!((v >> 39) & 1u))
+                                continue;
+                            const int e = spec_find(spec_key, (uint32_t)(v >> 40));
+                            if (e < 0 || spec_conf[e] == 2)
+                                seg_try[t] = v & ~((1ull << 19) | (1ull << 39));
+                        }
+                        __syncthreads();
+                    }
+                }
                 const uint32_t cut = uni(sh_next);
                 /* the new addresses whose messages stay accepted are known from here on */
-                for (uint32_t t = tid; t < ntries; t += RT) {
-                    const uint64_t v = seg_try[t];
-                    if ((v >> 19) & 1u)
-                        continue;
-                    const uint32_t addr = (uint32_t)(v >> 40);
-                    for (uint32_t f = 0; f < nf; ++f)
-                        if (f_addr[f] == addr && f_idx[f] < cut) {
-                            seg_try[t] = v | (1ull << 19);
-                            break;
-                        }
+                if (nf) {
+                    for (uint32_t t = tid; t < ntries; t += RT) {
+                        const uint64_t v = seg_try[t];
+                        if ((v >> 19) & 1u)
+                            continue;
+                        const uint32_t addr = (uint32_t)(v >> 40);
+                        for (uint32_t f = 0; f < nf; ++f)
+                            if (f_addr[f] == addr && f_idx[f] < cut) {
+                                seg_try[t] = v | (1ull << 19);
+                                break;
+                            }
+                    }
                 }
                 if (tid == 0) { /* drop the accepted messages at or behind the cut */
                     uint32_t na = sh_na;
@@ -946,7 +1066,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     if (a_is[q]) {
                         const uint32_t ia = nadds0 + (off & 0xffffu);
                         if (ia < MSD_RB_MSG_CAP)
-                            out_adds[ia] = a_addr[q];
+                            adds[ia] = a_addr[q]; /* the complete list stays in device memory */
                         if (a_short[q]) {
                             const uint32_t is = nshort0 + (off >> 16);
                             if (is < MSD_RB_ADD_INLINE)
@@ -1196,9 +1316,6 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
     }
 
     { /* flush the lists, coalesced */
-        const uint32_t na = sh_nadds < MSD_RB_MSG_CAP ? sh_nadds : MSD_RB_MSG_CAP;
-        for (uint32_t i = tid; i < na; i += RT)
-            adds[i] = out_adds[i];
         const uint32_t ns = sh_nshort < MSD_RB_ADD_INLINE ? sh_nshort : MSD_RB_ADD_INLINE;
         for (uint32_t i = tid; i < ns; i += RT)
             rb->adds[i] = out_short[i];
