@@ -34,6 +34,27 @@
 
 #include "msd_internal.h"
 #include "msd_kernels.h"
+
+/* Candidate arenas (hits, tries): written once by the scan, read once by the next kernel.  MSD_ARENA_NT=1 marks the
+ * stores non-temporal, so that the lines leave the L2 while the kernel runs instead of in its end-of-kernel write-back. */
+#ifndef MSD_ARENA_NT
+#define MSD_ARENA_NT 1
+#endif
+#if MSD_ARENA_NT
+#define MSD_ARENA_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define MSD_ARENA_STORE(v, p) (*(p) = (v))
+#endif
+typedef uint32_t msd_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
+{
+#if MSD_ARENA_NT
+    msd_v4u x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<msd_v4u *>(p));
+#else
+    *p = v;
+#endif
+}
 #include "msd_emit_impl.h"
 #include "msd_pred_impl.h"
 #include "msd_mag_impl.h"
@@ -565,7 +586,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             msd_hit rec = (tile_pos0 + pos) | ((msd_hit)my_m << 28) | ((msd_hit)nlive << 31);
             if (nlive)
                 rec |= (msd_hit)(try_base + idx) << 34;
-            hit_out[lane] = rec;
+            MSD_ARENA_STORE(rec, &hit_out[lane]);
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
@@ -574,12 +595,13 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
                 if (idx < P.tcap) {
                     uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
                     const uint4 m16 = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
-                    dst[0] = m16;
+                    arena_store16(m16, &dst[0]);
                     const uint32_t cw = sres[2 * u + 1];
                     /* the last word repeats the first byte (DF), the trial phase and the first corrected bit beside the
                      * second one: the resolve kernel reads this half of the record only */
-                    dst[1] = make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos),
-                                        (cw >> 24) | ((m16.x & 0xffu) << 8) | (m16.w & 0xffff0000u));
+                    arena_store16(make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos),
+                                             (cw >> 24) | ((m16.x & 0xffu) << 8) | (m16.w & 0xffff0000u)),
+                                  &dst[1]);
                 }
                 ++idx;
             }
