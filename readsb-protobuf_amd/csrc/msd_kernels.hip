@@ -2307,7 +2307,8 @@ __device__ __forceinline__ uint32_t ac_compact(uint32_t n, const uint16_t *src, 
 }
 
 template <int FMT>
-__global__ void __launch_bounds__(ACNT) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
+/* six wavefronts per SIMD (what the 24 KB of LDS allow) take <= 85 vector registers; left alone the compiler uses 92 */
+__global__ void __launch_bounds__(ACNT, 6) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
                                                       const uint32_t *noise_levels /* or NULL: from the sums */,
                                                       const uint64_t *sums, const float *fmeans, int use_float, msd_ac_hit *out,
                                                       uint32_t cap, msd_wg_counts *counts)
