@@ -1621,7 +1621,7 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
                         magsq = sq_i + sq_q;
                         if (magsq > 1.0f)
                             magsq = 1.0f;
-                        m = __builtin_sqrtf(magsq);
+                        m = msd_sqrt_cr(magsq);
                     }
                     vals[c & 1][0][i] = m;
                     vals[c & 1][1][i] = magsq;
@@ -1698,7 +1698,7 @@ __device__ __forceinline__ void fm_block_values(const uint32_t *src, uint32_t n,
             magsq = sq_i + sq_q;
             if (magsq > 1.0f)
                 magsq = 1.0f;
-            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : __builtin_sqrtf(magsq);
+            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : msd_sqrt_cr(magsq);
         }
         lvl[k] = m;
         pwr[k] = magsq;

@@ -15,6 +15,21 @@ __device__ __forceinline__ uint32_t fold8(uint32_t b)
     return (b ^ ((b >> 7) - 1u)) & 0x7fu;
 }
 
+/* sqrtf, correctly rounded, for the values a magnitude square takes: zero or a normal float in [2^-40, 2] (the smallest
+ * non-zero one is 2^-30).  The hardware's v_sqrt_f32 is within one ulp; the two neighbours are tried with an exact
+ * residual each (FMA), as in the compiler's own expansion of sqrtf -- minus its rescaling of inputs below 2^-96 and
+ * its special-value select, which cost 7 of its 16 instructions and cannot trigger here (scripts/micro/sqrt_check.hip
+ * compares the two over every float in the range). */
+__device__ __forceinline__ float msd_sqrt_cr(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
+    const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+    float y = em <= 0.0f ? rm : r;
+    y = ep > 0.0f ? rp : y;
+    return y;
+}
+
 /* convert.c:215-253 / :332-370 float path: separate multiply and add (no FMA contraction), correctly rounded sqrt */
 __device__ __forceinline__ uint32_t mag_from_s16(int I, int Q, float inv_scale)
 {
@@ -24,7 +39,7 @@ __device__ __forceinline__ uint32_t mag_from_s16(int I, int Q, float inv_scale)
     float magsq = sq_i + sq_q;
     if (magsq > 1.0f)
         magsq = 1.0f;
-    const float m = __builtin_sqrtf(magsq);
+    const float m = msd_sqrt_cr(magsq);
     const float scaled = m * 65535.0f;
     return (uint32_t)(uint16_t)(scaled + 0.5f);
 }
