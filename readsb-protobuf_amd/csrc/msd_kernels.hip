@@ -1665,6 +1665,7 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
  *           summed exactly with fsum_block.  Bit-identical to the sequential sum by construction: every
  *           shortcut is verified against the exact state before it is used. */
 constexpr int FB_MAX = 128; /* blocks of FS_BLOCK elements per buffer (MSD_CHUNK_SAMPLES / 1024) */
+constexpr int FM_SLOTS = 24; /* slow blocks per sum whose sub-block totals are kept (about ten occur) */
 
 /* the block's elements in fsum_block's layout: lane L holds elements 16 L .. 16 L + 15 */
 template <int FMT, bool APPROX /* the native square root: good enough to predict a binade */>
@@ -1765,6 +1766,80 @@ __device__ __forceinline__ bool fsum_block_total(const float (&x)[FS_PER], int e
     return true;
 }
 
+/* s + x(lane 0) + x(lane 1) + ... + x(lane 63), one addition after the other (convert.c:241-242).  Sixteen lanes' values
+ * go to scalar registers first: a v_readlane in front of every addition would make each of them wait for it. */
+__device__ __forceinline__ float fsum_lanes_in_order(float s, float x)
+{
+#pragma unroll
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+        float xs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            xs[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), q0 + i));
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "s"(xs[i]));
+    }
+    return s;
+}
+
+/* a sample word as the level sum (which = 0) or the power sum (1) sees it */
+template <int FMT>
+__device__ __forceinline__ float fm_word_value(uint32_t w, float inv, int which)
+{
+    float m, magsq;
+    if (FMT == MSD_FMT_MAGSQ) { /* --dcfilter: the clamped squares msd_dcfilter_kernel left */
+        magsq = __uint_as_float(w);
+        m = __builtin_sqrtf(magsq);
+    } else {
+        const float fi = (float)(int)(int16_t)(w & 0xffffu) * inv, fq = (float)(int)(int16_t)(w >> 16) * inv;
+        const float sq_i = fi * fi, sq_q = fq * fq;
+        magsq = sq_i + sq_q;
+        if (magsq > 1.0f)
+            magsq = 1.0f;
+        m = msd_sqrt_cr(magsq);
+    }
+    return which ? magsq : m;
+}
+
+/* The totals of the block's sixteen 64-sample sub-blocks (lanes 4 j .. 4 j + 3) for a sum with exponent ca and with
+ * exponent ca + 1 (ca >= 2), in units of the respective u, and which of them contain a tie (bit j). */
+__device__ __forceinline__ void fsum_sub_totals(const float (&x)[FS_PER], int ca, int lane, uint32_t (&sub)[2][16], uint32_t (&tie)[2])
+{
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int e = ca + c;
+        const float A = __uint_as_float((uint32_t)(e + 127) << 23);
+        const float half_u = __uint_as_float((uint32_t)(e - 24 + 127) << 23);
+        const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23);
+        uint32_t p = 0;
+        bool t_any = false;
+#pragma unroll
+        for (int k0 = 0; k0 < FS_PER; k0 += 4) { /* four elements at a time: their float sum is exact from e = 2 on */
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = k0; k < k0 + 4; ++k) {
+                const float t = (A + x[k]) - A;
+                t_any |= __builtin_fabsf(x[k] - t) == half_u;
+                acc += t;
+            }
+            p += (uint32_t)(acc * scale);
+        }
+        p += (uint32_t)__shfl_xor((int)p, 1, 64);
+        p += (uint32_t)__shfl_xor((int)p, 2, 64);
+        const unsigned long long bal = __ballot(t_any);
+        if ((lane & 3) == 0)
+            sub[c][lane >> 2] = p;
+        if (lane == 0) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                m |= ((bal >> (4 * j)) & 0xfull) ? 1u << j : 0u;
+            tie[c] = m;
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
 #pragma unroll
@@ -1774,13 +1849,14 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 }
 
 #ifdef MSD_FM_TIMERS
-__device__ unsigned long long msd_fm_cyc[8]; /* pass 1, prefix, pass 2, apply (100 MHz ticks, workgroup sums); slow blocks, blocks, workgroups */
+__device__ unsigned long long msd_fm_cyc[10]; /* pass 1, prefix, pass 2, apply (100 MHz ticks, workgroup sums); slow blocks, blocks, workgroups,
+                                                  sub-blocks summed sample by sample, blocks summed whole */
 #define FM_T(k) if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&msd_fm_cyc[k], n_ - t_last); t_last = n_; }
 #else
 #define FM_T(k)
 #endif
 template <int FMT>
-__global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
+__global__ void __launch_bounds__(FM_THREADS, 4) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
                                                                       uint64_t buffer_len, uint32_t nbuffers,
                                                                       float *out /* [nbuffers][2] */,
                                                                       const float *tile_sums /* or NULL */)
@@ -1788,6 +1864,15 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
     __shared__ float blk_tot[2][FB_MAX];    /* approximate totals, then approximate prefix at the block's start */
     __shared__ uint32_t blk_f0[2][FB_MAX], blk_f1[2][FB_MAX];
     __shared__ int blk_e[2][FB_MAX];        /* predicted exponent at the block's start; INT_MIN: slow block */
+    /* A slow block -- the sum changes its exponent inside it, or the prediction sits too close to a power of two to be
+     * trusted -- is not summed element by element any more: pass 2 leaves the totals of its sixteen 64-sample sub-blocks
+     * for the two exponents in question (slow_ca and slow_ca + 1), and the apply loop walks those; only the sub-block
+     * the sum really leaves its binade in (or one with a tie) is added sample by sample. */
+    __shared__ uint32_t fm_next_blk, blk0_bits[2]; /* pass 2's block counter; the two sums behind the buffer's first block */
+    __shared__ int blk_ca[2][FB_MAX];        /* first of the two exponents; INT_MIN: none (the old way) */
+    __shared__ uint8_t blk_slot[2][FB_MAX];  /* where its sub-block totals are; 0xff: none */
+    __shared__ uint32_t slow_sub[2][FM_SLOTS][2][16];
+    __shared__ uint32_t slow_tie[2][FM_SLOTS][2];
     const uint32_t b = blockIdx.x;
     if (b >= nbuffers)
         return;
@@ -1801,6 +1886,8 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWV = FM_THREADS / 64;
     const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK; /* <= FB_MAX: buffer_len <= MSD_CHUNK_SAMPLES */
+    if (threadIdx.x == 0)
+        fm_next_blk = 1u; /* block 0 is summed apart */
     constexpr int SLOW = -2147483647 - 1;
 #ifdef MSD_FM_TIMERS
     unsigned long long t_last = wall_clock64();
@@ -1873,28 +1960,68 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
         }
         const float run0 = incl - (t0 + t1) < 0.0f ? 0.0f : incl - (t0 + t1);
         const float runs[2] = {run0, run0 + t0}, tots[2] = {t0, t1};
+        int cas[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float run = runs[j], next = run + tots[j];
             const int e0 = (int)(__float_as_uint(run) >> 23) - 127, e1 = (int)(__float_as_uint(next) >> 23) - 127;
             /* a block inside which the sum changes its exponent, or whose sum is still tiny, is summed exactly;
-             * so is a block that starts within 2^-12 of a power of two (the approximate prefix could be on the
+             * so is a block that starts within 2^-10 of a power of two (the approximate prefix could be on the
              * wrong side of it -- and if it still is, the apply loop notices) */
             const uint32_t mant = __float_as_uint(run) & 0x7fffffu;
-            const bool near_edge = mant < 0x800u || mant > 0x7ff800u;
+            const bool near_edge = mant < 0x2000u || mant > 0x7fe000u;
+            const bool slow = e0 != e1 || e0 < -7 || near_edge || tots[j] == 0.0f;
+            /* the two exponents a slow block's sub-blocks are prepared for: the one it starts with and the next, or the
+             * one below if the sum may not have reached this one yet; fsum_sub_totals is exact from 2^2 on */
+            int ca = e0 != e1 ? e0 : (near_edge && mant < 0x2000u ? e0 - 1 : e0);
+            if (!slow || ca < 2 || tots[j] == 0.0f || b0 + j >= nblk)
+                ca = SLOW;
+            cas[j] = ca;
             if (b0 + j < nblk)
-                blk_e[wave][b0 + j] = (e0 != e1 || e0 < -7 || near_edge || tots[j] == 0.0f) ? SLOW : e0;
+                blk_e[wave][b0 + j] = slow ? SLOW : e0;
+        }
+        { /* slots in block order */
+            const uint32_t mine_n = (cas[0] != SLOW ? 1u : 0u) + (cas[1] != SLOW ? 1u : 0u);
+            uint32_t at = wave_incl_scan(mine_n) - mine_n;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (b0 + j < nblk) {
+                    const bool has = cas[j] != SLOW && at < (uint32_t)FM_SLOTS;
+                    blk_ca[wave][b0 + j] = has ? cas[j] : SLOW;
+                    blk_slot[wave][b0 + j] = has ? (uint8_t)at : (uint8_t)0xff;
+                    at += cas[j] != SLOW ? 1u : 0u;
+                }
         }
     }
     __syncthreads();
     FM_T(1)
-    /* pass 2 */
-    for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
+    /* pass 2: the blocks go to whichever wavefront is free (an LDS counter).  The buffer's first block starts from a
+     * sum of exactly zero, whatever else happens: the last two wavefronts sum it the long way first, one sum each, and
+     * the apply loop starts behind it. */
+    if (wave >= NWV - 2) {
+        float lvl[FS_PER], pwr[FS_PER];
+        fm_block_values<FMT, false>(src, n, 0u, lane, inv, lvl, pwr);
+        const float s0 = wave == NWV - 2 ? fsum_block(0.0f, lvl, lane) : fsum_block(0.0f, pwr, lane);
+        if (lane == 0)
+            blk0_bits[wave - (NWV - 2)] = __float_as_uint(s0);
+    }
+    for (;;) {
+        uint32_t blk = 0;
+        if (lane == 0)
+            blk = atomicAdd(&fm_next_blk, 1u);
+        blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
+        if (blk >= nblk)
+            break;
         const int el = blk_e[0][blk], ep = blk_e[1][blk];
-        if (el == SLOW && ep == SLOW)
+        const int cl = blk_ca[0][blk], cp = blk_ca[1][blk];
+        if (el == SLOW && ep == SLOW && cl == SLOW && cp == SLOW)
             continue; /* wave-uniform */
         float lvl[FS_PER], pwr[FS_PER];
         fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
+        if (cl != SLOW)
+            fsum_sub_totals(lvl, cl, lane, slow_sub[0][blk_slot[0][blk]], slow_tie[0][blk_slot[0][blk]]);
+        if (cp != SLOW)
+            fsum_sub_totals(pwr, cp, lane, slow_sub[1][blk_slot[1][blk]], slow_tie[1][blk_slot[1][blk]]);
         if (el != SLOW) {
             uint32_t f0, f1;
             if (el >= 1 && fsum_block_total(lvl, el, f0))
@@ -1924,41 +2051,133 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
     if (wave < 2) {
         /* the blocks' predictions and functions in registers, lane L: blocks L and L + 64; the walk then reads
          * them with v_readlane instead of three dependent LDS loads per block */
-        int re[2];
-        uint32_t rf0[2], rf1[2];
+        int re[2], rca[2];
+        uint32_t rf0[2], rf1[2], rslot[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t blk = (uint32_t)lane + 64u * j;
             re[j] = blk < nblk ? blk_e[wave][blk] : SLOW;
             rf0[j] = blk < nblk ? blk_f0[wave][blk] : 0u;
             rf1[j] = blk < nblk ? blk_f1[wave][blk] : 0u;
+            rca[j] = blk < nblk ? blk_ca[wave][blk] : SLOW;
+            rslot[j] = blk < nblk ? blk_slot[wave][blk] : 0xffu;
         }
-        float sum = 0.0f;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
+        /* The sum lives in a scalar register (its bits): a block whose prediction holds is a dozen scalar instructions.
+         * The samples of the next block that will be walked sub-block by sub-block are fetched ahead -- which blocks
+         * those are is known from the start -- lane L: sample 64 j + L of the block in w[j], one per sub-block. */
+        const unsigned long long walk_lo = __ballot(re[0] == SLOW && rca[0] != SLOW), walk_hi = __ballot(re[1] == SLOW && rca[1] != SLOW);
+        auto next_walk = [&](uint32_t from) -> uint32_t { /* first such block at or behind `from`; nblk: none */
+            if (from < 64u) {
+                const unsigned long long m = walk_lo >> from;
+                if (m)
+                    return from + (uint32_t)__builtin_ctzll(m);
+                from = 64u;
+            }
+            if (from < 128u) {
+                const unsigned long long m = walk_hi >> (from - 64u);
+                if (m)
+                    return from + (uint32_t)__builtin_ctzll(m);
+            }
+            return nblk;
+        };
+        uint32_t w[16], w_blk = next_walk(1u);
+        auto fetch = [&](uint32_t blk) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+                w[j] = src[g < n ? g : 0u]; /* unconditional: sixteen loads in flight */
+            }
+        };
+        if (w_blk < nblk)
+            fetch(w_blk);
+#ifdef MSD_FM_TIMERS
+        uint32_t n_slow = 0, n_seq = 0, n_whole = 0;
+        unsigned long long t_slow = 0;
+#endif
+        uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk0_bits[wave]); /* the bits of the sum, behind block 0 */
+        for (uint32_t blk = 1; blk < nblk; ++blk) {
             const int hi = blk >= 64u, l = (int)(blk & 63u);
             const int e = __builtin_amdgcn_readlane(hi ? re[1] : re[0], l);
             const uint32_t bf0 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf0[1] : rf0[0]), l);
             const uint32_t bf1 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf1[1] : rf1[0]), l);
-            const uint32_t sb = __float_as_uint(sum);
             bool fast = e != SLOW && (int)(sb >> 23) - 127 == e;
             if (fast) {
                 const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
                 const uint32_t S = S0 + ((S0 & 1u) ? bf1 : bf0);
                 if (S < (1u << 24))
-                    sum = __uint_as_float((sb & 0xff800000u) | (S & 0x7fffffu));
+                    sb = (sb & 0xff800000u) | (S & 0x7fffffu);
                 else
                     fast = false; /* left the binade after all */
             }
-            if (!fast) { /* wave-uniform */
+            if (fast)
+                continue;
+            /* wave-uniform from here */
 #ifdef MSD_FM_TIMERS
-                if (lane == 0)
-                    atomicAdd(&msd_fm_cyc[4], 1ull);
+            ++n_slow;
+            const unsigned long long t_slow0 = wall_clock64();
 #endif
-                float lvl[FS_PER], pwr[FS_PER];
-                fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
-                sum = wave == 0 ? fsum_block(sum, lvl, lane) : fsum_block(sum, pwr, lane);
+            if (blk == w_blk) {
+                /* sub-block by sub-block with the totals pass 2 left (lane 16 c + j: exponent ca + c, sub-block j) */
+                const int ca = __builtin_amdgcn_readlane(hi ? rca[1] : rca[0], l);
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rslot[1] : rslot[0]), l);
+                const uint32_t sub = lane < 32 ? slow_sub[wave][slot][lane >> 4][lane & 15] : 0u;
+                const uint32_t ties[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)slow_tie[wave][slot][0]),
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)slow_tie[wave][slot][1])};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int c = ((int)(sb >> 23) - 127) - ca;
+                    bool ok = false;
+                    if (c == 0 || c == 1) {
+                        const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)sub, 16 * c + j);
+                        const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+                        if (!((ties[c] >> j) & 1u) && S0 + tj < (1u << 24)) {
+                            sb = (sb & 0xff800000u) | ((S0 + tj) & 0x7fffffu);
+                            ok = true;
+                        }
+                    }
+                    if (!ok) { /* the sum leaves its binade in here (or an element is a tie): 64 additions, in order */
+#ifdef MSD_FM_TIMERS
+                        ++n_seq;
+#endif
+                        const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+                        const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
+                        float sum = __uint_as_float(sb);
+                        sum = fsum_lanes_in_order(sum, x);
+                        sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+                    }
+                }
+                w_blk = next_walk(blk + 1u);
+                if (w_blk < nblk)
+                    fetch(w_blk);
+            } else { /* no sub-block totals (a misprediction, a sum that is still tiny): the whole block sample by sample */
+#ifdef MSD_FM_TIMERS
+                ++n_whole;
+#endif
+                fetch(blk);
+                float sum = __uint_as_float(sb);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+                    const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
+                    sum = fsum_lanes_in_order(sum, x);
+                }
+                sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+                if (w_blk < nblk)
+                    fetch(w_blk); /* the registers held the next walked block's samples */
             }
+#ifdef MSD_FM_TIMERS
+            t_slow += wall_clock64() - t_slow0;
+#endif
         }
+#ifdef MSD_FM_TIMERS
+        if (lane == 0) { /* once, behind the walk: an atomic in it would sit in front of the prefetched loads */
+            atomicAdd(&msd_fm_cyc[4], (unsigned long long)n_slow);
+            atomicAdd(&msd_fm_cyc[7], (unsigned long long)n_seq);
+            atomicAdd(&msd_fm_cyc[8], (unsigned long long)n_whole);
+            atomicAdd(&msd_fm_cyc[9], t_slow);
+        }
+#endif
+        const float sum = __uint_as_float(sb);
         if (lane == 0)
             out[2 * b + wave] = sum;
     }
@@ -1975,12 +2194,13 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means2_kernel(const uint
 #ifdef MSD_FM_TIMERS
 extern "C" void msd_fm_report(void)
 {
-    unsigned long long h[8] = {0};
+    unsigned long long h[10] = {0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(msd_fm_cyc), sizeof h) != hipSuccess || !h[6])
         return;
     const double w = (double)h[6];
-    fprintf(stderr, "float means, mean us per workgroup: pass 1 %.1f, prefix %.1f, pass 2 %.1f, apply %.1f; slow blocks %.2f of %.0f per buffer\n",
-            h[0] / w / 100, h[1] / w / 100, h[2] / w / 100, h[3] / w / 100, h[4] / w, h[5] / w);
+    fprintf(stderr, "float means, mean us per workgroup: pass 1 %.1f, prefix %.1f, pass 2 %.1f, apply %.1f; slow blocks %.2f of %.0f per buffer, "
+            "%.2f of them summed whole, %.2f sub-blocks summed sample by sample; %.1f us of the apply step per wavefront in slow blocks\n",
+            h[0] / w / 100, h[1] / w / 100, h[2] / w / 100, h[3] / w / 100, h[4] / w, h[5] / w, h[8] / w, h[7] / w, h[9] / w / 100 / 2);
 }
 #endif
 
