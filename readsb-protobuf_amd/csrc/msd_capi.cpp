@@ -181,8 +181,6 @@ struct Slot {
      * candidate lists stay in this slot's own region arenas until the batch's records are out, the resolve
      * workgroups read their buffer's region slices, the first resolve pass publishes sums and totals */
     bool lean = false;
-    msd_wire *d_stage_rec = nullptr;           /* [buffer][MSD_RB_MSG_CAP] records as the resolve workgroups leave them ... */
-    unsigned long long *d_stage_side = nullptr; /* ... for the next batch's first resolve pass to copy home (emit_via_resolve) */
     bool power_done = false; /* the batch's signal power kernel has been queued (d_powr, d_rec_off) */
     bool ahead_done = false; /* its resolve passes are through and its filter changes committed (by the msd_collect of
                                 the batch before it); counters and delivery wait for its own msd_collect */
@@ -311,8 +309,6 @@ struct msd_ctx {
     std::vector<double> bg_means;
     std::vector<uint64_t> bg_scaled; /* per message: power sum | signal_len << 48 (msd_emit_impl.h) */
     bool emit_fused = false;
-    bool emit_via_resolve = false; /* in-order layout, Mode S only, no fields: the records travel with the resolve kernels
-                                      (MsdResolveParams.copy), the scan carries nothing (MSD_EMIT_VIA_RESOLVE=0: the scan does) */
     bool power_fused = true; /* no signal power kernel: the resolve workgroups sum it (MSD_POWER_FUSED=0 keeps the kernel) */
     struct Slot *pending_emit = nullptr;
     bool chain_inline = true; /* MSD_CHAIN_INLINE=0: resolve chain on side streams instead of in order on the scan stream */
@@ -569,7 +565,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         p.timers = c->d_timers;
         p.debug_flags = c->debug_flags;
         Slot *carried = nullptr;
-        if (c->pending_emit && c->pending_emit != &s && !c->emit_via_resolve) {
+        if (c->pending_emit && c->pending_emit != &s) {
             Slot &a = *c->pending_emit;
             if (nwg >= a.nbuffers && a.nbuffers) { /* this scan's wavefronts write that batch's records */
                 MsdResolveParams rp{};
@@ -925,10 +921,6 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
         rp.nsamples = sp.nsamples;
         rp.lut = sp.lut;
         rp.format = c->scan_format;
-        if (c->emit_via_resolve) {
-            rp.stage_rec = s.d_stage_rec;
-            rp.stage_side = s.d_stage_side;
-        }
     }
     if (s.lean) {
         rp.hits = s.d_rhits;
@@ -998,19 +990,6 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     rp.batch_samples = s.nsamples;
     rp.h_pred = c->h_pred;
     rp.h_pred_count = c->h_pred_count;
-    Slot *carried = nullptr;
-    if (first_pass && c->emit_via_resolve && ks == c->stream && c->pending_emit && c->pending_emit != &s) {
-        Slot &a = *c->pending_emit; /* its passes are through (this batch's first pass is only queued then) */
-        rp.copy.nbuffers = a.nbuffers;
-        rp.copy.cap = (uint32_t)a.req_cap;
-        rp.copy.totals = a.d_totals;
-        rp.copy.nmsgs = a.d_nmsgs;
-        rp.copy.src_rec = a.d_stage_rec;
-        rp.copy.src_side = a.d_stage_side;
-        rp.copy.dst_rec = a.h_wire;
-        rp.copy.dst_side = a.h_side;
-        carried = &a;
-    }
     if (!first_pass) /* (the first pass finds the table as the batch's scan kernel left it) */
         rc = msd_launch_pred_patch(reinterpret_cast<unsigned long long *>(s.d_pred), c->h_patches, c->npatches, ks);
     if (rc)
@@ -1018,14 +997,6 @@ int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
     rc = msd_launch_resolve(&rp, s.resolve_ntodo, ks);
     if (rc)
         return fail(c, rc, "resolve kernel launch failed");
-    if (carried) {
-        c->pending_emit = nullptr;
-        const hipError_t e = hipEventRecord(carried->ev_records, ks);
-        if (e != hipSuccess) { /* nobody could tell when those records are complete */
-            c->failed = true;
-            return fail(c, -EIO, "hipEventRecord(ev_records) failed: %s", hipGetErrorString(e));
-        }
-    }
     return 0;
 }
 
@@ -1809,7 +1780,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_stage_rec); (void)hipFree(s.d_stage_side); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
+        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_side) (void)hipHostFree(s.h_side);
@@ -2059,11 +2030,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         { const char *pf = getenv("MSD_POWER_FUSED"); c->power_fused = pf && *pf ? *pf != '0' : c->chain_inline; }
         { const char *ra = getenv("MSD_RESOLVE_AHEAD"); c->resolve_ahead = !(ra && *ra == '0'); }
         c->wait_inputs_on_stream = getenv("MSD_WAIT_INPUTS_ON_STREAM") != nullptr;
-        { const char *ev = getenv("MSD_EMIT_VIA_RESOLVE");
-          c->emit_via_resolve = c->emit_fused && c->power_fused && !cfg->mode_ac && ev && *ev == '1'; }
-        /* (not the default: measured -- the scan without its record slice takes 0.153 instead of 0.164 ms, but 512
-         * workgroups posting 2.3 MB of PCIe writes at once stall their own waves, and the stage's reads of the control
-         * arrays in host memory, for as long as the link needs: resolve kernel 82 -> 107 us, whole job 248 -> 230 GS/s) */
         c->helper.device = cfg->device;
         if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
             c->debug_flags = atoi(dbg);
@@ -2105,10 +2071,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_pred), sizeof(uint32_t) * MSD_PRED_WORDS));
             CK(hipMemset(s.d_pred, 0xFF, sizeof(uint32_t) * MSD_PRED_WORDS)); /* every slot vacant (generation 0xff) */
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_powr), sizeof(uint64_t) * MSD_RB_MSG_CAP * c->max_buffers));
-            if (c->emit_via_resolve) {
-                CK(hipMalloc(reinterpret_cast<void **>(&s.d_stage_rec), sizeof(msd_wire) * MSD_RB_MSG_CAP * c->max_buffers));
-                CK(hipMalloc(reinterpret_cast<void **>(&s.d_stage_side), sizeof(unsigned long long) * MSD_RB_MSG_CAP * c->max_buffers));
-            }
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ctl), ctl_bytes));
             memset(s.h_ctl, 0, ctl_bytes);
             CK(hipEventCreateWithFlags(&s.ev_resolve, hipEventDisableTiming));

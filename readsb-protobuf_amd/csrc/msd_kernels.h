@@ -126,21 +126,6 @@ typedef struct MsdResolveParams {
     int have_prev, format;
     uint64_t batch_first, nsamples;
     const uint16_t *lut;
-    /* Message records through the resolve kernels (in-order layout, Mode S only): every workgroup finishes by putting
-     * its buffer's records together in device memory (stage_rec[buffer][MSD_RB_MSG_CAP], stage_side likewise), and
-     * the first pass of the NEXT batch begins by copying the previous batch's (copy.*) into the host arrays -- posted
-     * PCIe writes that drain while the workgroups resolve.  The scan kernel then carries nothing. */
-    msd_wire *stage_rec;
-    unsigned long long *stage_side;
-    struct {
-        uint32_t nbuffers, cap;       /* 0: nothing to copy */
-        const uint64_t *totals;       /* that batch's overflow flag */
-        const uint32_t *nmsgs;        /* [buffer] */
-        const msd_wire *src_rec;      /* its stage_rec / stage_side */
-        const unsigned long long *src_side;
-        msd_wire *dst_rec;            /* pinned host memory: cap dense records */
-        unsigned long long *dst_side;
-    } copy;
 } MsdResolveParams;
 
 #ifdef __cplusplus

@@ -377,37 +377,6 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
             }
         }
     }
-    if (P.first_pass && P.copy.nbuffers) {
-        /* the previous batch's message records, device memory -> the host's dense arrays: workgroup j takes buffer j;
-         * the stores are posted and drain while this workgroup resolves its own buffer */
-        for (uint32_t j = blockIdx.x; j < P.copy.nbuffers; j += gridDim.x) {
-            uint32_t mine = 0;
-            for (uint32_t i = tid; i < j; i += RT)
-                mine += P.copy.nmsgs[i];
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1)
-                mine += __shfl_down(mine, d, 64);
-            __syncthreads();
-            if ((tid & 63) == 0)
-                sh_wsum[tid >> 6] = mine;
-            __syncthreads();
-            uint32_t o = 0;
-            for (int w = 0; w < RT / 64; ++w)
-                o += sh_wsum[w];
-            const uint32_t nm = P.copy.nmsgs[j];
-            if (!P.copy.totals[2] && o < P.copy.cap) {
-                const uint32_t n = min(nm, P.copy.cap - o);
-                constexpr uint32_t W = sizeof(msd_wire) / 8;
-                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(P.copy.src_rec + (size_t)j * MSD_RB_MSG_CAP);
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(P.copy.dst_rec + o);
-                for (uint32_t w = tid; w < n * W; w += RT)
-                    __builtin_nontemporal_store(src[w], &dst[w]);
-                for (uint32_t w = tid; w < n; w += RT)
-                    __builtin_nontemporal_store(P.copy.src_side[(size_t)j * MSD_RB_MSG_CAP + w], &P.copy.dst_side[o + w]);
-            }
-        }
-        __syncthreads();
-    }
     if (ovf || ac_ovf)
         return; /* the candidate arenas overflowed: the host rescans the batch in pieces */
     if (blockIdx.x == 0 && P.first_pass) { /* the prediction list of the batch, for the host's replay */
@@ -1221,17 +1190,6 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
         case MSD_FMT_SC16: power_of_accepted<MSD_FMT_SC16>(P, acc, nm, out, tid); break;
         case MSD_FMT_SC16Q11: power_of_accepted<MSD_FMT_SC16Q11>(P, acc, nm, out, tid); break;
         default: power_of_accepted<MSD_FMT_MAG16>(P, acc, nm, out, tid); break;
-        }
-        if (P.stage_rec) { /* ... and the buffer's message records, for the next batch's first pass to send home */
-            __syncthreads();
-            const uint64_t sample_ts = sample_ts_b;
-            for (uint32_t m = tid; m < nm; m += RT) {
-                unsigned long long side;
-                msd_wire w;
-                w.mm = msd_emit_mode_s(acc[m], P.tries, out[m], sample_ts, sys_ts, (uint32_t)base, side);
-                P.stage_rec[(size_t)b * MSD_RB_MSG_CAP + m] = w;
-                P.stage_side[(size_t)b * MSD_RB_MSG_CAP + m] = side;
-            }
         }
         PHASE(6)
     }

@@ -74,7 +74,7 @@ for f in "" "--fix 1" "--fix 2" "--fields" "--mode-ac --fix 1" "--format sc16 --
   echo -n "bench.py $f : " >> $O/configs.txt
   python bench.py --no-cpu-baseline --check $f 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'msgs', d['messages_per_step'], 'diff', d.get('message_set_diff_vs_oracle'))" >> $O/configs.txt
 done
-for e in "MSD_EMIT_FUSED=0" "MSD_LEAN=0" "MSD_RESOLVE_AHEAD=0" "MSD_POWER_FUSED=0" "MSD_EMIT_VIA_RESOLVE=1" "MSD_WAIT_INPUTS_ON_STREAM=1" "MSD_CHAIN_INLINE=0" "MSD_LEAN=0 MSD_RESOLVE_AHEAD=0 MSD_POWER_FUSED=0 MSD_WAIT_INPUTS_ON_STREAM=1"; do
+for e in "MSD_EMIT_FUSED=0" "MSD_LEAN=0" "MSD_RESOLVE_AHEAD=0" "MSD_POWER_FUSED=0" "MSD_WAIT_INPUTS_ON_STREAM=1" "MSD_CHAIN_INLINE=0" "MSD_LEAN=0 MSD_RESOLVE_AHEAD=0 MSD_POWER_FUSED=0 MSD_WAIT_INPUTS_ON_STREAM=1"; do
   echo -n "$e : " >> $O/configs.txt; env $e python bench.py --no-cpu-baseline --no-check 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'])" >> $O/configs.txt
 done
 python scripts/pcie_rate.py >> $O/configs.txt 2>&1
