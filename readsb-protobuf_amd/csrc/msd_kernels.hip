@@ -572,42 +572,56 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     wave_lds_sync();
 
     /* ---- step D: lane = hit ---- */
-    uint32_t nlive = 0;
-    if ((uint32_t)lane < nh) {
+    uint32_t u5[5], nlive = 0;
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
-            nlive += sidx[lane * 8 + q] != 0xffffu ? 1u : 0u;
+    for (int q = 0; q < 5; ++q) {
+        u5[q] = (uint32_t)lane < nh ? (uint32_t)sidx[lane * 8 + q] : 0xffffu;
+        nlive += u5[q] != 0xffffu ? 1u : 0u;
     }
     const uint32_t lincl = wave_incl_scan(nlive);
-    if ((uint32_t)lane < nh) {
+    const uint32_t ntry_round = wave_last(lincl);
+    if ((uint32_t)lane < nh && (uint32_t)lane < hits_room) {
         const uint32_t pos = my_hit & 0x1fffu;
-        uint32_t idx = tcur + lincl - nlive;
-        if ((uint32_t)lane < hits_room) {
-            msd_hit rec = (tile_pos0 + pos) | ((msd_hit)my_m << 28) | ((msd_hit)nlive << 31);
-            if (nlive)
-                rec |= (msd_hit)(try_base + idx) << 34;
-            MSD_ARENA_STORE(rec, &hit_out[lane]);
-        }
+        msd_hit rec = (tile_pos0 + pos) | ((msd_hit)my_m << 28) | ((msd_hit)nlive << 31);
+        if (nlive)
+            rec |= (msd_hit)(try_base + tcur + lincl - nlive) << 34;
+        hit_out[lane] = rec; /* 8 bytes a lane, a few lanes a round: left to the L2 to merge (non-temporal, every round's ragged ends went to memory on their own) */
+    }
+    /* The round's tries in output order (slot of the candidate scratch | owning lane << 9), in the index array every
+     * lane has just read its row of; then two lanes per record write its two 16-byte halves, so that one store
+     * instruction covers 1 KB of consecutive addresses -- whole lines, which is what a non-temporal store wants (a
+     * lane per record, half by half, sent every 32-byte sector to memory twice). */
+    wave_lds_sync();
+    {
+        uint32_t k = lincl - nlive;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const uint32_t u = sidx[lane * 8 + q];
-            if (u != 0xffffu) {
-                if (idx < P.tcap) {
-                    uint4 *dst = reinterpret_cast<uint4 *>(my_tries + idx);
-                    const uint4 m16 = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
-                    arena_store16(m16, &dst[0]);
-                    const uint32_t cw = sres[2 * u + 1];
-                    /* the last word repeats the first byte (DF), the trial phase and the first corrected bit beside the
-                     * second one: the resolve kernel reads this half of the record only */
-                    arena_store16(make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos),
-                                             (cw >> 24) | ((m16.x & 0xffu) << 8) | (m16.w & 0xffff0000u)),
-                                  &dst[1]);
-                }
-                ++idx;
+        for (int q = 0; q < 5; ++q)
+            if (u5[q] != 0xffffu)
+                sidx[k++] = (uint16_t)(u5[q] | ((uint32_t)lane << 9));
+    }
+    wave_lds_sync();
+    for (uint32_t e0 = 0; e0 < ntry_round; e0 += 32u) { /* wave-uniform */
+        const uint32_t e = e0 + ((uint32_t)lane >> 1);
+        const bool mine = e < ntry_round && tcur + e < P.tcap;
+        const uint32_t ent = mine ? (uint32_t)sidx[e] : 0u;
+        const uint32_t u = ent & 0x1ffu;
+        const uint32_t pos = (uint32_t)__shfl((int)(my_hit & 0x1fffu), (int)(ent >> 9), 64);
+        if (mine) {
+            uint4 *dst = reinterpret_cast<uint4 *>(my_tries + tcur + e);
+            const uint4 m16 = *reinterpret_cast<const uint4 *>(smsg32 + 4u * u);
+            if (!(lane & 1)) {
+                arena_store16(m16, &dst[0]);
+            } else {
+                const uint32_t cw = sres[2 * u + 1];
+                /* the last word repeats the first byte (DF), the trial phase and the first corrected bit beside the
+                 * second one: the resolve kernel reads this half of the record only */
+                arena_store16(make_uint4(sres[2 * u], cw & 0xffffffu, (uint32_t)(tile_pos0 + pos),
+                                         (cw >> 24) | ((m16.x & 0xffu) << 8) | (m16.w & 0xffff0000u)),
+                              &dst[1]);
             }
         }
     }
-    tcur += wave_last(lincl);
+    tcur += ntry_round;
     wave_lds_sync();
     return true;
 }
