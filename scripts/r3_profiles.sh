@@ -7,7 +7,7 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 
 kstats() { # <name> <bench args...>: rocprofv3 --kernel-trace --stats summary + the scan kernel's first dispatches
   local name=$1; shift
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $O/${name}_bench_under_profiler.json 2> $O/${name}_rocprof.log)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --settle-seconds 0 --no-cpu-baseline "$@" > $O/${name}_bench_under_profiler.json 2> $O/${name}_rocprof.log)
   for f in $(find $O/trace_$name -name "*kernel_stats.csv"); do cp $f $O/${name}_kernel_stats.csv; done
   for f in $(find $O/trace_$name -name "*kernel_trace.csv"); do head -1 $f > $O/${name}_scan_kernel_trace_head.csv; grep msd_scan $f | head -12 >> $O/${name}_scan_kernel_trace_head.csv; done
   rm -rf $O/trace_$name $O/${name}_rocprof.log
@@ -19,7 +19,7 @@ kstats modeac --mode-ac --fix 1
 traffic() { # <name> <bench args...>: FETCH_SIZE / WRITE_SIZE of the scan kernel, separate --pmc passes, no trace domains
   local name=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-check --batch $((1<<26)) "$@" > $O/pmc_$name/$ctr.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --batch $((1<<26)) "$@" > $O/pmc_$name/$ctr.log 2>&1)
   done
   python3 - $O/pmc_$name $O/${name}_traffic.json "$*" <<'PY'
 import csv, glob, json, sys, collections
@@ -67,7 +67,7 @@ for cfg in "uc8:" "sc16:--format sc16 --samples 268435456" "modeac:--mode-ac --f
   name=${cfg%%:*}; args=${cfg#*:}
   BACK=6 ROWS=40 bash scripts/r3_timeline.sh r03_tl_$name $args > /dev/null 2>&1; cp gpurun_out/r03_tl_$name/timeline.txt $O/${name}_timeline.txt
 done
-MSD_RESOLVE_TRACE=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2> $O/host_trace.txt > /dev/null
+MSD_RESOLVE_TRACE=1 python bench.py --steps 2 --warmup 1 --settle-seconds 0 --no-cpu-baseline 2> $O/host_trace.txt > /dev/null
 
 : > $O/configs.txt
 for f in "" "--fix 1" "--fix 2" "--fields" "--mode-ac --fix 1" "--format sc16 --samples 268435456" "--format sc16q11 --samples 268435456" "--format sc16 --samples 268435456 --mode-ac --fix 1"; do
