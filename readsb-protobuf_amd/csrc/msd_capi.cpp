@@ -219,6 +219,9 @@ struct Slot {
     uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
     bool buf_first_valid = false;
     uint64_t *d_sums = nullptr;
+    uint16_t *d_mag = nullptr;        /* Mode A/C: the batch's magnitudes as the scan computed them (MsdScanParams.mag_out) */
+    const uint16_t *d_mag_prev = nullptr; /* ... and the last MSD_HALO_FRONT of the batch before, in that batch's own array */
+    bool mag_pass = false;            /* this batch's Mode A/C candidate kernel reads d_mag */
     float *d_fmeans = nullptr;
     /* pinned host */
     uint64_t *h_totals = nullptr;
@@ -298,6 +301,7 @@ struct msd_ctx {
     bool finished = false;
     uint64_t pending_dropped = 0; /* msd_note_dropped() since the last launch */
     bool restart_pending = false; /* msd_restart() since the last launch */
+    const uint16_t *mag_prev = nullptr; /* Mode A/C: where the previous batch's last magnitudes are (its slot's d_mag) */
     uint32_t timing_interval = 1; /* msd_set_timing_interval() */
     /* experiment knobs, read from the environment once in msd_create */
     bool trace = false;      /* MSD_RESOLVE_TRACE */
@@ -561,6 +565,8 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
             s.lean_nreg = nwg;
         }
         p.chunk_sums = s.d_sums;
+        s.mag_pass = c->cfg.mode_ac && s.d_mag && pipelined && nwg && !host_noise;
+        p.mag_out = s.mag_pass ? s.d_mag : nullptr;
         p.tile_sums = (fm && !s.dc && tile == 1024) ? s.d_tile_sums : nullptr;
         p.timers = c->d_timers;
         p.debug_flags = c->debug_flags;
@@ -653,8 +659,16 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         MsdScanParams p{};
         fill_params(c, s, p);
         p.debug_flags = c->debug_flags;
-        int rc = msd_launch_ac(&p, format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
-                               host_noise != nullptr ? 1 : (s.dc ? 2 : 0),
+        int ac_format = format;
+        if (s.mag_pass) { /* the scan in front left the magnitudes: nothing is converted twice */
+            ac_format = MSD_FMT_MAG16;
+            p.iq = reinterpret_cast<const uint8_t *>(s.d_mag);
+            p.prev_tail = reinterpret_cast<const uint8_t *>(s.d_mag_prev);
+            p.have_prev = s.have_prev && s.d_mag_prev;
+            p.ragged = reinterpret_cast<const uint8_t *>(s.d_mag + (s.nsamples & ~7ull)); /* zeros behind the last sample */
+        }
+        int rc = msd_launch_ac(&p, ac_format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
+                               host_noise != nullptr ? 1 : ((s.dc || (s.mag_pass && fm)) ? 2 : 0), /* (16-bit IQ: the float sums, whatever the pass reads) */
                                c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
                                c->ac_arena, c->ac_max_wg, c->stream);
         if (rc)
@@ -1649,6 +1663,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.d_iq = static_cast<const uint8_t *>(d_iq);
     s.d_prev = c->d_tail[c->tail_cur];
     s.have_prev = c->have_prev ? 1 : 0;
+    s.d_mag_prev = c->mag_prev;
     s.batch_first = c->next_sample;
     s.nsamples = nsamples;
     s.last = last;
@@ -1710,6 +1725,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         s.tail_dst = nullptr;
         c->tail_cur = tail_nxt;
         c->have_prev = true;
+        c->mag_prev = s.mag_pass ? s.d_mag + (nsamples - TAIL_SAMPLES) : nullptr;
     }
     c->next_sample += nsamples;
     c->outstanding++;
@@ -1779,7 +1795,7 @@ void destroy(msd_ctx *c)
         (void)hipFree(s.d_req); (void)hipFree(s.d_pow);
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
-        (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_ragged);
+        (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_mag); (void)hipFree(s.d_ragged);
         (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
@@ -1987,6 +2003,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
         if (cfg->mode_ac) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac), c->ac_arena * sizeof(msd_ac_hit)));
+            if (!c->dc && cfg->format != MSD_FMT_MAG16) /* (those scan magnitudes already) */
+                CK(hipMalloc(reinterpret_cast<void **>(&s.d_mag), (cfg->max_batch_samples + 4096) * sizeof(uint16_t)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac_totals), 4 * sizeof(uint64_t)));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ac_totals), 4 * sizeof(uint64_t)));
         }

@@ -38,6 +38,8 @@ typedef struct MsdScanParams {
     const uint8_t *iq;        /* first sample of this batch (16-byte aligned) */
     const uint8_t *prev_tail; /* the MSD_HALO_FRONT samples before it */
     const uint8_t *ragged;    /* 32 readable bytes holding the last nsamples % 8 samples, zero padded */
+    uint16_t *mag_out;        /* or NULL: the batch's magnitudes, sample by sample (zero where there is none), for the Mode A/C
+                                 candidate kernel behind the scan -- which then converts nothing a second time */
     int have_prev;            /* 0: start of stream or discontinuity -> zero magnitudes (fifo.c:180) */
     int threshold;            /* Modes.preambleThreshold */
     uint64_t batch_first;     /* absolute index of iq[0]; multiple of MSD_CHUNK_SAMPLES */

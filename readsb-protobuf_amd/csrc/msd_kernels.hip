@@ -759,6 +759,8 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             mask_group(cur_valid[k], mg);
             const uint4 packed = pack8(mg);
             *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) = packed;
+            if (P.mag_out) /* wave-uniform: Mode A/C is on, its candidate kernel reads these instead of the IQ */
+                arena_store16(packed, reinterpret_cast<uint4 *>(P.mag_out + tile_pos0 + 8u * (uint32_t)(lane + 64 * k)));
             const uint32_t pk[4] = {packed.x, packed.y, packed.z, packed.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { /* two magnitudes per instruction */
