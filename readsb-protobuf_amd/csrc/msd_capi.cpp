@@ -746,6 +746,8 @@ int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
             t.d_fmeans = s.d_fmeans + 2 * b0;
             t.h_sums = s.h_sums + 2 * b0;
             t.h_fmeans = s.h_fmeans + 2 * b0;
+            t.mag_pass = false; /* the pieces' Mode A/C passes convert the IQ themselves */
+            t.d_mag = nullptr;
             int rc = enqueue(c, t, format, nullptr);
             if (rc)
                 return rc;
