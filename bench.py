@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle-seconds", type=float, default=10.0,
                     help="untimed passes over the capture before the warm-up steps until their time has settled, at most this long")
     ap.add_argument("--samples", type=int, default=1 << 29, help="samples per capture (1 GiB UC8 = 2^29)")

@@ -81,7 +81,7 @@ struct Helper {
         (void)hipSetDevice(device);
         uint64_t taken = 0;
         for (;;) {
-            (void)spin_for([&] { return posted.load(std::memory_order_acquire) > taken; }, 500);
+            (void)spin_for([&] { return posted.load(std::memory_order_acquire) > taken; }, 2000);
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !jobs.empty() || stop; });
             if (jobs.empty())
@@ -116,7 +116,7 @@ struct Helper {
     void wait_delivered() /* the last job posted has passed its delivery point */
     {
         const uint64_t want = posted.load(std::memory_order_acquire);
-        if (spin_for([&] { return delivered.load(std::memory_order_acquire) >= want; }, 400))
+        if (spin_for([&] { return delivered.load(std::memory_order_acquire) >= want; }, 2000))
             return;
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return delivered.load(std::memory_order_acquire) >= want; });
@@ -142,11 +142,12 @@ struct Helper {
     }
 };
 
-/* hipEventSynchronize for events that are about to fire: poll for a few hundred microseconds first (the runtime's
- * wait may put the thread to sleep, and on a busy host it then comes back late) */
+/* hipEventSynchronize for events that are about to fire: poll for two milliseconds first -- eight batch periods; the
+ * runtime's wait may put the thread to sleep, and on a busy host it then comes back late, which the in-order chain
+ * feels at once (the next resolve pass can only be queued when this one has reported) */
 static hipError_t event_wait(hipEvent_t ev)
 {
-    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady)
