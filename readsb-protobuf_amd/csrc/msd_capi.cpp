@@ -1389,11 +1389,15 @@ int finish_gpu(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user)
                 begin_rc = arc;
             } else if (arc == 0) {
                 const GpuCtl gn = gpu_ctl(c, nx);
+                const auto a0 = tnow();
                 msd_gpu_resolve_commit_state(&c->resolver, nx.nbuffers, gn.h_valid, nx.h_rbuf);
                 nx.ahead_done = true;
                 nx.resolve_inflight = false;
+                const auto a1 = tnow();
                 if (c->outstanding > 2)
                     begin_rc = begin_successor(c, nx);
+                if (trace)
+                    fprintf(stderr, "ahead: commit %.3f ms, the batch behind it begun in %.3f ms\n", tms(a0, a1), tms(a1, tnow()));
             } else { /* the host resolver's case or an overflow: nothing is committed, that batch's msd_collect acts on it */
                 nx.ahead_verdict = arc;
             }
