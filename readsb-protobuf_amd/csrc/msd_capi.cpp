@@ -972,7 +972,6 @@ uint32_t slot_valid(const Slot &s, uint32_t b)
  * with a scan -- and the kernel waits for them through an event. */
 int gpu_queue_pass(msd_ctx *c, Slot &s, hipStream_t ks, bool first_pass)
 {
-    const GpuCtl g = gpu_ctl(c, s);
     const uint32_t nsn = msd_gpu_resolve_nsnaps(&c->resolver);
     for (uint32_t i = c->snaps_uploaded; i < nsn; ++i) {
         uint32_t *stage = c->h_snaps + (size_t)i * MSD_SNAP_WORDS;
