@@ -96,7 +96,7 @@ def run_also(extra):
     """One of the other BASELINE workloads through this same script in a process of its own, after the clock stopped:
     its bench line, cut down to what the `also` block reports."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--check", "--no-also"] + extra
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--check", "--no-also"] + extra
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         d = json.loads(res.stdout.strip().splitlines()[-1])
