@@ -2738,14 +2738,40 @@ __global__ void __launch_bounds__(ACNT, 6) msd_ac_kernel(const MsdScanParams P, 
     }
 }
 
-/* dense[offset[w] + i] = region[w][i] for the Mode A/C list (offsets from msd_offsets_kernel) */
-__global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts *counts, const uint64_t *offsets,
+/* dense[offset[w] + i] = region[w][i] for the Mode A/C list.  Every workgroup adds up the counts in front of its own
+ * (a thousand loads: cheaper than the single-workgroup offsets kernel and the launch gap it used to wait behind), and
+ * the last one, which has seen them all, leaves the batch's totals. */
+__global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts *counts, uint32_t nwg,
                                                             const msd_ac_hit *regions, uint32_t cap,
-                                                            msd_ac_hit *dense, uint64_t dense_cap)
+                                                            msd_ac_hit *dense, uint64_t dense_cap, uint64_t *totals /* [4] */)
 {
+    __shared__ unsigned long long part[4];
+    __shared__ uint32_t ovf_any;
     const uint32_t w = blockIdx.x;
+    if (threadIdx.x == 0)
+        ovf_any = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    uint32_t ovf = 0;
+    for (uint32_t i = threadIdx.x; i < w; i += 256) {
+        mine += counts[i].nhits;
+        ovf |= counts[i].overflow;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = mine;
+    if (ovf)
+        atomicOr(&ovf_any, 1u);
+    __syncthreads();
+    const uint64_t o = part[0] + part[1] + part[2] + part[3];
+    if (w == nwg - 1 && threadIdx.x == 0) {
+        totals[0] = o + counts[w].nhits;
+        totals[1] = 0;
+        totals[2] = (ovf_any || counts[w].overflow) ? 1u : 0u;
+    }
     const uint32_t n = counts[w].nhits < cap ? counts[w].nhits : cap;
-    const uint64_t o = offsets[2 * w];
     const uint4 *src = reinterpret_cast<const uint4 *>(regions + (size_t)w * cap);
     uint4 *dst = reinterpret_cast<uint4 *>(dense);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
@@ -2915,10 +2941,9 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     default:
         return -22;
     }
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(256), 0, stream, d_counts, nwg, d_offsets, d_totals,
-                       (uint64_t *)nullptr, 0u, (uint64_t *)nullptr, (uint64_t *)nullptr);
-    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nwg), dim3(256), 0, stream, d_counts, d_offsets, d_regions,
-                       (uint32_t)cap, d_dense, dense_cap);
+    (void)d_offsets;
+    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nwg), dim3(256), 0, stream, d_counts, nwg, d_regions, (uint32_t)cap, d_dense,
+                       dense_cap, d_totals);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
