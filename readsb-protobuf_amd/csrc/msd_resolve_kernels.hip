@@ -48,6 +48,31 @@ __device__ __forceinline__ uint32_t uni(uint32_t x)
 {
     return __builtin_amdgcn_readfirstlane(x);
 }
+/* inclusive prefix sum over the wavefront (lane L: lanes 0..L; lane 63: the total): six DPP additions (row_shr 1, 2, 4,
+ * 8, row_bcast 15 and 31) -- no LDS round trips, where a __shfl_up / __shfl_down ladder is six ds_bpermute, each waited
+ * for */
+__device__ __forceinline__ uint32_t wave_total_in_63(uint32_t v)
+{
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_max_in_63(uint32_t v) /* the same ladder with max (a running maximum): missing lanes read 0 */
+{
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
 __device__ __forceinline__ uint64_t uni(uint64_t x)
 {
     return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32);
@@ -286,13 +311,10 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
                 lo += sq & 0xffffu;
                 hi += sq >> 16;
             }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                lo += __shfl_down(lo, d, 64);
-                hi += __shfl_down(hi, d, 64);
-            }
+            lo = wave_total_in_63(lo);
+            hi = wave_total_in_63(hi);
             const uint32_t m = m0 + u * NW;
-            if (lane == 0 && m < nm)
+            if (lane == 63 && m < nm)
                 out[m] = (unsigned long long)lo + ((unsigned long long)hi << 16);
         }
     }
@@ -434,13 +456,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
             uint32_t c = 0;
             if ((uint32_t)tid < k && b * k + (uint32_t)tid < P.nregions)
                 c = min(P.region_counts[(size_t)b * k + tid].nhits, P.hcap);
-            uint32_t incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 64);
-                if (tid >= d)
-                    incl += up;
-            }
+            const uint32_t incl = wave_total_in_63(c);
             sh_rpre[tid] = incl - c; /* hits in the buffer's earlier regions */
             if (tid == 63) {
                 sh_range[0] = 0;
@@ -530,13 +546,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
             const uint32_t nl = v < he ? MSD_HIT_NLIVE(keep[c]) : 0u;
             const uint64_t bal = __ballot(nl != 0);
             const uint32_t lrank = (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-            uint32_t incl = nl;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 64);
-                if ((tid & 63) >= d)
-                    incl += up;
-            }
+            const uint32_t incl = wave_total_in_63(nl);
             place[c] = lrank | ((incl - nl) << 8); /* rank among the wavefront's hits with tries | its earlier lanes' tries */
             if ((tid & 63) == 63)
                 sh_cw[c][tid >> 6] = (uint32_t)__popcll(bal) | (incl << 16);
@@ -554,11 +564,13 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
         {
             const uint32_t x = (tid & 63) < MAXC * 8 ? (&sh_cw[0][0])[tid & 63] : 0u;
             uint32_t incl = x;
-#pragma unroll
-            for (int d = 1; d < 8; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 8);
-                if ((tid & 7) >= d)
-                    incl += up;
+            {
+                const uint32_t u1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+                incl += (tid & 7) >= 1 ? u1 : 0u;
+                const uint32_t u2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+                incl += (tid & 7) >= 2 ? u2 : 0u;
+                const uint32_t u4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+                incl += (tid & 7) >= 4 ? u4 : 0u;
             }
             cw_incl = incl;
             cw_excl = incl - x;
@@ -741,12 +753,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     m = 0;
                 uint32_t incl = (uint32_t)__popc(m);
                 const uint32_t cnt = incl;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d, 64);
-                    if (tid >= d)
-                        incl += up;
-                }
+                incl = wave_total_in_63(cnt);
                 uint32_t k = incl - cnt;
                 while (m) {
                     const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(m);
@@ -1011,13 +1018,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     }
                     mine += (a_is[q] ? 1u : 0u) + (a_short[q] ? 0x10000u : 0u);
                 }
-                uint32_t incl = mine;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d, 64);
-                    if ((tid & 63) >= d)
-                        incl += up;
-                }
+                const uint32_t incl = wave_total_in_63(mine);
                 if ((tid & 63) == 63)
                     sh_wsum[tid >> 6] = incl;
                 __syncthreads();
@@ -1057,13 +1058,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     run = x > run ? x : run;
                     f[k] = run;
                 }
-                uint32_t incl = run;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d, 64);
-                    if ((tid & 63) >= d)
-                        incl = up > incl ? up : incl;
-                }
+                const uint32_t incl = wave_max_in_63(run);
                 if ((tid & 63) == 63)
                     sh_wsum[tid >> 6] = incl;
                 uint32_t pre = __shfl_up(incl, 1, 64);
@@ -1109,15 +1104,11 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     last = i + 1; /* reached decodeModesMessage: it set Modes.ifile_now first */
             }
             { /* six counters of at most 4 per lane, packed ten bits apart, summed over the wavefront */
-                uint64_t pk = (uint64_t)c_pre | ((uint64_t)c_bad << 10) | ((uint64_t)c_unk << 20) | ((uint64_t)c_p01 << 30) |
-                              ((uint64_t)c_p23 << 40) | ((uint64_t)c_p4 << 50);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    pk += __shfl_down(pk, o, 64);
-                    const uint32_t l2 = __shfl_down(last, o, 64);
-                    last = l2 > last ? l2 : last;
-                }
-                if ((tid & 63) == 0 && pk) {
+                const uint32_t pk_lo = wave_total_in_63(c_pre | (c_bad << 10) | (c_unk << 20));
+                const uint32_t pk_hi = wave_total_in_63(c_p01 | (c_p23 << 10) | (c_p4 << 20));
+                const uint64_t pk = (uint64_t)pk_lo | ((uint64_t)pk_hi << 30);
+                last = wave_max_in_63(last);
+                if ((tid & 63) == 63 && pk) {
                     atomicAdd(&sh_ctr[0], (uint32_t)pk & 1023u);
                     atomicAdd(&sh_ctr[1], (uint32_t)(pk >> 10) & 1023u);
                     atomicAdd(&sh_ctr[2], (uint32_t)(pk >> 20) & 1023u);
@@ -1160,14 +1151,11 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                 d_p4 += (mask >> 2) & 1u;
             }
             /* every hit without a try that counted is a "bad" rejection (score -2) */
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                d_pre += __shfl_down(d_pre, o, 64);
-                d_p01 += __shfl_down(d_p01, o, 64);
-                d_p23 += __shfl_down(d_p23, o, 64);
-                d_p4 += __shfl_down(d_p4, o, 64);
-            }
-            if ((tid & 63) == 0 && d_pre) {
+            d_pre = wave_total_in_63(d_pre);
+            d_p01 = wave_total_in_63(d_p01);
+            d_p23 = wave_total_in_63(d_p23);
+            d_p4 = wave_total_in_63(d_p4);
+            if ((tid & 63) == 63 && d_pre) {
                 atomicAdd(&sh_ctr[0], d_pre);
                 atomicAdd(&sh_ctr[1], d_pre);
                 atomicAdd(&sh_ctr[6], d_p01);
