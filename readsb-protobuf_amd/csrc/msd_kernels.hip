@@ -677,12 +677,12 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                 }
             }
         } else if (P.chunk_sums) {
-            unsigned long long sl = sum_level, sp = power_sum(pw_mod, pw_top);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                sl += __shfl_down(sl, o);
-                sp += __shfl_down(sp, o);
-            }
+            /* at most 256 samples per lane: the level sums fit 24 bits, the power sums 41 -- three DPP ladders instead of
+             * two 64-bit shuffle ladders through the LDS */
+            const unsigned long long spl = power_sum(pw_mod, pw_top);
+            const unsigned long long sl = wave_last(wave_incl_scan((uint32_t)sum_level));
+            const unsigned long long sp = (unsigned long long)wave_last(wave_incl_scan((uint32_t)spl & 0xffffffu)) +
+                                          ((unsigned long long)wave_last(wave_incl_scan((uint32_t)(spl >> 24))) << 24);
             if (lane == 0 && (sl | sp)) {
                 atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk]), sl);
                 atomicAdd(reinterpret_cast<unsigned long long *>(&P.chunk_sums[2 * sum_chunk + 1]), sp);
