@@ -189,7 +189,11 @@ constexpr uint32_t TCAP = SEG + 3 * SEG / 10; /* tries staged per segment; a seg
 constexpr int MAXC = 5; /* a segment is made from at most MAXC x RT hits of the list */
 constexpr uint32_t FCAP = 64;     /* new aircraft handled per round of a segment */
 constexpr uint32_t ADDSET = 2048; /* > 2 x the 970 messages a buffer can hold */
-constexpr uint32_t SPEC = 256;    /* new aircraft of one buffer followed speculatively (the rest go the slow way) */
+#ifndef MSD_RESOLVE_SPEC
+#define MSD_RESOLVE_SPEC 256 /* a power of two <= 256; the tests also run with 8 (table-full paths) */
+#endif
+constexpr uint32_t SPEC = MSD_RESOLVE_SPEC; /* new aircraft of one buffer followed speculatively (the rest go the slow way) */
+static_assert(SPEC >= 2 && SPEC <= 256 && (SPEC & (SPEC - 1)) == 0, "hash is eight bits");
 
 __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr)
 {
@@ -206,7 +210,7 @@ __device__ __forceinline__ bool addset_has(const uint32_t *addset, uint32_t addr
 
 __device__ __forceinline__ int spec_find(const uint32_t *key, uint32_t addr)
 {
-    uint32_t h = (addr * 2654435761u) >> 24;
+    uint32_t h = ((addr * 2654435761u) >> 24) & (SPEC - 1);
     for (uint32_t probes = 0; probes < SPEC; ++probes) {
         const uint32_t k = key[h];
         if (k == addr)
@@ -659,7 +663,7 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                         if (!known && (v.w3 >> 24) == 0xffu && (df == 17 || (df == 11 && (v.crc & 0x7fu) == 0))) {
                             /* this message would add the address (mode_s.c:717-726): note the first one per address */
                             const uint32_t at = (uint32_t)(MSD_HIT_POS(seg_hits[seg_thit[t]]) - base);
-                            uint32_t h = (v.addr * 2654435761u) >> 24;
+                            uint32_t h = ((v.addr * 2654435761u) >> 24) & (SPEC - 1);
                             for (uint32_t probes = 0; probes < SPEC; ++probes) {
                                 const uint32_t old = atomicCAS(&spec_key[h], VACANT, v.addr);
                                 if (old == VACANT || old == v.addr) {
