@@ -823,6 +823,12 @@ __global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolvePara
                     for (uint64_t fp = passed & fresh; fp; fp &= fp - 1) { /* in order */
                         const uint32_t bit = (uint32_t)__builtin_ctzll(fp), kk = w0 + bit;
                         const uint32_t i = uni((uint32_t)ok_idx[kk]);
+                        { /* the message the probation table is waiting for: every later try of its address was staged as
+                           * known already (and the ones under the message are hidden), nothing is left to look for */
+                            const int e = spec_find(spec_key, uni((uint32_t)(seg_res[i] >> 40)));
+                            if (e >= 0 && uni(spec_val[e] >> 1) == uni(ok_pos[kk]))
+                                continue;
+                        }
                         if (nf == FCAP) { /* more new aircraft than the check handles at once: stop in front of this one */
                             next = i;
                             passed &= (1ull << bit) - 1ull;
