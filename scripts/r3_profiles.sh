@@ -19,7 +19,7 @@ kstats modeac --mode-ac --fix 1
 traffic() { # <name> <bench args...>: FETCH_SIZE / WRITE_SIZE of the scan kernel, separate --pmc passes, no trace domains
   local name=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --batch $((1<<26)) "$@" > $O/pmc_$name/$ctr.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$name/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check "$@" > $O/pmc_$name/$ctr.log 2>&1)
   done
   python3 - $O/pmc_$name $O/${name}_traffic.json "$*" <<'PY'
 import csv, glob, json, sys, collections
@@ -47,7 +47,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             res[ctr + "_KB_per_launch" + suffix] = v[len(v) // 2]
             res[ctr + "_launches" + suffix] = len(v)
     res[ctr + "_KB_per_launch_other_kernels"] = {k: sorted(d.values())[len(d) // 2] for k, d in other.items()}
-res["samples_per_launch"] = 1 << 26
+line = [l for l in open(f"{src}/FETCH_SIZE.log") if l.startswith("{")][-1]
+res["samples_per_launch"] = json.loads(line)["config"]["batch_samples"]  # the bench's own batch size in that run
 res["note"] = ("rocprofv3 --pmc, median over launches of msd_scan_kernel with the record slice (_scan_only: the launches without); "
                "gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads (MI355X_MICROARCH.md), so fetch bytes = 2 * FETCH_SIZE * 1024")
 json.dump(res, open(dst, "w"), indent=1)

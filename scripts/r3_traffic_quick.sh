@@ -2,7 +2,7 @@
 # FETCH_SIZE / WRITE_SIZE of the UC8 scan kernel (separate --pmc passes), median over launches
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/tq; rm -rf $O; mkdir -p $O
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --no-also --batch $((1<<26)) "$@" > $O/$ctr.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $ctr --output-format csv -d $O/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --no-also "$@" > $O/$ctr.log 2>&1)
   python3 - $O/$ctr $ctr <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
