@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--no-also", action="store_true",
                     help="skip the post-clock runs of BASELINE configs[2] and [4] that the default N=1 run appends ('also')")
     ap.add_argument("--no-pin", action="store_true", help="leave the process's CPU affinity alone")
-    ap.add_argument("--timing-interval", type=int, default=4,
-                    help="record the kernel timing events on one launch in N (msd_set_timing_interval)")
+    ap.add_argument("--timing-interval", type=int, default=3,
+                    help="record the kernel timing events on one launch in N (msd_set_timing_interval); 3 is coprime "
+                         "to the four batches of a pass, so the timed launch rotates over all of them")
     return ap.parse_args()
 
 
@@ -175,11 +176,13 @@ def main():
         d, inflight, counts = dems[0], [], {}
 
         def collect_one():
-            cap_id = inflight.pop(0)
+            cap_id, bidx = inflight.pop(0)
             got = d.collect_fields(copy=False)[0] if args.fields else d.collect(copy=False)
             counts[cap_id] = counts.get(cap_id, 0) + len(got)
             if collect_timing is not None:
-                collect_timing.append(d.timing())
+                t = d.timing()
+                t["batch_in_pass"] = bidx
+                collect_timing.append(t)
 
         for s in range(k):
             d.restart()
@@ -189,7 +192,7 @@ def main():
                     collect_one()
                 m = min(batch, n - off)
                 d.launch_device(d_iq.data_ptr() + off * bps, m, off + m >= n)
-                inflight.append(s)
+                inflight.append((s, off // batch))
                 off += m
         while inflight:
             collect_one()
@@ -235,16 +238,22 @@ def main():
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
     value = total_samples / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
 
-    # ---- roofline of the dominant kernel, from HIP events around every launch in the timed region ----
-    measured, last = [], 0  # the launches whose kernel times were taken (one in --timing-interval)
+    # ---- roofline of the dominant kernel, from HIP events around one launch in --timing-interval of the timed region ----
+    # (msd_timing.timed_batches counts on across msd_restart, so a launch was timed iff the count moved with its collect)
+    measured, last = [], None
     for t in timings:
-        if t["timed_batches"] != last:
+        if last is not None and t["timed_batches"] != last:
             measured.append(t)
-            last = t["timed_batches"]
-    scan_ms = [t["scan_kernel_ms"] for t in measured if t["scan_kernel_ms"] > 0]
+        last = t["timed_batches"]
     nb = (n + batch - 1) // batch
-    full_launch_ms = [t for i, t in enumerate(scan_ms) if (i % nb) != nb - 1 or n % batch == 0] or scan_ms
-    avg_ms = float(np.mean(full_launch_ms)) if full_launch_ms else float("nan")
+    full = [t for t in measured if t["scan_kernel_ms"] > 0 and (t["batch_in_pass"] != nb - 1 or n % batch == 0)] or \
+           [t for t in measured if t["scan_kernel_ms"] > 0]
+    scan_ms = [t["scan_kernel_ms"] for t in full]
+    # the first launch of a pass finds no finished predecessor whose message records it could carry:
+    # it runs the instantiation without the record slice
+    ms_rec = [t["scan_kernel_ms"] for t in full if t["batch_in_pass"] != 0]
+    ms_alone = [t["scan_kernel_ms"] for t in full if t["batch_in_pass"] == 0]
+    avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     launch_samples = batch if n >= batch else n
     achieved_gbs = launch_samples * bps / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
@@ -269,6 +278,9 @@ def main():
                 "traffic_unit": "bytes per launch (PMC, %s)" % (os.path.basename(tfile) if traffic else "not measured for this workload"),
                 "algorithmic_bytes_per_launch": launch_samples * bps, "kernel": "msd_scan_kernel",
                 "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
+                "avg_launch_ms_with_records": round(float(np.mean(ms_rec)), 4) if ms_rec else None,
+                "avg_launch_ms_scan_only": round(float(np.mean(ms_alone)), 4) if ms_alone else None,
+                "launch_ms_min_max": [round(min(scan_ms), 4), round(max(scan_ms), 4)] if scan_ms else None,
                 "algorithmic_bytes_per_sample": bps, "launches_timed": len(scan_ms), "launches": len(timings)}
     # what the kernel is really bound by (it is not HBM): from the latest profiles/*_binding.json, a summary of SQ counter
     # passes of this same command (scripts/r3_profiles.sh) and of the issue-rate microbenchmark

@@ -313,9 +313,12 @@ int msd_set_preamble_threshold(msd_ctx *ctx, int threshold);
  * MSD_PIPELINE_DEPTH batches may be outstanding.
  * msd_collect(n) also takes batch n + 1 through its resolve passes (it waits for them: they were queued when batch
  * n's filter changes were committed) and queues those of batch n + 2, so that the resolve chain runs one batch
- * ahead of the delivery and the GPU never waits for the caller between two scans; counters and messages of a batch
- * still appear with its own msd_collect.  Host cost per context while batches are in flight: the calling thread
- * polls for events for up to a few hundred microseconds at a time before it sleeps, and one helper thread per
+ * ahead of the delivery and the GPU never waits for the caller between two scans; the demodulator counters and the
+ * messages of a batch still appear with its own msd_collect.  Two things can show up to two collects early, because
+ * starting batch n + 2 on the GPU happens inside msd_collect(n): msd_stats.samples_dropped of a gap in front of that
+ * batch (msd_note_dropped), and -- across msd_restart -- the new capture's empty filter and zero clock.  Host cost per
+ * context while batches are in flight: the calling thread
+ * polls for events for up to 2 ms at a time before it sleeps, and one helper thread per
  * context (started by the first batch) does the same while it copies the message records and keeps the
  * order-sensitive power statistics -- two busy threads per receiver, plus a pool that only works when a batch has to
  * be resolved on the host.  Several receivers on one host should be pinned to disjoint cores near their GPU

@@ -16,6 +16,7 @@
 #define MODES_HIP_READSB_H
 
 #include <stdbool.h>
+#include <time.h>
 #include <stdint.h>
 
 #include "modes_hip.h"
@@ -96,9 +97,11 @@ void msd_fifo_release(struct msd_mag_buf *buf);                                 
 /* demodulators (demod_2400.h:37-38)                                                          */
 /* ------------------------------------------------------------------------------------------ */
 /* `void demodulate2400(struct mag_buf *)` / `void demodulate2400AC(struct mag_buf *)` for the consumer loop of
- * readsb.c:820-855.  What the reference's functions take from the global `Modes` is bound once: the GPU context
- * (created with the receiver's options, e.g. msd_converter_context() or msd_create) and the message sink that
- * stands for useModesMessage().  msd_demodulate2400 runs the buffer through the GPU (Mode S, Mode A/C if the
+ * readsb.c:820-855.  What the reference's functions take from the global `Modes` is bound once: the GPU context and
+ * the message sink that stands for useModesMessage().  The demodulator needs a context OF ITS OWN, made with msd_create
+ * from the receiver's options (threshold, nfix_crc, mode_ac; as msd_sdr_ifile.c does) -- not the converter's
+ * (msd_converter_context() has fixed options, and a context has no lock: the reader thread in msd_convert and the
+ * consumer in msd_demodulate2400 would race on it).  msd_demodulate2400 runs the buffer through the GPU (Mode S, Mode A/C if the
  * context has it, icaoFilterExpire) and delivers the Mode S messages; msd_demodulate2400AC on the SAME buffer
  * then delivers its Mode A/C replies -- the reference's order.  void like the reference's: after a device
  * failure nothing is delivered and msd_demod_error() says why.  ctx == NULL unbinds. */
@@ -141,6 +144,16 @@ typedef struct msd_ifile_hooks {
     void (*at_eof)(void);        /* `Modes.exit = 1` once the last block has been delivered (sdr_ifile.c:236) */
     void (*device_selected)(void); /* `Modes.sdr_type = SDR_IFILE` when the file name option arrives (sdr_ifile.c:86) */
 } msd_ifile_hooks;
+
+/* --throttle pacing (sdr_ifile.c:168-169,218-226): msd_pacer_wait blocks until the buffer may be released, then
+ * moves the deadline on by samples / sample_rate seconds.  Used by msd_ifileRun when the throttle option is set (one
+ * buffer per batch then, collected at once); exposed for hosts that feed msd_launch_host themselves. */
+typedef struct msd_pacer {
+    struct timespec next;
+    double sample_rate;
+} msd_pacer;
+void msd_pacer_start(msd_pacer *p, double sample_rate);
+void msd_pacer_wait(msd_pacer *p, uint64_t samples);
 
 void msd_ifileInitConfig(void);                    /* sdr_ifile.c:70-80 */
 /* sdr_ifile.c:82-107.  `key` is compared with the values registered through msd_ifileSetOptionKeys --

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmodes_hip.so")
+# MSD_LIBMODES_HIP: another build of the same library (kernel experiments: scripts/r4_variant_build.sh); never a fallback
+LIB_PATH = os.environ.get("MSD_LIBMODES_HIP") or os.path.join(_HERE, "csrc", "libmodes_hip.so")
 
 FMT_UC8, FMT_SC16, FMT_SC16Q11, FMT_MAG16 = 0, 1, 2, 3
 CHUNK = 131072

@@ -84,6 +84,7 @@ void msd_demodulate2400(struct msd_mag_buf *mag)
 {
     D.nheld = 0;
     D.held_for = NULL;
+    D.err[0] = 0; /* msd_demod_error() speaks for the latest buffer only */
     if (!mag)
         return;
     if (!D.ctx) {

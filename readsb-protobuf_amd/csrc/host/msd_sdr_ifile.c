@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "modes_hip_readsb.h"
@@ -18,7 +19,7 @@ static struct {
     char *filename;
     int format; /* MSD_FMT_* */
     int mode;
-    bool throttle; /* accepted for compatibility; replay is never slowed down here */
+    bool throttle; /* --throttle: buffers are released at the rate the receiver would deliver them (sdr_ifile.c:218-226) */
     int fd;
     unsigned bytes_per_sample;
     char *readbuf;
@@ -41,6 +42,26 @@ static struct {
     int name_key, format_key, throttle_key, mode_key;
     msd_ifile_hooks hooks;
 } G = {MSD_OPT_IFILE_NAME, MSD_OPT_IFILE_FORMAT, MSD_OPT_IFILE_THROTTLE, MSD_OPT_IFILE_MODE, {NULL, NULL, NULL, NULL}};
+
+/* ---- --throttle (sdr_ifile.c:168-169,218-226): a buffer may be released when the one before it has "played", i.e.
+ * samples / rate seconds after that one was released; the first one at once.  Absolute deadlines on CLOCK_MONOTONIC,
+ * so a slow consumer does not make the replay drift. ---- */
+void msd_pacer_start(msd_pacer *p, double sample_rate)
+{
+    clock_gettime(CLOCK_MONOTONIC, &p->next);
+    p->sample_rate = sample_rate;
+}
+
+void msd_pacer_wait(msd_pacer *p, uint64_t samples)
+{
+    while (clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &p->next, NULL) == EINTR)
+        ;
+    /* the time the next buffer can be delivered (normalize_timespec, util.c) */
+    const double ns = (double)samples * 1e9 / p->sample_rate;
+    const uint64_t total = (uint64_t)p->next.tv_nsec + (uint64_t)ns;
+    p->next.tv_sec += (time_t)(total / 1000000000ull);
+    p->next.tv_nsec = (long)(total % 1000000000ull);
+}
 
 const char *msd_ifileLastError(void)
 {
@@ -205,10 +226,10 @@ static void *magbuf_consumer(void *arg)
         int rc = msd_demodulate_magbuf(F.ctx, buf->data, buf->validLength, buf->overlap, buf->sampleTimestamp,
                                        buf->sysTimestamp, buf->mean_level, buf->mean_power, F.rx.sink,
                                        F.rx.sink_user);
+        msd_fifo_release(buf);
+        pthread_mutex_lock(&F.mu); /* (F.err is written by the reader thread too: under the lock) */
         if (rc)
             snprintf(F.err, sizeof F.err, "demodulate: %s", msd_last_error(F.ctx));
-        msd_fifo_release(buf);
-        pthread_mutex_lock(&F.mu);
         F.in_flight--;
         pthread_cond_signal(&F.idle);
         pthread_mutex_unlock(&F.mu);
@@ -230,6 +251,8 @@ static void run_magbuf(void)
     pthread_create(&consumer, NULL, magbuf_consumer, NULL);
     uint64_t sample_counter = 0;
     bool eof = false;
+    msd_pacer pacer;
+    msd_pacer_start(&pacer, 2400000.0); /* Modes.sample_rate, readsb.c:195 */
     while (!eof && !host_wants_exit()) {
         struct msd_mag_buf *out = msd_fifo_acquire(100);
         if (!out)
@@ -245,13 +268,15 @@ static void run_magbuf(void)
         const unsigned samples = (unsigned)(got / F.bytes_per_sample);
         F.converter(F.readbuf, &out->data[out->overlap], samples, F.converter_state, &out->mean_level,
                     &out->mean_power); /* sdr_ifile.c:214 */
-        if (msd_converter_error(F.converter_state)[0])
-            snprintf(F.err, sizeof F.err, "%s", msd_converter_error(F.converter_state));
         out->validLength = out->overlap + samples;
         out->flags = 0;
         pthread_mutex_lock(&F.mu);
+        if (msd_converter_error(F.converter_state)[0])
+            snprintf(F.err, sizeof F.err, "%s", msd_converter_error(F.converter_state));
         F.in_flight++;
         pthread_mutex_unlock(&F.mu);
+        if (F.throttle)
+            msd_pacer_wait(&pacer, samples); /* sdr_ifile.c:218-226: wait until this buffer may be released */
         msd_fifo_enqueue(out);
         /* The converter owns a GPU context of its own (msd_init_converter), the consumer demodulates on F.ctx:
          * the next block is read and converted while this one is demodulated, as the reference's reader and
@@ -283,15 +308,31 @@ static void run_fused(void)
         bool eof = false;
         int in_flight = 0;
         unsigned k = 0;
+        /* --throttle: the real-time form of the same loop.  One buffer per batch, released when the receiver would
+         * have delivered it, and its messages collected at once -- what a live feed looks like to the GPU path. */
+        const size_t turn_bytes = F.throttle ? (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample : F.readbuf_bytes;
+        msd_pacer pacer;
+        msd_pacer_start(&pacer, 2400000.0);
         while (!eof && !host_wants_exit()) {
             if (G.hooks.monitor)
                 G.hooks.monitor(); /* sdrMonitor(), sdr_ifile.c:184 */
             char *buf = ring[k++ % RING]; /* the batch that used it RING turns ago has been collected */
-            const size_t got = read_fully(buf, F.readbuf_bytes);
-            if (got < F.readbuf_bytes)
+            const size_t got = read_fully(buf, turn_bytes);
+            if (got < turn_bytes)
                 eof = true;
             const uint64_t samples = got / F.bytes_per_sample;
             int rc = 0;
+            if (F.throttle) {
+                msd_pacer_wait(&pacer, samples);
+                rc = msd_launch_host(F.ctx, buf, samples, eof ? 1 : 0);
+                if (!rc)
+                    rc = msd_collect(F.ctx, F.rx.sink, F.rx.sink_user);
+                if (rc) {
+                    snprintf(F.err, sizeof F.err, "submit: %s", msd_last_error(F.ctx));
+                    goto out;
+                }
+                continue;
+            }
             if (in_flight == MSD_PIPELINE_DEPTH) {
                 rc = msd_collect(F.ctx, F.rx.sink, F.rx.sink_user);
                 in_flight--;

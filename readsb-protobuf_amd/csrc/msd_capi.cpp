@@ -487,6 +487,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
     const uint32_t tiles_per_buffer = (uint32_t)(MSD_CHUNK_SAMPLES / tile);
     uint32_t lean_k = 0, lean_tpr = 0;
     s.lean = false;
+    s.mag_pass = false; /* set by the scan block below; an empty batch has none and must not inherit the slot's last one */
     if (pipelined && c->lean_ok && nwg && gpu_eligible(c, s) && s.nbuffers <= c->max_wg && !(c->debug_flags & 0x1f)) {
         /* (the buffers that hold samples: a capture's last batch ends with one more, empty or short, buffer --
          * counting it would cost a full batch of 512 buffers an eighth of its regions, 4096 / 513 = 7) */
@@ -1447,7 +1448,14 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         else
             msd_resolver_reset(&c->resolver);
         s.state_reset_done = false;
-        memset(&c->timing, 0, sizeof c->timing);
+        { /* the counters start over with the capture; the kernel-time sampling (one batch in timing_interval) runs on */
+            const uint64_t timed = c->timing.timed_batches;
+            const float scan_ms = c->timing.scan_kernel_ms, other_ms = c->timing.other_kernels_ms;
+            memset(&c->timing, 0, sizeof c->timing);
+            c->timing.timed_batches = timed;
+            c->timing.scan_kernel_ms = scan_ms;
+            c->timing.other_kernels_ms = other_ms;
+        }
         s.reset_before = false;
     }
     int rc = start_download(c, s, format);

@@ -37,10 +37,10 @@ extern "C" {
                             as the LDS copy inside the full kernel, and it leaves the LDS to the wavefronts' tiles);
                             0: a copy in LDS (needs MSD_TILE 1024) */
 #endif
-#ifndef MSD_TILE
 #ifndef MSD_SLICER_NG
 #define MSD_SLICER_NG 3 /* bit groups (of five bits) one lane slices per item of step B */
 #endif
+#ifndef MSD_TILE
 #define MSD_TILE 2048u /* scan positions per wavefront tile: 2048 (two runs of 16 per lane) or 1024 */
 #endif
 #ifndef MSD_TESTS_V2

@@ -55,6 +55,36 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
     *p = v;
 #endif
 }
+/* MSD_GATHER_AHEAD: where the UC8 table gathers of a tile are issued (they go through the texture addresser, one
+ * 64-lane gather per ~32 cycles: the busiest unit of the conversion and the one a wavefront waits for longest).
+ *   0  at the top of the tile, waited for at once (rounds 1-3)
+ *   1  the NEXT tile's gathers go out between this tile's preamble tests and its candidate rounds: they are served while
+ *      the wavefront works in LDS, and the top of the next tile finds its magnitudes in registers
+ *   2  the next tile's gathers are spread over this tile's preamble tests, one per scan position (32 positions per lane
+ *      and tile = 32 gathers): the addresser never sees a burst, and the raw IQ is fetched a tile further ahead */
+#ifndef MSD_GATHER_AHEAD
+#define MSD_GATHER_AHEAD 0
+#endif
+/* s_setprio per phase of a tile (0..3; the SIMD's issue arbitration takes the highest priority first, then the oldest
+ * wavefront).  With all phases alike the four wavefronts of a SIMD are served by age, and a wavefront in its candidate
+ * rounds -- short bursts of a few instructions between LDS round trips -- queues behind the long instruction runs of a
+ * neighbour's preamble tests every time it comes back from a wait. */
+#ifndef MSD_PRIO_CONV
+#define MSD_PRIO_CONV 0
+#endif
+#ifndef MSD_PRIO_TESTS
+#define MSD_PRIO_TESTS 1
+#endif
+#ifndef MSD_PRIO_CAND
+#define MSD_PRIO_CAND 3 /* measured (profiles/r04_priorities.txt): 0/0/0 0.297 ms per 128 Mi samples, 0/1/3 0.266, 0/0/1..3 0.269-0.273,
+                           0/1/2 0.267, 1/2/3 0.264, 1/1/3 0.278, 0/1/3 with step B at 0 / 1 / 2: 0.284 / 0.278 / 0.269 */
+#endif
+#ifndef MSD_STEPB_BATCH
+#define MSD_STEPB_BATCH 0
+#endif
+#ifndef MSD_PRIO_STEPB
+#define MSD_PRIO_STEPB MSD_PRIO_CAND /* step B of a candidate round: its one long run of instructions */
+#endif
 #include "msd_emit_impl.h"
 #include "msd_pred_impl.h"
 #include "msd_mag_impl.h"
@@ -69,10 +99,17 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
 #ifdef MSD_KERNEL_TIMING
 /* section timers for experiments (never in the shipped build): wall cycles per wavefront */
 __device__ unsigned long long g_msd_tlast_dummy;
-#define TDECL unsigned long long tacc_[12] = {0}; unsigned long long tlast_ = __builtin_readcyclecounter();
-#define TMARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); tacc_[k] += n_ - tlast_; tlast_ = n_; }
-#define TMARKF(k) { const unsigned long long n_ = __builtin_readcyclecounter(); tacc[k] += n_ - *tlast; *tlast = n_; }
-#define TFLUSH if (P.timers && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&P.timers[k_], tacc_[k_]); }
+/* (gfx950 has no SHADER_CYCLES register: s_memtime it is -- a scalar memory operation whose s_waitcnt also waits for
+ * every LDS access in flight, so the marks distort what they measure; keep them few) */
+__device__ __forceinline__ uint32_t msd_cycles()
+{
+    return (uint32_t)__builtin_readcyclecounter();
+}
+#define TDECL uint32_t tacc_[12] = {0}; uint32_t tlast_ = msd_cycles();
+#define TCOARSE(k) (MSD_KERNEL_TIMING + 0 != 2 || (k) == 0 || (k) == 2 || (k) == 9) /* -DMSD_KERNEL_TIMING=2: three marks per tile */
+#define TMARK(k) if (TCOARSE(k)) { const uint32_t n_ = msd_cycles(); tacc_[k] += n_ - tlast_; tlast_ = n_; }
+#define TMARKF(k) if (MSD_KERNEL_TIMING + 0 != 2) { const uint32_t n_ = msd_cycles(); tacc[k] += n_ - *tlast; *tlast = n_; }
+#define TFLUSH if (P.timers && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&P.timers[k_], (unsigned long long)tacc_[k_]); }
 #else
 #define TDECL
 #define TMARK(k)
@@ -114,7 +151,8 @@ constexpr int W_SMETA = W_SIDX + HC * 8 * 2;                /* u32[SC] */
 constexpr int W_SMSG = W_SMETA + SC * 4;                    /* uint4[SC] */
 constexpr int W_SCRC = W_SMSG + SC * 16;                    /* u32[SC] */
 constexpr int W_SRES = W_SCRC + SC * 4;                     /* u32[SC][2]: addr, crc */
-constexpr int W_BYTES = W_SRES + SC * 8;
+constexpr int W_SQOFF = W_SRES + SC * 8;                    /* u32[SC]: MSD_SL_QOFF of the slot's trial phase */
+constexpr int W_BYTES = W_SQOFF + SC * 4;
 constexpr int OFF_LUT = OFF_WAVE + WAVES * W_BYTES;         /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
 constexpr int LDS_UC8 = OFF_LUT + (MSD_LUT_GLOBAL ? 0 : 128 * LUT_STRIDE * 2);
@@ -200,6 +238,25 @@ __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t v
         for (int k = 0; k < 8; ++k)
             if (!((valid >> k) & 1u))
                 mg[k] = 0;
+    }
+}
+
+/* one magnitude of a group (element e of 8), unmasked: what convert_group<FMT, false> computes, one load at a time */
+template <int FMT>
+__device__ __forceinline__ uint32_t convert_one(const RawGroup<FMT> &r, int e, const uint16_t *lut)
+{
+    if (FMT == MSD_FMT_UC8) {
+        const uint32_t w = r.w[e >> 1];
+        const uint32_t top = w & 0x80808080u;
+        const uint32_t keep = top - (top >> 7);
+        const uint32_t f = (w ^ ~keep) & 0x7f7f7f7fu;
+        return (e & 1) ? lut[(f >> 24) * LUT_STRIDE + ((f >> 16) & 0xffu)] : lut[((f >> 8) & 0xffu) * LUT_STRIDE + (f & 0xffu)];
+    } else if (FMT == MSD_FMT_MAG16) {
+        return (r.w[(e >> 1) % RawGroup<FMT>::WORDS] >> (16 * (e & 1))) & 0xffffu;
+    } else {
+        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        const uint32_t w = r.w[e % RawGroup<FMT>::WORDS];
+        return mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
     }
 }
 
@@ -304,32 +361,65 @@ __device__ __forceinline__ void wave_lds_sync()
  * v_dot2_u32_u16 does not work here: with SRAM ECC a ds_read_u16_d16_hi zeroes the other half of its
  * destination instead of keeping it.) */
 template <int EXTRA>
-__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5])
+__device__ __forceinline__ void group_load(const unsigned char *const (&a)[5], uint32_t (&m)[5][4])
 {
     /* (an explicit LDS pointer: the compiler does not infer the address space of a volatile access and
      * would emit flat loads) */
     typedef __attribute__((address_space(3))) const volatile uint16_t lds_sample;
-    uint32_t m[5][4];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         lds_sample *p = (lds_sample *)(a[c] + EXTRA);
+#ifdef MSD_EXP_FEWER_READS /* timing experiment only (wrong results): what would step B cost with a third of its LDS reads? */
+        m[c][0] = p[0];
+        m[c][1] = m[c][0] + 3u;
+        m[c][2] = m[c][0] ^ 5u;
+        m[c][3] = c == 4 ? m[c][0] + 1u : 0u;
+#else
         m[c][0] = p[0];
         m[c][1] = p[1];
         m[c][2] = p[2];
         m[c][3] = c == 4 ? p[3] : 0u;
+#endif
     }
+}
+
+/* The five verdicts of a group from its samples, as the group's five bits under trial phase 4 (q = 0): there bit k is
+ * correlator (4 + 2 k) % 5 = 4, 1, 3, 0, 2, and under trial phase 4 + q every correlator's bit moves 2 q places on
+ * (mod 5) -- the group's bits are this code rotated right by (2 q) % 5 within its five bits (group_bits). */
+__device__ __forceinline__ uint32_t group_code(const uint32_t (&m)[5][4])
+{
     uint32_t code = 0;
-    const uint64_t b0 = __ballot(18u * m[0][0] > 15u * m[0][1] + 3u * m[0][2]);
-    MSD_PUSH(code, b0);
-    const uint64_t b1 = __ballot(14u * m[1][0] > 5u * m[1][1] + 9u * m[1][2]);
-    MSD_PUSH(code, b1);
-    const uint64_t b2 = __ballot(16u * m[2][0] + 5u * m[2][1] > 20u * m[2][2]);
-    MSD_PUSH(code, b2);
-    const uint64_t b3 = __ballot(7u * m[3][0] + 11u * m[3][1] > 18u * m[3][2]);
-    MSD_PUSH(code, b3);
     const uint64_t b4 = __ballot(4u * m[4][0] + 15u * m[4][1] + m[4][3] > 20u * m[4][2]);
     MSD_PUSH(code, b4);
+    const uint64_t b1 = __ballot(14u * m[1][0] > 5u * m[1][1] + 9u * m[1][2]);
+    MSD_PUSH(code, b1);
+    const uint64_t b3 = __ballot(7u * m[3][0] + 11u * m[3][1] > 18u * m[3][2]);
+    MSD_PUSH(code, b3);
+    const uint64_t b0 = __ballot(18u * m[0][0] > 15u * m[0][1] + 3u * m[0][2]);
+    MSD_PUSH(code, b0);
+    const uint64_t b2 = __ballot(16u * m[2][0] + 5u * m[2][1] > 20u * m[2][2]);
+    MSD_PUSH(code, b2);
     return code;
+}
+
+/* (2 q) % 5 for q = 0..4: how far the bits of a group move between trial phase 4 and trial phase 4 + q */
+__device__ __forceinline__ uint32_t phase_rot(uint32_t q)
+{
+    return (0x31420u >> (4u * q)) & 7u;
+}
+
+/* the group's five message bits (first bit in bit 4) from group_code and phase_rot(q) */
+__device__ __forceinline__ uint32_t group_bits(uint32_t code, uint32_t rot)
+{
+    return ((code | (code << 5)) >> rot) & 31u;
+}
+
+template <int EXTRA>
+__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5], uint32_t rot)
+{
+    uint32_t m[5][4];
+    group_load<EXTRA>(a, m);
+    return group_bits(group_code(m), rot);
 }
 
 /* Everything a wavefront needs besides its parameters: its private LDS block and the shared tables. */
@@ -357,7 +447,11 @@ struct WaveCtx {
 template <bool FIX2>
 __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const WaveCtx &X, uint32_t nh, uint64_t tile_pos0,
                                                 msd_hit *hit_out, uint32_t hits_room, msd_try *my_tries,
-                                                uint32_t &tcur, uint32_t try_base /* of my_tries[0] in the hit records */)
+                                                uint32_t &tcur, uint32_t try_base /* of my_tries[0] in the hit records */
+#ifdef MSD_KERNEL_TIMING
+                                                , uint32_t *tacc, uint32_t *tlast
+#endif
+                                                )
 {
     const int lane = X.lane;
     const unsigned char *mbytes = X.w + W_MAGS;
@@ -368,7 +462,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     uint32_t *smsg32 = reinterpret_cast<uint32_t *>(X.w + W_SMSG);
     uint32_t *scrc = reinterpret_cast<uint32_t *>(X.w + W_SCRC);
     uint32_t *sres = reinterpret_cast<uint32_t *>(X.w + W_SRES);
-    const uint8_t *perm = reinterpret_cast<const uint8_t *>(X.sl + MSD_SL_PERM);
+    uint32_t *sqoff = reinterpret_cast<uint32_t *>(X.w + W_SQOFF);
 
     /* ---- tries: lane h expands hit h ---- */
     uint32_t my_hit = 0, my_m = 0;
@@ -414,7 +508,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
 #pragma unroll
         for (int c = 0; c < 5; ++c)
             a[c] = base + ((qoff >> (6 * c)) & 63u);
-        const uint32_t df = perm[q * 32u + group_verdicts<0>(a)];
+        const uint32_t df = group_verdicts<0>(a, phase_rot(q));
         const uint32_t nb = bytes_for_df(df);
         const bool is_s = act && nb == 7, is_l = act && nb == 14;
         const uint64_t bs = __ballot(is_s), bl = __ballot(is_l);
@@ -429,16 +523,20 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             smeta[u] = pos | (q << 13) | (nb << 16) | (h << 20);
             *reinterpret_cast<uint4 *>(smsg32 + 4u * u) = make_uint4(df << 27, 0u, 0u, 0u);
             scrc[u] = X.sl[(is_l ? MSD_SL_GLONG : MSD_SL_GSHORT) + df];
+            sqoff[u] = qoff;
             sidx[h * 8u + q] = (uint16_t)u;
         }
     }
     wave_lds_sync();
+    TMARKF(4)
 
     /* ---- step B: item = (slot, NG consecutive groups from NG it + 1 on).  Groups 1..11 carry bits 5..55 of
      * a short message (the last one one bit), groups 1..22 bits 5..111 of a long one (the last one two).
      * NG groups = 24 NG bytes of samples per item: with NG = 3 the items of a try start 18 LDS banks apart,
      * all on different banks (with four groups per item, 24 banks apart, every try collided with itself) ---- */
     if (!(P.debug_flags & 4)) {
+        if (MSD_PRIO_STEPB != MSD_PRIO_CAND)
+            __builtin_amdgcn_s_setprio(MSD_PRIO_STEPB);
         constexpr uint32_t NG = MSD_SLICER_NG, IS = (11 + NG - 1) / NG, IL = (22 + NG - 1) / NG;
         constexpr uint32_t VB = 5 * NG; /* bits per item */
         constexpr uint32_t LAST_S = 51 - VB * (IS - 1), LAST_L = 107 - VB * (IL - 1); /* bits of the last item */
@@ -453,21 +551,36 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             const uint32_t it = j - t * (lng ? IL : IS);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
+            const uint32_t qoff = sqoff[u]; /* (with the slot's record: one LDS round trip, not two) */
             const uint32_t pos = me & (uint32_t)(WT_MAX - 1), q = (me >> 13) & 7u;
-            const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
             const uint32_t g1 = NG * it + 1u;
             const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
             const unsigned char *a[5];
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 a[c] = base + ((qoff >> (6 * c)) & 63u);
-            const uint8_t *pq = perm + q * 32u;
+            const uint32_t rot = phase_rot(q);
             uint32_t v[NG];
-            v[0] = pq[group_verdicts<0>(a)];
-            if (NG > 1) v[1 % NG] = pq[group_verdicts<24>(a)];
-            if (NG > 2) v[2 % NG] = pq[group_verdicts<48>(a)];
-            if (NG > 3) v[3 % NG] = pq[group_verdicts<72>(a)];
-            if (NG > 4) v[4 % NG] = pq[group_verdicts<96>(a)];
+#if MSD_STEPB_BATCH
+            /* every sample of the item's NG groups first, then the verdicts: one LDS round trip per item instead of NG.
+             * Measured slower (+3 %): the wavefront's latency is not what the step waits for, the LDS pipe is, and 48
+             * loads in one burst fill its queue for the other fifteen wavefronts. */
+            uint32_t m[NG][5][4];
+            group_load<0>(a, m[0]);
+            if (NG > 1) group_load<24>(a, m[1 % NG]);
+            if (NG > 2) group_load<48>(a, m[2 % NG]);
+            if (NG > 3) group_load<72>(a, m[3 % NG]);
+            if (NG > 4) group_load<96>(a, m[4 % NG]);
+#pragma unroll
+            for (uint32_t c = 0; c < NG; ++c)
+                v[c] = group_bits(group_code(m[c]), rot);
+#else
+            v[0] = group_verdicts<0>(a, rot);
+            if (NG > 1) v[1 % NG] = group_verdicts<24>(a, rot);
+            if (NG > 2) v[2 % NG] = group_verdicts<48>(a, rot);
+            if (NG > 3) v[3 % NG] = group_verdicts<72>(a, rot);
+            if (NG > 4) v[4 % NG] = group_verdicts<96>(a, rot);
+#endif
             uint32_t val = 0; /* message bits 5 g1 .. 5 g1 + VB - 1 */
 #pragma unroll
             for (uint32_t c = 0; c < NG; ++c)
@@ -493,8 +606,11 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
                     atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], __builtin_amdgcn_alignbit(top, 0u, s)); /* top << (32 - s) */
             }
         }
+        if (MSD_PRIO_STEPB != MSD_PRIO_CAND)
+            __builtin_amdgcn_s_setprio(MSD_PRIO_CAND);
     }
     wave_lds_sync();
+    TMARKF(5)
 
     /* ---- step C: lane = slot ---- */
     if ((uint32_t)lane < ns || (uint32_t)lane >= (uint32_t)SC - nl) {
@@ -570,6 +686,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
         }
     }
     wave_lds_sync();
+    TMARKF(6)
 
     /* ---- step D: lane = hit ---- */
     uint32_t u5[5], nlive = 0;
@@ -623,6 +740,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
     }
     tcur += ntry_round;
     wave_lds_sync();
+    TMARKF(7)
     return true;
 }
 
@@ -724,6 +842,43 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             nxt[k] = cur[k];
         }
     }
+    /* the raw IQ of tile `ti` (which exists) into nxt: one unconditional load per group from a selected address (see
+     * fetch_group); tiles that lie wholly inside the batch -- all but the last -- take the short way */
+    auto fetch_tile = [&](uint32_t ti) {
+        const int64_t rel = (int64_t)((uint64_t)ti * WT);
+        if ((uint64_t)rel + WT <= (P.nsamples & ~7ull)) { /* wave-uniform */
+            constexpr int BPS = RawGroup<FMT>::WORDS / 2;
+#pragma unroll
+            for (int k = 0; k < GPT; ++k) {
+                const uint8_t *src = P.iq + (rel + 8 * (lane + 64 * k)) * BPS;
+                const uint4 a = *reinterpret_cast<const uint4 *>(src);
+                nxt[k].w[0] = a.x; nxt[k].w[1] = a.y; nxt[k].w[2] = a.z; nxt[k].w[3] = a.w;
+                if (BPS == 4) {
+                    const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
+                    nxt[k].w[4 % RawGroup<FMT>::WORDS] = b.x; nxt[k].w[5 % RawGroup<FMT>::WORDS] = b.y;
+                    nxt[k].w[6 % RawGroup<FMT>::WORDS] = b.z; nxt[k].w[7 % RawGroup<FMT>::WORDS] = b.w;
+                }
+                nxt_valid[k] = 0xffu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < GPT; ++k)
+                nxt_valid[k] = fetch_group<FMT>(P, (int64_t)P.batch_first + rel + 8 * (lane + 64 * k), nxt[k]);
+        }
+    };
+#if MSD_GATHER_AHEAD
+    /* the magnitudes of the tile about to be written to LDS, unmasked, on their way since the tile before */
+    uint32_t mgs[GPT][8], mg_valid[GPT];
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+        convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
+        mg_valid[k] = cur_valid[k];
+    }
+#if MSD_GATHER_AHEAD == 2
+    if (tile_lo + 1 < tile_hi)
+        fetch_tile(tile_lo + 1);
+#endif
+#endif
 
     /* On the way: this wavefront's share of the previous batch's message records (its resolve and power kernels
      * ran before this launch), written inside one of its tiles from the candidate scratch -- a different tile for
@@ -731,8 +886,10 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
      * queueing up at its start (where every wavefront's next load would wait behind its own stores). */
     const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
 
+    TDECL
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         const uint64_t tile_pos0 = (uint64_t)tile * WT; /* first scan position, batch-relative */
+        TMARK(8)
         const uint64_t a0 = P.batch_first + tile_pos0;
 
         /* ---- stage 1: IQ -> magnitudes in LDS; prefetch the next tile's IQ ---- */
@@ -749,14 +906,18 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         }
         /* all of the tile's table loads first (8 per group, GPT groups), then their uses: the compiler keeps the
          * order it is given, and one round trip to the table instead of GPT is 3 us per tile */
-        uint32_t mgs[GPT][8];
+#if !MSD_GATHER_AHEAD
+        uint32_t mgs[GPT][8], mg_valid[GPT];
 #pragma unroll
-        for (int k = 0; k < GPT; ++k)
+        for (int k = 0; k < GPT; ++k) {
             convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
+            mg_valid[k] = cur_valid[k];
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             uint32_t(&mg)[8] = mgs[k];
-            mask_group(cur_valid[k], mg);
+            mask_group(mg_valid[k], mg);
             const uint4 packed = pack8(mg);
             *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) = packed;
             if (P.mag_out) /* wave-uniform: Mode A/C is on, its candidate kernel reads these instead of the IQ */
@@ -771,6 +932,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             }
         }
         wave_lds_sync();
+        TMARK(0)
 
         /* the record slice goes here, behind the tile's table loads and in front of the next tile's prefetch: tests
          * and candidate rounds need no global data, so nothing waits for the PCIe stores until the next tile's
@@ -780,32 +942,15 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 
         /* ---- prefetch the next tile's IQ (behind the record slice: at that point neither this tile's raw groups nor
          * the next one's are live, which is what keeps the slice out of the loop's register budget) ---- */
-        if (tile + 1 < tile_hi) {
-            /* one unconditional load per group from a selected address (see fetch_group); tiles that lie
-             * wholly inside the batch -- all but the last -- take the short way */
-            const int64_t rel = (int64_t)(tile_pos0 + WT);
-            if ((uint64_t)rel + WT <= (P.nsamples & ~7ull)) { /* wave-uniform */
-                constexpr int BPS = RawGroup<FMT>::WORDS / 2;
-#pragma unroll
-                for (int k = 0; k < GPT; ++k) {
-                    const uint8_t *src = P.iq + (rel + 8 * (lane + 64 * k)) * BPS;
-                    const uint4 a = *reinterpret_cast<const uint4 *>(src);
-                    nxt[k].w[0] = a.x; nxt[k].w[1] = a.y; nxt[k].w[2] = a.z; nxt[k].w[3] = a.w;
-                    if (BPS == 4) {
-                        const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
-                        nxt[k].w[4 % RawGroup<FMT>::WORDS] = b.x; nxt[k].w[5 % RawGroup<FMT>::WORDS] = b.y;
-                        nxt[k].w[6 % RawGroup<FMT>::WORDS] = b.z; nxt[k].w[7 % RawGroup<FMT>::WORDS] = b.w;
-                    }
-                    nxt_valid[k] = 0xffu;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < GPT; ++k)
-                    nxt_valid[k] = fetch_group<FMT>(P, (int64_t)a0 + WT + 8 * (lane + 64 * k), nxt[k]);
-            }
-        }
+#if MSD_GATHER_AHEAD != 2
+        if (tile + 1 < tile_hi)
+            fetch_tile(tile + 1);
+#endif
 
+        TMARK(1)
         if (!(P.debug_flags & 2)) {
+            if (MSD_PRIO_TESTS != MSD_PRIO_CONV)
+                __builtin_amdgcn_s_setprio(MSD_PRIO_TESTS);
             /* ---- stage 2: preamble tests for my NH runs of 16 consecutive positions (demod_2400.c:257-335) ---- */
             /* one bit plane per test and run, position q at bit 15 - q */
             uint32_t pl0[NH], pl1[NH], pl2[NH], any[NH], cnt[NH], rank0[NH];
@@ -886,6 +1031,11 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     MSD_PUSH(p0, f0);
                     MSD_PUSH(p1, f1);
                     MSD_PUSH(p2, f2);
+#if MSD_GATHER_AHEAD == 2
+                    /* one of the next tile's table gathers per position: 16 NH positions, 8 GPT = 16 NH gathers (on the
+                     * region's last tile they read the table for nothing: the raw groups then hold an older tile) */
+                    mgs[(16 * h + q) >> 3][(16 * h + q) & 7] = convert_one<FMT>(nxt[(16 * h + q) >> 3], (16 * h + q) & 7, lut);
+#endif
                 }
 #endif
                 /* positions past the last one the reference scans */
@@ -911,6 +1061,26 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                 H += wave_last(incl);
             }
 
+            TMARK(2)
+#if MSD_GATHER_AHEAD == 1
+            /* the next tile's magnitudes: their table gathers are served while this tile's candidates are worked on */
+            if (tile + 1 < tile_hi) { /* wave-uniform */
+#pragma unroll
+                for (int k = 0; k < GPT; ++k) {
+                    convert_group<FMT, false>(nxt[k], nxt_valid[k], lut, mgs[k]);
+                    mg_valid[k] = nxt_valid[k];
+                }
+            }
+#elif MSD_GATHER_AHEAD == 2
+            /* the gathers went out with the tests; now the raw IQ of the tile after the next */
+#pragma unroll
+            for (int k = 0; k < GPT; ++k)
+                mg_valid[k] = nxt_valid[k];
+            if (tile + 2 < tile_hi)
+                fetch_tile(tile + 2);
+#endif
+            if (MSD_PRIO_CAND != MSD_PRIO_TESTS)
+                __builtin_amdgcn_s_setprio(MSD_PRIO_CAND);
             if (!(P.debug_flags & 1) && H) {
                 /* ---- stage 4: candidate rounds of up to HC hits ---- */
                 uint32_t r0 = 0;
@@ -939,7 +1109,12 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     }
                     const uint32_t out0 = hcur + r0;
                     const uint32_t room = out0 < P.hcap ? P.hcap - out0 : 0u;
-                    if (!candidate_round<FIX2>(P, X, nh, tile_pos0, my_hits + out0, room, my_tries, tcur, try_base)) {
+                    TMARK(3)
+                    if (!candidate_round<FIX2>(P, X, nh, tile_pos0, my_hits + out0, room, my_tries, tcur, try_base
+#ifdef MSD_KERNEL_TIMING
+                                               , tacc_, &tlast_
+#endif
+                                               )) {
                         nh = (nh + 1) / 2; /* too many tries with a known DF: halve the round */
                         fill = false;
                         wave_lds_sync();
@@ -951,7 +1126,10 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                 }
             }
             hcur += H;
+            if (MSD_PRIO_CAND != MSD_PRIO_CONV)
+                __builtin_amdgcn_s_setprio(MSD_PRIO_CONV);
         }
+        TMARK(9)
 
         /* ---- carry the last 328 magnitudes over as the next tile's look-behind ---- */
         uint4 carry = make_uint4(0, 0, 0, 0);
@@ -960,12 +1138,16 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         wave_lds_sync();
         if (lane < FRONT / 8)
             *reinterpret_cast<uint4 *>(mags + 8 * lane) = carry;
+#if !MSD_GATHER_AHEAD
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             cur[k] = nxt[k];
             cur_valid[k] = nxt_valid[k];
         }
+#endif
     }
+    TMARK(8)
+    TFLUSH
     flush_sums();
     flush_chunk();
     hits_total = hcur;

@@ -17,7 +17,9 @@ __device__ inline void msd_pred_note(unsigned long long *table, uint32_t gen, ui
     uint32_t *count = reinterpret_cast<uint32_t *>(table + MSD_PRED_SLOTS), *list = count + 2;
     const unsigned long long key = msd_pred_key(gen, addr);
     uint32_t h = MSD_PRED_HASH(addr) & (MSD_PRED_SLOTS - 1);
-    for (;;) {
+    /* at most one trip round the table: a batch with more clean squitter addresses than the list holds is resolved on
+     * the host anyway (the count says so), and a probe must end even if a flood of them filled every slot */
+    for (uint32_t probes = 0; probes < MSD_PRED_SLOTS; ++probes) {
         const unsigned long long e = __atomic_load_n(&table[h], __ATOMIC_RELAXED);
         if ((e & 0xffffffff00000000ull) == key) { /* most tries find their aircraft's slot */
             if ((uint32_t)e > buffer)
@@ -25,6 +27,14 @@ __device__ inline void msd_pred_note(unsigned long long *table, uint32_t gen, ui
             return;
         }
         if ((uint32_t)(e >> 56) != gen) { /* vacant: another generation's, or never used */
+            /* the list is full: no more entries (the table stays at most half full), only the count goes past the list's
+             * size once, which hands the batch to the host resolver (msd_pred_count) */
+            const uint32_t seen = __atomic_load_n(count, __ATOMIC_RELAXED);
+            if ((seen >> 24) == gen && (seen & 0xffffffu) >= MSD_PRED_LIST) {
+                if ((seen & 0xffffffu) == MSD_PRED_LIST)
+                    atomicCAS(count, seen, seen + 1u);
+                return;
+            }
             if (atomicCAS(&table[h], e, key | buffer) == e) {
                 /* the counter cell carries the generation too: the first entry of a batch restarts it */
                 uint32_t k;
@@ -44,6 +54,7 @@ __device__ inline void msd_pred_note(unsigned long long *table, uint32_t gen, ui
                     list[k] = h;
                 return;
             }
+            --probes;
             continue; /* somebody else took it: look at the slot again */
         }
         h = (h + 1) & (MSD_PRED_SLOTS - 1);
@@ -55,7 +66,7 @@ __device__ __forceinline__ uint32_t msd_pred_lookup(const unsigned long long *ta
 {
     const unsigned long long key = msd_pred_key(gen, addr);
     uint32_t h = MSD_PRED_HASH(addr) & (MSD_PRED_SLOTS - 1);
-    for (;;) {
+    for (uint32_t probes = 0; probes < MSD_PRED_SLOTS; ++probes) { /* (a full table of this generation: one trip round) */
         const unsigned long long e = table[h];
         if ((e & 0xffffffff00000000ull) == key)
             return (uint32_t)e;
@@ -63,6 +74,7 @@ __device__ __forceinline__ uint32_t msd_pred_lookup(const unsigned long long *ta
             return MSD_PRED_NEVER;
         h = (h + 1) & (MSD_PRED_SLOTS - 1);
     }
+    return MSD_PRED_NEVER;
 }
 
 /* entries of the current generation (0 if the batch noted none) */
