@@ -56,18 +56,24 @@ def parse():
     ap.add_argument("--no-also", action="store_true",
                     help="skip the post-clock runs of BASELINE configs[2] and [4] that the default N=1 run appends ('also')")
     ap.add_argument("--no-pin", action="store_true", help="leave the process's CPU affinity alone")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group of the N>1 bookkeeping (barrier, MAX time, SUM counts): nccl = RCCL, one GPU per "
+                         "rank; gloo = CPU tensors, which also works with several ranks on one GPU "
+                         "(MSD_BENCH_DEVICE_OVERRIDE=<index>: every rank uses that device -- tests/test_gpu_bench_two_ranks.py)")
     ap.add_argument("--timing-interval", type=int, default=3,
                     help="record the kernel timing events on one launch in N (msd_set_timing_interval); 3 is coprime "
                          "to the four batches of a pass, so the timed launch rotates over all of them")
     return ap.parse_args()
 
 
-def pin_to_gpu_local_cpus(torch, local_rank, world):
+def pin_to_gpu_local_cpus(torch, local_rank, world, gpu_of=None):
     """The rank's threads (this one, the context's helper thread, the host resolver's pool) onto CPUs of the NUMA
     node its GPU hangs off, a disjoint slice per rank -- the reference pins its reader and demodulator threads too
     (readsb.c:275,749).  Every rank runs a calling thread that polls for events and a helper thread that copies the
-    records: eight ranks on one node must not end up on each other's cores.  Returns a description,
-    or None where sysfs does not tell (nothing is changed then)."""
+    records: eight ranks on one node must not end up on each other's cores.  gpu_of(rank) = the device
+    index a local rank uses (default: its own).  Returns a description, or None where sysfs does not tell (nothing is
+    changed then)."""
+    gpu_of = gpu_of or (lambda r: r)
     try:
         def cpulist(i):
             p = torch.cuda.get_device_properties(i)
@@ -78,17 +84,17 @@ def pin_to_gpu_local_cpus(torch, local_rank, world):
                 a, _, b = part.partition("-")
                 cpus.extend(range(int(a), int(b or a) + 1))
             return bdf, cpus
-        bdf, cpus = cpulist(local_rank)
+        bdf, cpus = cpulist(gpu_of(local_rank))
         allowed = sorted(set(cpus) & os.sched_getaffinity(0))
         if not allowed:
             return None
-        ngpu = torch.cuda.device_count()
-        mates = [i for i in range(min(ngpu, max(world, 1))) if cpulist(i)[1] == cpus]  # ranks whose GPU shares these CPUs
+        mates = [r for r in range(max(world, 1)) if cpulist(gpu_of(r))[1] == cpus]  # local ranks whose GPU shares these CPUs
         k, j = max(1, len(mates)), (mates.index(local_rank) if local_rank in mates else 0)
         per = max(2, len(allowed) // k)
         mine = allowed[j * per:(j + 1) * per] or allowed
         os.sched_setaffinity(0, mine)
-        return {"gpu": bdf, "cpus": "%d-%d (%d of the %d local to the GPU, slice %d of %d)" % (mine[0], mine[-1], len(mine), len(allowed), j, k)}
+        return {"gpu": bdf, "cpus": "%d-%d (%d of the %d local to the GPU, slice %d of %d)" % (mine[0], mine[-1], len(mine), len(allowed), j, k),
+                "cpu_list": mine}
     except (OSError, ValueError, AttributeError):
         return None
 
@@ -125,12 +131,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pinned = None if args.no_pin else pin_to_gpu_local_cpus(torch, local_rank, world)
+    override = os.environ.get("MSD_BENCH_DEVICE_OVERRIDE")  # every rank on this device (a one-GPU box running the N>1 path)
+    ngpu = torch.cuda.device_count()
+    gpu_of = (lambda r: int(override)) if override not in (None, "") else (lambda r: r % max(1, ngpu))
+    device_index = gpu_of(local_rank)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    pinned = None if args.no_pin else pin_to_gpu_local_cpus(torch, local_rank, world, gpu_of)
+    reduce_dev = dev
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+            reduce_dev = torch.device("cpu")
 
     # host threads of the buffer-parallel resolve: share the host's CPUs between the ranks of the node
     if "MSD_RESOLVE_THREADS" not in os.environ:
@@ -160,7 +175,7 @@ def main():
     # pass while the last batches of the current one are still in flight (every pass still begins with an
     # empty ICAO filter, a zero clock and zero counters, and all K passes are complete before the clock stops).
     nctx = 1
-    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=local_rank, dc_filter=args.dcfilter,
+    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=device_index, dc_filter=args.dcfilter,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
                             decode_fields=args.fields)
             for _ in range(nctx)]
@@ -228,12 +243,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     my_ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    per_rank_ms = [my_ms_per_step]
-    if world > 1:  # every rank's own time, beside the MAX the contract asks for
+    per_rank = [{"rank": rank, "ms_per_step": my_ms_per_step, "seed": seed, "device": device_index, "messages": nmsg,
+                 "cpus": (pinned or {}).get("cpu_list")}]
+    if world > 1:  # every rank's own time, capture and placement, beside the MAX / SUM the contract asks for
         gathered = [None] * world
-        dist.all_gather_object(gathered, my_ms_per_step)
-        per_rank_ms = [float(x) for x in gathered]
-    elapsed, nmsg_total, total_samples = pkg.sharding.reduce_job(elapsed, nmsg, n, device=dev)
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    per_rank_ms = [float(x["ms_per_step"]) for x in per_rank]
+    elapsed, nmsg_total, total_samples = pkg.sharding.reduce_job(elapsed, nmsg, n, device=reduce_dev)
 
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
     value = total_samples / (ms_per_step * 1e-3) / 1e6  # Msamples/s, whole job
@@ -314,7 +331,9 @@ def main():
         "capture_generation_s": round(gen_s, 2),
         "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3)},
         "settle_ms_per_pass": settle_log,  # untimed single passes before the warm-up, by half second (rank 0)
-        "host_placement": pinned or "process affinity left as found",
+        "host_placement": ({k: v for k, v in pinned.items() if k != "cpu_list"} if pinned else "process affinity left as found"),
+        "ranks": [{k: (("%d-%d" % (v[0], v[-1])) if k == "cpus" and v else v) for k, v in r.items()} for r in per_rank],
+        "dist_backend": args.dist_backend if world > 1 else None,
         "host_threads_per_rank": "2 busy (caller: polls events, replays filter changes, queues kernels; helper: copies the "
                                  "records, power statistics) + an idle pool for the host resolver",
         "resolve_stage": ("gpu, %.2f passes per batch, %d batches handed to the host resolver"

@@ -191,3 +191,74 @@ def test_stream_float_sums_on_structured_buffers(pkg, oracle, torch_cuda, fmt):
     got = pkg.replay_device(dem, d.data_ptr(), nsamples, 4 * pkg.CHUNK)
     want, wstats = oracle.Oracle(ofmt, 58, 1, 0).replay(iq, cap=1 << 16)
     assert_same(got, dem.stats(), want, wstats)
+
+
+class MagBuf(C.Structure):
+    pass
+
+
+MagBuf._fields_ = [("data", C.POINTER(C.c_uint16)), ("totalLength", C.c_uint), ("validLength", C.c_uint), ("overlap", C.c_uint),
+                   ("sampleTimestamp", C.c_uint64), ("sysTimestamp", C.c_uint64), ("flags", C.c_int), ("mean_level", C.c_double),
+                   ("mean_power", C.c_double), ("dropped", C.c_uint), ("next", C.POINTER(MagBuf))]
+
+
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", 1), ("sc16q11", 1), ("uc8", 0)])
+def test_bound_void_demodulators_deliver_the_oracles_order(pkg, oracle, torch_cuda, fmt, mode_ac):
+    """msd_demodulate2400(struct mag_buf *) / msd_demodulate2400AC(struct mag_buf *) with a bound context of their own
+    (msd_demod_bind), called like readsb.c:826-829 calls the reference's pair: all Mode S messages of a buffer, then its
+    Mode A/C replies, buffer after buffer -- message for message the oracle's list; msd_demod_error() speaks for the
+    latest buffer only (an error of an earlier call does not linger)."""
+    import os
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    H = C.CDLL(os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "libmsd_host.so"))
+    sink_t = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    H.msd_demod_bind.argtypes = [C.c_void_p, C.c_int, sink_t, C.c_void_p]
+    H.msd_demodulate2400.argtypes = H.msd_demodulate2400AC.argtypes = [C.POINTER(MagBuf)]
+    H.msd_demodulate2400.restype = H.msd_demodulate2400AC.restype = None
+    H.msd_demod_error.restype = C.c_char_p
+    n = 4 * CHUNK + 1234
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=78, fmt=f, msgs_per_sec=3000, n_aircraft=40,
+                                                 ac_per_sec=1500 if mode_ac else 0), n)
+    conv = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, mode_ac=mode_ac, max_batch_samples=CHUNK, message_capacity=1 << 15)
+    got, order = [], []
+
+    def sink(mm, user):
+        rec = np.frombuffer(C.string_at(mm, pkg.capi.MESSAGE_DTYPE.itemsize), dtype=pkg.capi.MESSAGE_DTYPE)[0].copy()
+        got.append(rec)
+        order.append(int(rec["msgtype"]) == 32)
+
+    cb = sink_t(sink)
+    # unbound: nothing is delivered and the error says so; binding clears it
+    H.msd_demod_bind(None, 0, cb, None)
+    dummy = MagBuf()
+    H.msd_demodulate2400(C.byref(dummy))
+    assert b"no receiver bound" in H.msd_demod_error()
+    assert H.msd_demod_bind(dem._h, mode_ac, cb, None) == 0
+    overlap = pkg.capi.OVERLAP
+    carry = np.zeros(overlap, dtype=np.uint16)
+    counter, per_buffer = 0, []
+    for b in range(n // CHUNK + 1):
+        m = min(CHUNK, n - b * CHUNK)
+        part = iq[b * CHUNK * bps:(b * CHUNK + m) * bps]
+        mag, level, power = conv.convert(part if m else np.zeros(16, np.uint8), m)
+        data = np.ascontiguousarray(np.concatenate([carry, mag]))
+        buf = MagBuf(data=data.ctypes.data_as(C.POINTER(C.c_uint16)), totalLength=data.size, validLength=overlap + m,
+                     overlap=overlap, sampleTimestamp=counter * 5, sysTimestamp=counter * 5 // 12000, flags=0,
+                     mean_level=level, mean_power=power, dropped=0)
+        k0 = len(got)
+        H.msd_demodulate2400(C.byref(buf))
+        assert H.msd_demod_error() == b""          # the unbound call's error did not linger
+        k1 = len(got)
+        assert not any(order[k0:k1])                # Mode S only from the first call
+        if mode_ac:
+            H.msd_demodulate2400AC(C.byref(buf))
+            assert all(order[k1:])                  # then the buffer's replies
+        per_buffer.append((k1 - k0, len(got) - k1))
+        carry = data[-overlap:]
+        counter += m
+    H.msd_demod_bind(None, 0, cb, None)
+    want, _ = oracle.Oracle(of, 58, 1, mode_ac).replay(iq, cap=1 << 16)
+    assert len(want) > 100 and (not mode_ac or sum(k for _, k in per_buffer) > 10)
+    assert_same_messages(np.array(got, dtype=pkg.capi.MESSAGE_DTYPE), want)

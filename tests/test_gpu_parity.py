@@ -515,3 +515,17 @@ def test_field_decoder_on_the_device_matches_the_oracle(pkg, oracle, torch_cuda)
     # and byte for byte against the host build of the same header
     host = np.array([pkg.capi.decode_fields(m) for m in msgs[:3000]])
     assert host.tobytes() == got[:3000].tobytes()
+
+
+def test_more_clean_squitter_addresses_than_the_prediction_table_holds(pkg, oracle, torch_cuda, resolve_stage):
+    """One batch with far more distinct CRC-clean DF17 / DF11 addresses than the scan kernel's prediction table has
+    slots (65536; its list 32768): the probes must end (msd_pred_impl.h bounds them and stops inserting once the list
+    is full), the batch goes to the host resolver, and the messages are the oracle's."""
+    n = 800 * 131072
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, n, seed=4242, nfix=1, n_aircraft=1000000, msgs_per_sec=8000,
+                        overlap_permille=0)
+    # the capture really holds that many: every accepted DF11 / DF17 carries its address in the clear
+    squitters = got[(got["msgtype"] == 17) | (got["msgtype"] == 11)]
+    assert len(np.unique(squitters["addr"])) > 66000, len(np.unique(squitters["addr"]))
+    if resolve_stage == "gpu-resolve":
+        assert dem.timing()["resolve_fallback"] >= 1
