@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--format", default="uc8", choices=["uc8", "sc16", "sc16q11"])
     ap.add_argument("--fix", type=int, default=0, help="nfix_crc (0 = --no-fix, the configs[1] setting)")
     ap.add_argument("--msgs-per-sec", type=int, default=2000)
+    ap.add_argument("--noise-fs", type=float, default=0.02, help="sigma of the I/Q noise in units of full scale (SURVEY.md 8(d): 0.02)")
+    ap.add_argument("--threshold", type=int, default=58, help="--preamble-threshold (readsb.c:503-505: 40..400, default 58)")
+    ap.add_argument("--input", default="siggen", choices=["siggen", "random"],
+                    help="random: uniformly random bytes instead of the synthetic capture (candidate-density sweeps)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 29, help="samples the CPU baseline replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true",
@@ -163,9 +167,13 @@ def main():
 
     # ---- synthetic capture, generated on the host from a seed, then made resident in HBM ----
     seed = pkg.sharding.capture_seed(rank)
-    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec, ac_per_sec=500 if args.mode_ac else 0)
+    cfg = pkg.siggen.make_cfg(seed=seed, fmt=fmt, msgs_per_sec=args.msgs_per_sec, ac_per_sec=500 if args.mode_ac else 0,
+                              noise_fs=args.noise_fs)
     t0 = time.time()
-    iq = pkg.siggen.generate(cfg, n)
+    if args.input == "random":
+        iq = np.random.default_rng(seed).integers(0, 256, size=n * bps, dtype=np.uint8)
+    else:
+        iq = pkg.siggen.generate(cfg, n)
     gen_s = time.time() - t0
     d_iq = torch.from_numpy(iq).to(dev)
     torch.cuda.synchronize()
@@ -175,7 +183,7 @@ def main():
     # pass while the last batches of the current one are still in flight (every pass still begins with an
     # empty ICAO filter, a zero clock and zero counters, and all K passes are complete before the clock stops).
     nctx = 1
-    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=58, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=device_index, dc_filter=args.dcfilter,
+    dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=args.threshold, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=device_index, dc_filter=args.dcfilter,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
                             decode_fields=args.fields)
             for _ in range(nctx)]
@@ -314,10 +322,13 @@ def main():
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32 (u8 IQ -> u16 magnitude -> int32 correlators, 24-bit CRC)", "data": "synthetic",
-        "config": {"workload": "%.3f GiB synthetic 2.4 MSPS %s capture per GPU, %s, %s, preamble threshold 58, "
-                               "%d frames/s, seeds 10901+rank" % (n * bps / 2**30, args.format.upper(),
-                                                                  "Mode S + Mode A/C" if args.mode_ac else "Mode S only",
-                                                                  "--no-fix" if args.fix == 0 else "--fix", args.msgs_per_sec),
+        "config": {"workload": "%.3f GiB synthetic 2.4 MSPS %s capture per GPU, %s, %s, preamble threshold %d, "
+                               "%s, seeds 10901+rank" % (n * bps / 2**30, args.format.upper(),
+                                                         "Mode S + Mode A/C" if args.mode_ac else "Mode S only",
+                                                         "--no-fix" if args.fix == 0 else "--fix", args.threshold,
+                                                         "uniformly random bytes" if args.input == "random" else
+                                                         "%d frames/s%s" % (args.msgs_per_sec, "" if args.noise_fs == 0.02
+                                                                            else ", noise sigma %.3f FS" % args.noise_fs)),
                    "samples_per_gpu": n, "batch_samples": batch, "parallelism": "independent capture per GPU, no collective",
                    "captures": "one context per GPU; passes over the capture back to back (msd_restart), each starting "
                                "from an empty ICAO filter, all complete inside the timed region"},
@@ -327,7 +338,9 @@ def main():
         "pipeline_ms": ({**{k: round(float(np.mean([t[k] for t in measured])), 4) for k in
                             ("scan_kernel_ms", "other_kernels_ms")},
                          **{k: round(float(np.mean([t[k] for t in timings])), 4) for k in
-                            ("d2h_ms", "resolve_ms", "hits", "tries")}} if timings and measured else None),
+                            ("d2h_ms", "resolve_ms", "hits", "tries")},
+                         "reruns": int(max(t["reruns"] for t in timings)),
+                         "resolve_fallback": int(max(t["resolve_fallback"] for t in timings))} if timings and measured else None),
         "capture_generation_s": round(gen_s, 2),
         "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3)},
         "settle_ms_per_pass": settle_log,  # untimed single passes before the warm-up, by half second (rank 0)
@@ -353,7 +366,7 @@ def main():
         # (a) one thread doing everything (orc_replay: IQ -> magnitude -> demodulator), whole passes for ~10 s
         passes, cpu_s = 0, 0.0
         while passes < 1 or (cpu_s < 10.0 and passes < 8):
-            orc = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac), dc_filter=args.dcfilter)
+            orc = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter)
             t0 = time.perf_counter()
             w, ws = orc.replay(iq[: ns * bps], cap=1 << 21)
             cpu_s += time.perf_counter() - t0
@@ -368,8 +381,8 @@ def main():
         if not args.dcfilter:
             nb2 = min(ns, 1 << 28) // pkg.CHUNK
             q = queue.Queue(maxsize=12)
-            conv = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac))
-            demo = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac))
+            conv = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
+            demo = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
             cpu_t = {}
 
             def reader():
@@ -410,7 +423,7 @@ def main():
         O = graft.load_oracle()
         if want is None:
             ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-            want, wstats = O.Oracle(ofmt, 58, args.fix, int(args.mode_ac), dc_filter=args.dcfilter).replay(iq, cap=1 << 21)
+            want, wstats = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter).replay(iq, cap=1 << 21)
         dem.reset()
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
         ndiff = abs(len(got) - len(want))

@@ -1119,7 +1119,8 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
          * meets a scan waits for it; the latency-bound kernels behind the scan (float sums, Mode A/C) leave
          * room.  If the next batch is queued already, the chain starts when that batch's scan has retired. */
         Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES)
+        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES &&
+            !getenv("MSD_EXP_SIDE_NOWAIT")) /* (experiment: a resolve kernel small enough to sit beside a scan workgroup) */
             HIPCHK(c, hipStreamWaitEvent(ks, nx.ev_scanned, 0));
     }
     rc = gpu_queue_pass(c, s, ks, true);
@@ -1932,8 +1933,10 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     { /* the resolve/power follow-ups are short and on the critical path: let them jump the queued scans */
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
-        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, greatest));
+        const char *ap = getenv("MSD_EXP_AUX_PRIO"); /* experiment: "least" = the follow-up kernels only fill what the scans leave */
+        const int prio = (ap && ap[0] == 'l') ? least : greatest;
+        CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio));
+        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, prio));
     }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));

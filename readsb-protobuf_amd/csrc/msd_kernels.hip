@@ -76,14 +76,14 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
 #define MSD_PRIO_TESTS 1
 #endif
 #ifndef MSD_PRIO_CAND
-#define MSD_PRIO_CAND 3 /* measured (profiles/r04_priorities.txt): 0/0/0 0.297 ms per 128 Mi samples, 0/1/3 0.266, 0/0/1..3 0.269-0.273,
+#define MSD_PRIO_CAND 2 /* measured (profiles/r04_priorities.txt): 0/0/0 0.297 ms per 128 Mi samples, 0/1/3 0.266, 0/0/1..3 0.269-0.273,
                            0/1/2 0.267, 1/2/3 0.264, 1/1/3 0.278, 0/1/3 with step B at 0 / 1 / 2: 0.284 / 0.278 / 0.269 */
 #endif
 #ifndef MSD_STEPB_BATCH
 #define MSD_STEPB_BATCH 0
 #endif
 #ifndef MSD_PRIO_STEPB
-#define MSD_PRIO_STEPB MSD_PRIO_CAND /* step B of a candidate round: its one long run of instructions */
+#define MSD_PRIO_STEPB 3 /* step B of a candidate round: most of the round's LDS traffic */
 #endif
 #include "msd_emit_impl.h"
 #include "msd_pred_impl.h"
