@@ -118,7 +118,8 @@ def run_also(extra):
     return {"workload": d["config"]["workload"], "options": " ".join(extra), "value": d["value"], "unit": d["unit"],
             "ms_per_step": d["ms_per_step"], "dominant_kernel": "msd_scan_kernel" if (scan or 0) >= (rest or 0) else "kernels behind the scan",
             "kernel_ms": scan, "kernels_behind_the_scan_ms": rest, "frac": d["roofline"]["frac"],
-            "traffic": d["roofline"]["traffic"], "messages_per_step": d["messages_per_step"],
+            "traffic": d["roofline"]["traffic"], "traffic_of_kernels_behind_the_scan": d["roofline"].get("traffic_of_kernels_behind_the_scan"),
+            "messages_per_step": d["messages_per_step"],
             "message_set_diff_vs_oracle": d.get("message_set_diff_vs_oracle"), "resolve_stage": d.get("resolve_stage")}
 
 
@@ -287,20 +288,29 @@ def main():
     traffic = None
     # the latest round's measurement for this sample format; the launches of the in-order layout also carry the
     # previous batch's message records (fused), the others are the scan alone (_scan_only)
-    fused = (os.environ.get("MSD_EMIT_FUSED", "1") != "0" and not args.fields and
-             os.environ.get("MSD_CHAIN_INLINE", "0" if (args.mode_ac or args.format != "uc8" or args.dcfilter) else "1") != "0")
-    tag = "_traffic.json" if args.format == "uc8" else "_sc16_traffic.json" if args.format == "sc16" else None
+    side = (dem.flags & pkg.capi.CFG_CHAIN_SIDE_STREAMS) or (not (dem.flags & pkg.capi.CFG_CHAIN_IN_ORDER) and
+                                                             (args.mode_ac or args.format != "uc8" or args.dcfilter))
+    fused = not (dem.flags & pkg.capi.CFG_EMIT_KERNEL) and not args.fields and not side
+    # one traffic file per workload: the Mode A/C scan also stores the magnitudes (mag_out), the 16-bit formats read 4 B per sample
+    kind = ("modeac" if args.mode_ac else "") + ("" if args.format == "uc8" else "sc16" if args.format == "sc16" else "sc16q11")
+    tag = "_%straffic.json" % (kind + "_" if kind else "")
     tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                    if tag and f.endswith(tag) and (args.format != "uc8" or "sc16" not in f))
+                    if f.endswith(tag) and (kind or not any(k in f for k in ("sc16", "modeac"))))
     tfile = os.path.join(ROOT, "profiles", tfiles[-1]) if tfiles else ""
+    traffic_kernels = None
     if tfile and not args.dcfilter:
         t = json.load(open(tfile))
-        sfx = "" if fused else "_scan_only"
+        sfx = "" if fused and ("FETCH_SIZE_KB_per_launch" in t) else "_scan_only"
         if t.get("samples_per_launch") == launch_samples and ("FETCH_SIZE_KB_per_launch" + sfx) in t:
             traffic = int((2 * t["FETCH_SIZE_KB_per_launch" + sfx] + t["WRITE_SIZE_KB_per_launch" + sfx]) * 1024)
+            # the kernels behind the scan that pass over the batch again (Mode A/C candidates, float sums): their bytes too
+            fo, wo = t.get("FETCH_SIZE_KB_per_launch_other_kernels", {}), t.get("WRITE_SIZE_KB_per_launch_other_kernels", {})
+            traffic_kernels = {k: int((2 * fo.get(k, 0) + wo.get(k, 0)) * 1024) for k in sorted(set(fo) | set(wo))
+                               if (2 * fo.get(k, 0) + wo.get(k, 0)) * 1024 > 0.02 * launch_samples * bps}
     roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC, %s)" % (os.path.basename(tfile) if traffic else "not measured for this workload"),
+                "traffic_of_kernels_behind_the_scan": traffic_kernels,
                 "algorithmic_bytes_per_launch": launch_samples * bps, "kernel": "msd_scan_kernel",
                 "avg_launch_ms": round(avg_ms, 4), "samples_per_launch": launch_samples,
                 "avg_launch_ms_with_records": round(float(np.mean(ms_rec)), 4) if ms_rec else None,
@@ -315,7 +325,7 @@ def main():
     # in the in-order layout without field decoding the scan's wavefronts also write the previous batch's message
     # records; MSD_EMIT_FUSED=0 gives them a kernel of their own and times the scan alone
     roofline["launch_includes"] = ("the previous batch's message records (35 000 x 56 B to host memory); "
-                                   "MSD_EMIT_FUSED=0 times the scan alone") if fused else "the scan only"
+                                   "MSD_CFG_EMIT_KERNEL times the scan alone") if fused else "the scan only"
 
     out = {
         "metric": "IQ Msamples/s, 2.4 MSPS %s, Mode S demodulation (CRC-valid msgs/s alongside)" % args.format.upper(),
@@ -442,6 +452,40 @@ def main():
         out["messages_checked"] = int(len(want))
         if ndiff:
             raise SystemExit("bench: GPU messages differ from the oracle: " + json.dumps(out))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dcfilter:
+        # ---- the drop-in figure: the same capture handed over in host memory (what --ifile sees, sdr_ifile.c:192-216) -- upload
+        # over PCIe + kernels + records home, batches in flight, page-locked buffers.  Reported beside `value`, never as it. ----
+        try:
+            pb = min(batch, 1 << 26)
+            nbuf = (n + pb - 1) // pb
+            bufs = [dem.host_buffer(pb * bps) for _ in range(nbuf)]
+            for i, b in enumerate(bufs):
+                m = min(pb, n - i * pb)
+                b[: m * bps] = iq[i * pb * bps:(i * pb + m) * bps]
+            best = None
+            for rep in range(3):
+                dem.reset()
+                torch.cuda.synchronize()
+                t0, inflight, nm = time.perf_counter(), 0, 0
+                for i, b in enumerate(bufs):
+                    m = min(pb, n - i * pb)
+                    if inflight == DEPTH:
+                        nm += len(dem.collect(copy=False))
+                        inflight -= 1
+                    dem.launch_host(b, m, last=i == nbuf - 1)
+                    inflight += 1
+                while inflight:
+                    nm += len(dem.collect(copy=False))
+                    inflight -= 1
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["pcie_inclusive"] = {"value": round(n / best / 1e6, 1), "unit": "Msamples/s", "link_GBps": round(n * bps / best / 1e9, 1),
+                                     "messages": nm, "batch_samples": pb,
+                                     "what": "msd_launch_host + msd_collect from page-locked host buffers, %d batches in flight, "
+                                             "best of 3 passes over the same capture; PCIe Gen5 x16 = 63 GB/s" % DEPTH}
+            del bufs
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+            out["pcie_inclusive"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_also and not args.no_cpu_baseline and args.format == "uc8" and \
             not (args.mode_ac or args.fields or args.dcfilter or args.fix) and n == 1 << 29:
         # BASELINE configs[2] and configs[4] at full size, after the clock stopped, each against the oracle

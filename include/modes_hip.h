@@ -6,8 +6,8 @@
  * only; one context per receiver / GPU / host thread; no shared mutable globals (the reference
  * keeps this state in file statics: readsb.c:60 `Modes`, convert.c:33, icao_filter.c:38-40,
  * crc.c:84-88).  All functions return 0 or a negative errno-style code, never throw, and never
- * print (the experiment switches MSD_RESOLVE_TRACE / MSD_KERNEL_TIMING of DESIGN.md 6.1 aside, which write
- * timings to stderr when the caller sets them); the last error text of a context is available from
+ * print (MSD_CFG_TRACE and -DMSD_KERNEL_TIMING builds aside, which write timings to stderr for experiments), and never
+ * read the environment: every switch is a field of the context's msd_config; the last error text of a context is available from
  * msd_last_error(ctx), the reason of the calling thread's last failed msd_create from msd_last_error(NULL).
  * After a batch could not be finished (msd_collect / msd_submit_* returned a negative code) the context
  * accepts msd_reset() and msd_destroy() only; a failed msd_launch_* consumed nothing (samples reported
@@ -44,6 +44,16 @@ typedef struct msd_config {
     int32_t flags;              /* MSD_CFG_* */
     uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk */
     void *stream;               /* hipStream_t to launch on; NULL = the context creates one */
+    /* ---- tuning and test settings of THIS context (0 = default); nothing in the library reads the environment ---- */
+    int32_t resolve_threads;      /* host threads of the buffer-parallel resolve when a batch is resolved on the host;
+                                     0 = an eighth of the CPUs, 4..64 */
+    int32_t test_arena_permille;  /* tests: candidate arenas at this many thousandths of their size (provokes the
+                                     overflow path, a batch rescanned in pieces) */
+    int32_t test_inline_adds;     /* tests: at most this many entries in a buffer's short add list (< MSD_RB_ADD_INLINE);
+                                     0 = all of them */
+    int32_t debug_flags;          /* kernel ablations for timing experiments (results are then incomplete): 1 stop after the
+                                     preamble tests, 2 after the conversion, 4 no step B, 64 / 128 record writers without
+                                     their stores / altogether */
 } msd_config;
 
 /* The part of struct modesMessage (readsb.h:340-547) the demodulator determines; this is what
@@ -65,6 +75,21 @@ typedef struct msd_message {
 } msd_message;
 
 /* msd_config.flags */
+/* Stream layout of a context.  The defaults are the measured best per configuration; the switches exist
+ * so that every layout stays tested (tests/test_gpu_configs.py) and measurable (profiles/). */
+#define MSD_CFG_HOST_RESOLVE (1 << 4)      /* the ordered resolve stage on host threads instead of the GPU */
+#define MSD_CFG_CHAIN_IN_ORDER (1 << 5)    /* resolve chain in order on the scan stream (default for UC8 / magnitudes, Mode S) */
+#define MSD_CFG_CHAIN_SIDE_STREAMS (1 << 6) /* ... on side streams (default with 16-bit IQ, Mode A/C, --dcfilter) */
+#define MSD_CFG_NO_LEAN (1 << 7)           /* gather kernel + dense candidate lists instead of region slices read in place */
+#define MSD_CFG_NO_RESOLVE_AHEAD (1 << 8)  /* a batch is resolved in its own msd_collect only */
+#define MSD_CFG_POWER_KERNEL (1 << 9)      /* signal power in a kernel of its own (default on side streams) */
+#define MSD_CFG_POWER_IN_RESOLVE (1 << 10) /* ... at the end of the resolve workgroups (default in order) */
+#define MSD_CFG_EMIT_KERNEL (1 << 11)      /* message records by a kernel of their own, not by the next scan's wavefronts */
+#define MSD_CFG_WAIT_INPUTS_ON_STREAM (1 << 12) /* the resolve stream waits for the snapshot upload, not the caller */
+#define MSD_CFG_NO_HELPER (1 << 13)        /* no helper thread: the per-message half of a batch on the calling thread */
+#define MSD_CFG_REPASS_AUX (1 << 14)       /* repeated resolve passes on the high-priority side stream */
+#define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records fetched with a copy instead of written by the kernels */
+#define MSD_CFG_TRACE (1 << 16)            /* per-batch host timings on stderr (experiments) */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums

@@ -65,6 +65,40 @@ FIELDS_DTYPE = np.dtype(
 assert FIELDS_DTYPE.itemsize == 140
 CFG_DECODE_FIELDS = 1
 CFG_DC_FILTER = 2
+CFG_HOST_RESOLVE, CFG_CHAIN_IN_ORDER, CFG_CHAIN_SIDE_STREAMS, CFG_NO_LEAN, CFG_NO_RESOLVE_AHEAD = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
+CFG_POWER_KERNEL, CFG_POWER_IN_RESOLVE, CFG_EMIT_KERNEL, CFG_WAIT_INPUTS_ON_STREAM = 1 << 9, 1 << 10, 1 << 11, 1 << 12
+CFG_NO_HELPER, CFG_REPASS_AUX, CFG_RECORDS_DMA, CFG_TRACE = 1 << 13, 1 << 14, 1 << 15, 1 << 16
+
+
+def layout_from_environment():
+    """The library itself never reads the environment (modes_hip.h: every switch is a field of msd_config).  The test
+    suite and the benchmark scripts select stream layouts and test settings for a whole process through MSD_*
+    variables; this turns them into (flags, fields) for msd_create -- a convenience of the Python binding only."""
+    e = os.environ.get
+    flags = 0
+    if e("MSD_GPU_RESOLVE", "1") == "0":
+        flags |= CFG_HOST_RESOLVE
+    if e("MSD_CHAIN_INLINE") not in (None, ""):
+        flags |= CFG_CHAIN_IN_ORDER if e("MSD_CHAIN_INLINE") != "0" else CFG_CHAIN_SIDE_STREAMS
+    if e("MSD_LEAN", "1") == "0":
+        flags |= CFG_NO_LEAN
+    if e("MSD_RESOLVE_AHEAD", "1") == "0":
+        flags |= CFG_NO_RESOLVE_AHEAD
+    if e("MSD_POWER_FUSED") not in (None, ""):
+        flags |= CFG_POWER_IN_RESOLVE if e("MSD_POWER_FUSED") != "0" else CFG_POWER_KERNEL
+    if e("MSD_EMIT_FUSED", "1") == "0":
+        flags |= CFG_EMIT_KERNEL
+    for name, bit in (("MSD_WAIT_INPUTS_ON_STREAM", CFG_WAIT_INPUTS_ON_STREAM), ("MSD_NO_HELPER", CFG_NO_HELPER),
+                      ("MSD_REPASS_AUX", CFG_REPASS_AUX), ("MSD_RESOLVE_TRACE", CFG_TRACE)):
+        if e(name) is not None:
+            flags |= bit
+    if e("MSD_RECORDS_DMA", "0") not in ("0", ""):
+        flags |= CFG_RECORDS_DMA
+    fields = dict(resolve_threads=int(e("MSD_RESOLVE_THREADS", "0") or 0),
+                  test_arena_permille=int(e("MSD_ARENA_SCALE_PERMILLE", "0") or 0),
+                  test_inline_adds=int(e("MSD_RESOLVE_INLINE_ADDS", "0") or 0),
+                  debug_flags=int(e("MSD_DEBUG_FLAGS", "0") or 0))
+    return flags, fields
 INVALID_ALTITUDE = -9999
 
 
@@ -78,6 +112,10 @@ class Config(C.Structure):
         ("flags", C.c_int32),
         ("max_batch_samples", C.c_uint64),
         ("stream", C.c_void_p),
+        ("resolve_threads", C.c_int32),
+        ("test_arena_permille", C.c_int32),
+        ("test_inline_adds", C.c_int32),
+        ("debug_flags", C.c_int32),
     ]
 
 
@@ -221,12 +259,19 @@ class Demodulator:
     """One receiver context on one GPU (its own ICAO filter, clock, counters and HIP streams)."""
 
     def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, device=0,
-                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16, decode_fields=False, dc_filter=False):
+                 max_batch_samples=CHUNK, stream=None, message_capacity=1 << 16, decode_fields=False, dc_filter=False,
+                 flags=None, **fields):
+        """flags / fields: msd_config.flags (CFG_*) and its tuning / test fields; None = from the MSD_* environment
+        variables of the test suite (layout_from_environment)."""
         self._h = C.c_void_p()
         self.fmt = fmt
+        if flags is None:
+            flags, env_fields = layout_from_environment()
+            fields = {**env_fields, **fields}
+        self.flags = flags | (CFG_DECODE_FIELDS if decode_fields else 0) | (CFG_DC_FILTER if dc_filter else 0)
         cfg = Config(device=device, format=fmt, preamble_threshold=preamble_threshold, nfix_crc=nfix_crc,
-                     mode_ac=mode_ac, flags=(CFG_DECODE_FIELDS if decode_fields else 0) | (CFG_DC_FILTER if dc_filter else 0), max_batch_samples=max_batch_samples,
-                     stream=C.c_void_p(stream) if stream else None)
+                     mode_ac=mode_ac, flags=self.flags, max_batch_samples=max_batch_samples,
+                     stream=C.c_void_p(stream) if stream else None, **fields)
         rc = lib().msd_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()

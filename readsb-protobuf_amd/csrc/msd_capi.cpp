@@ -279,7 +279,7 @@ struct msd_ctx {
     bool gpu_resolve = false;
     uint32_t *d_snaps = nullptr, *h_snaps = nullptr;
     uint32_t snaps_uploaded = 0;
-    uint32_t inline_adds = MSD_RB_ADD_INLINE; /* MSD_RESOLVE_INLINE_ADDS (test knob) lowers it */
+    uint32_t inline_adds = MSD_RB_ADD_INLINE; /* msd_config.test_inline_adds lowers it */
     bool want_fields = false;       /* MSD_CFG_DECODE_FIELDS */
     msd_fields_fn fsink = nullptr;  /* set while msd_collect_fields runs: messages go here with their fields */
     void *fuser = nullptr;
@@ -1119,8 +1119,7 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
          * meets a scan waits for it; the latency-bound kernels behind the scan (float sums, Mode A/C) leave
          * room.  If the next batch is queued already, the chain starts when that batch's scan has retired. */
         Slot &nx = c->slots[((&s - c->slots) + 1) % MSD_PIPELINE_DEPTH];
-        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES &&
-            !getenv("MSD_EXP_SIDE_NOWAIT")) /* (experiment: a resolve kernel small enough to sit beside a scan workgroup) */
+        if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES)
             HIPCHK(c, hipStreamWaitEvent(ks, nx.ev_scanned, 0));
     }
     rc = gpu_queue_pass(c, s, ks, true);
@@ -1933,10 +1932,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     { /* the resolve/power follow-ups are short and on the critical path: let them jump the queued scans */
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const char *ap = getenv("MSD_EXP_AUX_PRIO"); /* experiment: "least" = the follow-up kernels only fill what the scans leave */
-        const int prio = (ap && ap[0] == 'l') ? least : greatest;
-        CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio));
-        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, prio));
+        CK(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest));
+        CK(hipStreamCreateWithPriority(&c->emit_stream, hipStreamNonBlocking, greatest));
     }
 
     c->tables = static_cast<msd_tables *>(malloc(sizeof(msd_tables)));
@@ -1977,12 +1974,10 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
 
     const uint64_t B = c->cfg.max_batch_samples;
     uint64_t hit_want = B / 8, try_want = B / 16;
-    if (const char *scale = getenv("MSD_ARENA_SCALE_PERMILLE")) { /* test knob: provoke the overflow path */
-        const uint64_t pm = (uint64_t)atoi(scale);
-        if (pm > 0) {
-            hit_want = hit_want * pm / 1000;
-            try_want = try_want * pm / 1000;
-        }
+    if (cfg->test_arena_permille > 0) { /* test setting: provoke the overflow path */
+        const uint64_t pm = (uint64_t)cfg->test_arena_permille;
+        hit_want = hit_want * pm / 1000;
+        try_want = try_want * pm / 1000;
     }
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
@@ -2040,49 +2035,42 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMemset(c->d_dcstate, 0, 2 * sizeof(float))); /* convert.c:476-477 */
     }
     {
-        c->trace = getenv("MSD_RESOLVE_TRACE") != nullptr;
+        c->trace = (cfg->flags & MSD_CFG_TRACE) != 0;
         c->resolver.trace = c->trace;
-        c->repass_aux = getenv("MSD_REPASS_AUX") != nullptr;
+        c->resolver.threads = cfg->resolve_threads > 0 ? cfg->resolve_threads : 0;
+        c->repass_aux = (cfg->flags & MSD_CFG_REPASS_AUX) != 0;
         /* Where the resolve chain (prediction, resolve, power, records) runs.  In order on the
          * scan stream when that stream carries nothing but scans (UC8 / magnitudes, Mode S only): a kernel that
          * shares the GPU with a scan slows it by about its own duration, so side streams buy 2 % there and make
          * the scan launches 15 % longer.  On side streams (prediction + resolve on a high-priority one, power +
          * records on a third) when the scan stream also carries the latency-bound float-sum or Mode A/C
-         * kernels, which the chain overlaps well: +13..17 % whole-job rate, measured.  MSD_CHAIN_INLINE=0/1
-         * overrides. */
+         * kernels, which the chain overlaps well: +13..17 % whole-job rate, measured.  MSD_CFG_CHAIN_IN_ORDER /
+         * MSD_CFG_CHAIN_SIDE_STREAMS override. */
         {
-            const char *ci = getenv("MSD_CHAIN_INLINE");
             const bool follow_ups = cfg->mode_ac || cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11 ||
                                     (cfg->flags & MSD_CFG_DC_FILTER);
-            c->chain_inline = ci && *ci ? *ci != '0' : !follow_ups;
+            c->chain_inline = (cfg->flags & MSD_CFG_CHAIN_IN_ORDER) ? true : (cfg->flags & MSD_CFG_CHAIN_SIDE_STREAMS) ? false : !follow_ups;
         }
-        c->no_helper = getenv("MSD_NO_HELPER") != nullptr;
-        { const char *ef = getenv("MSD_EMIT_FUSED"); c->emit_fused = c->chain_inline && !c->repass_aux /* a re-pass on another stream would race the scan that carries the records */ && !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(ef && *ef == '0'); }
+        c->no_helper = (cfg->flags & MSD_CFG_NO_HELPER) != 0;
+        c->emit_fused = c->chain_inline && !c->repass_aux /* a re-pass on another stream would race the scan that carries the records */ &&
+                        !(cfg->flags & MSD_CFG_DECODE_FIELDS) && !(cfg->flags & MSD_CFG_EMIT_KERNEL);
         /* the signal power in the resolve workgroups (no kernel of its own): in the in-order layout it takes a kernel
          * and a gap off the stream; on side streams, where the resolve kernel shares the GPU with a scan, a longer
          * resolve kernel costs more than the small power kernel behind it (measured: SC16 121 -> 124.5, Mode A/C 149 ->
          * 156 GS/s with the kernel) */
-        { const char *pf = getenv("MSD_POWER_FUSED"); c->power_fused = pf && *pf ? *pf != '0' : c->chain_inline; }
-        { const char *ra = getenv("MSD_RESOLVE_AHEAD"); c->resolve_ahead = !(ra && *ra == '0'); }
-        c->wait_inputs_on_stream = getenv("MSD_WAIT_INPUTS_ON_STREAM") != nullptr;
+        c->power_fused = (cfg->flags & MSD_CFG_POWER_IN_RESOLVE) ? true : (cfg->flags & MSD_CFG_POWER_KERNEL) ? false : c->chain_inline;
+        c->resolve_ahead = !(cfg->flags & MSD_CFG_NO_RESOLVE_AHEAD);
+        c->wait_inputs_on_stream = (cfg->flags & MSD_CFG_WAIT_INPUTS_ON_STREAM) != 0;
         c->helper.device = cfg->device;
-        if (const char *dbg = getenv("MSD_DEBUG_FLAGS"))
-            c->debug_flags = atoi(dbg);
-        const char *g = getenv("MSD_GPU_RESOLVE"); /* 0: keep the resolve stage on host threads */
-        c->gpu_resolve = g ? atoi(g) != 0 : true;
+        c->debug_flags = cfg->debug_flags;
+        c->gpu_resolve = !(cfg->flags & MSD_CFG_HOST_RESOLVE);
         c->want_fields = (cfg->flags & MSD_CFG_DECODE_FIELDS) != 0;
-        if (const char *rd = getenv("MSD_RECORDS_DMA"))
-            c->records_dma = atoi(rd) != 0;
-        const char *ia = getenv("MSD_RESOLVE_INLINE_ADDS");
-        if (ia && atoi(ia) >= 0 && (uint32_t)atoi(ia) < MSD_RB_ADD_INLINE)
-            c->inline_adds = (uint32_t)atoi(ia);
+        c->records_dma = (cfg->flags & MSD_CFG_RECORDS_DMA) != 0;
+        if (cfg->test_inline_adds > 0 && (uint32_t)cfg->test_inline_adds < MSD_RB_ADD_INLINE)
+            c->inline_adds = (uint32_t)cfg->test_inline_adds;
     }
-    {
-        const char *le = getenv("MSD_LEAN"); /* 0: keep the gather kernel and the dense lists everywhere */
-        const bool fm = cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11 || c->dc;
-        (void)fm; /* every layout: UC8 / magnitudes in order, 16-bit IQ and Mode A/C with the chain on side streams */
-        c->lean_ok = c->gpu_resolve && !c->dc && !(le && *le == '0');
-    }
+    /* (every layout: UC8 / magnitudes in order, 16-bit IQ and Mode A/C with the chain on side streams) */
+    c->lean_ok = c->gpu_resolve && !c->dc && !(cfg->flags & MSD_CFG_NO_LEAN);
     if (c->lean_ok)
         for (Slot &s : c->slots) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rhits), c->hit_arena * sizeof(msd_hit)));
@@ -2125,10 +2113,12 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->gpu_resolve = false;
     }
 #undef CK
-    if (getenv("MSD_KERNEL_TIMING")) {
+#ifdef MSD_KERNEL_TIMING /* -DMSD_KERNEL_TIMING builds only: the scan kernel's section clocks, printed by msd_destroy */
+    {
         if (hipMalloc(reinterpret_cast<void **>(&c->d_timers), 16 * sizeof(unsigned long long)) == hipSuccess)
             (void)hipMemset(c->d_timers, 0, 16 * sizeof(unsigned long long));
     }
+#endif
     c->resolver.stats = &c->stats;
     c->resolver.mode_ac = cfg->mode_ac;
     msd_resolver_reset(&c->resolver);

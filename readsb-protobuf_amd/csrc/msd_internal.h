@@ -212,7 +212,7 @@ typedef struct msd_resolver {
     uint64_t ifile_now;      /* Modes.ifile_now, readsb.h:289 */
     uint64_t sample_counter; /* samples consumed so far (sdr_ifile.c:172) */
     int mode_ac;
-    int threads; /* host threads of the speculative batch resolve; 0 = MSD_RESOLVE_THREADS or ncpu/8 */
+    int threads; /* host threads of the speculative batch resolve (msd_config.resolve_threads); 0 = ncpu/8 */
     int trace;   /* MSD_RESOLVE_TRACE was set when the context was created */
     struct msd_stats *stats;
     struct msd_batch_state *batch; /* scratch of msd_resolve_batch, owned by the resolver */

@@ -591,9 +591,6 @@ static double now_ms(void)
 
 static int default_threads(void)
 {
-    const char *e = getenv("MSD_RESOLVE_THREADS");
-    if (e && atoi(e) > 0)
-        return atoi(e);
     /* an eighth of the host's CPUs (an 8-GPU node runs 8 contexts), between 4 and 64 */
     long n = sysconf(_SC_NPROCESSORS_ONLN) / 8;
     return (int)(n < 4 ? 4 : (n > 64 ? 64 : n));
