@@ -15,7 +15,7 @@ S[F]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE
 cd /tmp
 for k in ${SETS:-A B C D}; do
   rm -rf $OUT/p
-  rocprofv3 --pmc ${S[$k]} --output-format csv -d $OUT/p -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --no-also --samples $((1<<26)) --batch $((1<<26)) "$@" > $OUT/p.log 2>&1
+  timeout 180 rocprofv3 --pmc ${S[$k]} --output-format csv -d $OUT/p -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --settle-seconds 0 --no-cpu-baseline --no-check --no-also --samples $((1<<26)) --batch $((1<<26)) "$@" > $OUT/p.log 2>&1
   f=$(find $OUT/p -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
   python3 - "$f" "$TAG" $k <<'PY' | tee -a $OUT/$TAG.txt
