@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "modes_hip_readsb.h"
 #include "msd_wire.h"
@@ -107,7 +108,12 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s\n", msd_ifileLastError());
         return 1;
     }
+    struct timespec run0, run1;
+    clock_gettime(CLOCK_MONOTONIC, &run0);
     msd_ifileRun();
+    clock_gettime(CLOCK_MONOTONIC, &run1);
+    if (want_stats) /* how long the reader ran: in signal time under --throttle (sdr_ifile.c:218-226) */
+        fprintf(stderr, "run_seconds %.3f\n", (double)(run1.tv_sec - run0.tv_sec) + 1e-9 * (double)(run1.tv_nsec - run0.tv_nsec));
     if (msd_ifileLastError()[0])
         fprintf(stderr, "%s\n", msd_ifileLastError());
     if (!g_exit) { /* readsb.c:279-281: a reader that returns without the exit flag set is an abnormal exit */

@@ -44,11 +44,12 @@ extern "C" {
 #define MSD_TILE 2048u /* scan positions per wavefront tile: 2048 (two runs of 16 per lane) or 1024 */
 #endif
 #ifndef MSD_TESTS_V2
-#define MSD_TESTS_V2 0 /* 1: the preamble tests of the scan kernel written in full-rate instructions only (msd_kernels.hip
-                          stage 2; scripts/micro/valu_issue.hip says which those are).  Measured: 20 instead of 24
-                          instructions per position and two thirds of the issue cycles, and the launch is 1 us (0.7 %)
-                          shorter without the record slice, 4 us longer with it (16 instead of 9 spilled registers):
-                          the kernel does not wait for vector-ALU issue slots.  Not the default. */
+#define MSD_TESTS_V2 1 /* 1: the preamble tests of the scan kernel written in full-rate instructions only (msd_kernels.hip
+                          stage 2; scripts/micro/valu_issue.hip says which those are): 20 instead of 24 instructions per
+                          position and two thirds of the issue cycles.  Round 3 measured no gain from it (the launch 1 us
+                          shorter) and left it off; since the phases of a tile run at different s_setprio levels (round 4,
+                          MSD_PRIO_*) the candidate rounds no longer queue behind the tests, the tests' own issue time
+                          shows, and the launch is 2-3 % shorter with it (profiles/r04_priorities.txt, v2*). */
 #endif
 #define MSD_HALO_FRONT 328u     /* samples staged ahead of a tile: overlap 326 rounded up to 8 */
 #define MSD_MAX_BATCH_SAMPLES (1ull << 28) /* hit positions are 28-bit, batch-relative */

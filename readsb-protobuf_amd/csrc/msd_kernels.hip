@@ -69,6 +69,9 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
  * wavefront).  With all phases alike the four wavefronts of a SIMD are served by age, and a wavefront in its candidate
  * rounds -- short bursts of a few instructions between LDS round trips -- queues behind the long instruction runs of a
  * neighbour's preamble tests every time it comes back from a wait. */
+#ifndef MSD_EMIT_SPAN_PCT
+#define MSD_EMIT_SPAN_PCT 100 /* the share of a wavefront's tiles (from its first) over which the record slices are spread */
+#endif
 #ifndef MSD_TESTS_SWZ
 #define MSD_TESTS_SWZ 1 /* the preamble tests' 16-byte LDS reads in an order that uses every bank (stage 2): SQ_LDS_BANK_CONFLICT
                            27.9 M -> 20.9 M, SQ_LDS_IDX_ACTIVE 50.9 M -> 43.5 M cycles per 64 Mi-sample launch, the launch itself
@@ -888,8 +891,11 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
     /* On the way: this wavefront's share of the previous batch's message records (its resolve and power kernels
      * ran before this launch), written inside one of its tiles from the candidate scratch -- a different tile for
      * neighbouring wavefronts, so that the PCIe writes of the 2 MB spread over the whole launch instead of
-     * queueing up at its start (where every wavefront's next load would wait behind its own stores). */
-    const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
+     * queueing up at its start (where every wavefront's next load would wait behind its own stores) -- but not over its
+     * last third: the kernel only ends when the last store to host memory has arrived, and with slices in the final
+     * tiles the kernel behind it started 15 us after the last wavefront had finished instead of 6 (MSD_EMIT_SPAN_PCT). */
+    const uint32_t emit_span = max(1u, (tile_hi - tile_lo) * MSD_EMIT_SPAN_PCT / 100u);
+    const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % emit_span : 0xffffffffu;
 
     TDECL
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
