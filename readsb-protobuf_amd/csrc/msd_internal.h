@@ -178,18 +178,7 @@ typedef struct msd_acc {
 #define MSD_SL_GSHORT_ROWS 13u
 #define MSD_SL_QOFF (MSD_SL_GSHORT + 32u * MSD_SL_GSHORT_ROWS)
 #define MSD_SL_PERM (MSD_SL_QOFF + 8u) /* bytes [5][32] */
-/*  - the scan kernel keeps its magnitudes in LDS as packed pairs with the top bit of every sample flipped (m - 32768 as
- *    a signed 16-bit value) and reads a correlator's three or four taps as two (three) aligned dwords, whatever the
- *    parity of its first sample; the taps' weights come as signed 16-bit pairs for v_dot2_i32_i16, NEGATED, so that a
- *    correlator says "one" iff the sum comes out negative (its sign bit is the verdict):
- *      MSD_SL_TAPS[2 q + P][20]  P = parity of the try's scan position; dwords 2 c, 2 c + 1 = the weight pairs of
- *                          correlator c for its first and second dword, dword 10 = correlator 4's third, dword 11 = five
- *                          6-bit fields, field c = byte offset of correlator c's first DWORD from the dword that holds
- *                          sample pa[12 g] - P (i.e. from 4 * ((pos + 2 + 12 g) / 2)) */
-#define MSD_SL_TAPS ((MSD_SL_PERM + 40u + 3u) & ~3u) /* 16-byte aligned rows */
-#define MSD_SL_TAPS_ROW 20u /* dwords: rows 80 bytes apart start 20 LDS banks apart, so that lanes reading the same chunk of
-                               different rows (ds_read_b128) never meet on a bank (64-byte rows: rows 0, 4, 8 would) */
-#define MSD_SLICER_WORDS (MSD_SL_TAPS + 10u * MSD_SL_TAPS_ROW)
+#define MSD_SLICER_WORDS (MSD_SL_PERM + 40u)
 #define MSD_LUT_STRIDE 136u /* folded UC8 table row pitch in u16 (bank spread) */
 typedef struct msd_tables {
     uint16_t uc8_folded[128 * MSD_LUT_STRIDE]; /* [fold(Q)][fold(I)] of convert.c:35-61 */

@@ -87,6 +87,9 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
 #define MSD_PRIO_CAND 2 /* measured (profiles/r04_priorities.txt): 0/0/0 0.297 ms per 128 Mi samples, 0/1/3 0.266, 0/0/1..3 0.269-0.273,
                            0/1/2 0.267, 1/2/3 0.264, 1/1/3 0.278, 0/1/3 with step B at 0 / 1 / 2: 0.284 / 0.278 / 0.269 */
 #endif
+#ifndef MSD_STEPB_BATCH
+#define MSD_STEPB_BATCH 0
+#endif
 #ifndef MSD_PRIO_STEPB
 #define MSD_PRIO_STEPB 3 /* step B of a candidate round: most of the round's LDS traffic */
 #endif
@@ -156,7 +159,7 @@ constexpr int W_SMETA = W_SIDX + HC * 8 * 2;                /* u32[SC] */
 constexpr int W_SMSG = W_SMETA + SC * 4;                    /* uint4[SC] */
 constexpr int W_SCRC = W_SMSG + SC * 16;                    /* u32[SC] */
 constexpr int W_SRES = W_SCRC + SC * 4;                     /* u32[SC][2]: addr, crc */
-constexpr int W_SQOFF = W_SRES + SC * 8;                    /* u32[SC]: dword 11 of the slot's MSD_SL_TAPS row (the taps' dword offsets) */
+constexpr int W_SQOFF = W_SRES + SC * 8;                    /* u32[SC]: MSD_SL_QOFF of the slot's trial phase */
 constexpr int W_BYTES = W_SQOFF + SC * 4;
 constexpr int OFF_LUT = OFF_WAVE + WAVES * W_BYTES;         /* u16[128 * LUT_STRIDE], UC8 only */
 constexpr int LDS_COMMON = OFF_LUT;
@@ -365,64 +368,46 @@ __device__ __forceinline__ void wave_lds_sync()
  * costs one LDS latency, not five.  (Loading the samples straight into the halves of packed pairs for
  * v_dot2_u32_u16 does not work here: with SRAM ECC a ds_read_u16_d16_hi zeroes the other half of its
  * destination instead of keeping it.) */
-/* The magnitudes of a tile live in LDS as packed pairs with the top bit of every sample flipped: m - 32768 as a signed
- * 16-bit value, which is what v_dot2_i32_i16 multiplies.  (The preamble tests flip them back as they unpack; sums and
- * the Mode A/C copy are taken before the flip.) */
-constexpr uint32_t MAG_BIAS2 = 0x80008000u;
-
-__device__ __forceinline__ int sdot2(uint32_t pair, uint32_t weights, int acc)
-{
-    typedef short ss2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2, pair), __builtin_bit_cast(ss2, weights), acc, false);
-}
-
-/* The five correlators of demod_2400.c:73-93 on one 5-bit group.  Correlator c looks at three (c == 4: four)
- * consecutive samples whose first one is only 2-byte aligned; round 1-3 read them one `u16` at a time (a misaligned
- * ds_read_b32/b64 is replayed lane by lane on gfx950), sixteen LDS reads a group.  Now: the two (c == 4: three) ALIGNED
- * dwords that hold them, d[c] + EXTRA (EXTRA = 24 bytes per further group of the same try: twelve samples, so the
- * alignment does not change), and the taps' weights as signed pairs from the try's MSD_SL_TAPS row -- chosen by the
- * parity of the first sample, negated, so that "18 m0 - 15 m1 - 3 m2 > 0" is the sign bit of two v_dot2_i32_i16:
- * eleven LDS dwords and eleven multiply-adds a group instead of sixteen reads and fifteen multiplies.  (The flipped
- * top bits cancel: every correlator's weights add up to zero but correlator 2's, which add up to one: its sum starts
- * at -32768.)  The verdicts are pushed as the group's five bits under trial phase 4 (q = 0): there bit k is correlator
- * (4 + 2 k) % 5 = 4, 1, 3, 0, 2, and under trial phase 4 + q every correlator's bit moves 2 q places on (mod 5) -- the
- * group's bits are this code rotated right by (2 q) % 5 within its five bits (group_bits). */
 template <int EXTRA>
-__device__ __forceinline__ uint32_t group_code(const unsigned char *const (&d)[5], const uint32_t (&tw)[11])
+__device__ __forceinline__ void group_load(const unsigned char *const (&a)[5], uint32_t (&m)[5][4])
 {
-    typedef __attribute__((address_space(3))) const uint32_t lds_word;
-    uint32_t x[5][3];
+    /* (an explicit LDS pointer: the compiler does not infer the address space of a volatile access and
+     * would emit flat loads) */
+    typedef __attribute__((address_space(3))) const volatile uint16_t lds_sample;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-        lds_word *p = (lds_word *)(d[c] + EXTRA);
-        x[c][0] = p[0];
-        x[c][1] = p[1];
-        x[c][2] = c == 4 ? p[2] : 0u;
+        lds_sample *p = (lds_sample *)(a[c] + EXTRA);
+#ifdef MSD_EXP_FEWER_READS /* timing experiment only (wrong results): what would step B cost with a third of its LDS reads? */
+        m[c][0] = p[0];
+        m[c][1] = m[c][0] + 3u;
+        m[c][2] = m[c][0] ^ 5u;
+        m[c][3] = c == 4 ? m[c][0] + 1u : 0u;
+#else
+        m[c][0] = p[0];
+        m[c][1] = p[1];
+        m[c][2] = p[2];
+        m[c][3] = c == 4 ? p[3] : 0u;
+#endif
     }
-    uint32_t code = 0;
-    constexpr int order[5] = {4, 1, 3, 0, 2};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = order[k];
-        int acc = c == 2 ? -32768 : 0;
-        acc = sdot2(x[c][0], tw[2 * c], acc);
-        acc = sdot2(x[c][1], tw[2 * c + 1], acc);
-        if (c == 4)
-            acc = sdot2(x[c][2], tw[10], acc);
-        code = __builtin_amdgcn_alignbit(code, (uint32_t)acc, 31); /* code = 2 * code + (acc < 0) */
-    }
-    return code;
 }
 
-/* the weight pairs (dwords 0..10) and the dword offsets (dword 11) of a try: row 2 q + (pos & 1) of MSD_SL_TAPS */
-__device__ __forceinline__ void load_taps(const uint32_t *sl, uint32_t q, uint32_t pos, uint32_t (&tw)[11], uint32_t &doff)
+/* The five verdicts of a group from its samples, as the group's five bits under trial phase 4 (q = 0): there bit k is
+ * correlator (4 + 2 k) % 5 = 4, 1, 3, 0, 2, and under trial phase 4 + q every correlator's bit moves 2 q places on
+ * (mod 5) -- the group's bits are this code rotated right by (2 q) % 5 within its five bits (group_bits). */
+__device__ __forceinline__ uint32_t group_code(const uint32_t (&m)[5][4])
 {
-    const uint4 *row = reinterpret_cast<const uint4 *>(sl + MSD_SL_TAPS + (2u * q + (pos & 1u)) * MSD_SL_TAPS_ROW);
-    const uint4 a = row[0], b = row[1], c = row[2];
-    tw[0] = a.x; tw[1] = a.y; tw[2] = a.z; tw[3] = a.w;
-    tw[4] = b.x; tw[5] = b.y; tw[6] = b.z; tw[7] = b.w;
-    tw[8] = c.x; tw[9] = c.y; tw[10] = c.z;
-    doff = c.w;
+    uint32_t code = 0;
+    const uint64_t b4 = __ballot(4u * m[4][0] + 15u * m[4][1] + m[4][3] > 20u * m[4][2]);
+    MSD_PUSH(code, b4);
+    const uint64_t b1 = __ballot(14u * m[1][0] > 5u * m[1][1] + 9u * m[1][2]);
+    MSD_PUSH(code, b1);
+    const uint64_t b3 = __ballot(7u * m[3][0] + 11u * m[3][1] > 18u * m[3][2]);
+    MSD_PUSH(code, b3);
+    const uint64_t b0 = __ballot(18u * m[0][0] > 15u * m[0][1] + 3u * m[0][2]);
+    MSD_PUSH(code, b0);
+    const uint64_t b2 = __ballot(16u * m[2][0] + 5u * m[2][1] > 20u * m[2][2]);
+    MSD_PUSH(code, b2);
+    return code;
 }
 
 /* (2 q) % 5 for q = 0..4: how far the bits of a group move between trial phase 4 and trial phase 4 + q */
@@ -435,6 +420,14 @@ __device__ __forceinline__ uint32_t phase_rot(uint32_t q)
 __device__ __forceinline__ uint32_t group_bits(uint32_t code, uint32_t rot)
 {
     return ((code | (code << 5)) >> rot) & 31u;
+}
+
+template <int EXTRA>
+__device__ __forceinline__ uint32_t group_verdicts(const unsigned char *const (&a)[5], uint32_t rot)
+{
+    uint32_t m[5][4];
+    group_load<EXTRA>(a, m);
+    return group_bits(group_code(m), rot);
 }
 
 /* Everything a wavefront needs besides its parameters: its private LDS block and the shared tables. */
@@ -516,15 +509,14 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
         const uint32_t e = act ? tryl[i] : 0u;
         const uint32_t h = e & 0xffu, q = e >> 8;
         const uint32_t pos = hitl[h] & 0x1fffu;
+        const uint32_t qoff = X.sl[MSD_SL_QOFF + q];
         /* pa[0] = mags[pos + 2]: the tile stages 328 samples ahead, the reference's overlap is 326 */
-        uint32_t tw[11], doff;
-        load_taps(X.sl, q < 5u ? q : 0u, pos, tw, doff);
-        const unsigned char *base4 = mbytes + 4u * ((pos + 2u) >> 1);
-        const unsigned char *d[5];
+        const unsigned char *base = mbytes + 2u * pos + 4u;
+        const unsigned char *a[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c)
-            d[c] = base4 + ((doff >> (6 * c)) & 63u);
-        const uint32_t df = group_bits(group_code<0>(d, tw), phase_rot(q));
+            a[c] = base + ((qoff >> (6 * c)) & 63u);
+        const uint32_t df = group_verdicts<0>(a, phase_rot(q));
         const uint32_t nb = bytes_for_df(df);
         const bool is_s = act && nb == 7, is_l = act && nb == 14;
         const uint64_t bs = __ballot(is_s), bl = __ballot(is_l);
@@ -539,7 +531,7 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             smeta[u] = pos | (q << 13) | (nb << 16) | (h << 20);
             *reinterpret_cast<uint4 *>(smsg32 + 4u * u) = make_uint4(df << 27, 0u, 0u, 0u);
             scrc[u] = X.sl[(is_l ? MSD_SL_GLONG : MSD_SL_GSHORT) + df];
-            sqoff[u] = doff;
+            sqoff[u] = qoff;
             sidx[h * 8u + q] = (uint16_t)u;
         }
     }
@@ -567,23 +559,36 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
             const uint32_t it = j - t * (lng ? IL : IS);
             const uint32_t u = lng ? (uint32_t)(SC - 1) - t : t;
             const uint32_t me = smeta[u];
-            const uint32_t doff = sqoff[u]; /* (with the slot's record: one LDS round trip, not two) */
+            const uint32_t qoff = sqoff[u]; /* (with the slot's record: one LDS round trip, not two) */
             const uint32_t pos = me & (uint32_t)(WT_MAX - 1), q = (me >> 13) & 7u;
             const uint32_t g1 = NG * it + 1u;
-            uint32_t tw[11], doff_again;
-            load_taps(X.sl, q < 5u ? q : 0u, pos, tw, doff_again);
-            const unsigned char *base4 = mbytes + 4u * ((pos + 2u) >> 1) + 24u * g1;
-            const unsigned char *d[5];
+            const unsigned char *base = mbytes + 2u * pos + 4u + 24u * g1;
+            const unsigned char *a[5];
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                d[c] = base4 + ((doff >> (6 * c)) & 63u);
+                a[c] = base + ((qoff >> (6 * c)) & 63u);
             const uint32_t rot = phase_rot(q);
             uint32_t v[NG];
-            v[0] = group_bits(group_code<0>(d, tw), rot);
-            if (NG > 1) v[1 % NG] = group_bits(group_code<24>(d, tw), rot);
-            if (NG > 2) v[2 % NG] = group_bits(group_code<48>(d, tw), rot);
-            if (NG > 3) v[3 % NG] = group_bits(group_code<72>(d, tw), rot);
-            if (NG > 4) v[4 % NG] = group_bits(group_code<96>(d, tw), rot);
+#if MSD_STEPB_BATCH
+            /* every sample of the item's NG groups first, then the verdicts: one LDS round trip per item instead of NG.
+             * Measured slower (+3 %): the wavefront's latency is not what the step waits for, the LDS pipe is, and 48
+             * loads in one burst fill its queue for the other fifteen wavefronts. */
+            uint32_t m[NG][5][4];
+            group_load<0>(a, m[0]);
+            if (NG > 1) group_load<24>(a, m[1 % NG]);
+            if (NG > 2) group_load<48>(a, m[2 % NG]);
+            if (NG > 3) group_load<72>(a, m[3 % NG]);
+            if (NG > 4) group_load<96>(a, m[4 % NG]);
+#pragma unroll
+            for (uint32_t c = 0; c < NG; ++c)
+                v[c] = group_bits(group_code(m[c]), rot);
+#else
+            v[0] = group_verdicts<0>(a, rot);
+            if (NG > 1) v[1 % NG] = group_verdicts<24>(a, rot);
+            if (NG > 2) v[2 % NG] = group_verdicts<48>(a, rot);
+            if (NG > 3) v[3 % NG] = group_verdicts<72>(a, rot);
+            if (NG > 4) v[4 % NG] = group_verdicts<96>(a, rot);
+#endif
             uint32_t val = 0; /* message bits 5 g1 .. 5 g1 + VB - 1 */
 #pragma unroll
             for (uint32_t c = 0; c < NG; ++c)
@@ -597,19 +602,16 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
                 for (uint32_t c = 0; c < NG; ++c) {
                     const uint32_t e = (val >> (5u * (NG - 1u - c))) & 31u;
                     if (NG * IL <= 24u && NG * IS <= 12u)
-                        syn ^= (P.debug_flags & 16) ? e : gt[32u * c + e];
+                        syn ^= gt[32u * c + e];
                     else if (e) /* rows past the last group do not exist */
                         syn ^= gt[32u * c + e];
                 }
-                if (!(P.debug_flags & 8))
                 atomicXor(&scrc[u], syn);
                 /* message bit n lives in bit 31 - (n & 31) of word n >> 5 until step C */
                 const uint32_t n0 = 5u * g1, s = n0 & 31u, top = val << (32u - VB);
-                if (!(P.debug_flags & 8)) {
                 atomicOr(&smsg32[4u * u + (n0 >> 5)], top >> s);
                 if (s > 32u - VB)
                     atomicOr(&smsg32[4u * u + (n0 >> 5) + 1u], __builtin_amdgcn_alignbit(top, 0u, s)); /* top << (32 - s) */
-                } else if (syn + top == 0x12345u) smsg32[0] = 1;
             }
         }
         if (MSD_PRIO_STEPB != MSD_PRIO_CAND)
@@ -834,9 +836,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * lane, r);
             uint32_t mg[8];
             convert_group<FMT>(r, valid, lut, mg);
-            uint4 pk = pack8(mg);
-            pk.x ^= MAG_BIAS2; pk.y ^= MAG_BIAS2; pk.z ^= MAG_BIAS2; pk.w ^= MAG_BIAS2;
-            *reinterpret_cast<uint4 *>(mags + 8 * lane) = pk;
+            *reinterpret_cast<uint4 *>(mags + 8 * lane) = pack8(mg);
         }
     }
     RawGroup<FMT> cur[GPT], nxt[GPT];
@@ -930,8 +930,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             uint32_t(&mg)[8] = mgs[k];
             mask_group(mg_valid[k], mg);
             const uint4 packed = pack8(mg);
-            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) =
-                make_uint4(packed.x ^ MAG_BIAS2, packed.y ^ MAG_BIAS2, packed.z ^ MAG_BIAS2, packed.w ^ MAG_BIAS2);
+            *reinterpret_cast<uint4 *>(mags + FRONT + 8 * (lane + 64 * k)) = packed;
             if (P.mag_out) /* wave-uniform: Mode A/C is on, its candidate kernel reads these instead of the IQ */
                 arena_store16(packed, reinterpret_cast<uint4 *>(P.mag_out + tile_pos0 + 8u * (uint32_t)(lane + 64 * k)));
             const uint32_t pk[4] = {packed.x, packed.y, packed.z, packed.w};
@@ -991,12 +990,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         const uint4 q = src[k];
-#ifdef MSD_EXP_NO_TEST_XOR /* timing experiment only (wrong results) */
                         v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-#else
-                        v[4 * k] = q.x ^ MAG_BIAS2; v[4 * k + 1] = q.y ^ MAG_BIAS2;
-                        v[4 * k + 2] = q.z ^ MAG_BIAS2; v[4 * k + 3] = q.w ^ MAG_BIAS2;
-#endif
                     }
 #endif
                 }

@@ -110,33 +110,6 @@ static void build_slicer_tables(msd_tables *t)
             perm[q * 32 + x] = (uint8_t)v;
         }
     }
-    /* the correlators of demod_2400.c:73-93 as dword reads + signed dot products (MSD_SL_TAPS) */
-    static const int corr_w[5][4] = {{18, -15, -3, 0}, {14, -5, -9, 0}, {16, 5, -20, 0}, {7, 11, -18, 0}, {4, 15, -20, 1}};
-    for (int q = 0; q < 5; ++q)
-        for (int P = 0; P < 2; ++P) {
-            uint32_t *row = &t->slicer[MSD_SL_TAPS + (uint32_t)(2 * q + P) * MSD_SL_TAPS_ROW];
-            memset(row, 0, MSD_SL_TAPS_ROW * sizeof *row);
-            uint32_t doff = 0;
-            for (int c = 0; c < 5; ++c) {
-                const uint32_t off = (t->slicer[MSD_SL_QOFF + q] >> (6 * c)) & 63u; /* bytes from &pa[12 g] to the first tap */
-                const uint32_t byte = 2u * (uint32_t)P + off;                         /* ... from the dword of pa[12 g] - P */
-                const int odd = (int)((byte >> 1) & 1u);
-                const int *w = corr_w[c];
-#define PK(lo, hi) ((uint32_t)(uint16_t)(int16_t)(-(lo)) | ((uint32_t)(uint16_t)(int16_t)(-(hi)) << 16))
-                if (!odd) {
-                    row[2 * c] = PK(w[0], w[1]);
-                    row[2 * c + 1] = PK(w[2], w[3]);
-                } else {
-                    row[2 * c] = PK(0, w[0]);
-                    row[2 * c + 1] = PK(w[1], w[2]);
-                    if (c == 4)
-                        row[10] = PK(w[3], 0);
-                }
-#undef PK
-                doff |= (byte & ~3u) << (6 * c);
-            }
-            row[11] = doff;
-        }
     for (int bits = 56; bits <= 112; bits += 56) {
         const uint32_t base = bits == 112 ? MSD_SL_GLONG : MSD_SL_GSHORT;
         const uint32_t rows = bits == 112 ? MSD_SL_GLONG_ROWS : MSD_SL_GSHORT_ROWS;
@@ -266,44 +239,6 @@ int msd_tables_selftest(const msd_tables *t)
             if (sample != tt / 5 || perm[q * 32 + (1 << (4 - c))] != (1 << (4 - k)))
                 ++bad;
         }
-    /* MSD_SL_TAPS against the correlators themselves: magnitudes as the kernel keeps them (pairs, top bits flipped),
-     * every trial phase, both parities of the scan position, groups 0..22, samples that include 0 and 65535 */
-    {
-        enum { NS = 400 };
-        uint16_t m[NS];
-        uint32_t img[NS / 2];
-        uint32_t r = 0x1234567u;
-        for (int round = 0; round < 40; ++round) {
-            for (int i = 0; i < NS; ++i) {
-                r ^= r << 13; r ^= r >> 17; r ^= r << 5;
-                m[i] = (round & 3) == 0 ? (uint16_t)((r & 1u) ? 65535u : 0u) : (round & 3) == 1 ? (uint16_t)(r >> 20) : (uint16_t)(r >> 9);
-            }
-            for (int i = 0; i < NS / 2; ++i)
-                img[i] = ((uint32_t)m[2 * i] | ((uint32_t)m[2 * i + 1] << 16)) ^ 0x80008000u;
-            static const int cw[5][4] = {{18, -15, -3, 0}, {14, -5, -9, 0}, {16, 5, -20, 0}, {7, 11, -18, 0}, {4, 15, -20, 1}};
-            for (int q = 0; q < 5; ++q)
-                for (int pos = 0; pos < 2; ++pos)       /* pa[0] = m[pos + 2] */
-                    for (int g = 0; g < 23; ++g) {
-                        const uint32_t *row = &t->slicer[MSD_SL_TAPS + (uint32_t)(2 * q + (pos & 1)) * MSD_SL_TAPS_ROW];
-                        const uint32_t base4 = 4u * (uint32_t)((pos + 2 + 12 * g) / 2); /* byte address of the dword holding pa[12 g] - P */
-                        for (int c = 0; c < 5; ++c) {
-                            const uint32_t off = (t->slicer[MSD_SL_QOFF + q] >> (6 * c)) & 63u;
-                            const int s0 = pos + 2 + 12 * g + (int)off / 2; /* first tap */
-                            const long want = (long)cw[c][0] * m[s0] + (long)cw[c][1] * m[s0 + 1] + (long)cw[c][2] * m[s0 + 2] +
-                                              (long)cw[c][3] * m[s0 + 3];
-                            const uint32_t d = (base4 + ((row[11] >> (6 * c)) & 63u)) / 4u;
-                            long acc = c == 2 ? -32768 : 0;
-                            const uint32_t wd[3] = {row[2 * c], row[2 * c + 1], c == 4 ? row[10] : 0u};
-                            for (int k = 0; k < 3; ++k) {
-                                const uint32_t x = img[d + (uint32_t)k];
-                                acc += (long)(int16_t)(x & 0xffffu) * (int16_t)(wd[k] & 0xffffu) + (long)(int16_t)(x >> 16) * (int16_t)(wd[k] >> 16);
-                            }
-                            if ((acc < 0) != (want > 0))
-                                ++bad;
-                        }
-                    }
-        }
-    }
     /* per-group syndromes against modesChecksum on pseudo-random messages */
     uint32_t x = 0x2545F491u;
     for (int trial = 0; trial < 2000; ++trial) {
