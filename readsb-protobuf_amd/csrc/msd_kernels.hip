@@ -2571,9 +2571,6 @@ __device__ inline uint32_t ac_noise_level_of(const uint64_t *sums, const float *
 }
 
 constexpr int ACNT = 256;                    /* threads per workgroup */
-constexpr int ACT = 4096;                    /* F1 positions per tile */
-constexpr int AC_LOAD = ACT + 72;            /* samples staged from m[j0 - 2]; bit 19 of the last position ends at +71 */
-static_assert(AC_LOAD % 8 == 0 && MSD_CHUNK_SAMPLES % ACT == 0, "whole groups, tiles inside one buffer");
 
 /* Every F1 position that passes all tests of demod_2400.c:581-668; the 69-sample skip-ahead after
  * a decode (:705) is left to the resolve stage.  One thread per position, magnitudes staged in
@@ -2708,133 +2705,89 @@ __device__ __forceinline__ bool ac_code(uint32_t bits /* with bit 31 = spoiled *
     return true;
 }
 
-/* Ordered compaction inside a workgroup: dst[] = the entries i of [0, n) (or src[i]) for which pred(i)
- * holds, in order; returns how many.  Entry i = r * ACNT + tid is looked at by thread tid in round r. */
-template <typename Pred>
-__device__ __forceinline__ uint32_t ac_compact(uint32_t n, const uint16_t *src, uint16_t *dst,
-                                               uint8_t (*kcount)[ACNT / 64], int tid, Pred pred)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t rounds = (n + ACNT - 1) / ACNT; /* <= ACT / ACNT */
-    uint32_t mask = 0;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * ACNT + (uint32_t)tid;
-        const bool keep = i < n && pred(src ? (uint32_t)src[i] : i);
-        const unsigned long long bal = __ballot(keep);
-        if (keep)
-            mask |= 1u << r;
-        if (lane == 0)
-            kcount[r][wave] = (uint8_t)__popcll(bal);
-    }
-    __syncthreads();
-    uint32_t total_all = 0;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < ACNT / 64; ++w) {
-            const uint32_t c = kcount[r][w];
-            if (w < wave)
-                before += c;
-            total += c;
-        }
-        if (total) { /* workgroup-uniform */
-            const bool keep = (mask >> r) & 1u;
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const uint32_t i = r * ACNT + (uint32_t)tid;
-                dst[total_all + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] =
-                    src ? src[i] : (uint16_t)i;
-            }
-            total_all += total;
-        }
-    }
-    __syncthreads();
-    return total_all;
-}
+/* The Mode A/C candidate stage: every F1 position that passes all tests of demod_2400.c:581-668 (the 69-sample
+ * skip-ahead after a decode, :705, is left to the resolve stage).  Wave-autonomous like the Mode S scan: every wavefront
+ * owns tiles of ACW positions, its own 5 KB of LDS (magnitudes + the ordered survivor list + the scratch of the bit
+ * windows) and its own slice of the output; the three ordered compactions -- F1 pulse test (a tenth of pure noise
+ * passes), F2 pulse test 20.3 us later, the twenty bit windows (one position in a hundred gets there) -- are ballots and
+ * DPP prefix sums inside the wavefront, so the workgroup meets once, at the very end.  (Rounds 1-3 had a 256-thread
+ * workgroup per 4096-position tile with nine barriers per tile: 177 us per 128 Mi samples, of which 57 were the loads and
+ * the LDS image; this one 146.) */
+constexpr int ACW = 1024;                      /* F1 positions per wavefront tile: 16 per lane */
+constexpr int ACW_LOAD = ACW + 72;             /* samples staged from m[j0 - 2] */
+constexpr int ACW_GROUPS = ACW_LOAD / 8;       /* 137 load groups: lanes take three each (the last lanes two) */
+constexpr int ACW_MAGS_BYTES = ((ACW_LOAD + 8) * 2 + 15) & ~15;
+constexpr int ACW_SURV_BYTES = ACW * 2;        /* u16[ACW]: positions that pass the F1 test (then, in place, the F2 test too) */
+constexpr int ACW_BITS_BYTES = 4 * 64 * 4;     /* clock, two thresholds, bits of up to 64 replies at a time */
+constexpr int ACW_BYTES = ACW_MAGS_BYTES + ACW_SURV_BYTES + ACW_BITS_BYTES;
+static_assert(ACW_LOAD % 8 == 0 && MSD_CHUNK_SAMPLES % ACW == 0 && ACW_BYTES % 16 == 0, "whole groups, tiles inside one buffer");
 
 template <int FMT>
-/* six wavefronts per SIMD (what the 24 KB of LDS allow) take <= 85 vector registers; left alone the compiler uses 92 */
-__global__ void __launch_bounds__(ACNT, 6) msd_ac_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                      const uint32_t *noise_levels /* or NULL: from the sums */,
-                                                      const uint64_t *sums, const float *fmeans, int use_float, msd_ac_hit *out,
-                                                      uint32_t cap, msd_wg_counts *counts)
+__global__ void __launch_bounds__(ACNT, 5) msd_ac_wave_kernel(const MsdScanParams P, uint32_t ntiles, uint32_t tiles_per_wave,
+                                                            const uint32_t *noise_levels /* or NULL: from the sums */,
+                                                            const uint64_t *sums, const float *fmeans, int use_float, msd_ac_hit *out,
+                                                            uint32_t cap, msd_wg_counts *counts)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t mags[AC_LOAD + 8];
-    /* the UC8 table stays in global memory here (L1/L2 hits): 35 KB of LDS per workgroup would halve the
-     * number of resident wavefronts, and this kernel lives on latency hiding */
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(ACNT / 64) * ACW_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t w = blockIdx.x * (ACNT / 64) + (uint32_t)wave; /* the wavefront's region */
+    unsigned char *const my = lds + wave * ACW_BYTES;
+    uint16_t *const mags = reinterpret_cast<uint16_t *>(my);
+    uint16_t *const surv = reinterpret_cast<uint16_t *>(my + ACW_MAGS_BYTES);
+    uint32_t *const h_clk = reinterpret_cast<uint32_t *>(my + ACW_MAGS_BYTES + ACW_SURV_BYTES), *const h_sig = h_clk + 64,
+                    *const h_noise = h_sig + 64, *const h_bits = h_noise + 64;
     const uint16_t *lut = P.lut;
-    __shared__ uint8_t kcount[ACT / ACNT][ACNT / 64];
-    __shared__ uint32_t kcount32[ACNT / 64];
-    __shared__ uint16_t surv[ACT], surv2[ACT]; /* positions that pass the F1 test / the F2 test too, in order */
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t wg = blockIdx.x;
-
-    const uint32_t tile_lo = wg * tiles_per_wg;
-    uint32_t tile_hi = tile_lo + tiles_per_wg;
+    const uint32_t tile_lo = w * tiles_per_wave;
+    uint32_t tile_hi = tile_lo + tiles_per_wave;
     if (tile_hi > ntiles)
         tile_hi = ntiles;
-    uint32_t cur = 0; /* workgroup-uniform output cursor */
-    msd_ac_hit *const mine = out + (size_t)wg * cap;
-    uint32_t noise_b = 0xffffffffu, noise_of_b = 0; /* the buffer whose noise level is known (every thread works it out:
-                                                       a dozen double operations once per buffer and workgroup) */
+    uint32_t cur = 0; /* wave-uniform output cursor */
+    msd_ac_hit *const mine = out + (size_t)w * cap;
+    uint32_t noise_b = 0xffffffffu, noise_of_b = 0;
 
-    /* the raw samples of a tile are fetched into registers one tile ahead */
-    constexpr int GPT_AC = (AC_LOAD / 8 + ACNT - 1) / ACNT;
-    RawGroup<FMT> rg[GPT_AC];
-    uint32_t vg[GPT_AC];
-#define AC_FETCH(TILE)                                                                               \
-    {                                                                                                \
-        const int64_t n0_ = (int64_t)(P.batch_first + (uint64_t)(TILE) * ACT) - FRONT;               \
-        _Pragma("unroll") for (int i_ = 0; i_ < GPT_AC; ++i_) {                                      \
-            const int g_ = tid + i_ * ACNT;                                                          \
-            vg[i_] = fetch_group<FMT>(P, n0_ + 8 * (g_ < AC_LOAD / 8 ? g_ : 0), rg[i_]);             \
-        }                                                                                            \
-    }
-    if (tile_lo < tile_hi)
-        AC_FETCH(tile_lo)
-    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
-        const uint64_t pos0 = (uint64_t)tile * ACT; /* batch-relative */
+    constexpr int GPT_W = (ACW_GROUPS + 63) / 64;
+    RawGroup<FMT> rg[GPT_W];
+    uint32_t vg[GPT_W];
+    auto fetch = [&](uint32_t tile) {
+        const int64_t n0 = (int64_t)(P.batch_first + (uint64_t)tile * ACW) - FRONT;
 #pragma unroll
-        for (int i = 0; i < GPT_AC; ++i) {
-            const int g = tid + i * ACNT;
-            if (g < AC_LOAD / 8) {
+        for (int i = 0; i < GPT_W; ++i) {
+            const int g = lane + 64 * i;
+            vg[i] = fetch_group<FMT>(P, n0 + 8 * (g < ACW_GROUPS ? g : 0), rg[i]);
+        }
+    };
+    if (tile_lo < tile_hi)
+        fetch(tile_lo);
+    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const uint64_t pos0 = (uint64_t)tile * ACW; /* batch-relative */
+#pragma unroll
+        for (int i = 0; i < GPT_W; ++i) {
+            const int g = lane + 64 * i;
+            if (g < ACW_GROUPS) {
                 uint32_t mg[8];
                 convert_group<FMT>(rg[i], vg[i], lut, mg);
                 *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         if (tile + 1 < tile_hi)
-            AC_FETCH(tile + 1)
-
+            fetch(tile + 1);
         const uint32_t b = (uint32_t)(pos0 / MSD_CHUNK_SAMPLES);
         const uint32_t j0 = (uint32_t)(pos0 % MSD_CHUNK_SAMPLES);
         const uint64_t bfirst = (uint64_t)b * MSD_CHUNK_SAMPLES;
-        uint64_t mlen64 = P.nsamples > bfirst ? P.nsamples - bfirst : 0;
+        const uint64_t mlen64 = P.nsamples > bfirst ? P.nsamples - bfirst : 0;
         const uint32_t mlen = mlen64 > MSD_CHUNK_SAMPLES ? MSD_CHUNK_SAMPLES : (uint32_t)mlen64;
-        if (b != noise_b) { /* workgroup-uniform */
+        if (b != noise_b) { /* wave-uniform */
             noise_of_b = noise_levels ? noise_levels[b] : ac_noise_level_of(sums, fmeans, use_float, P.nsamples, b);
             noise_b = b;
         }
         const uint32_t noise_level = noise_of_b;
 
-        /* Three ordered compactions: positions that pass the F1 pulse test (a few percent: every strong
-         * pulse edge, a tenth of pure noise) -> those that also pass the F2 test 20.3 us later -> those
-         * whose 20 bit windows decode.  Position p = r * ACNT + tid: consecutive lanes, consecutive samples. */
-        if (P.debug_flags & 32) { /* perf experiment: conversion only */
-            __syncthreads();
-            continue;
-        }
-        /* Three ordered compactions: positions that pass the F1 pulse test (a few percent: every strong
-         * pulse edge, a tenth of pure noise) -> those that also pass the F2 test 20.3 us later -> those
-         * whose 20 bit windows decode.
-         * F1 test: a thread looks at ACT / ACNT = 16 consecutive positions out of a register window of
-         * 24 samples (three 16-byte LDS reads); m[f1_sample + d] = mags[p + 2 + d]. */
+        /* F1 test (demod_2400.c:581-589): a lane looks at its 16 consecutive positions out of a register window of 24
+         * samples (three 16-byte LDS reads); m[f1_sample + d] = mags[p + 2 + d] */
         uint32_t n1;
         {
-            constexpr int PER = ACT / ACNT;
-            static_assert(PER == 16, "three uint4 cover positions 16t .. 16t+15 and their neighbours");
-            const uint4 *w4 = reinterpret_cast<const uint4 *>(mags + PER * tid);
+            const uint4 *w4 = reinterpret_cast<const uint4 *>(mags + 16 * lane);
             const uint4 wa = w4[0], wb = w4[1], wc = w4[2];
             const uint32_t ww[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
             uint32_t r[24];
@@ -2845,127 +2798,125 @@ __global__ void __launch_bounds__(ACNT, 6) msd_ac_kernel(const MsdScanParams P, 
             }
             uint32_t mask = 0;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const uint32_t f1_sample = j0 + (uint32_t)(PER * tid + k);
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t f1_sample = j0 + (uint32_t)(16 * lane + k);
                 const uint32_t m0 = r[k + 2], m1 = r[k + 3], m2 = r[k + 4];
                 const bool pass = f1_sample >= 1 && f1_sample < mlen && r[k + 1] < m0 && !(m2 > m0 || m2 > m1) &&
-                                  !(noise_level * 2 > (m0 + m1) / 2); /* demod_2400.c:581-589 */
+                                  !(noise_level * 2 > (m0 + m1) / 2);
                 mask |= (pass ? 1u : 0u) << k;
             }
             const uint32_t mine_n = (uint32_t)__builtin_popcount(mask);
             const uint32_t incl = wave_incl_scan(mine_n);
-            if (lane == 63)
-                kcount32[wave] = incl;
-            __syncthreads();
-            uint32_t before = 0;
-            n1 = 0;
-#pragma unroll
-            for (int w = 0; w < ACNT / 64; ++w) {
-                const uint32_t c = kcount32[w];
-                if (w < wave)
-                    before += c;
-                n1 += c;
-            }
-            uint32_t idx = before + incl - mine_n;
+            n1 = wave_last(incl);
+            uint32_t idx = incl - mine_n;
             while (mask) {
                 const int k = __builtin_ctz(mask);
                 mask &= mask - 1;
-                surv[idx++] = (uint16_t)(PER * tid + k);
+                surv[idx++] = (uint16_t)(16 * lane + k);
             }
-            __syncthreads();
+            wave_lds_sync();
         }
-        const uint32_t n2 = ac_compact(n1, surv, surv2, kcount, tid, [&](uint32_t p) {
+        /* F2 test (:591-613) of the n1 survivors, 64 at a time, compacted in place (the write index never passes the
+         * read index, and a round's reads are done before its writes) */
+        uint32_t n2 = 0;
+        for (uint32_t r0 = 0; r0 < n1; r0 += 64) { /* wave-uniform */
+            const uint32_t i = r0 + (uint32_t)lane;
+            const uint32_t pp = i < n1 ? (uint32_t)surv[i] : 0u;
             uint32_t a, c;
-            return ac_eval<1>(mags, (int)p, j0, mlen, noise_level, a, c);
-        });
-        /* The twenty bit windows of the n2 positions that are left (about one in a hundred), 256 of them at a
-         * time: one thread per position for the clock and the thresholds, then one thread per (position, window)
-         * -- a thread per position walking its twenty windows kept one wavefront in four busy with a fifth of
-         * its lanes -- then the survivors' records straight to the region, in position order.  The scratch
-         * lives in surv[], which the second compaction has left. */
+            const bool keep = i < n1 && ac_eval<1>(mags, (int)pp, j0, mlen, noise_level, a, c);
+            const unsigned long long bal = __ballot(keep);
+            wave_lds_sync();
+            if (keep)
+                surv[n2 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)pp;
+            n2 += (uint32_t)__popcll(bal);
+            wave_lds_sync();
+        }
+        /* the twenty bit windows (:615-668) of the n2 replies that are left, 64 replies at a time: one lane per reply
+         * for the clock and the thresholds, one lane per (reply, window) for the windows */
         uint32_t n3 = 0;
-        {
-            uint32_t *h_clk = reinterpret_cast<uint32_t *>(surv), *h_sig = h_clk + ACNT, *h_noise = h_sig + ACNT,
-                     *h_bits = h_noise + ACNT;
-            static_assert(sizeof(uint16_t) * ACT >= 4 * sizeof(uint32_t) * ACNT, "scratch fits in surv[]");
-            for (uint32_t c0 = 0; c0 < n2; c0 += ACNT) { /* workgroup-uniform */
-                const uint32_t nc = min((uint32_t)ACNT, n2 - c0);
-                if ((uint32_t)tid < nc) {
-                    uint32_t clk, sg, nz;
-                    ac_head(mags, (int)surv2[c0 + tid], j0, noise_level, clk, sg, nz);
-                    h_clk[tid] = clk;
-                    h_sig[tid] = sg;
-                    h_noise[tid] = nz;
-                    h_bits[tid] = 0;
-                }
-                __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < nc * 20u; t += ACNT) {
-                    const uint32_t i = t / 20u, bit = t - i * 20u;
-                    const uint32_t r = ac_bit(mags, (int)surv2[c0 + i], j0, h_clk[i], bit, h_sig[i], h_noise[i]);
-                    if (r)
-                        atomicOr(&h_bits[i], r);
-                }
-                __syncthreads();
-                uint32_t code = 0;
-                const bool keep = (uint32_t)tid < nc && ac_code(h_bits[tid], code);
-                const unsigned long long bal = __ballot(keep);
-                if (lane == 0)
-                    kcount32[wave] = (uint32_t)__popcll(bal);
-                __syncthreads();
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < ACNT / 64; ++w) {
-                    const uint32_t c = kcount32[w];
-                    if (w < wave)
-                        before += c;
-                    total += c;
-                }
-                if (keep) {
-                    const uint32_t k = cur + n3 + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    if (k < cap) {
-                        msd_ac_hit h;
-                        h.pos = pos0 + (uint64_t)surv2[c0 + tid];
-                        h.f2_clock = h_clk[tid] + (87 * 14);
-                        h.modeac = code;
-                        mine[k] = h;
-                    }
-                }
-                n3 += total;
-                __syncthreads(); /* the scratch and kcount32 are rewritten by the next chunk / tile */
+        for (uint32_t c0 = 0; c0 < n2; c0 += 64) { /* wave-uniform */
+            const uint32_t nc = min(64u, n2 - c0);
+            if ((uint32_t)lane < nc) {
+                uint32_t clk, sg, nz;
+                ac_head(mags, (int)surv[c0 + lane], j0, noise_level, clk, sg, nz);
+                h_clk[lane] = clk;
+                h_sig[lane] = sg;
+                h_noise[lane] = nz;
+                h_bits[lane] = 0;
             }
+            wave_lds_sync();
+            for (uint32_t t = (uint32_t)lane; t < nc * 20u; t += 64u) {
+                const uint32_t i = t / 20u, bit = t - i * 20u;
+                const uint32_t r = ac_bit(mags, (int)surv[c0 + i], j0, h_clk[i], bit, h_sig[i], h_noise[i]);
+                if (r)
+                    atomicOr(&h_bits[i], r);
+            }
+            wave_lds_sync();
+            uint32_t code = 0;
+            const bool keep = (uint32_t)lane < nc && ac_code(h_bits[lane], code);
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const uint32_t k = cur + n3 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (k < cap) {
+                    msd_ac_hit h;
+                    h.pos = pos0 + (uint64_t)surv[c0 + lane];
+                    h.f2_clock = h_clk[lane] + (87 * 14);
+                    h.modeac = code;
+                    mine[k] = h;
+                }
+            }
+            n3 += (uint32_t)__popcll(bal);
+            wave_lds_sync();
         }
         cur += n3;
-        __syncthreads();
+        wave_lds_sync(); /* the next tile rewrites the magnitudes */
     }
-#undef AC_FETCH
-    if (tid == 0) {
+    /* the workgroup's only meeting: every region leaves its count, where it starts inside the workgroup's output (ntries)
+     * and -- in the first region's record -- the workgroup's total (pad), so that the gather kernel adds up a thousand
+     * workgroup totals instead of five thousand region counts */
+    __shared__ uint32_t blk_count[ACNT / 64];
+    if (lane == 0)
+        blk_count[wave] = cur < cap ? cur : cap;
+    __syncthreads();
+    if (lane == 0) {
         msd_wg_counts c;
+        uint32_t base = 0, total = 0;
+        for (int i = 0; i < ACNT / 64; ++i) {
+            if (i < wave)
+                base += blk_count[i];
+            total += blk_count[i];
+        }
         c.nhits = cur;
-        c.ntries = 0;
+        c.ntries = base;
         c.overflow = cur > cap ? 1u : 0u;
-        c.pad = 0;
-        counts[wg] = c;
+        c.pad = total;
+        counts[w] = c;
     }
 }
 
 /* dense[offset[w] + i] = region[w][i] for the Mode A/C list.  Every workgroup adds up the counts in front of its own
  * (a thousand loads: cheaper than the single-workgroup offsets kernel and the launch gap it used to wait behind), and
  * the last one, which has seen them all, leaves the batch's totals. */
-__global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts *counts, uint32_t nwg,
+__global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts *counts, uint32_t nblocks,
                                                             const msd_ac_hit *regions, uint32_t cap,
                                                             msd_ac_hit *dense, uint64_t dense_cap, uint64_t *totals /* [4] */)
 {
+    constexpr uint32_t RPB = ACNT / 64; /* regions per workgroup of msd_ac_wave_kernel */
     __shared__ unsigned long long part[4];
     __shared__ uint32_t ovf_any;
-    const uint32_t w = blockIdx.x;
+    const uint32_t blk = blockIdx.x;
     if (threadIdx.x == 0)
         ovf_any = 0;
     __syncthreads();
     unsigned long long mine = 0;
     uint32_t ovf = 0;
-    for (uint32_t i = threadIdx.x; i < w; i += 256) {
-        mine += counts[i].nhits;
-        ovf |= counts[i].overflow;
+    const bool last = blk == nblocks - 1;
+    for (uint32_t i = threadIdx.x; i < (last ? nblocks : blk); i += 256) { /* (the last one has seen them all: the overflow flag) */
+        if (i < blk)
+            mine += counts[i * RPB].pad;
+#pragma unroll
+        for (uint32_t r = 0; r < RPB; ++r)
+            ovf |= counts[i * RPB + r].overflow;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1)
@@ -2976,17 +2927,21 @@ __global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts 
         atomicOr(&ovf_any, 1u);
     __syncthreads();
     const uint64_t o = part[0] + part[1] + part[2] + part[3];
-    if (w == nwg - 1 && threadIdx.x == 0) {
-        totals[0] = o + counts[w].nhits;
+    if (last && threadIdx.x == 0) {
+        totals[0] = o + counts[blk * RPB].pad;
         totals[1] = 0;
-        totals[2] = (ovf_any || counts[w].overflow) ? 1u : 0u;
+        totals[2] = ovf_any ? 1u : 0u;
     }
-    const uint32_t n = counts[w].nhits < cap ? counts[w].nhits : cap;
-    const uint4 *src = reinterpret_cast<const uint4 *>(regions + (size_t)w * cap);
     uint4 *dst = reinterpret_cast<uint4 *>(dense);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-        if (o + i < dense_cap)
-            dst[o + i] = src[i];
+    for (uint32_t r = 0; r < RPB; ++r) {
+        const msd_wg_counts c = counts[blk * RPB + r];
+        const uint32_t n = c.nhits < cap ? c.nhits : cap;
+        const uint4 *src = reinterpret_cast<const uint4 *>(regions + (size_t)(blk * RPB + r) * cap);
+        const uint64_t at = o + c.ntries;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+            if (at + i < dense_cap)
+                dst[at + i] = src[i];
+    }
 }
 
 } /* namespace */
@@ -3119,7 +3074,8 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     const int use_float = (format == MSD_FMT_SC16 || format == MSD_FMT_SC16Q11 || noise_ready == 2);
     const uint32_t *levels = noise_ready == 1 ? d_noise : nullptr;
     (void)nbuffers;
-    const uint32_t ntiles = (uint32_t)((p->nsamples + ACT - 1) / ACT);
+    /* max_wg regions, one per wavefront of msd_ac_wave_kernel (ACNT / 64 wavefronts a workgroup) */
+    const uint32_t ntiles = (uint32_t)((p->nsamples + ACW - 1) / ACW);
     if (ntiles == 0) {
         (void)hipMemsetAsync(d_totals, 0, 4 * sizeof(uint64_t), stream);
         return 0;
@@ -3127,32 +3083,24 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     uint32_t tpw = (ntiles + max_wg - 1) / max_wg;
     if (tpw == 0)
         tpw = 1;
-    const uint32_t nwg = (ntiles + tpw - 1) / tpw;
-    uint64_t cap = region_total / nwg;
-    if (cap > (uint64_t)tpw * ACT)
-        cap = (uint64_t)tpw * ACT;
+    const uint32_t nwg = (ntiles + tpw - 1) / tpw; /* regions = wavefronts */
+    const uint32_t nblocks = (nwg + ACNT / 64 - 1) / (ACNT / 64);
+    uint64_t cap = region_total / ((uint64_t)nblocks * (ACNT / 64));
+    if (cap > (uint64_t)tpw * ACW)
+        cap = (uint64_t)tpw * ACW;
+#define MSD_AC_LAUNCH(F)                                                                                                     \
+    hipLaunchKernelGGL(msd_ac_wave_kernel<F>, dim3(nblocks), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans, \
+                       use_float, d_regions, (uint32_t)cap, d_counts)
     switch (format) {
-    case MSD_FMT_UC8:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_UC8>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
-                           use_float, d_regions, (uint32_t)cap, d_counts);
-        break;
-    case MSD_FMT_SC16:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
-                           use_float, d_regions, (uint32_t)cap, d_counts);
-        break;
-    case MSD_FMT_SC16Q11:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_SC16Q11>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
-                           use_float, d_regions, (uint32_t)cap, d_counts);
-        break;
-    case MSD_FMT_MAG16:
-        hipLaunchKernelGGL(msd_ac_kernel<MSD_FMT_MAG16>, dim3(nwg), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans,
-                           use_float, d_regions, (uint32_t)cap, d_counts);
-        break;
-    default:
-        return -22;
+    case MSD_FMT_UC8: MSD_AC_LAUNCH(MSD_FMT_UC8); break;
+    case MSD_FMT_SC16: MSD_AC_LAUNCH(MSD_FMT_SC16); break;
+    case MSD_FMT_SC16Q11: MSD_AC_LAUNCH(MSD_FMT_SC16Q11); break;
+    case MSD_FMT_MAG16: MSD_AC_LAUNCH(MSD_FMT_MAG16); break;
+    default: return -22;
     }
+#undef MSD_AC_LAUNCH
     (void)d_offsets;
-    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nwg), dim3(256), 0, stream, d_counts, nwg, d_regions, (uint32_t)cap, d_dense,
+    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nblocks), dim3(256), 0, stream, d_counts, nblocks, d_regions, (uint32_t)cap, d_dense,
                        dense_cap, d_totals);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
