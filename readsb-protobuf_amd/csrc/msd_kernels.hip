@@ -72,6 +72,9 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
 #ifndef MSD_EMIT_SPAN_PCT
 #define MSD_EMIT_SPAN_PCT 100 /* the share of a wavefront's tiles (from its first) over which the record slices are spread */
 #endif
+#ifndef MSD_AC_PRIO
+#define MSD_AC_PRIO 2 /* msd_ac_wave_kernel: the F2 test and the bit windows above the F1 test (145 -> 138 us) */
+#endif
 #ifndef MSD_TESTS_SWZ
 #define MSD_TESTS_SWZ 1 /* the preamble tests' 16-byte LDS reads in an order that uses every bank (stage 2): SQ_LDS_BANK_CONFLICT
                            27.9 M -> 20.9 M, SQ_LDS_IDX_ACTIVE 50.9 M -> 43.5 M cycles per 64 Mi-sample launch, the launch itself
@@ -2816,6 +2819,8 @@ __global__ void __launch_bounds__(ACNT, 5) msd_ac_wave_kernel(const MsdScanParam
             }
             wave_lds_sync();
         }
+        if (MSD_AC_PRIO)
+            __builtin_amdgcn_s_setprio(MSD_AC_PRIO); /* the short dependent steps behind the F1 test, as in the Mode S scan */
         /* F2 test (:591-613) of the n1 survivors, 64 at a time, compacted in place (the write index never passes the
          * read index, and a round's reads are done before its writes) */
         uint32_t n2 = 0;
@@ -2869,6 +2874,8 @@ __global__ void __launch_bounds__(ACNT, 5) msd_ac_wave_kernel(const MsdScanParam
             wave_lds_sync();
         }
         cur += n3;
+        if (MSD_AC_PRIO)
+            __builtin_amdgcn_s_setprio(0);
         wave_lds_sync(); /* the next tile rewrites the magnitudes */
     }
     /* the workgroup's only meeting: every region leaves its count, where it starts inside the workgroup's output (ntries)
@@ -2914,9 +2921,11 @@ __global__ void __launch_bounds__(256) msd_ac_gather_kernel(const msd_wg_counts 
     for (uint32_t i = threadIdx.x; i < (last ? nblocks : blk); i += 256) { /* (the last one has seen them all: the overflow flag) */
         if (i < blk)
             mine += counts[i * RPB].pad;
+        if (last) {
 #pragma unroll
-        for (uint32_t r = 0; r < RPB; ++r)
-            ovf |= counts[i * RPB + r].overflow;
+            for (uint32_t r = 0; r < RPB; ++r)
+                ovf |= counts[i * RPB + r].overflow;
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1)
