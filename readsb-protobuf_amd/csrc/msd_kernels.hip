@@ -55,23 +55,10 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
     *p = v;
 #endif
 }
-/* MSD_GATHER_AHEAD: where the UC8 table gathers of a tile are issued (they go through the texture addresser, one
- * 64-lane gather per ~32 cycles: the busiest unit of the conversion and the one a wavefront waits for longest).
- *   0  at the top of the tile, waited for at once (rounds 1-3)
- *   1  the NEXT tile's gathers go out between this tile's preamble tests and its candidate rounds: they are served while
- *      the wavefront works in LDS, and the top of the next tile finds its magnitudes in registers
- *   2  the next tile's gathers are spread over this tile's preamble tests, one per scan position (32 positions per lane
- *      and tile = 32 gathers): the addresser never sees a burst, and the raw IQ is fetched a tile further ahead */
-#ifndef MSD_GATHER_AHEAD
-#define MSD_GATHER_AHEAD 0
-#endif
 /* s_setprio per phase of a tile (0..3; the SIMD's issue arbitration takes the highest priority first, then the oldest
  * wavefront).  With all phases alike the four wavefronts of a SIMD are served by age, and a wavefront in its candidate
  * rounds -- short bursts of a few instructions between LDS round trips -- queues behind the long instruction runs of a
  * neighbour's preamble tests every time it comes back from a wait. */
-#ifndef MSD_EMIT_SPAN_PCT
-#define MSD_EMIT_SPAN_PCT 100 /* the share of a wavefront's tiles (from its first) over which the record slices are spread */
-#endif
 #ifndef MSD_AC_PRIO
 #define MSD_AC_PRIO 2 /* msd_ac_wave_kernel: the F2 test and the bit windows above the F1 test (145 -> 138 us) */
 #endif
@@ -89,9 +76,6 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
 #ifndef MSD_PRIO_CAND
 #define MSD_PRIO_CAND 2 /* measured (profiles/r04_priorities.txt): 0/0/0 0.297 ms per 128 Mi samples, 0/1/3 0.266, 0/0/1..3 0.269-0.273,
                            0/1/2 0.267, 1/2/3 0.264, 1/1/3 0.278, 0/1/3 with step B at 0 / 1 / 2: 0.284 / 0.278 / 0.269 */
-#endif
-#ifndef MSD_STEPB_BATCH
-#define MSD_STEPB_BATCH 0
 #endif
 #ifndef MSD_PRIO_STEPB
 #define MSD_PRIO_STEPB 3 /* step B of a candidate round: most of the round's LDS traffic */
@@ -252,25 +236,6 @@ __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t v
     }
 }
 
-/* one magnitude of a group (element e of 8), unmasked: what convert_group<FMT, false> computes, one load at a time */
-template <int FMT>
-__device__ __forceinline__ uint32_t convert_one(const RawGroup<FMT> &r, int e, const uint16_t *lut)
-{
-    if (FMT == MSD_FMT_UC8) {
-        const uint32_t w = r.w[e >> 1];
-        const uint32_t top = w & 0x80808080u;
-        const uint32_t keep = top - (top >> 7);
-        const uint32_t f = (w ^ ~keep) & 0x7f7f7f7fu;
-        return (e & 1) ? lut[(f >> 24) * LUT_STRIDE + ((f >> 16) & 0xffu)] : lut[((f >> 8) & 0xffu) * LUT_STRIDE + (f & 0xffu)];
-    } else if (FMT == MSD_FMT_MAG16) {
-        return (r.w[(e >> 1) % RawGroup<FMT>::WORDS] >> (16 * (e & 1))) & 0xffffu;
-    } else {
-        const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-        const uint32_t w = r.w[e % RawGroup<FMT>::WORDS];
-        return mag_from_s16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16), inv);
-    }
-}
-
 /* samples of the group that do not exist (before the stream, behind a gap, past the end) are silence (fifo.c:179-182) */
 __device__ __forceinline__ void mask_group(uint32_t valid, uint32_t (&mg)[8])
 {
@@ -380,17 +345,10 @@ __device__ __forceinline__ void group_load(const unsigned char *const (&a)[5], u
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         lds_sample *p = (lds_sample *)(a[c] + EXTRA);
-#ifdef MSD_EXP_FEWER_READS /* timing experiment only (wrong results): what would step B cost with a third of its LDS reads? */
-        m[c][0] = p[0];
-        m[c][1] = m[c][0] + 3u;
-        m[c][2] = m[c][0] ^ 5u;
-        m[c][3] = c == 4 ? m[c][0] + 1u : 0u;
-#else
         m[c][0] = p[0];
         m[c][1] = p[1];
         m[c][2] = p[2];
         m[c][3] = c == 4 ? p[3] : 0u;
-#endif
     }
 }
 
@@ -572,26 +530,11 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
                 a[c] = base + ((qoff >> (6 * c)) & 63u);
             const uint32_t rot = phase_rot(q);
             uint32_t v[NG];
-#if MSD_STEPB_BATCH
-            /* every sample of the item's NG groups first, then the verdicts: one LDS round trip per item instead of NG.
-             * Measured slower (+3 %): the wavefront's latency is not what the step waits for, the LDS pipe is, and 48
-             * loads in one burst fill its queue for the other fifteen wavefronts. */
-            uint32_t m[NG][5][4];
-            group_load<0>(a, m[0]);
-            if (NG > 1) group_load<24>(a, m[1 % NG]);
-            if (NG > 2) group_load<48>(a, m[2 % NG]);
-            if (NG > 3) group_load<72>(a, m[3 % NG]);
-            if (NG > 4) group_load<96>(a, m[4 % NG]);
-#pragma unroll
-            for (uint32_t c = 0; c < NG; ++c)
-                v[c] = group_bits(group_code(m[c]), rot);
-#else
             v[0] = group_verdicts<0>(a, rot);
             if (NG > 1) v[1 % NG] = group_verdicts<24>(a, rot);
             if (NG > 2) v[2 % NG] = group_verdicts<48>(a, rot);
             if (NG > 3) v[3 % NG] = group_verdicts<72>(a, rot);
             if (NG > 4) v[4 % NG] = group_verdicts<96>(a, rot);
-#endif
             uint32_t val = 0; /* message bits 5 g1 .. 5 g1 + VB - 1 */
 #pragma unroll
             for (uint32_t c = 0; c < NG; ++c)
@@ -877,28 +820,14 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                 nxt_valid[k] = fetch_group<FMT>(P, (int64_t)P.batch_first + rel + 8 * (lane + 64 * k), nxt[k]);
         }
     };
-#if MSD_GATHER_AHEAD
-    /* the magnitudes of the tile about to be written to LDS, unmasked, on their way since the tile before */
-    uint32_t mgs[GPT][8], mg_valid[GPT];
-#pragma unroll
-    for (int k = 0; k < GPT; ++k) {
-        convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
-        mg_valid[k] = cur_valid[k];
-    }
-#if MSD_GATHER_AHEAD == 2
-    if (tile_lo + 1 < tile_hi)
-        fetch_tile(tile_lo + 1);
-#endif
-#endif
 
     /* On the way: this wavefront's share of the previous batch's message records (its resolve and power kernels
      * ran before this launch), written inside one of its tiles from the candidate scratch -- a different tile for
      * neighbouring wavefronts, so that the PCIe writes of the 2 MB spread over the whole launch instead of
-     * queueing up at its start (where every wavefront's next load would wait behind its own stores) -- but not over its
-     * last third: the kernel only ends when the last store to host memory has arrived, and with slices in the final
-     * tiles the kernel behind it started 15 us after the last wavefront had finished instead of 6 (MSD_EMIT_SPAN_PCT). */
-    const uint32_t emit_span = max(1u, (tile_hi - tile_lo) * MSD_EMIT_SPAN_PCT / 100u);
-    const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % emit_span : 0xffffffffu;
+     * queueing up at its start (where every wavefront's next load would wait behind its own stores).  (Round 4: confining
+     * the slices to the first 25-66 % of the tiles, so that the host-memory stores drain before the kernel ends, bought
+     * nothing; 25 % was 15 % slower.) */
+    const uint32_t emit_at = EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers ? tile_lo + region % (tile_hi - tile_lo) : 0xffffffffu;
 
     TDECL
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
@@ -920,14 +849,12 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         }
         /* all of the tile's table loads first (8 per group, GPT groups), then their uses: the compiler keeps the
          * order it is given, and one round trip to the table instead of GPT is 3 us per tile */
-#if !MSD_GATHER_AHEAD
         uint32_t mgs[GPT][8], mg_valid[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
             mg_valid[k] = cur_valid[k];
         }
-#endif
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             uint32_t(&mg)[8] = mgs[k];
@@ -956,10 +883,8 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 
         /* ---- prefetch the next tile's IQ (behind the record slice: at that point neither this tile's raw groups nor
          * the next one's are live, which is what keeps the slice out of the loop's register budget) ---- */
-#if MSD_GATHER_AHEAD != 2
         if (tile + 1 < tile_hi)
             fetch_tile(tile + 1);
-#endif
 
         TMARK(1)
         if (!(P.debug_flags & 2)) {
@@ -1062,11 +987,6 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     MSD_PUSH(p0, f0);
                     MSD_PUSH(p1, f1);
                     MSD_PUSH(p2, f2);
-#if MSD_GATHER_AHEAD == 2
-                    /* one of the next tile's table gathers per position: 16 NH positions, 8 GPT = 16 NH gathers (on the
-                     * region's last tile they read the table for nothing: the raw groups then hold an older tile) */
-                    mgs[(16 * h + q) >> 3][(16 * h + q) & 7] = convert_one<FMT>(nxt[(16 * h + q) >> 3], (16 * h + q) & 7, lut);
-#endif
                 }
 #endif
                 /* positions past the last one the reference scans */
@@ -1093,23 +1013,6 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             }
 
             TMARK(2)
-#if MSD_GATHER_AHEAD == 1
-            /* the next tile's magnitudes: their table gathers are served while this tile's candidates are worked on */
-            if (tile + 1 < tile_hi) { /* wave-uniform */
-#pragma unroll
-                for (int k = 0; k < GPT; ++k) {
-                    convert_group<FMT, false>(nxt[k], nxt_valid[k], lut, mgs[k]);
-                    mg_valid[k] = nxt_valid[k];
-                }
-            }
-#elif MSD_GATHER_AHEAD == 2
-            /* the gathers went out with the tests; now the raw IQ of the tile after the next */
-#pragma unroll
-            for (int k = 0; k < GPT; ++k)
-                mg_valid[k] = nxt_valid[k];
-            if (tile + 2 < tile_hi)
-                fetch_tile(tile + 2);
-#endif
             if (MSD_PRIO_CAND != MSD_PRIO_TESTS)
                 __builtin_amdgcn_s_setprio(MSD_PRIO_CAND);
             if (!(P.debug_flags & 1) && H) {
@@ -1169,13 +1072,11 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         wave_lds_sync();
         if (lane < FRONT / 8)
             *reinterpret_cast<uint4 *>(mags + 8 * lane) = carry;
-#if !MSD_GATHER_AHEAD
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
             cur[k] = nxt[k];
             cur_valid[k] = nxt_valid[k];
         }
-#endif
     }
     TMARK(8)
     TFLUSH

@@ -30,6 +30,7 @@ for case in range(first, first + ncases):
     nfix = int(rng.integers(0, 3))
     mode_ac = int(kw["ac_per_sec"] > 0 and rng.integers(0, 2))
     gpu_resolve = int(rng.integers(0, 2))
+    thr = int(rng.choice([58, 58, 58, 40, 75, 400]))  # --preamble-threshold, readsb.c:503-505
     os.environ["MSD_GPU_RESOLVE"] = str(gpu_resolve)
     os.environ["MSD_RESOLVE_THREADS"] = str(int(rng.choice([1, 4, 16])))
     cfg = pkg.siggen.make_cfg(seed=case, fmt=fmt, **kw)
@@ -37,10 +38,10 @@ for case in range(first, first + ncases):
     d = torch.from_numpy(iq).to("cuda:0")
     with_fields = int(rng.integers(0, 2))
     dc = bool(rng.integers(0, 8) == 0) and n <= 12 * 131072  # the DC block runs at ~0.06 GS/s: short captures only
-    dem = pkg.Demodulator(fmt=fmt, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19,
+    dem = pkg.Demodulator(fmt=fmt, preamble_threshold=thr, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19,
                           decode_fields=bool(with_fields), dc_filter=dc)
     desc = (f"case {case}: {fmt_name} n={n} batch={batch // 131072} nfix={nfix} ac={mode_ac} gpu_resolve={gpu_resolve} "
-            f"fields={with_fields} dc={int(dc)} {kw}")
+            f"fields={with_fields} dc={int(dc)} thr={thr} {kw}")
     if with_fields:
         parts, fparts, bps = [], [], dem.bytes_per_sample
         for off in list(range(0, n, batch)) or [0]:
@@ -50,10 +51,10 @@ for case in range(first, first + ncases):
             parts.append(mm)
             fparts.append(ff)
         got, gfields = np.concatenate(parts), np.concatenate(fparts)
-        want, wfields, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac, dc_filter=dc).replay_fields(iq, cap=1 << 19)
+        want, wfields, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc).replay_fields(iq, cap=1 << 19)
     else:
         got = pkg.replay_device(dem, d.data_ptr(), n, batch)
-        want, wstats = orc.Oracle(ofmt, 58, nfix, mode_ac, dc_filter=dc).replay(iq, cap=1 << 19)
+        want, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc).replay(iq, cap=1 << 19)
     try:
         assert_same(got, dem.stats(), want, wstats)
         if with_fields:
