@@ -1989,7 +1989,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_wg_totals), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
-        c->ac_max_wg = (uint32_t)c->cu_count * 20u; /* regions of the Mode A/C candidate kernel: one per wavefront, 20 resident per CU */
+        c->ac_max_wg = (uint32_t)c->cu_count * 28u; /* regions of the Mode A/C candidate kernel: one per wavefront, 28 resident per CU (54 registers, 5 KB of LDS each) */
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_regions), c->ac_arena * sizeof(msd_ac_hit)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_counts), c->ac_max_wg * sizeof(msd_wg_counts)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_offsets), c->ac_max_wg * 2 * sizeof(uint64_t)));
