@@ -273,6 +273,7 @@ struct msd_ctx {
     msd_wg_counts *d_ac_counts = nullptr;
     uint64_t *d_ac_offsets = nullptr;
     uint32_t *d_noise = nullptr;
+    void *d_fm_work = nullptr;       /* 16-bit IQ, --dcfilter: the float-sum kernels' hand-over (msd_fm_work_bytes) */
     uint32_t ac_max_wg = 0;
     unsigned long long *d_timers = nullptr; /* MSD_KERNEL_TIMING experiments */
     /* GPU resolve stage: per-buffer reports, accepted-message records, filter snapshots, control arrays */
@@ -647,10 +648,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
     if (fm && s.nbuffers) {
-        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, c->stream)
+        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, c->d_fm_work, c->stream)
                       : msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
                                                nwg && msd_scan_tile(format) == 1024 ? s.d_tile_sums : nullptr,
-                                               c->stream);
+                                               c->d_fm_work, c->stream);
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
     }
@@ -1833,7 +1834,7 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
-    (void)hipFree(c->d_dcstate);
+    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
     (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -1995,6 +1996,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_offsets), c->ac_max_wg * 2 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_noise), c->max_buffers * sizeof(uint32_t)));
     }
+    if (cfg->format != MSD_FMT_UC8 || (cfg->flags & MSD_CFG_DC_FILTER))
+        CK(hipMalloc(&c->d_fm_work, msd_fm_work_bytes(c->max_buffers)));
     for (uint8_t *&t : c->d_tail) {
         CK(hipMalloc(reinterpret_cast<void **>(&t), (size_t)TAIL_SAMPLES * 4));
         CK(hipMemset(t, 0, (size_t)TAIL_SAMPLES * 4));
@@ -2424,7 +2427,7 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
         if (rc)
             return fail(c, rc, "convert kernel launch failed");
         if (c->cfg.format != MSD_FMT_UC8) {
-            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->stream);
+            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->d_fm_work, c->stream);
             if (rc)
                 return fail(c, rc, "float means kernel launch failed");
         }

@@ -187,10 +187,13 @@ int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const ui
 int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
                         uint16_t *d_mag, float *d_magsq, hipStream_t stream);
 int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
-                       hipStream_t stream);
+                       void *d_work, hipStream_t stream);
 /* tile_sums: the scan kernel's per-1024-sample approximate sums of the same batch (buffer_len a multiple of 1024), or NULL */
+/* d_work: msd_fm_work_bytes(nbuffers) of device memory for the three kernels' hand-over (buffers of at most 131072 samples);
+ * NULL or longer buffers: the one-wavefront-per-sum kernel */
+size_t msd_fm_work_bytes(uint32_t nbuffers);
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                           uint32_t nbuffers, float *d_out, const float *tile_sums, hipStream_t stream);
+                           uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -123,9 +123,12 @@ constexpr int WT_MAX = MSD_TILE;      /* scan positions per wavefront tile: 16 p
 constexpr int FRONT = MSD_HALO_FRONT; /* 328 samples of look-behind staged ahead of a tile */
 /* runs of 16 consecutive positions per lane and tile: two for the byte formats; the 16-bit IQ formats hold
  * twice the raw data per sample in registers (current and prefetched tile) and stay at one */
+#ifndef MSD_SC16_RUNS
+#define MSD_SC16_RUNS 1
+#endif
 __host__ __device__ constexpr int tile_runs(int fmt)
 {
-    return (fmt == MSD_FMT_SC16 || fmt == MSD_FMT_SC16Q11) ? 1 : WT_MAX / 1024;
+    return (fmt == MSD_FMT_SC16 || fmt == MSD_FMT_SC16Q11) ? MSD_SC16_RUNS : WT_MAX / 1024;
 }
 constexpr int HC = 64;                /* hits per candidate round: one per lane */
 constexpr int SC = 64;                /* tries with a known DF per round: one per lane in step C; a round
@@ -1824,118 +1827,25 @@ __global__ void __launch_bounds__(FM_THREADS) msd_float_means_kernel(const uint8
 constexpr int FB_MAX = 128; /* blocks of FS_BLOCK elements per buffer (MSD_CHUNK_SAMPLES / 1024) */
 constexpr int FM_SLOTS = 24; /* slow blocks per sum whose sub-block totals are kept (about ten occur) */
 
-/* the block's elements in fsum_block's layout: lane L holds elements 16 L .. 16 L + 15 */
-template <int FMT, bool APPROX /* the native square root: good enough to predict a binade */>
-__device__ __forceinline__ void fm_block_values(const uint32_t *src, uint32_t n, uint32_t blk, int lane, float inv,
-                                                float (&lvl)[FS_PER], float (&pwr)[FS_PER])
+/* s + x(lane 0) + x(lane 1) + ... + x(lane 63), one addition after the other (convert.c:241-242).  The 64 values go
+ * through 256 bytes of the wavefront's LDS and come back to every lane, sixteen broadcast reads of four: the chain is
+ * then 64 dependent additions with nothing between them.  (A v_readlane per element in front of its addition: 19 cycles
+ * per element; the sum travelling from lane to lane by DPP wave_shr:1, 63 additions and no reads at all: slower still.) */
+__device__ __forceinline__ float fsum_lanes_in_order(float s, float x, float *lds64, int lane)
 {
-    const uint32_t g0 = blk * FS_BLOCK + (uint32_t)lane * FS_PER;
-    uint32_t w[FS_PER];
-    if (g0 + FS_PER <= n) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(src + g0);
+    lds64[lane] = x;
+    wave_lds_sync();
+    float4 q[16];
 #pragma unroll
-        for (int k = 0; k < FS_PER / 4; ++k) {
-            const uint4 v = q[k];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        }
-    } else {
+    for (int i = 0; i < 16; ++i)
+        q[i] = reinterpret_cast<const float4 *>(lds64)[i];
+    wave_lds_sync(); /* the next call's stores come behind these loads */
 #pragma unroll
-        for (int k = 0; k < FS_PER; ++k)
-            w[k] = g0 + k < n ? src[g0 + k] : 0u; /* past the end: zero samples add nothing */
-    }
-#pragma unroll
-    for (int k = 0; k < FS_PER; ++k) {
-        float m = 0.0f, magsq = 0.0f;
-        if (FMT == MSD_FMT_MAGSQ) { /* --dcfilter: the clamped squares msd_dcfilter_kernel left */
-            magsq = g0 + k < n ? __uint_as_float(w[k]) : 0.0f;
-            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : __builtin_sqrtf(magsq);
-        } else if (g0 + k < n) {
-            const int I = (int)(int16_t)(w[k] & 0xffffu), Q = (int)(int16_t)(w[k] >> 16);
-            const float fi = (float)I * inv, fq = (float)Q * inv;
-            const float sq_i = fi * fi, sq_q = fq * fq;
-            magsq = sq_i + sq_q;
-            if (magsq > 1.0f)
-                magsq = 1.0f;
-            m = APPROX ? __builtin_amdgcn_sqrtf(magsq) : msd_sqrt_cr(magsq);
-        }
-        lvl[k] = m;
-        pwr[k] = magsq;
-    }
-}
-
-/* the composite function of the wavefront's 1024 elements for a sum with exponent e: increment of S for an
- * even / odd S in front of the block; FS_SAT or more = "leaves the binade" (all lanes return it) */
-__device__ __forceinline__ void fsum_block_function(const float (&x)[FS_PER], int e, int lane, uint32_t &f0, uint32_t &f1)
-{
-    uint32_t base[FS_PER], tie[FS_PER];
-#pragma unroll
-    for (int k = 0; k < FS_PER; ++k)
-        fsum_element(__float_as_uint(x[k]), e, base[k], tie[k]);
-    uint32_t c0 = 0, c1 = 1;
-#pragma unroll
-    for (int k = 0; k < FS_PER; ++k) {
-        c0 += base[k] + ((tie[k] >> (~c0 & 1u)) & 1u);
-        c1 += base[k] + ((tie[k] >> (~c1 & 1u)) & 1u);
-    }
-    c1 -= 1u;
-    c0 = min(c0, FS_SAT);
-    c1 = min(c1, FS_SAT);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { /* ordered composition: (lanes .. L-d) then (L-d+1 .. L) */
-        const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
-        if (lane >= d) {
-            const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
-            c0 = min(n0, FS_SAT);
-            c1 = min(n1, FS_SAT);
-        }
-    }
-    f0 = (uint32_t)__shfl((int)c0, 63, 64);
-    f1 = (uint32_t)__shfl((int)c1, 63, 64);
-}
-
-/* The same for a block without ties, with the adder itself: for a sum with exponent e >= 1 (so that no
- * element, x <= 1, can lift it out of its binade on its own) and unit u = 2^(e-23), what an element adds is
- * a + [f > 1/2] + [f == 1/2 and the sum in front of it is odd], x / u = a + f.  fl(2^e + x) - 2^e is that
- * for an even sum, fl((2^e + u) + x) - (2^e + u) for an odd one (both differences are exact); they differ
- * exactly when the element is a tie.  Without a tie in the block its function is "add the total", an
- * integer sum.  Returns false (wave-uniform) if some element is a tie: the caller then builds the general
- * function.  total is clamped so that 64 of them fit; anything >= 2^24 means "leaves the binade". */
-__device__ __forceinline__ bool fsum_block_total(const float (&x)[FS_PER], int e, uint32_t &total)
-{
-    const float A = __uint_as_float((uint32_t)(e + 127) << 23);          /* 2^e */
-    const float half_u = __uint_as_float((uint32_t)(e - 24 + 127) << 23); /* u / 2 (e >= 1: normal) */
-    const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23); /* 1 / u */
-    /* t = fl(2^e + x) - 2^e is x rounded to a multiple of u (ties to even = what an even sum does); x - t is
-     * exact, and the element is a tie exactly when it is +-u/2.  The t's are summed as floats: exact below
-     * 2^24 u, and a sum that reaches 2^24 u stays at or above it, which is all the caller needs to know. */
-    float acc = 0.0f;
-    bool tie = false;
-#pragma unroll
-    for (int k = 0; k < FS_PER; ++k) {
-        const float t = (A + x[k]) - A;
-        tie |= __builtin_fabsf(x[k] - t) == half_u;
-        acc += t;
-    }
-    const uint32_t mine = (uint32_t)(acc * scale);
-    if (__ballot(tie))
-        return false;
-    total = wave_last(wave_incl_scan(min(mine, 1u << 25)));
-    return true;
-}
-
-/* s + x(lane 0) + x(lane 1) + ... + x(lane 63), one addition after the other (convert.c:241-242).  Sixteen lanes' values
- * go to scalar registers first: a v_readlane in front of every addition would make each of them wait for it. */
-__device__ __forceinline__ float fsum_lanes_in_order(float s, float x)
-{
-#pragma unroll
-    for (int q0 = 0; q0 < 64; q0 += 16) {
-        float xs[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            xs[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), q0 + i));
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "s"(xs[i]));
+    for (int i = 0; i < 16; ++i) {
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(q[i].x));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(q[i].y));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(q[i].z));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(q[i].w));
     }
     return s;
 }
@@ -1959,44 +1869,6 @@ __device__ __forceinline__ float fm_word_value(uint32_t w, float inv, int which)
     return which ? magsq : m;
 }
 
-/* The totals of the block's sixteen 64-sample sub-blocks (lanes 4 j .. 4 j + 3) for a sum with exponent ca and with
- * exponent ca + 1 (ca >= 2), in units of the respective u, and which of them contain a tie (bit j). */
-__device__ __forceinline__ void fsum_sub_totals(const float (&x)[FS_PER], int ca, int lane, uint32_t (&sub)[2][16], uint32_t (&tie)[2])
-{
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int e = ca + c;
-        const float A = __uint_as_float((uint32_t)(e + 127) << 23);
-        const float half_u = __uint_as_float((uint32_t)(e - 24 + 127) << 23);
-        const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23);
-        uint32_t p = 0;
-        bool t_any = false;
-#pragma unroll
-        for (int k0 = 0; k0 < FS_PER; k0 += 4) { /* four elements at a time: their float sum is exact from e = 2 on */
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = k0; k < k0 + 4; ++k) {
-                const float t = (A + x[k]) - A;
-                t_any |= __builtin_fabsf(x[k] - t) == half_u;
-                acc += t;
-            }
-            p += (uint32_t)(acc * scale);
-        }
-        p += (uint32_t)__shfl_xor((int)p, 1, 64);
-        p += (uint32_t)__shfl_xor((int)p, 2, 64);
-        const unsigned long long bal = __ballot(t_any);
-        if ((lane & 3) == 0)
-            sub[c][lane >> 2] = p;
-        if (lane == 0) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                m |= ((bal >> (4 * j)) & 0xfull) ? 1u << j : 0u;
-            tie[c] = m;
-        }
-    }
-}
-
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
 #pragma unroll
@@ -2005,34 +1877,119 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
-#ifdef MSD_FM_TIMERS
-__device__ unsigned long long msd_fm_cyc[10]; /* pass 1, prefix, pass 2, apply (100 MHz ticks, workgroup sums); slow blocks, blocks, workgroups,
-                                                  sub-blocks summed sample by sample, blocks summed whole */
-#define FM_T(k) if (tid == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&msd_fm_cyc[k], n_ - t_last); t_last = n_; }
-#else
-#define FM_T(k)
+/* ---- the same again as three launches (round 4) ----
+ * In msd_float_means2_kernel a buffer belongs to one workgroup from beginning to end: pass 2 (vector-ALU work, the
+ * correctly rounded square root of every sample) runs at four wavefronts per SIMD with every load's latency exposed, and
+ * while two wavefronts walk the blocks in order the other six wait.  Here the parts are kernels of their own:
+ *   msd_fm_totals_kernel     only without a scan in front (--dcfilter, the converter entry): approximate block totals
+ *   msd_fm_functions_kernel  pass 2 for all blocks of all buffers, PARTS workgroups per buffer, at most 64 registers
+ *                            (eight wavefronts per SIMD): the samples are converted on the way through -- no arrays of
+ *                            values -- and converted again in the few blocks that need the general function
+ *   msd_fm_apply_kernel      two wavefronts per buffer: the first block from zero, then the walk
+ * with the predictions, functions and sub-block totals in an FmBufWork per buffer in device memory. */
+struct FmBufWork {
+    int e[2][FB_MAX], ca[2][FB_MAX];          /* predicted exponent at the block's start / first exponent of its sub-block totals */
+    uint32_t f0[2][FB_MAX], f1[2][FB_MAX];    /* the block's function under e */
+    uint32_t slot[2][FB_MAX];                 /* where its sub-block totals are; 0xff: none */
+    uint32_t sub[2][FM_SLOTS][2][2][16];      /* [sum][slot][exponent ca, ca + 1][S even, odd][sub-block]: its function */
+    float tot[2 * FB_MAX];                    /* approximate totals (level, power interleaved) when no scan left them */
+};
+constexpr int FMK_THREADS = 256, FMK_WAVES = FMK_THREADS / 64;
+#ifndef MSD_FM_OCC
+#define MSD_FM_OCC 8 /* wavefronts per SIMD the functions kernel is held to */
 #endif
+#ifndef MSD_FM_PARTS
+#define MSD_FM_PARTS 4
+#endif
+constexpr int FM_PARTS = MSD_FM_PARTS, FM_BPP = FB_MAX / FM_PARTS; /* workgroups per buffer, blocks per workgroup */
+
+/* one sample word as (level value, power value): convert.c:228-240 (SC16), :345-357 (SC16Q11); zero words give zeros */
 template <int FMT>
-__global__ void __launch_bounds__(FM_THREADS, 4) msd_float_means2_kernel(const uint8_t *iq, uint64_t nsamples,
-                                                                      uint64_t buffer_len, uint32_t nbuffers,
-                                                                      float *out /* [nbuffers][2] */,
-                                                                      const float *tile_sums /* or NULL */)
+__device__ __forceinline__ void fm_convert(uint32_t w, float inv, float &m, float &magsq)
 {
-    __shared__ float blk_tot[2][FB_MAX];    /* approximate totals, then approximate prefix at the block's start */
-    __shared__ uint32_t blk_f0[2][FB_MAX], blk_f1[2][FB_MAX];
-    __shared__ int blk_e[2][FB_MAX];        /* predicted exponent at the block's start; INT_MIN: slow block */
-    /* A slow block -- the sum changes its exponent inside it, or the prediction sits too close to a power of two to be
-     * trusted -- is not summed element by element any more: pass 2 leaves the totals of its sixteen 64-sample sub-blocks
-     * for the two exponents in question (slow_ca and slow_ca + 1), and the apply loop walks those; only the sub-block
-     * the sum really leaves its binade in (or one with a tie) is added sample by sample. */
-    __shared__ uint32_t fm_next_blk, blk0_bits[2]; /* pass 2's block counter; the two sums behind the buffer's first block */
-    __shared__ int blk_ca[2][FB_MAX];        /* first of the two exponents; INT_MIN: none (the old way) */
-    __shared__ uint8_t blk_slot[2][FB_MAX];  /* where its sub-block totals are; 0xff: none */
-    __shared__ uint32_t slow_sub[2][FM_SLOTS][2][16];
-    __shared__ uint32_t slow_tie[2][FM_SLOTS][2];
-    const uint32_t b = blockIdx.x;
-    if (b >= nbuffers)
-        return;
+    if (FMT == MSD_FMT_MAGSQ) { /* --dcfilter: the clamped squares msd_dcfilter_kernel left */
+        magsq = __uint_as_float(w);
+        m = __builtin_sqrtf(magsq);
+    } else {
+        const float fi = (float)(int)(int16_t)(w & 0xffffu) * inv, fq = (float)(int)(int16_t)(w >> 16) * inv;
+        const float sq_i = fi * fi, sq_q = fq * fq;
+        magsq = sq_i + sq_q;
+        if (magsq > 1.0f)
+            magsq = 1.0f;
+        m = msd_sqrt_cr(magsq);
+    }
+}
+
+/* the block's sixteen words of this lane (elements 16 L .. 16 L + 15), zeros past the buffer's end */
+__device__ __forceinline__ void fm_block_words(const uint32_t *src, uint32_t n, uint32_t blk, int lane, uint32_t (&w)[FS_PER])
+{
+    const uint32_t g0 = blk * FS_BLOCK + (uint32_t)lane * FS_PER;
+    if (g0 + FS_PER <= n) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(src + g0);
+#pragma unroll
+        for (int k = 0; k < FS_PER / 4; ++k) {
+            const uint4 v = q[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k)
+            w[k] = g0 + k < n ? src[g0 + k] : 0u;
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(FMK_THREADS) msd_fm_totals_kernel(const uint8_t *iq, uint64_t nsamples, uint64_t buffer_len,
+                                                                    uint32_t nbuffers, FmBufWork *work)
+{
+    const uint32_t b = blockIdx.x / FM_PARTS, part = blockIdx.x % FM_PARTS;
+    const uint64_t first = (uint64_t)b * buffer_len;
+    uint64_t n64 = nsamples > first ? nsamples - first : 0;
+    if (n64 > buffer_len)
+        n64 = buffer_len;
+    const uint32_t n = (uint32_t)n64;
+    const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + first;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK;
+    const uint32_t hi = min(nblk, (part + 1u) * FM_BPP);
+    for (uint32_t blk = part * FM_BPP + (uint32_t)wave; blk < hi; blk += FMK_WAVES) {
+        uint32_t w[FS_PER];
+        fm_block_words(src, n, blk, lane, w);
+        float sl = 0.0f, sp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k) {
+            float magsq;
+            if (FMT == MSD_FMT_MAGSQ) {
+                magsq = __uint_as_float(w[k]);
+            } else { /* I^2 + Q^2 as one v_dot2 on the packed sample: a relative 2^-23 off the float path, a prediction does not care */
+                typedef short short2_t __attribute__((ext_vector_type(2)));
+                const short2_t v = __builtin_bit_cast(short2_t, w[k]);
+                const uint32_t d = (uint32_t)__builtin_amdgcn_sdot2(v, v, 0, false); /* <= 2^31 */
+                magsq = fminf((float)d * (inv * inv), 1.0f);
+            }
+            sl += __builtin_amdgcn_sqrtf(magsq);
+            sp += magsq;
+        }
+        sl = wave_sum_f32(sl);
+        sp = wave_sum_f32(sp);
+        if (lane == 0) {
+            work[b].tot[2 * blk] = sl;
+            work[b].tot[2 * blk + 1] = sp;
+        }
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(FMK_THREADS, MSD_FM_OCC) msd_fm_functions_kernel(const uint8_t *iq, uint64_t nsamples, uint64_t buffer_len,
+                                                                          uint32_t nbuffers, FmBufWork *work,
+                                                                          const float *tile_sums /* or NULL: work[].tot */)
+{
+    __shared__ float blk_tot[2][FB_MAX];
+    __shared__ int blk_e[2][FB_MAX], blk_ca[2][FB_MAX];
+    __shared__ uint32_t blk_slot[2][FB_MAX];
+    __shared__ uint32_t fm_next_blk;
+    const uint32_t b = blockIdx.x / FM_PARTS, part = blockIdx.x % FM_PARTS;
     const uint64_t first = (uint64_t)b * buffer_len;
     uint64_t n64 = nsamples > first ? nsamples - first : 0;
     if (n64 > buffer_len)
@@ -2041,70 +1998,21 @@ __global__ void __launch_bounds__(FM_THREADS, 4) msd_float_means2_kernel(const u
     const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + first;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NWV = FM_THREADS / 64;
-    const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK; /* <= FB_MAX: buffer_len <= MSD_CHUNK_SAMPLES */
-    if (threadIdx.x == 0)
-        fm_next_blk = 1u; /* block 0 is summed apart */
+    const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK; /* <= FB_MAX */
     constexpr int SLOW = -2147483647 - 1;
-#ifdef MSD_FM_TIMERS
-    unsigned long long t_last = wall_clock64();
-#endif
-
-    /* pass 1: approximate totals.  I^2 + Q^2 is one v_dot2 on the packed sample (an exact integer; the float
-     * path rounds each square and the sum -- a relative 2^-23 that a prediction does not care about) */
-    if (tile_sums) { /* the scan kernel of the same batch left them: one load per block instead of a pass over the samples */
-        const float *ts = tile_sums + 2 * (first / FS_BLOCK);
-        for (uint32_t blk = (uint32_t)tid; blk < nblk; blk += FM_THREADS) {
+    FmBufWork &W = work[b];
+    {
+        const float *ts = tile_sums ? tile_sums + 2 * (first / FS_BLOCK) : W.tot;
+        for (uint32_t blk = (uint32_t)tid; blk < nblk; blk += FMK_THREADS) {
             blk_tot[0][blk] = ts[2 * blk];
             blk_tot[1][blk] = ts[2 * blk + 1];
         }
-    } else
-    for (uint32_t blk = (uint32_t)wave; blk < nblk; blk += NWV) {
-        float sl = 0.0f, sp = 0.0f;
-        if (FMT == MSD_FMT_MAGSQ) {
-            float lvl[FS_PER], pwr[FS_PER];
-            fm_block_values<FMT, true>(src, n, blk, lane, inv, lvl, pwr);
-#pragma unroll
-            for (int k = 0; k < FS_PER; ++k) {
-                sl += lvl[k];
-                sp += pwr[k];
-            }
-        } else {
-            const uint32_t g0 = blk * FS_BLOCK + (uint32_t)lane * FS_PER;
-            uint32_t w[FS_PER];
-            if (g0 + FS_PER <= n) {
-                const uint4 *q = reinterpret_cast<const uint4 *>(src + g0);
-#pragma unroll
-                for (int k = 0; k < FS_PER / 4; ++k) {
-                    const uint4 v = q[k];
-                    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < FS_PER; ++k)
-                    w[k] = g0 + k < n ? src[g0 + k] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < FS_PER; ++k) {
-                typedef short short2_t __attribute__((ext_vector_type(2)));
-                const short2_t v = __builtin_bit_cast(short2_t, w[k]);
-                const uint32_t d = (uint32_t)__builtin_amdgcn_sdot2(v, v, 0, false); /* <= 2^31 */
-                const float magsq = fminf((float)d * (inv * inv), 1.0f);
-                sl += __builtin_amdgcn_sqrtf(magsq);
-                sp += magsq;
-            }
-        }
-        sl = wave_sum_f32(sl);
-        sp = wave_sum_f32(sp);
-        if (lane == 0) {
-            blk_tot[0][blk] = sl;
-            blk_tot[1][blk] = sp;
-        }
+        if (tid == 0)
+            fm_next_blk = part ? part * FM_BPP : 1u; /* the buffer's first block is the apply kernel's */
     }
     __syncthreads();
-    FM_T(0)
-    /* prefix (approximate, any order): wavefront 0 the levels, wavefront 1 the powers; lane L has blocks 2 L
-     * and 2 L + 1 */
+    /* predictions (every workgroup of the buffer works them out; part 0 leaves them for the apply kernel): wavefront 0
+     * the levels, wavefront 1 the powers, lane L has blocks 2 L and 2 L + 1 -- see msd_float_means2_kernel */
     if (wave < 2) {
         const uint32_t b0 = 2u * (uint32_t)lane, b1 = b0 + 1u;
         const float t0 = b0 < nblk ? blk_tot[wave][b0] : 0.0f, t1 = b1 < nblk ? blk_tot[wave][b1] : 0.0f;
@@ -2122,244 +2030,337 @@ __global__ void __launch_bounds__(FM_THREADS, 4) msd_float_means2_kernel(const u
         for (int j = 0; j < 2; ++j) {
             const float run = runs[j], next = run + tots[j];
             const int e0 = (int)(__float_as_uint(run) >> 23) - 127, e1 = (int)(__float_as_uint(next) >> 23) - 127;
-            /* a block inside which the sum changes its exponent, or whose sum is still tiny, is summed exactly;
-             * so is a block that starts within 2^-10 of a power of two (the approximate prefix could be on the
-             * wrong side of it -- and if it still is, the apply loop notices) */
             const uint32_t mant = __float_as_uint(run) & 0x7fffffu;
             const bool near_edge = mant < 0x2000u || mant > 0x7fe000u;
             const bool slow = e0 != e1 || e0 < -7 || near_edge || tots[j] == 0.0f;
-            /* the two exponents a slow block's sub-blocks are prepared for: the one it starts with and the next, or the
-             * one below if the sum may not have reached this one yet; fsum_sub_totals is exact from 2^2 on */
             int ca = e0 != e1 ? e0 : (near_edge && mant < 0x2000u ? e0 - 1 : e0);
-            if (!slow || ca < 2 || tots[j] == 0.0f || b0 + j >= nblk)
+            if (!slow || ca < -7 || tots[j] == 0.0f || b0 + j >= nblk)
                 ca = SLOW;
             cas[j] = ca;
-            if (b0 + j < nblk)
+            if (b0 + j < nblk) {
                 blk_e[wave][b0 + j] = slow ? SLOW : e0;
+                if (part == 0)
+                    W.e[wave][b0 + j] = slow ? SLOW : e0;
+            }
         }
-        { /* slots in block order */
-            const uint32_t mine_n = (cas[0] != SLOW ? 1u : 0u) + (cas[1] != SLOW ? 1u : 0u);
-            uint32_t at = wave_incl_scan(mine_n) - mine_n;
+        const uint32_t mine_n = (cas[0] != SLOW ? 1u : 0u) + (cas[1] != SLOW ? 1u : 0u);
+        uint32_t at = wave_incl_scan(mine_n) - mine_n;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (b0 + j < nblk) {
-                    const bool has = cas[j] != SLOW && at < (uint32_t)FM_SLOTS;
-                    blk_ca[wave][b0 + j] = has ? cas[j] : SLOW;
-                    blk_slot[wave][b0 + j] = has ? (uint8_t)at : (uint8_t)0xff;
-                    at += cas[j] != SLOW ? 1u : 0u;
+        for (int j = 0; j < 2; ++j)
+            if (b0 + j < nblk) {
+                const bool has = cas[j] != SLOW && at < (uint32_t)FM_SLOTS;
+                blk_ca[wave][b0 + j] = has ? cas[j] : SLOW;
+                blk_slot[wave][b0 + j] = has ? at : 0xffu;
+                if (part == 0) {
+                    W.ca[wave][b0 + j] = has ? cas[j] : SLOW;
+                    W.slot[wave][b0 + j] = has ? at : 0xffu;
                 }
-        }
+                at += cas[j] != SLOW ? 1u : 0u;
+            }
     }
     __syncthreads();
-    FM_T(1)
-    /* pass 2: the blocks go to whichever wavefront is free (an LDS counter).  The buffer's first block starts from a
-     * sum of exactly zero, whatever else happens: the last two wavefronts sum it the long way first, one sum each, and
-     * the apply loop starts behind it. */
-    if (wave >= NWV - 2) {
-        float lvl[FS_PER], pwr[FS_PER];
-        fm_block_values<FMT, false>(src, n, 0u, lane, inv, lvl, pwr);
-        const float s0 = wave == NWV - 2 ? fsum_block(0.0f, lvl, lane) : fsum_block(0.0f, pwr, lane);
-        if (lane == 0)
-            blk0_bits[wave - (NWV - 2)] = __float_as_uint(s0);
-    }
+    const uint32_t blk_hi = min(nblk, (part + 1u) * FM_BPP);
     for (;;) {
         uint32_t blk = 0;
         if (lane == 0)
             blk = atomicAdd(&fm_next_blk, 1u);
         blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
-        if (blk >= nblk)
+        if (blk >= blk_hi)
             break;
-        const int el = blk_e[0][blk], ep = blk_e[1][blk];
-        const int cl = blk_ca[0][blk], cp = blk_ca[1][blk];
-        if (el == SLOW && ep == SLOW && cl == SLOW && cp == SLOW)
+        const int es[2] = {blk_e[0][blk], blk_e[1][blk]};
+        const int cs[2] = {blk_ca[0][blk], blk_ca[1][blk]};
+        if (es[0] == SLOW && es[1] == SLOW && cs[0] == SLOW && cs[1] == SLOW)
             continue; /* wave-uniform */
-        float lvl[FS_PER], pwr[FS_PER];
-        fm_block_values<FMT, false>(src, n, blk, lane, inv, lvl, pwr);
-        if (cl != SLOW)
-            fsum_sub_totals(lvl, cl, lane, slow_sub[0][blk_slot[0][blk]], slow_tie[0][blk_slot[0][blk]]);
-        if (cp != SLOW)
-            fsum_sub_totals(pwr, cp, lane, slow_sub[1][blk_slot[1][blk]], slow_tie[1][blk_slot[1][blk]]);
-        if (el != SLOW) {
-            uint32_t f0, f1;
-            if (el >= 1 && fsum_block_total(lvl, el, f0))
-                f1 = f0;
-            else
-                fsum_block_function(lvl, el, lane, f0, f1);
-            if (lane == 0) {
-                blk_f0[0][blk] = f0;
-                blk_f1[0][blk] = f1;
-            }
+        uint32_t w[FS_PER];
+        fm_block_words(src, n, blk, lane, w);
+        /* The lane's sixteen elements as the function S -> S + c(S mod 2), with the adder itself: the sequential sum from
+         * 2^e (an even S) and from 2^e + u (an odd one) -- while a sum stays inside the binade every addition rounds to a
+         * multiple of u exactly as the real one does, ties to even included, and what is left above 2^e is the increment.  A
+         * chain that leaves the binade stays outside (the elements are not negative) and then holds at least 2^23 units:
+         * "leaves the binade" for the apply kernel, whatever the sum in front of the block.  Two dependent chains of
+         * sixteen 2-cycle additions per sum, instead of an integer rounding per element, a tie test and a second
+         * conversion of the block where a tie was found (the power sums of a quiet band tie in every block).  A sum
+         * without a prediction runs under a stand-in exponent; its function is not used. */
+        float A[2], acc0[2], acc1[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int e = es[s] != SLOW ? es[s] : 1; /* >= -7 */
+            A[s] = __uint_as_float((uint32_t)(e + 127) << 23);
+            acc0[s] = A[s];
+            acc1[s] = A[s] + __uint_as_float((uint32_t)(e - 23 + 127) << 23);
         }
-        if (ep != SLOW) {
-            uint32_t f0, f1;
-            if (ep >= 1 && fsum_block_total(pwr, ep, f0))
-                f1 = f0;
-            else
-                fsum_block_function(pwr, ep, lane, f0, f1);
-            if (lane == 0) {
-                blk_f0[1][blk] = f0;
-                blk_f1[1][blk] = f1;
+#pragma unroll
+        for (int k = 0; k < FS_PER; ++k) {
+            float m, magsq;
+            fm_convert<FMT>(w[k], inv, m, magsq);
+            acc0[0] += m;
+            acc1[0] += m;
+            acc0[1] += magsq;
+            acc1[1] += magsq;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int e = es[s];
+            if (e != SLOW) { /* wave-uniform */
+                const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23), sat = (float)FS_SAT;
+                uint32_t c0 = (uint32_t)fminf((acc0[s] - A[s]) * scale, sat);
+                uint32_t c1 = (uint32_t)fminf((acc1[s] - A[s]) * scale, sat) - 1u; /* the start's own unit is not part of the increment */
+                uint32_t f0, f1;
+                if (!__ballot(c0 != c1)) { /* no lane's elements care about the parity: the block adds its total */
+                    f0 = f1 = wave_last(wave_incl_scan(min(c0, 1u << 25)));
+                } else {
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { /* ordered composition: (lanes .. L-d) then (L-d+1 .. L) */
+                        const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
+                        if (lane >= d) {
+                            const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
+                            c0 = min(n0, FS_SAT);
+                            c1 = min(n1, FS_SAT);
+                        }
+                    }
+                    f0 = (uint32_t)__shfl((int)c0, 63, 64);
+                    f1 = (uint32_t)__shfl((int)c1, 63, 64);
+                }
+                if (lane == 0) {
+                    W.f0[s][blk] = f0;
+                    W.f1[s][blk] = f1;
+                }
+            }
+            const int ca = cs[s];
+            if (ca != SLOW) { /* wave-uniform: the functions of the sixteen 64-sample sub-blocks (lanes 4 j .. 4 j + 3) for the
+                                 exponents ca and ca + 1 -- the same chains, composed over four lanes */
+                const uint32_t slot = blk_slot[s][blk];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int e = ca + c;
+                    const float A2 = __uint_as_float((uint32_t)(e + 127) << 23);
+                    float a0 = A2, a1 = A2 + __uint_as_float((uint32_t)(e - 23 + 127) << 23);
+#pragma unroll
+                    for (int k = 0; k < FS_PER; ++k) {
+                        float m, magsq;
+                        fm_convert<FMT>(w[k], inv, m, magsq);
+                        a0 += s ? magsq : m;
+                        a1 += s ? magsq : m;
+                    }
+                    const float scale = __uint_as_float((uint32_t)(23 - e + 127) << 23), sat = (float)FS_SAT;
+                    uint32_t c0 = (uint32_t)fminf((a0 - A2) * scale, sat);
+                    uint32_t c1 = (uint32_t)fminf((a1 - A2) * scale, sat) - 1u;
+#pragma unroll
+                    for (int d = 1; d < 4; d <<= 1) {
+                        const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
+                        if ((lane & 3) >= d) {
+                            const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
+                            c0 = min(n0, FS_SAT);
+                            c1 = min(n1, FS_SAT);
+                        }
+                    }
+                    if ((lane & 3) == 3) {
+                        W.sub[s][slot][c][0][lane >> 2] = c0;
+                        W.sub[s][slot][c][1][lane >> 2] = c1;
+                    }
+                }
             }
         }
     }
-    __syncthreads();
-    FM_T(2)
-    /* apply: wavefront 0 the level sum, wavefront 1 the power sum */
-    if (wave < 2) {
-        /* the blocks' predictions and functions in registers, lane L: blocks L and L + 64; the walk then reads
-         * them with v_readlane instead of three dependent LDS loads per block */
-        int re[2], rca[2];
-        uint32_t rf0[2], rf1[2], rslot[2];
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(128) msd_fm_apply_kernel(const uint8_t *iq, uint64_t nsamples, uint64_t buffer_len,
+                                                           uint32_t nbuffers, const FmBufWork *work, float *out /* [nbuffers][2] */)
+{
+    __shared__ uint32_t slow_sub[2][FM_SLOTS][64]; /* [exponent][parity][sub-block] */
+    __shared__ __attribute__((aligned(16))) float seq_vals[2][64];
+    const uint32_t b = blockIdx.x;
+    const uint64_t first = (uint64_t)b * buffer_len;
+    uint64_t n64 = nsamples > first ? nsamples - first : 0;
+    if (n64 > buffer_len)
+        n64 = buffer_len;
+    const uint32_t n = (uint32_t)n64;
+    const float inv = (FMT == MSD_FMT_SC16) ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nblk = (n + FS_BLOCK - 1) / FS_BLOCK;
+    constexpr int SLOW = -2147483647 - 1;
+    const FmBufWork &W = work[b];
+    if (n == 0) { /* a batch that ends on a buffer boundary counts one more, empty buffer: its samples are not there to read */
+        if (lane == 0)
+            out[2 * b + wave] = 0.0f;
+        return;
+    }
+    /* the blocks' predictions and functions in registers, lane L: blocks L and L + 64; the sub-block totals in LDS */
+    int re[2], rca[2];
+    uint32_t rf0[2], rf1[2], rslot[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t blk = (uint32_t)lane + 64u * j;
-            re[j] = blk < nblk ? blk_e[wave][blk] : SLOW;
-            rf0[j] = blk < nblk ? blk_f0[wave][blk] : 0u;
-            rf1[j] = blk < nblk ? blk_f1[wave][blk] : 0u;
-            rca[j] = blk < nblk ? blk_ca[wave][blk] : SLOW;
-            rslot[j] = blk < nblk ? blk_slot[wave][blk] : 0xffu;
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t blk = (uint32_t)lane + 64u * j;
+        const bool in = blk < nblk;
+        re[j] = in ? W.e[wave][blk] : SLOW;
+        rca[j] = in ? W.ca[wave][blk] : SLOW;
+        rslot[j] = in ? W.slot[wave][blk] : 0xffu;
+        rf0[j] = in && re[j] != SLOW ? W.f0[wave][blk] : 0u; /* a slow block's function was never written */
+        rf1[j] = in && re[j] != SLOW ? W.f1[wave][blk] : 0u;
+    }
+    {
+        const uint32_t used = min((uint32_t)FM_SLOTS, (uint32_t)__popcll(__ballot(rca[0] != SLOW)) + (uint32_t)__popcll(__ballot(rca[1] != SLOW)));
+        const uint32_t *gs = &W.sub[wave][0][0][0][0];
+        uint32_t *ls = &slow_sub[wave][0][0];
+        for (uint32_t i = (uint32_t)lane; i < used * 64u; i += 64u)
+            ls[i] = gs[i];
+    }
+    const unsigned long long walk_lo = __ballot(re[0] == SLOW && rca[0] != SLOW), walk_hi = __ballot(re[1] == SLOW && rca[1] != SLOW);
+    auto next_walk = [&](uint32_t from) -> uint32_t { /* first block with sub-block totals at or behind `from`; nblk: none */
+        if (from < 64u) {
+            const unsigned long long m = walk_lo >> from;
+            if (m)
+                return from + (uint32_t)__builtin_ctzll(m);
+            from = 64u;
         }
-        /* The sum lives in a scalar register (its bits): a block whose prediction holds is a dozen scalar instructions.
-         * The samples of the next block that will be walked sub-block by sub-block are fetched ahead -- which blocks
-         * those are is known from the start -- lane L: sample 64 j + L of the block in w[j], one per sub-block. */
-        const unsigned long long walk_lo = __ballot(re[0] == SLOW && rca[0] != SLOW), walk_hi = __ballot(re[1] == SLOW && rca[1] != SLOW);
-        auto next_walk = [&](uint32_t from) -> uint32_t { /* first such block at or behind `from`; nblk: none */
-            if (from < 64u) {
-                const unsigned long long m = walk_lo >> from;
-                if (m)
-                    return from + (uint32_t)__builtin_ctzll(m);
-                from = 64u;
+        if (from < 128u) {
+            const unsigned long long m = walk_hi >> (from - 64u);
+            if (m)
+                return from + (uint32_t)__builtin_ctzll(m);
+        }
+        return nblk;
+    };
+    uint32_t w[16], w_blk = next_walk(1u);
+    auto fetch = [&](uint32_t blk) { /* lane L: sample 64 j + L of the block in w[j], one per sub-block */
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+            w[j] = src[g < n ? g : 0u]; /* unconditional: sixteen loads in flight */
+        }
+    };
+    /* The composite functions of the runs of blocks between two slow ones, a segmented scan over the lanes: the walk
+     * then takes such a run in one step.  A head is a block that starts a run: every slow block (an identity on its own),
+     * a block behind a slow one or behind one with another exponent, block 64 (the two registers are scanned apart). */
+    uint32_t sf0[2], sf1[2];
+    unsigned long long heads[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int up = __shfl_up(re[j], 1, 64);
+        const int e_prev = lane ? up : SLOW;
+        const bool slow = re[j] == SLOW || (j == 0 && lane == 0); /* block 0 is summed apart */
+        bool flag = slow || e_prev != re[j] || (j == 0 && lane == 1);
+        uint32_t c0 = slow ? 0u : min(rf0[j], FS_SAT), c1 = slow ? 0u : min(rf1[j], FS_SAT);
+        heads[j] = __ballot(flag);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
+            const bool pflag = __shfl_up((int)flag, d, 64) != 0;
+            if (lane >= d && !flag) {
+                const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
+                c0 = min(n0, FS_SAT);
+                c1 = min(n1, FS_SAT);
+                flag = pflag;
             }
-            if (from < 128u) {
-                const unsigned long long m = walk_hi >> (from - 64u);
-                if (m)
-                    return from + (uint32_t)__builtin_ctzll(m);
+        }
+        sf0[j] = c0;
+        sf1[j] = c1;
+    }
+    auto next_head = [&](uint32_t from) -> uint32_t { /* first head at or behind `from`; 128: none */
+        if (from < 64u) {
+            const unsigned long long m = heads[0] >> from;
+            if (m)
+                return from + (uint32_t)__builtin_ctzll(m);
+            from = 64u;
+        }
+        if (from < 128u) {
+            const unsigned long long m = heads[1] >> (from - 64u);
+            if (m)
+                return from + (uint32_t)__builtin_ctzll(m);
+        }
+        return 128u;
+    };
+    uint32_t sb;
+    { /* the buffer's first block starts from a sum of exactly zero and passes through a dozen binades: 1024 additions in order */
+        fetch(0u);
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t g = 64u * j + (uint32_t)lane;
+            const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
+            sum = fsum_lanes_in_order(sum, x, seq_vals[wave], lane);
+        }
+        sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+    }
+    if (w_blk < nblk)
+        fetch(w_blk);
+    wave_lds_sync();
+    for (uint32_t blk = 1; blk < nblk; ++blk) {
+        const int hi = blk >= 64u, l = (int)(blk & 63u);
+        const int e = __builtin_amdgcn_readlane(hi ? re[1] : re[0], l);
+        bool fast = e != SLOW && (int)(sb >> 23) - 127 == e;
+        if (fast && (((hi ? heads[1] : heads[0]) >> l) & 1ull)) { /* the whole run of blocks this one starts */
+            const uint32_t last = min(next_head(blk + 1u), nblk) - 1u;
+            const int lh = last >= 64u, ll = (int)(last & 63u);
+            const uint32_t rf0s = (uint32_t)__builtin_amdgcn_readlane((int)(lh ? sf0[1] : sf0[0]), ll);
+            const uint32_t rf1s = (uint32_t)__builtin_amdgcn_readlane((int)(lh ? sf1[1] : sf1[0]), ll);
+            const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+            const uint32_t S = S0 + ((S0 & 1u) ? rf1s : rf0s);
+            if (S < (1u << 24)) { /* the functions do not decrease: no block of the run left the binade either */
+                sb = (sb & 0xff800000u) | (S & 0x7fffffu);
+                blk = last;
+                continue;
             }
-            return nblk;
-        };
-        uint32_t w[16], w_blk = next_walk(1u);
-        auto fetch = [&](uint32_t blk) {
+        }
+        if (fast) {
+            const uint32_t bf0 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf0[1] : rf0[0]), l);
+            const uint32_t bf1 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf1[1] : rf1[0]), l);
+            const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+            const uint32_t S = S0 + ((S0 & 1u) ? bf1 : bf0);
+            if (S < (1u << 24))
+                sb = (sb & 0xff800000u) | (S & 0x7fffffu);
+            else
+                fast = false; /* left the binade after all */
+        }
+        if (fast)
+            continue;
+        /* wave-uniform from here */
+        if (blk == w_blk) {
+            /* sub-block by sub-block with the totals the functions kernel left (lane 16 c + j: exponent ca + c, sub-block j) */
+            const int ca = __builtin_amdgcn_readlane(hi ? rca[1] : rca[0], l);
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rslot[1] : rslot[0]), l);
+            const uint32_t sub = slow_sub[wave][slot][lane]; /* lane 32 c + 16 p + j: exponent ca + c, S even / odd, sub-block j */
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = ((int)(sb >> 23) - 127) - ca;
+                bool ok = false;
+                if (c == 0 || c == 1) {
+                    const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
+                    const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)sub, 32 * c + 16 * (int)(S0 & 1u) + j);
+                    if (S0 + tj < (1u << 24)) {
+                        sb = (sb & 0xff800000u) | ((S0 + tj) & 0x7fffffu);
+                        ok = true;
+                    }
+                }
+                if (!ok) { /* the sum leaves its binade in here: 64 additions, in order */
+                    const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+                    const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
+                    float sum = __uint_as_float(sb);
+                    sum = fsum_lanes_in_order(sum, x, seq_vals[wave], lane);
+                    sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+                }
+            }
+            w_blk = next_walk(blk + 1u);
+            if (w_blk < nblk)
+                fetch(w_blk);
+        } else { /* no sub-block totals (a misprediction, a sum that is still tiny): the whole block sample by sample */
+            fetch(blk);
+            float sum = __uint_as_float(sb);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
-                w[j] = src[g < n ? g : 0u]; /* unconditional: sixteen loads in flight */
+                const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
+                sum = fsum_lanes_in_order(sum, x, seq_vals[wave], lane);
             }
-        };
-        if (w_blk < nblk)
-            fetch(w_blk);
-#ifdef MSD_FM_TIMERS
-        uint32_t n_slow = 0, n_seq = 0, n_whole = 0;
-        unsigned long long t_slow = 0;
-#endif
-        uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk0_bits[wave]); /* the bits of the sum, behind block 0 */
-        for (uint32_t blk = 1; blk < nblk; ++blk) {
-            const int hi = blk >= 64u, l = (int)(blk & 63u);
-            const int e = __builtin_amdgcn_readlane(hi ? re[1] : re[0], l);
-            const uint32_t bf0 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf0[1] : rf0[0]), l);
-            const uint32_t bf1 = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rf1[1] : rf1[0]), l);
-            bool fast = e != SLOW && (int)(sb >> 23) - 127 == e;
-            if (fast) {
-                const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
-                const uint32_t S = S0 + ((S0 & 1u) ? bf1 : bf0);
-                if (S < (1u << 24))
-                    sb = (sb & 0xff800000u) | (S & 0x7fffffu);
-                else
-                    fast = false; /* left the binade after all */
-            }
-            if (fast)
-                continue;
-            /* wave-uniform from here */
-#ifdef MSD_FM_TIMERS
-            ++n_slow;
-            const unsigned long long t_slow0 = wall_clock64();
-#endif
-            if (blk == w_blk) {
-                /* sub-block by sub-block with the totals pass 2 left (lane 16 c + j: exponent ca + c, sub-block j) */
-                const int ca = __builtin_amdgcn_readlane(hi ? rca[1] : rca[0], l);
-                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? rslot[1] : rslot[0]), l);
-                const uint32_t sub = lane < 32 ? slow_sub[wave][slot][lane >> 4][lane & 15] : 0u;
-                const uint32_t ties[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)slow_tie[wave][slot][0]),
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)slow_tie[wave][slot][1])};
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int c = ((int)(sb >> 23) - 127) - ca;
-                    bool ok = false;
-                    if (c == 0 || c == 1) {
-                        const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)sub, 16 * c + j);
-                        const uint32_t S0 = (sb & 0x7fffffu) | 0x800000u;
-                        if (!((ties[c] >> j) & 1u) && S0 + tj < (1u << 24)) {
-                            sb = (sb & 0xff800000u) | ((S0 + tj) & 0x7fffffu);
-                            ok = true;
-                        }
-                    }
-                    if (!ok) { /* the sum leaves its binade in here (or an element is a tie): 64 additions, in order */
-#ifdef MSD_FM_TIMERS
-                        ++n_seq;
-#endif
-                        const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
-                        const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
-                        float sum = __uint_as_float(sb);
-                        sum = fsum_lanes_in_order(sum, x);
-                        sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
-                    }
-                }
-                w_blk = next_walk(blk + 1u);
-                if (w_blk < nblk)
-                    fetch(w_blk);
-            } else { /* no sub-block totals (a misprediction, a sum that is still tiny): the whole block sample by sample */
-#ifdef MSD_FM_TIMERS
-                ++n_whole;
-#endif
-                fetch(blk);
-                float sum = __uint_as_float(sb);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
-                    const float x = g < n ? fm_word_value<FMT>(w[j], inv, wave) : 0.0f;
-                    sum = fsum_lanes_in_order(sum, x);
-                }
-                sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
-                if (w_blk < nblk)
-                    fetch(w_blk); /* the registers held the next walked block's samples */
-            }
-#ifdef MSD_FM_TIMERS
-            t_slow += wall_clock64() - t_slow0;
-#endif
+            sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+            if (w_blk < nblk)
+                fetch(w_blk); /* the registers held the next walked block's samples */
         }
-#ifdef MSD_FM_TIMERS
-        if (lane == 0) { /* once, behind the walk: an atomic in it would sit in front of the prefetched loads */
-            atomicAdd(&msd_fm_cyc[4], (unsigned long long)n_slow);
-            atomicAdd(&msd_fm_cyc[7], (unsigned long long)n_seq);
-            atomicAdd(&msd_fm_cyc[8], (unsigned long long)n_whole);
-            atomicAdd(&msd_fm_cyc[9], t_slow);
-        }
-#endif
-        const float sum = __uint_as_float(sb);
-        if (lane == 0)
-            out[2 * b + wave] = sum;
     }
-#ifdef MSD_FM_TIMERS
-    __syncthreads();
-    FM_T(3)
-    if (tid == 0) {
-        atomicAdd(&msd_fm_cyc[5], 2ull * nblk);
-        atomicAdd(&msd_fm_cyc[6], 1ull);
-    }
-#endif
+    if (lane == 0)
+        out[2 * b + wave] = __uint_as_float(sb);
 }
-
-#ifdef MSD_FM_TIMERS
-extern "C" void msd_fm_report(void)
-{
-    unsigned long long h[10] = {0};
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(msd_fm_cyc), sizeof h) != hipSuccess || !h[6])
-        return;
-    const double w = (double)h[6];
-    fprintf(stderr, "float means, mean us per workgroup: pass 1 %.1f, prefix %.1f, pass 2 %.1f, apply %.1f; slow blocks %.2f of %.0f per buffer, "
-            "%.2f of them summed whole, %.2f sub-blocks summed sample by sample; %.1f us of the apply step per wavefront in slow blocks\n",
-            h[0] / w / 100, h[1] / w / 100, h[2] / w / 100, h[3] / w / 100, h[4] / w, h[5] / w, h[8] / w, h[7] / w, h[9] / w / 100 / 2);
-}
-#endif
 
 /* --dcfilter: the "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11).
  * Per channel z = f * dc_a + z * dc_b runs through the WHOLE stream (the converter state survives
@@ -3096,34 +3097,51 @@ extern "C" int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsampl
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers,
-                                  float *d_out, hipStream_t stream)
+extern "C" size_t msd_fm_work_bytes(uint32_t nbuffers)
 {
-    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, nullptr, stream);
+    return sizeof(FmBufWork) * (size_t)(nbuffers ? nbuffers : 1u);
+}
+
+extern "C" int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers,
+                                  float *d_out, void *d_work, hipStream_t stream)
+{
+    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, nullptr, d_work, stream);
+}
+
+template <int FMT>
+static void launch_fm(const uint8_t *iq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
+                      const float *tile_sums, FmBufWork *work, hipStream_t stream)
+{
+    if (!tile_sums)
+        hipLaunchKernelGGL(msd_fm_totals_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
+                           buffer_len, nbuffers, work);
+    hipLaunchKernelGGL(msd_fm_functions_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
+                       buffer_len, nbuffers, work, tile_sums);
+    hipLaunchKernelGGL(msd_fm_apply_kernel<FMT>, dim3(nbuffers), dim3(128), 0, stream, iq, nsamples, buffer_len, nbuffers,
+                       static_cast<const FmBufWork *>(work), d_out);
 }
 
 extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                                      uint32_t nbuffers, float *d_out, const float *tile_sums, hipStream_t stream)
+                                      uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work,
+                                      hipStream_t stream)
 {
     if (buffer_len % FS_BLOCK)
         tile_sums = nullptr;
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
     const uint32_t grid = nbuffers; /* one workgroup per buffer */
-    static const bool v1 = getenv("MSD_FMEANS_V1") != nullptr; /* the one-wavefront-per-sum kernel, for comparison */
-    if (!v1 && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK) {
+    if (d_work && nbuffers && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK) {
+        FmBufWork *work = static_cast<FmBufWork *>(d_work);
         if (format == MSD_FMT_SC16)
-            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out, tile_sums);
+            launch_fm<MSD_FMT_SC16>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, stream);
         else if (format == MSD_FMT_SC16Q11)
-            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_SC16Q11>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out, tile_sums);
+            launch_fm<MSD_FMT_SC16Q11>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, stream);
         else if (format == MSD_FMT_MAGSQ) /* msd_launch_dc_sums */
-            hipLaunchKernelGGL(msd_float_means2_kernel<MSD_FMT_MAGSQ>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
-                               nsamples, buffer_len, nbuffers, d_out, static_cast<const float *>(nullptr));
+            launch_fm<MSD_FMT_MAGSQ>(iq, nsamples, buffer_len, nbuffers, d_out, nullptr, work, stream);
         else
             return -22;
         return hipGetLastError() == hipSuccess ? 0 : -5;
     }
+    /* a buffer longer than FB_MAX blocks (the converter entry takes any length): one wavefront per sum */
     if (format == MSD_FMT_SC16)
         hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
                            nsamples, buffer_len, nbuffers, d_out);

@@ -23,7 +23,7 @@ import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(float); disp=set()
 for r in rows:
-    if 'msd_scan' in r['Kernel_Name']:
+    if (__import__('os').environ.get('KFILTER') or 'msd_scan') in r['Kernel_Name']:
         agg[r['Counter_Name']]+=float(r['Counter_Value']); disp.add(r['Dispatch_Id'])
 n=max(1,len(disp))
 print(sys.argv[2], 'set', sys.argv[3], 'scan dispatches', n, {k: round(v/n/1e6,3) for k,v in sorted(agg.items())})
