@@ -37,8 +37,7 @@ __device__ __forceinline__ uint32_t mag_from_s16(int I, int Q, float inv_scale)
     const float fq = (float)Q * inv_scale;
     const float sq_i = fi * fi, sq_q = fq * fq;
     float magsq = sq_i + sq_q;
-    if (magsq > 1.0f)
-        magsq = 1.0f;
+    magsq = fminf(magsq, 1.0f); /* convert.c: if (magsq > 1) magsq = 1 -- the sum of two squares is not a NaN */
     const float m = msd_sqrt_cr(magsq);
     const float scaled = m * 65535.0f;
     return (uint32_t)(uint16_t)(scaled + 0.5f);
