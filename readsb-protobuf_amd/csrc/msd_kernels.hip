@@ -2183,6 +2183,15 @@ __global__ void __launch_bounds__(128) msd_fm_apply_kernel(const uint8_t *iq, ui
             out[2 * b + wave] = 0.0f;
         return;
     }
+    uint32_t w[16];
+    auto fetch = [&](uint32_t blk) { /* lane L: sample 64 j + L of the block in w[j], one per sub-block */
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
+            w[j] = src[g < n ? g : 0u]; /* unconditional: sixteen loads in flight */
+        }
+    };
+    fetch(0u); /* the first block's samples are on their way while the tables are read */
     /* the blocks' predictions and functions in registers, lane L: blocks L and L + 64; the sub-block totals in LDS */
     int re[2], rca[2];
     uint32_t rf0[2], rf1[2], rslot[2];
@@ -2218,14 +2227,7 @@ __global__ void __launch_bounds__(128) msd_fm_apply_kernel(const uint8_t *iq, ui
         }
         return nblk;
     };
-    uint32_t w[16], w_blk = next_walk(1u);
-    auto fetch = [&](uint32_t blk) { /* lane L: sample 64 j + L of the block in w[j], one per sub-block */
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t g = blk * (uint32_t)FS_BLOCK + 64u * j + (uint32_t)lane;
-            w[j] = src[g < n ? g : 0u]; /* unconditional: sixteen loads in flight */
-        }
-    };
+    uint32_t w_blk = next_walk(1u);
     /* The composite functions of the runs of blocks between two slow ones, a segmented scan over the lanes: the walk
      * then takes such a run in one step.  A head is a block that starts a run: every slow block (an identity on its own),
      * a block behind a slow one or behind one with another exponent, block 64 (the two registers are scanned apart). */
@@ -2269,7 +2271,6 @@ __global__ void __launch_bounds__(128) msd_fm_apply_kernel(const uint8_t *iq, ui
     };
     uint32_t sb;
     { /* the buffer's first block starts from a sum of exactly zero and passes through a dozen binades: 1024 additions in order */
-        fetch(0u);
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
