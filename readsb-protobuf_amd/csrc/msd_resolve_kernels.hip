@@ -35,6 +35,9 @@ namespace {
 #ifndef MSD_RESOLVE_TIMING
 #define MSD_RESOLVE_TIMING 0 /* 1: per-phase clocks of every workgroup in msd_rbuf.cyc (MSD_TRACE prints their means) */
 #endif
+#ifndef MSD_RESOLVE_OCC
+#define MSD_RESOLVE_OCC 4 /* wavefronts per SIMD the resolve kernel is held to (two workgroups per CU) */
+#endif
 #ifndef MSD_RESOLVE_SEG
 #define MSD_RESOLVE_SEG 1280
 #endif
@@ -324,7 +327,7 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
     }
 }
 
-__global__ void __launch_bounds__(RT, 4) msd_resolve_kernel(const MsdResolveParams P)
+__global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const MsdResolveParams P)
 {
     __shared__ msd_hit seg_hits[SEG];
     __shared__ uint64_t seg_res[SEG];
