@@ -2676,25 +2676,58 @@ __global__ void __launch_bounds__(ACNT, 5) msd_ac_wave_kernel(const MsdScanParam
     constexpr int GPT_W = (ACW_GROUPS + 63) / 64;
     RawGroup<FMT> rg[GPT_W];
     uint32_t vg[GPT_W];
+    /* A tile whose samples all lie inside the batch -- every tile but a batch's first and last -- is loaded from computed
+     * addresses (fetch_group selects one of four sources per lane and group: a dozen 64-bit compares and selects), and in
+     * the 16-bit-magnitude instantiation, the one the pipeline uses, its words go to the LDS as they came. */
+    bool inside_next = false;
     auto fetch = [&](uint32_t tile) {
-        const int64_t n0 = (int64_t)(P.batch_first + (uint64_t)tile * ACW) - FRONT;
+        const int64_t rel0 = (int64_t)((uint64_t)tile * ACW) - FRONT;
+        inside_next = rel0 >= 0 && (uint64_t)rel0 + ACW_LOAD <= (P.nsamples & ~7ull); /* wave-uniform */
+        if (inside_next) {
+            constexpr int BPS = RawGroup<FMT>::WORDS / 2;
 #pragma unroll
-        for (int i = 0; i < GPT_W; ++i) {
-            const int g = lane + 64 * i;
-            vg[i] = fetch_group<FMT>(P, n0 + 8 * (g < ACW_GROUPS ? g : 0), rg[i]);
+            for (int i = 0; i < GPT_W; ++i) {
+                const int g = lane + 64 * i;
+                const uint8_t *src = P.iq + (rel0 + 8 * (g < ACW_GROUPS ? g : 0)) * BPS;
+                const uint4 a = *reinterpret_cast<const uint4 *>(src);
+                rg[i].w[0] = a.x; rg[i].w[1] = a.y; rg[i].w[2] = a.z; rg[i].w[3] = a.w;
+                if (BPS == 4) {
+                    const uint4 b = *reinterpret_cast<const uint4 *>(src + 16);
+                    rg[i].w[4 % RawGroup<FMT>::WORDS] = b.x; rg[i].w[5 % RawGroup<FMT>::WORDS] = b.y;
+                    rg[i].w[6 % RawGroup<FMT>::WORDS] = b.z; rg[i].w[7 % RawGroup<FMT>::WORDS] = b.w;
+                }
+                vg[i] = 0xffu;
+            }
+        } else {
+            const int64_t n0 = (int64_t)P.batch_first + rel0;
+#pragma unroll
+            for (int i = 0; i < GPT_W; ++i) {
+                const int g = lane + 64 * i;
+                vg[i] = fetch_group<FMT>(P, n0 + 8 * (g < ACW_GROUPS ? g : 0), rg[i]);
+            }
         }
     };
     if (tile_lo < tile_hi)
         fetch(tile_lo);
     for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
         const uint64_t pos0 = (uint64_t)tile * ACW; /* batch-relative */
+        const bool inside = inside_next;
+        if (FMT == MSD_FMT_MAG16 && inside) { /* wave-uniform */
 #pragma unroll
-        for (int i = 0; i < GPT_W; ++i) {
-            const int g = lane + 64 * i;
-            if (g < ACW_GROUPS) {
-                uint32_t mg[8];
-                convert_group<FMT>(rg[i], vg[i], lut, mg);
-                *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
+            for (int i = 0; i < GPT_W; ++i) {
+                const int g = lane + 64 * i;
+                if (g < ACW_GROUPS)
+                    *reinterpret_cast<uint4 *>(mags + 8 * g) = make_uint4(rg[i].w[0], rg[i].w[1], rg[i].w[2], rg[i].w[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GPT_W; ++i) {
+                const int g = lane + 64 * i;
+                if (g < ACW_GROUPS) {
+                    uint32_t mg[8];
+                    convert_group<FMT>(rg[i], vg[i], lut, mg);
+                    *reinterpret_cast<uint4 *>(mags + 8 * g) = pack8(mg);
+                }
             }
         }
         wave_lds_sync();

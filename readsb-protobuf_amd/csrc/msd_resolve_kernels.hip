@@ -36,7 +36,8 @@ namespace {
 #define MSD_RESOLVE_TIMING 0 /* 1: per-phase clocks of every workgroup in msd_rbuf.cyc (MSD_TRACE prints their means) */
 #endif
 #ifndef MSD_RESOLVE_OCC
-#define MSD_RESOLVE_OCC 4 /* wavefronts per SIMD the resolve kernel is held to (two workgroups per CU) */
+#define MSD_RESOLVE_OCC 4 /* wavefronts per SIMD the resolve kernel is held to (two workgroups per CU; round 4: three per CU with
+                             640- or 768-hit segments -- 50-56 KB of LDS, 80-90 registers -- were 4-5 % slower over the whole job) */
 #endif
 #ifndef MSD_RESOLVE_SEG
 #define MSD_RESOLVE_SEG 1280
