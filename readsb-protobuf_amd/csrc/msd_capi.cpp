@@ -216,6 +216,14 @@ struct Slot {
     msd_try *d_tries = nullptr;
     uint64_t *d_totals = nullptr;
     float *d_tile_sums = nullptr;    /* SC16 / SC16Q11: the scan's per-tile float sums, for the float-sum kernel's predictions */
+    void *d_fm_work = nullptr;       /* 16-bit IQ, --dcfilter: the float-sum kernels' hand-over (msd_fm_work_bytes) */
+    msd_ac_hit *d_ac_regions = nullptr; /* Mode A/C: the candidate kernel's region slices and counts, gathered into d_ac */
+    msd_wg_counts *d_ac_counts = nullptr;
+    /* MSD_CFG_DEFER_TAILS: latency-bound tail kernels of the batch -- the float sums' apply walk, the Mode A/C gather -- that
+     * were left off the scan stream: gpu_begin() puts them at the head of the batch's resolve chain (side streams), where
+     * they run beside the next batch's kernels instead of in front of its scan. */
+    bool fm_apply_pending = false, ac_gather_pending = false;
+    int ac_format_pending = 0;
     uint32_t *d_rec_off = nullptr;   /* [max_buffers + 2] records in front of each buffer's (power kernel) */
     uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
     bool buf_first_valid = false;
@@ -268,9 +276,7 @@ struct msd_ctx {
     msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
     uint32_t max_wg = 0, max_buffers = 0;  /* max_wg: most regions a scan is split into */
     /* Mode A/C candidate regions */
-    msd_ac_hit *d_ac_regions = nullptr;
     uint64_t ac_arena = 0;
-    msd_wg_counts *d_ac_counts = nullptr;
     uint64_t *d_ac_offsets = nullptr;
     uint32_t *d_noise = nullptr;
     void *d_fm_work = nullptr;       /* 16-bit IQ, --dcfilter: the float-sum kernels' hand-over (msd_fm_work_bytes) */
@@ -647,11 +653,19 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
     } else if (s.timed) {
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
+    /* what may wait for the head of the batch's resolve chain (see Slot::fm_apply_pending; MSD_CFG_DEFER_TAILS): only a batch
+     * whose totals and sums nobody reads before its first resolve pass (lean), resolved on side streams; Mode A/C needs the
+     * sums at once.  Off by default: 37 us of apply walk / 10 us of gather leave the scan stream, but the chain they now head
+     * has to be through before the scan after next, and it is not -- SC16 198.6 against 203.4, Mode A/C 251.0 against 256.7 */
+    const bool defer_tails = pipelined && s.lean && s.gpu_resolve && !c->chain_inline && (c->cfg.flags & MSD_CFG_DEFER_TAILS);
+    s.fm_apply_pending = s.ac_gather_pending = false;
     if (fm && s.nbuffers) {
-        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, c->d_fm_work, c->stream)
+        const int fm_phase = defer_tails && !c->cfg.mode_ac && msd_fm_deferrable(s.d_fm_work, MSD_CHUNK_SAMPLES, s.nbuffers) ? 1 : 0;
+        s.fm_apply_pending = fm_phase == 1;
+        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, s.d_fm_work, fm_phase, c->stream)
                       : msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
                                                nwg && msd_scan_tile(format) == 1024 ? s.d_tile_sums : nullptr,
-                                               c->d_fm_work, c->stream);
+                                               s.d_fm_work, fm_phase, c->stream);
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
     }
@@ -670,10 +684,12 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
             p.have_prev = s.have_prev && s.d_mag_prev;
             p.ragged = reinterpret_cast<const uint8_t *>(s.d_mag + (s.nsamples & ~7ull)); /* zeros behind the last sample */
         }
+        s.ac_gather_pending = defer_tails && host_noise == nullptr;
+        s.ac_format_pending = ac_format;
         int rc = msd_launch_ac(&p, ac_format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
                                host_noise != nullptr ? 1 : ((s.dc || (s.mag_pass && fm)) ? 2 : 0), /* (16-bit IQ: the float sums, whatever the pass reads) */
-                               c->d_ac_regions, c->ac_arena, c->d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
-                               c->ac_arena, c->ac_max_wg, c->stream);
+                               s.d_ac_regions, c->ac_arena, s.d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
+                               c->ac_arena, c->ac_max_wg, s.ac_gather_pending ? 1 : 0, c->stream);
         if (rc)
             return fail(c, rc, "Mode A/C kernel launch failed");
     }
@@ -1095,6 +1111,29 @@ void apply_dropped(msd_ctx *c, Slot &s)
     s.dropped_before = 0;
 }
 
+/* the batch's tail kernels enqueue() left out (Slot::fm_apply_pending), on `stream`, which is behind the batch's kernels */
+int launch_deferred_tails(msd_ctx *c, Slot &s, hipStream_t stream)
+{
+    if (s.fm_apply_pending) {
+        s.fm_apply_pending = false;
+        const int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, s.d_fm_work, 2, stream)
+                            : msd_launch_float_means(c->scan_format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
+                                                     nullptr, s.d_fm_work, 2, stream);
+        if (rc)
+            return fail(c, rc, "float means apply kernel launch failed");
+    }
+    if (s.ac_gather_pending) {
+        s.ac_gather_pending = false;
+        MsdScanParams p{};
+        p.nsamples = s.nsamples; /* all the gather's launch geometry depends on */
+        const int rc = msd_launch_ac(&p, s.ac_format_pending, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise, 0, s.d_ac_regions, c->ac_arena,
+                                     s.d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac, c->ac_arena, c->ac_max_wg, 2, stream);
+        if (rc)
+            return fail(c, rc, "Mode A/C gather kernel launch failed");
+    }
+    return 0;
+}
+
 int gpu_begin(msd_ctx *c, Slot &s, int format)
 {
     apply_dropped(c, s);
@@ -1123,6 +1162,9 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
         if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES)
             HIPCHK(c, hipStreamWaitEvent(ks, nx.ev_scanned, 0));
     }
+    rc = launch_deferred_tails(c, s, ks);
+    if (rc)
+        return rc;
     rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
@@ -1802,6 +1844,7 @@ void destroy(msd_ctx *c)
     }
     for (Slot &s : c->slots) {
         (void)hipFree(s.d_hits); (void)hipFree(s.d_tries); (void)hipFree(s.d_totals); (void)hipFree(s.d_buf_first); (void)hipFree(s.d_rec_off); (void)hipFree(s.d_tile_sums); (void)hipFree(s.d_sums); (void)hipFree(s.d_fmeans);
+        (void)hipFree(s.d_fm_work); (void)hipFree(s.d_ac_regions); (void)hipFree(s.d_ac_counts);
         if (s.h_totals) (void)hipHostFree(s.h_totals);
         if (s.h_sums) (void)hipHostFree(s.h_sums);
         if (s.h_fmeans) (void)hipHostFree(s.h_fmeans);
@@ -1836,7 +1879,7 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
-    (void)hipFree(c->d_ac_regions); (void)hipFree(c->d_ac_counts); (void)hipFree(c->d_ac_offsets);
+    (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
     (void)hipFree(c->d_snaps);
     if (c->h_snaps) (void)hipHostFree(c->h_snaps);
@@ -1991,13 +2034,11 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     if (cfg->mode_ac) {
         c->ac_arena = B / 32 > MIN_HIT_ARENA ? B / 32 : MIN_HIT_ARENA;
         c->ac_max_wg = (uint32_t)c->cu_count * 28u; /* regions of the Mode A/C candidate kernel: one per wavefront, 28 resident per CU (54 registers, 5 KB of LDS each) */
-        CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_regions), c->ac_arena * sizeof(msd_ac_hit)));
-        CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_counts), c->ac_max_wg * sizeof(msd_wg_counts)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_ac_offsets), c->ac_max_wg * 2 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_noise), c->max_buffers * sizeof(uint32_t)));
     }
     if (cfg->format != MSD_FMT_UC8 || (cfg->flags & MSD_CFG_DC_FILTER))
-        CK(hipMalloc(&c->d_fm_work, msd_fm_work_bytes(c->max_buffers)));
+        CK(hipMalloc(&c->d_fm_work, msd_fm_work_bytes(1))); /* the converter entry's one buffer; the batches have their slots' */
     for (uint8_t *&t : c->d_tail) {
         CK(hipMalloc(reinterpret_cast<void **>(&t), (size_t)TAIL_SAMPLES * 4));
         CK(hipMemset(t, 0, (size_t)TAIL_SAMPLES * 4));
@@ -2007,6 +2048,12 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
+        if (cfg->format != MSD_FMT_UC8 || (cfg->flags & MSD_CFG_DC_FILTER))
+            CK(hipMalloc(&s.d_fm_work, msd_fm_work_bytes(c->max_buffers)));
+        if (cfg->mode_ac) {
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac_regions), c->ac_arena * sizeof(msd_ac_hit)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac_counts), c->ac_max_wg * sizeof(msd_wg_counts)));
+        }
         if (cfg->format == MSD_FMT_SC16 || cfg->format == MSD_FMT_SC16Q11)
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_tile_sums), ((size_t)c->max_buffers * (MSD_CHUNK_SAMPLES / 1024) + 2) * 2 * sizeof(float)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_rec_off), (c->max_buffers + 2) * sizeof(uint32_t)));
@@ -2427,7 +2474,7 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
         if (rc)
             return fail(c, rc, "convert kernel launch failed");
         if (c->cfg.format != MSD_FMT_UC8) {
-            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->d_fm_work, c->stream);
+            rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->d_fm_work, 0, c->stream);
             if (rc)
                 return fail(c, rc, "float means kernel launch failed");
         }

@@ -175,11 +175,13 @@ int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_t
 int msd_launch_power(const MsdScanParams *p, int format, const uint64_t *d_req, uint32_t nreq,
                      unsigned long long *d_out, hipStream_t stream);
 /* Mode A/C candidate stage: noise levels (unless noise_ready), candidate kernel, ordered gather.
- * d_totals[0] receives the number of candidates, d_totals[2] an overflow flag. */
+ * d_totals[0] receives the number of candidates, d_totals[2] an overflow flag.  phase 0: both kernels; 1: the candidate
+ * kernel; 2: the gather of what phase 1 left in d_regions / d_counts (10 us of latency that the pipeline moves to the head of
+ * the batch's resolve chain, off the scan stream). */
 int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, const float *d_fmeans,
                   uint32_t nbuffers, uint32_t *d_noise, int noise_ready, msd_ac_hit *d_regions,
                   uint64_t region_total, msd_wg_counts *d_counts, uint64_t *d_offsets, uint64_t *d_totals,
-                  msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, hipStream_t stream);
+                  msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, int phase, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
 /* --dcfilter: IQ -> DC-blocked u16 magnitudes + f32 squares, the converter state (z1_I, z1_Q, device
@@ -187,13 +189,18 @@ int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const ui
 int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
                         uint16_t *d_mag, float *d_magsq, hipStream_t stream);
 int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
-                       void *d_work, hipStream_t stream);
+                       void *d_work, int phase, hipStream_t stream);
 /* tile_sums: the scan kernel's per-1024-sample approximate sums of the same batch (buffer_len a multiple of 1024), or NULL */
 /* d_work: msd_fm_work_bytes(nbuffers) of device memory for the three kernels' hand-over (buffers of at most 131072 samples);
  * NULL or longer buffers: the one-wavefront-per-sum kernel */
 size_t msd_fm_work_bytes(uint32_t nbuffers);
+/* phase 0: all of it; 1: the block functions (vector-ALU work, behind the scan); 2: the apply walk (latency-bound: two
+ * wavefronts per buffer), on any stream behind phase 1 -- the pipeline puts it at the head of the batch's resolve chain,
+ * where it runs beside the next batch's kernels.  msd_fm_deferrable: the call has the two phases. */
+int msd_fm_deferrable(const void *d_work, uint64_t buffer_len, uint32_t nbuffers);
 int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                           uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work, hipStream_t stream);
+                           uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work, int phase,
+                           hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -3066,9 +3066,11 @@ extern "C" int msd_launch_power_buffers(const MsdScanParams *p, int format, cons
 extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, const float *d_fmeans,
                              uint32_t nbuffers, uint32_t *d_noise, int noise_ready, msd_ac_hit *d_regions,
                              uint64_t region_total, msd_wg_counts *d_counts, uint64_t *d_offsets,
-                             uint64_t *d_totals, msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg,
+                             uint64_t *d_totals, msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, int phase,
                              hipStream_t stream)
 {
+    /* phase 0: candidates and gather; 1: the candidate kernel only, 2: the gather only (of what phase 1 of the same batch
+     * left in d_regions / d_counts, on any stream behind it) */
     if (nbuffers == 0)
         return 0;
     /* noise_ready 1: the caller's levels (d_noise); else the candidate kernel works them out from the buffers' sums
@@ -3079,7 +3081,8 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     /* max_wg regions, one per wavefront of msd_ac_wave_kernel (ACNT / 64 wavefronts a workgroup) */
     const uint32_t ntiles = (uint32_t)((p->nsamples + ACW - 1) / ACW);
     if (ntiles == 0) {
-        (void)hipMemsetAsync(d_totals, 0, 4 * sizeof(uint64_t), stream);
+        if (phase != 1)
+            (void)hipMemsetAsync(d_totals, 0, 4 * sizeof(uint64_t), stream);
         return 0;
     }
     uint32_t tpw = (ntiles + max_wg - 1) / max_wg;
@@ -3093,16 +3096,18 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
 #define MSD_AC_LAUNCH(F)                                                                                                     \
     hipLaunchKernelGGL(msd_ac_wave_kernel<F>, dim3(nblocks), dim3(ACNT), 0, stream, *p, ntiles, tpw, levels, d_sums, d_fmeans, \
                        use_float, d_regions, (uint32_t)cap, d_counts)
-    switch (format) {
-    case MSD_FMT_UC8: MSD_AC_LAUNCH(MSD_FMT_UC8); break;
-    case MSD_FMT_SC16: MSD_AC_LAUNCH(MSD_FMT_SC16); break;
-    case MSD_FMT_SC16Q11: MSD_AC_LAUNCH(MSD_FMT_SC16Q11); break;
-    case MSD_FMT_MAG16: MSD_AC_LAUNCH(MSD_FMT_MAG16); break;
-    default: return -22;
-    }
+    if (phase != 2)
+        switch (format) {
+        case MSD_FMT_UC8: MSD_AC_LAUNCH(MSD_FMT_UC8); break;
+        case MSD_FMT_SC16: MSD_AC_LAUNCH(MSD_FMT_SC16); break;
+        case MSD_FMT_SC16Q11: MSD_AC_LAUNCH(MSD_FMT_SC16Q11); break;
+        case MSD_FMT_MAG16: MSD_AC_LAUNCH(MSD_FMT_MAG16); break;
+        default: return -22;
+        }
 #undef MSD_AC_LAUNCH
     (void)d_offsets;
-    hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nblocks), dim3(256), 0, stream, d_counts, nblocks, d_regions, (uint32_t)cap, d_dense,
+    if (phase != 1)
+        hipLaunchKernelGGL(msd_ac_gather_kernel, dim3(nblocks), dim3(256), 0, stream, d_counts, nblocks, d_regions, (uint32_t)cap, d_dense,
                        dense_cap, d_totals);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -3167,44 +3172,56 @@ extern "C" size_t msd_fm_work_bytes(uint32_t nbuffers)
 }
 
 extern "C" int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers,
-                                  float *d_out, void *d_work, hipStream_t stream)
+                                  float *d_out, void *d_work, int phase, hipStream_t stream)
 {
-    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, nullptr, d_work, stream);
+    return msd_launch_float_means(MSD_FMT_MAGSQ, d_magsq, nsamples, buffer_len, nbuffers, d_out, nullptr, d_work, phase, stream);
 }
 
 template <int FMT>
 static void launch_fm(const uint8_t *iq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
-                      const float *tile_sums, FmBufWork *work, hipStream_t stream)
+                      const float *tile_sums, FmBufWork *work, int phase, hipStream_t stream)
 {
-    if (!tile_sums)
-        hipLaunchKernelGGL(msd_fm_totals_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
-                           buffer_len, nbuffers, work);
-    hipLaunchKernelGGL(msd_fm_functions_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
-                       buffer_len, nbuffers, work, tile_sums);
-    hipLaunchKernelGGL(msd_fm_apply_kernel<FMT>, dim3(nbuffers), dim3(128), 0, stream, iq, nsamples, buffer_len, nbuffers,
-                       static_cast<const FmBufWork *>(work), d_out);
+    if (phase != 2) {
+        if (!tile_sums)
+            hipLaunchKernelGGL(msd_fm_totals_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
+                               buffer_len, nbuffers, work);
+        hipLaunchKernelGGL(msd_fm_functions_kernel<FMT>, dim3(nbuffers * FM_PARTS), dim3(FMK_THREADS), 0, stream, iq, nsamples,
+                           buffer_len, nbuffers, work, tile_sums);
+    }
+    if (phase != 1)
+        hipLaunchKernelGGL(msd_fm_apply_kernel<FMT>, dim3(nbuffers), dim3(128), 0, stream, iq, nsamples, buffer_len, nbuffers,
+                           static_cast<const FmBufWork *>(work), d_out);
+}
+
+/* phase 0: everything; 1: the block functions only, 2: the apply walk only (what phase 1 left in d_work, on any stream
+ * behind it).  msd_fm_deferrable(): whether the two phases exist for this call (else phase 1 does everything, 2 nothing). */
+extern "C" int msd_fm_deferrable(const void *d_work, uint64_t buffer_len, uint32_t nbuffers)
+{
+    return d_work && nbuffers && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK;
 }
 
 extern "C" int msd_launch_float_means(int format, const void *d_iq, uint64_t nsamples, uint64_t buffer_len,
-                                      uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work,
+                                      uint32_t nbuffers, float *d_out, const float *tile_sums, void *d_work, int phase,
                                       hipStream_t stream)
 {
     if (buffer_len % FS_BLOCK)
         tile_sums = nullptr;
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
     const uint32_t grid = nbuffers; /* one workgroup per buffer */
-    if (d_work && nbuffers && buffer_len <= (uint64_t)FB_MAX * FS_BLOCK) {
+    if (msd_fm_deferrable(d_work, buffer_len, nbuffers)) {
         FmBufWork *work = static_cast<FmBufWork *>(d_work);
         if (format == MSD_FMT_SC16)
-            launch_fm<MSD_FMT_SC16>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, stream);
+            launch_fm<MSD_FMT_SC16>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, phase, stream);
         else if (format == MSD_FMT_SC16Q11)
-            launch_fm<MSD_FMT_SC16Q11>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, stream);
+            launch_fm<MSD_FMT_SC16Q11>(iq, nsamples, buffer_len, nbuffers, d_out, tile_sums, work, phase, stream);
         else if (format == MSD_FMT_MAGSQ) /* msd_launch_dc_sums */
-            launch_fm<MSD_FMT_MAGSQ>(iq, nsamples, buffer_len, nbuffers, d_out, nullptr, work, stream);
+            launch_fm<MSD_FMT_MAGSQ>(iq, nsamples, buffer_len, nbuffers, d_out, nullptr, work, phase, stream);
         else
             return -22;
         return hipGetLastError() == hipSuccess ? 0 : -5;
     }
+    if (phase == 2)
+        return 0;
     /* a buffer longer than FB_MAX blocks (the converter entry takes any length): one wavefront per sum */
     if (format == MSD_FMT_SC16)
         hipLaunchKernelGGL(msd_float_means_kernel<MSD_FMT_SC16>, dim3(grid), dim3(FM_THREADS), 0, stream, iq,
