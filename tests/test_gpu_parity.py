@@ -529,3 +529,26 @@ def test_more_clean_squitter_addresses_than_the_prediction_table_holds(pkg, orac
     assert len(np.unique(squitters["addr"])) > 66000, len(np.unique(squitters["addr"]))
     if resolve_stage == "gpu-resolve":
         assert dem.timing()["resolve_fallback"] >= 1
+
+
+@pytest.mark.parametrize("fmt,noise_fs", [("sc16", 0.002), ("sc16", 0.3), ("sc16q11", 0.02)])
+def test_float_sums_of_a_full_batch_that_ends_on_a_buffer_boundary(pkg, oracle, torch_cuda, fmt, noise_fs):
+    """convert.c:241-252 at the benchmark's batch size: 512 full buffers of 16-bit IQ in one batch, which the reader counts
+    as 513 (sdr_ifile.c:192-216: the end of the file is only noticed by a short read), the last one empty.  The float sums
+    of every buffer -- sequential in the reference, evaluated block-parallel by msd_fm_functions_kernel /
+    msd_fm_apply_kernel -- must equal the oracle's bit for bit, and the empty buffer must not be read (round 4: the apply
+    kernel fetched its first sample, one word past the capture; only a capture that ends on a page boundary faults).
+    A quiet band puts the power sum below 16, where every block holds ties; a loud one drives both sums through
+    seventeen binades."""
+    f, of = (pkg.FMT_SC16, oracle.FMT_SC16) if fmt == "sc16" else (pkg.FMT_SC16Q11, oracle.FMT_SC16Q11)
+    n = 512 * 131072
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=20260, fmt=f, msgs_per_sec=3000, noise_fs=noise_fs), n)
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=f, nfix_crc=0, max_batch_samples=n, message_capacity=1 << 18)
+    got = dem.submit_device(d.data_ptr(), n, last=True)
+    want, wstats, wmeans = oracle.Oracle(of, 58, 0, 0).replay(iq, cap=1 << 18, want_means=True)
+    assert wstats["buffers"] == 513
+    assert_same(got, dem.stats(), want, wstats)
+    gm = dem.buffer_means()
+    assert len(gm) == 513 and np.array_equal(gm, wmeans[:513], equal_nan=True)
+    assert np.isfinite(gm[:512]).all() and gm[:512, 0].min() > 0
