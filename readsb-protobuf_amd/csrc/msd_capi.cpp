@@ -1811,17 +1811,10 @@ int collect(msd_ctx *c, msd_message_fn sink, void *user)
     return rc;
 }
 
-#ifdef MSD_FM_TIMERS
-extern "C" void msd_fm_report(void);
-#endif
-
 void destroy(msd_ctx *c)
 {
     if (!c)
         return;
-#ifdef MSD_FM_TIMERS
-    msd_fm_report();
-#endif
     c->helper.shutdown();
     (void)hipSetDevice(c->cfg.device);
     if (c->stream)
