@@ -90,9 +90,6 @@ typedef struct msd_message {
 #define MSD_CFG_REPASS_AUX (1 << 14)       /* repeated resolve passes on the high-priority side stream */
 #define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records fetched with a copy instead of written by the kernels */
 #define MSD_CFG_TRACE (1 << 16)            /* per-batch host timings on stderr (experiments) */
-#define MSD_CFG_QUEUED_REGIONS (1 << 18)   /* lean layout: four shorter regions per resident wavefront of the scan, handed out at run
-                                              time, instead of one each (measured: the region switches cost more than the tail they
-                                              remove) */
 #define MSD_CFG_DEFER_TAILS (1 << 17)      /* side streams: the float sums' apply walk and the Mode A/C gather head the batch's
                                               resolve chain instead of following its scan (measured: 2 % slower, the chain
                                               has no slack either) */

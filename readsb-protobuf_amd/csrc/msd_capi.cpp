@@ -195,9 +195,6 @@ struct Slot {
     msd_region_counts *d_rcounts = nullptr;
     msd_wg_totals *d_rwgt = nullptr;
     uint32_t lean_k = 0, lean_hcap = 0, lean_tcap = 0, lean_nreg = 0; /* regions per buffer, slice capacities, regions */
-    uint32_t lean_wgs = 0; /* workgroups its scan was launched with (what left msd_wg_totals) */
-    bool lean_queued = false; /* its regions were handed out at run time: no bases inside the scan workgroups (lean_gather_now) */
-    msd_wg_totals *d_rgroups = nullptr; /* ... the totals of every 16 regions, worked out when dense lists are wanted after all */
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
@@ -277,10 +274,7 @@ struct msd_ctx {
     uint64_t hit_arena = 0, try_arena = 0;
     msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
     msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
-    uint32_t max_wg = 0, max_buffers = 0;  /* max_wg: most regions a scan is split into (one per resident wavefront) */
-    uint32_t max_regions = 0;              /* ... when the regions are handed out at run time (lean layout): MSD_SCAN_REGION_FACTOR x that */
-    uint32_t *d_region_queue = nullptr;    /* two counters, used in turn by the queued launches (MsdScanParams::region_queue) */
-    uint64_t queue_seq = 0;
+    uint32_t max_wg = 0, max_buffers = 0;  /* max_wg: most regions a scan is split into */
     /* Mode A/C candidate regions */
     uint64_t ac_arena = 0;
     uint64_t *d_ac_offsets = nullptr;
@@ -500,14 +494,12 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
     const uint32_t tiles_per_buffer = (uint32_t)(MSD_CHUNK_SAMPLES / tile);
     uint32_t lean_k = 0, lean_tpr = 0;
     s.lean = false;
-    s.lean_queued = false;
     s.mag_pass = false; /* set by the scan block below; an empty batch has none and must not inherit the slot's last one */
     if (pipelined && c->lean_ok && nwg && gpu_eligible(c, s) && s.nbuffers <= c->max_wg && !(c->debug_flags & 0x1f)) {
-        const uint32_t region_budget = (c->cfg.flags & MSD_CFG_QUEUED_REGIONS) ? c->max_regions : c->max_wg;
         /* (the buffers that hold samples: a capture's last batch ends with one more, empty or short, buffer --
          * counting it would cost a full batch of 512 buffers an eighth of its regions, 4096 / 513 = 7) */
         const uint32_t nb_data = (uint32_t)((s.nsamples + MSD_CHUNK_SAMPLES - 1) / MSD_CHUNK_SAMPLES);
-        uint32_t k = region_budget / (nb_data ? nb_data : 1);
+        uint32_t k = c->max_wg / (nb_data ? nb_data : 1);
         if (k > 64)
             k = 64;
         if (k > tiles_per_buffer)
@@ -572,17 +564,6 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         if (s.lean) {
             p.regions_per_buffer = lean_k;
             p.tiles_per_region = lean_tpr;
-            p.nregions = nwg;
-            p.queue_wgs = (uint32_t)c->cu_count * MSD_SCAN_WGS_PER_CU;
-            if ((c->cfg.flags & MSD_CFG_QUEUED_REGIONS) && c->d_region_queue) {
-                p.region_queue = c->d_region_queue + (c->queue_seq & 1u);
-                p.region_queue_next = c->d_region_queue + ((c->queue_seq + 1u) & 1u);
-                c->queue_seq++;
-            }
-            s.lean_queued = p.region_queue != nullptr;
-            s.lean_wgs = (nwg + MSD_SCAN_WAVES - 1) / MSD_SCAN_WAVES;
-            if (p.region_queue && s.lean_wgs > p.queue_wgs)
-                s.lean_wgs = p.queue_wgs;
             p.overflow = reinterpret_cast<unsigned long long *>(s.d_totals + 2);
             if (tail_here) {
                 p.tail_src = reinterpret_cast<const uint32_t *>(s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format));
@@ -984,7 +965,7 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp)
         rp.wg_totals = s.d_rwgt;
         rp.regions_per_buffer = s.lean_k;
         rp.hcap = s.lean_hcap;
-        rp.nscan_wg = s.lean_wgs;
+        rp.nscan_wg = (s.lean_nreg + MSD_SCAN_WAVES - 1) / MSD_SCAN_WAVES;
         rp.nregions = s.lean_nreg;
         rp.sums = s.d_sums;
         rp.h_sums = s.h_sums;
@@ -1234,10 +1215,7 @@ void means_from_sums(msd_ctx *c, const Slot &s)
  * over the slot's region slices, synchronously.  Totals land in h_totals; the sums were published already. */
 int lean_gather_now(msd_ctx *c, Slot &s)
 {
-    int rc = s.lean_queued ? msd_launch_region_bases(s.d_rcounts, s.d_rgroups, s.lean_nreg, c->stream) : 0;
-    if (rc)
-        return fail(c, rc, "region bases kernel launch failed");
-    rc = msd_launch_gather(s.d_rcounts, s.lean_queued ? s.d_rgroups : s.d_rwgt, s.lean_nreg, s.d_totals, s.d_rhits, s.d_rtries, s.lean_hcap, s.lean_tcap,
+    int rc = msd_launch_gather(s.d_rcounts, s.d_rwgt, s.lean_nreg, s.d_totals, s.d_rhits, s.d_rtries, s.lean_hcap, s.lean_tcap,
                                s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers, s.h_totals, nullptr,
                                nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 1, c->stream);
     if (rc)
@@ -1855,61 +1833,6 @@ void destroy(msd_ctx *c)
                 fprintf(stderr, " [%d]=%llu", k, t[k]);
             fprintf(stderr, "\n");
         }
-        std::vector<unsigned long long> w(2 * 8192);
-        if (hipMemcpy(w.data(), c->d_timers + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            /* -DMSD_KERNEL_TIMING=3: begin / end of every wavefront's region in the last launch (100 MHz ticks) */
-            unsigned long long first = ~0ull, last = 0, n = 0;
-            double sum_busy = 0;
-            for (size_t r = 0; r < 8192; ++r)
-                if (w[2 * r + 1]) {
-                    first = std::min(first, w[2 * r]);
-                    last = std::max(last, w[2 * r + 1]);
-                    sum_busy += (double)(w[2 * r + 1] - w[2 * r]);
-                    ++n;
-                }
-            if (n) {
-                std::vector<double> ends;
-                for (size_t r = 0; r < 8192; ++r)
-                    if (w[2 * r + 1])
-                        ends.push_back((double)(w[2 * r + 1] - first) / 100.0);
-                std::sort(ends.begin(), ends.end());
-                fprintf(stderr, "scan regions of the last launch: %llu wavefronts, span %.1f us, mean busy %.1f us; region ends (us after the first start): "
-                        "p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", n, (double)(last - first) / 100.0, sum_busy / (double)n / 100.0,
-                        ends[ends.size() / 10], ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back());
-                /* how much of the spread is between workgroups (compute units) and how much inside them */
-                double wg_mean_sum = 0, wg_mean_sq = 0, inside = 0, start_spread = 0;
-                size_t nwg_ = 0;
-                for (size_t g = 0; g + 16 <= 8192; g += 16) {
-                    double m = 0, lo = 1e30, hi = 0, st_lo = 1e30, st_hi = 0;
-                    int cnt = 0;
-                    for (size_t r = g; r < g + 16; ++r)
-                        if (w[2 * r + 1]) {
-                            const double e = (double)(w[2 * r + 1] - first) / 100.0, b0 = (double)(w[2 * r] - first) / 100.0;
-                            m += e; lo = std::min(lo, e); hi = std::max(hi, e); st_lo = std::min(st_lo, b0); st_hi = std::max(st_hi, b0);
-                            ++cnt;
-                        }
-                    if (cnt == 16) {
-                        m /= 16;
-                        wg_mean_sum += m; wg_mean_sq += m * m; inside += hi - lo; start_spread = std::max(start_spread, st_hi);
-                        ++nwg_;
-                    }
-                }
-                {
-                    double byw[16] = {0}; int nb[16] = {0};
-                    for (size_t r = 0; r < 8192; ++r)
-                        if (w[2 * r + 1]) { byw[r & 15] += (double)(w[2 * r + 1] - first) / 100.0; nb[r & 15]++; }
-                    fprintf(stderr, "  mean end by wavefront of the workgroup:");
-                    for (int i = 0; i < 16; ++i)
-                        fprintf(stderr, " %.0f", nb[i] ? byw[i] / nb[i] : 0.0);
-                    fprintf(stderr, "\n");
-                }
-                if (nwg_) {
-                    const double mu = wg_mean_sum / (double)nwg_;
-                    fprintf(stderr, "  per workgroup: mean of the 16 ends %.1f us, sigma between workgroups %.1f us, mean (last - first end) inside a workgroup %.1f us, "
-                            "latest region start %.1f us\n", mu, std::sqrt(std::max(0.0, wg_mean_sq / (double)nwg_ - mu * mu)), inside / (double)nwg_, start_spread);
-                }
-            }
-        }
         (void)hipFree(c->d_timers);
     }
     for (Slot &s : c->slots) {
@@ -1924,7 +1847,7 @@ void destroy(msd_ctx *c)
         if (s.h_req) (void)hipHostFree(s.h_req);
         if (s.h_pow) (void)hipHostFree(s.h_pow);
         (void)hipFree(s.d_ac); (void)hipFree(s.d_ac_totals); (void)hipFree(s.d_mag); (void)hipFree(s.d_ragged);
-        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_rgroups); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
+        (void)hipFree(s.d_acc); if (s.d_adds) (void)hipHostFree(s.d_adds); (void)hipFree(s.d_nmsgs); (void)hipFree(s.d_powr); (void)hipFree(s.d_pred); (void)hipFree(s.d_rhits); (void)hipFree(s.d_rtries); (void)hipFree(s.d_rcounts); (void)hipFree(s.d_rwgt); (void)hipFree(s.d_acc_ac); (void)hipFree(s.d_nac);
         if (s.h_rbuf) (void)hipHostFree(s.h_rbuf);
         if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.h_side) (void)hipHostFree(s.h_side);
@@ -1949,7 +1872,6 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
-    (void)hipFree(c->d_region_queue);
     (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
     (void)hipFree(c->d_snaps);
@@ -2097,9 +2019,6 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
     c->max_wg = (uint32_t)c->cu_count * MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU;
-    c->max_regions = c->max_wg * MSD_SCAN_REGION_FACTOR;
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_queue), 2 * sizeof(uint32_t)));
-    CK(hipMemset(c->d_region_queue, 0, 2 * sizeof(uint32_t)));
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
@@ -2199,8 +2118,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         for (Slot &s : c->slots) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rhits), c->hit_arena * sizeof(msd_hit)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rtries), c->try_arena * sizeof(msd_try)));
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rcounts), c->max_regions * sizeof(msd_region_counts)));
-            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rgroups), (c->max_regions / MSD_SCAN_WAVES + 1) * sizeof(msd_wg_totals)));
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_rcounts), c->max_wg * sizeof(msd_region_counts)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rwgt), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
             CK(hipMemset(s.d_totals, 0, 4 * sizeof(uint64_t)));
         }
@@ -2240,8 +2158,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
 #undef CK
 #ifdef MSD_KERNEL_TIMING /* -DMSD_KERNEL_TIMING builds only: the scan kernel's section clocks, printed by msd_destroy */
     {
-        if (hipMalloc(reinterpret_cast<void **>(&c->d_timers), (16 + 2 * 8192) * sizeof(unsigned long long)) == hipSuccess)
-            (void)hipMemset(c->d_timers, 0, (16 + 2 * 8192) * sizeof(unsigned long long));
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_timers), 16 * sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(c->d_timers, 0, 16 * sizeof(unsigned long long));
     }
 #endif
     c->resolver.stats = &c->stats;

@@ -40,9 +40,6 @@ extern "C" {
 #ifndef MSD_SLICER_NG
 #define MSD_SLICER_NG 3 /* bit groups (of five bits) one lane slices per item of step B */
 #endif
-#ifndef MSD_SCAN_REGION_FACTOR
-#define MSD_SCAN_REGION_FACTOR 4u /* lean layout: regions per resident wavefront of the scan kernel, taken from a queue */
-#endif
 #ifndef MSD_TILE
 #define MSD_TILE 2048u /* scan positions per wavefront tile: 2048 (two runs of 16 per lane) or 1024 */
 #endif

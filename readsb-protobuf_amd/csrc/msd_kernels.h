@@ -68,13 +68,6 @@ typedef struct MsdScanParams {
      * boundary), so that the resolve workgroup of a buffer reads its k region slices where they are; the try index
      * in a hit record is then arena-absolute (region * tcap + index). */
     uint32_t regions_per_buffer, tiles_per_region;
-    /* Lean layout, regions handed out at run time: a wavefront that is through with a region takes the next one from
-     * *region_queue (an index into [0, nregions); zero when the launch starts) until none is left -- the regions are shorter
-     * than a wavefront's share, so that the wavefronts of a compute unit end together instead of 44 us apart (round 4: the
-     * last 15 % of a launch ran with one or two wavefronts per SIMD).  The first workgroup zeroes *region_queue_next for the
-     * launch after this one.  NULL: region = workgroup * 16 + wavefront, as before. */
-    uint32_t *region_queue, *region_queue_next;
-    uint32_t nregions, queue_wgs; /* regions of this launch; workgroups to launch (the resident ones) */
     unsigned long long *overflow; /* the batch's totals[2]: set by any region whose slice overflowed */
     /* predicted adds, written as the tries are found: every CRC-clean DF17 / DF11(II=0) address with the first buffer
      * holding one (msd_internal.h); NULL: nobody wants them */
@@ -173,9 +166,6 @@ int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nregions, hipSt
  * next batch.  wipe[0..wipe_bytes) (a multiple of 16) is set to all-ones, tail_bytes (a multiple of
  * 4) are copied from tail_src to tail_dst on the way.  buf_first[b], b = 0 .. nbuffers: index in the dense list
  * of the first hit at or behind sample b * MSD_CHUNK_SAMPLES (a region is region_len scan positions). */
-/* dense lists from a queued scan's region counts: fills in hbase / tbase and the totals of every group of 16 regions,
- * which msd_launch_gather then takes for the scan workgroups' (wg_totals = groups) */
-int msd_launch_region_bases(msd_region_counts *counts, msd_wg_totals *groups, uint32_t nregions, hipStream_t stream);
 int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_totals, uint32_t nwg, uint64_t *totals,
                       const msd_hit *hits,
                       const msd_try *tries, uint32_t hcap, uint32_t tcap, msd_hit *dense_hits, uint64_t dense_hcap,

@@ -103,19 +103,11 @@ __device__ __forceinline__ uint32_t msd_cycles()
 {
     return (uint32_t)__builtin_readcyclecounter();
 }
-#if MSD_KERNEL_TIMING + 0 == 3 /* no marks inside the loop: when every wavefront started and ended its region (100 MHz wall clock), for the tail */
-#define TDECL uint32_t tacc_[12] = {0}; uint32_t tlast_ = 0; (void)tacc_; (void)tlast_;
-#define TMARK(k)
-#define TMARKF(k)
-#define TFLUSH
-#define MSD_WAVE_SPAN 1 /* msd_scan_kernel records every wavefront's first start and last end */
-#else
 #define TDECL uint32_t tacc_[12] = {0}; uint32_t tlast_ = msd_cycles();
 #define TCOARSE(k) (MSD_KERNEL_TIMING + 0 != 2 || (k) == 0 || (k) == 2 || (k) == 9) /* -DMSD_KERNEL_TIMING=2: three marks per tile */
 #define TMARK(k) if (TCOARSE(k)) { const uint32_t n_ = msd_cycles(); tacc_[k] += n_ - tlast_; tlast_ = n_; }
 #define TMARKF(k) if (MSD_KERNEL_TIMING + 0 != 2) { const uint32_t n_ = msd_cycles(); tacc[k] += n_ - *tlast; *tlast = n_; }
 #define TFLUSH if (P.timers && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&P.timers[k_], (unsigned long long)tacc_[k_]); }
-#endif
 #else
 #define TDECL
 #define TMARK(k)
@@ -1152,100 +1144,46 @@ __global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3)
     __syncthreads();
 
     /* from here to the end of the batch the wavefronts do not meet again */
-#ifdef MSD_WAVE_SPAN
-    const unsigned long long t_wave_begin = wall_clock64();
-#endif
-    uint32_t nhits = 0, ntries = 0, wave_ovf = 0;
-    const bool queued = P.region_queue != nullptr; /* (implies the lean layout) */
-    if (queued && blockIdx.x == 0 && tid == 0)
-        *P.region_queue_next = 0u;
-    for (uint32_t turn = 0;; ++turn) {
-        uint32_t region;
-        if (queued) {
-            uint32_t r = 0;
-            if (lane == 0)
-                r = atomicAdd(P.region_queue, 1u);
-            region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-            if (region >= P.nregions)
-                break;
-        } else {
-            if (turn)
-                break;
-            region = blockIdx.x * WAVES + (uint32_t)wave;
-        }
-        uint32_t tile_lo, tile_hi;
-        if (P.regions_per_buffer) { /* lean layout: piece region % k of buffer region / k, never across a buffer boundary */
-            constexpr uint32_t TPB = MSD_CHUNK_SAMPLES / (1024u * tile_runs(FMT)); /* tiles per buffer */
-            const uint32_t b = region / P.regions_per_buffer, piece = region - b * P.regions_per_buffer;
-            tile_lo = b * TPB + piece * P.tiles_per_region;
-            tile_hi = tile_lo + P.tiles_per_region;
-            if (tile_hi > (b + 1) * TPB)
-                tile_hi = (b + 1) * TPB;
-            if (tile_lo > tile_hi)
-                tile_lo = tile_hi;
-            if (region == 0 && P.tail_words) /* the batch's last samples, for the look-behind of its successor */
-                for (uint32_t i = (uint32_t)lane; i < P.tail_words; i += 64)
-                    P.tail_dst[i] = P.tail_src[i];
-        } else {
-            tile_lo = region * P.tiles_per_wg;
-            tile_hi = tile_lo + P.tiles_per_wg;
-        }
-        if (tile_hi > P.ntiles)
-            tile_hi = P.ntiles;
-        uint32_t rh = 0, rt = 0;
-        if (tile_lo < tile_hi) { /* wave-uniform */
-            WaveCtx X;
-            X.w = smem + OFF_WAVE + wave * W_BYTES;
-            X.syn = syn;
-            X.sl = sl;
-            X.lane = lane;
-            scan_region<FMT, FIX2, EMIT>(P, X, lut, region, tile_lo, tile_hi, rh, rt);
-        } else if (EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers && !(P.debug_flags & 128)) {
-            /* a region without tiles (lean layout: the pieces of a short last buffer) still owes its share of the
-             * previous batch's records */
-            msd_emit_slice<FMT>(P.emit, P.lut, region, lane, smem + OFF_WAVE + wave * W_BYTES + W_HITS, (P.debug_flags & 64) != 0);
-        }
-        const uint32_t rovf = (rh > P.hcap || rt > P.tcap) ? 1u : 0u;
-        if (queued) {
-            if (lane == 0) { /* the region's own record; nobody asks a queued launch for the bases inside a workgroup */
-                msd_region_counts c = {};
-                c.nhits = rh;
-                c.ntries = rt;
-                c.overflow = rovf;
-                P.counts[region] = c;
-            }
-            wave_lds_sync(); /* the next region's look-behind goes where this one's last tile was read */
-        }
-        nhits += rh;
-        ntries += rt;
-        wave_ovf |= rovf;
+    const uint32_t region = blockIdx.x * WAVES + (uint32_t)wave;
+    uint32_t tile_lo, tile_hi;
+    if (P.regions_per_buffer) { /* lean layout: piece region % k of buffer region / k, never across a buffer boundary */
+        constexpr uint32_t TPB = MSD_CHUNK_SAMPLES / (1024u * tile_runs(FMT)); /* tiles per buffer */
+        const uint32_t b = region / P.regions_per_buffer, piece = region - b * P.regions_per_buffer;
+        tile_lo = b * TPB + piece * P.tiles_per_region;
+        tile_hi = tile_lo + P.tiles_per_region;
+        if (tile_hi > (b + 1) * TPB)
+            tile_hi = (b + 1) * TPB;
+        if (tile_lo > tile_hi)
+            tile_lo = tile_hi;
+        if (region == 0 && P.tail_words) /* the batch's last samples, for the look-behind of its successor */
+            for (uint32_t i = (uint32_t)lane; i < P.tail_words; i += 64)
+                P.tail_dst[i] = P.tail_src[i];
+    } else {
+        tile_lo = region * P.tiles_per_wg;
+        tile_hi = tile_lo + P.tiles_per_wg;
     }
-#ifdef MSD_WAVE_SPAN
-    if (P.timers && lane == 0 && blockIdx.x * WAVES + (uint32_t)wave < 8192u) {
-        P.timers[16 + 2 * (blockIdx.x * WAVES + wave)] = t_wave_begin;
-        P.timers[17 + 2 * (blockIdx.x * WAVES + wave)] = wall_clock64();
+    if (tile_hi > P.ntiles)
+        tile_hi = P.ntiles;
+    uint32_t nhits = 0, ntries = 0;
+    if (tile_lo < tile_hi) { /* wave-uniform */
+        WaveCtx X;
+        X.w = smem + OFF_WAVE + wave * W_BYTES;
+        X.syn = syn;
+        X.sl = sl;
+        X.lane = lane;
+        scan_region<FMT, FIX2, EMIT>(P, X, lut, region, tile_lo, tile_hi, nhits, ntries);
+    } else if (EMIT && P.emit.nbuffers && region / P.emit.stride < P.emit.nbuffers && !(P.debug_flags & 128)) {
+        /* a region without tiles (lean layout: the pieces of a short last buffer) still owes its share of the
+         * previous batch's records */
+        msd_emit_slice<FMT>(P.emit, P.lut, region, lane, smem + OFF_WAVE + wave * W_BYTES + W_HITS, (P.debug_flags & 64) != 0);
     }
-#endif
     if (lane == 0) {
         wgc[4 * wave] = nhits;
         wgc[4 * wave + 1] = ntries;
-        wgc[4 * wave + 2] = wave_ovf;
+        wgc[4 * wave + 2] = (nhits > P.hcap || ntries > P.tcap) ? 1u : 0u;
     }
     __syncthreads();
-    if (queued) { /* the workgroup's totals only: its wavefronts' regions have left their own records */
-        if (tid == 0) {
-            uint32_t hb = 0, tb = 0, ovf = 0;
-            for (int i = 0; i < WAVES; ++i) {
-                hb += wgc[4 * i];
-                tb += wgc[4 * i + 1];
-                ovf |= wgc[4 * i + 2];
-            }
-            msd_wg_totals t = {hb, tb, ovf, 0};
-            P.wg_totals[blockIdx.x] = t;
-            if (ovf && P.overflow)
-                atomicOr(P.overflow, 1ull);
-        }
-    } else if (tid < WAVES) {
+    if (tid < WAVES) {
         msd_region_counts c = {};
         uint32_t hb = 0, tb = 0, ovf = 0;
         for (int i = 0; i < WAVES; ++i) {
@@ -3028,9 +2966,7 @@ template <int FMT, bool FIX2, bool EMIT>
 static int launch_scan_fix(const MsdScanParams *p, uint32_t nregions, hipStream_t stream)
 {
     const size_t lds = msd_scan_lds_bytes(FMT);
-    uint32_t nwg = (nregions + WAVES - 1) / WAVES;
-    if (p->region_queue && p->queue_wgs && nwg > p->queue_wgs) /* regions from the queue: the resident workgroups take them all */
-        nwg = p->queue_wgs;
+    const uint32_t nwg = (nregions + WAVES - 1) / WAVES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_scan_kernel<FMT, FIX2, EMIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
@@ -3058,35 +2994,6 @@ extern "C" int msd_launch_scan(const MsdScanParams *p, int format, uint32_t nreg
     case MSD_FMT_MAG16: return launch_scan_fmt<MSD_FMT_MAG16>(p, nregions, stream);
     default: return -22;
     }
-}
-
-/* A queued scan (MsdScanParams::region_queue) leaves every region's counts but not what the gather kernel takes from a
- * scan workgroup's meeting -- the hits / tries of the earlier regions of each group of WAVES consecutive regions and the
- * groups' totals.  The rare batch that needs dense lists after all (a lean batch handed to the host resolver) gets them
- * here: one wavefront per group. */
-__global__ void __launch_bounds__(64) msd_region_bases_kernel(msd_region_counts *counts, msd_wg_totals *groups, uint32_t nregions)
-{
-    const uint32_t g = blockIdx.x, lane = threadIdx.x, r = g * WAVES + lane;
-    const bool in = lane < (uint32_t)WAVES && r < nregions;
-    const uint32_t h = in ? counts[r].nhits : 0u, t = in ? counts[r].ntries : 0u, o = in ? counts[r].overflow : 0u;
-    const uint32_t hi = wave_incl_scan(h), ti = wave_incl_scan(t);
-    const unsigned long long ovf = __ballot(o != 0);
-    if (in) {
-        counts[r].hbase = hi - h;
-        counts[r].tbase = ti - t;
-    }
-    if (lane == 63) {
-        msd_wg_totals tt = {hi, ti, ovf ? 1u : 0u, 0};
-        groups[g] = tt;
-    }
-}
-
-extern "C" int msd_launch_region_bases(msd_region_counts *counts, msd_wg_totals *groups, uint32_t nregions, hipStream_t stream)
-{
-    if (!nregions)
-        return 0;
-    hipLaunchKernelGGL(msd_region_bases_kernel, dim3((nregions + WAVES - 1) / WAVES), dim3(64), 0, stream, counts, groups, nregions);
-    return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 extern "C" int msd_launch_gather(const msd_region_counts *counts, const msd_wg_totals *wg_totals, uint32_t nwg,

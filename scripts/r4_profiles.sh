@@ -78,5 +78,8 @@ done
 for e in "MSD_EMIT_FUSED=0" "MSD_LEAN=0" "MSD_RESOLVE_AHEAD=0" "MSD_POWER_FUSED=0" "MSD_WAIT_INPUTS_ON_STREAM=1" "MSD_CHAIN_INLINE=0" "MSD_LEAN=0 MSD_RESOLVE_AHEAD=0 MSD_POWER_FUSED=0 MSD_WAIT_INPUTS_ON_STREAM=1"; do
   echo -n "$e : " >> $O/configs.txt; env $e timeout 600 python bench.py --no-cpu-baseline --no-also --no-check 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'])" >> $O/configs.txt
 done
+for a in "--format sc16 --samples 268435456" "--mode-ac --fix 1"; do
+  echo -n "MSD_DEFER_TAILS=1 bench.py $a : " >> $O/configs.txt; MSD_DEFER_TAILS=1 timeout 600 python bench.py --no-cpu-baseline --no-also --no-check $a 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'])" >> $O/configs.txt
+done
 cat $O/configs.txt
 tail -1 $O/bench_default.json | cut -c1-400
