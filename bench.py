@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--mode-ac", action="store_true", help="BASELINE configs[4]: Mode A/C demodulator on, 500 replies/s")
     ap.add_argument("--fields", action="store_true",
                     help="MSD_CFG_DECODE_FIELDS: also decode header and extended squitter fields of every message")
+    ap.add_argument("--sc16q11-table-bits", type=int, default=0,
+                    help="--format sc16q11 only: the converter of a reference built with -DSC16Q11_TABLE_BITS=n (convert.c:264-328)")
     ap.add_argument("--dcfilter", action="store_true",
                     help="MSD_CFG_DC_FILTER: the DC-blocking converters (sequential by nature, ~0.1 GS/s); use a small --samples")
     ap.add_argument("--no-also", action="store_true",
@@ -186,7 +188,7 @@ def main():
     nctx = 1
     dems = [pkg.Demodulator(fmt=fmt, preamble_threshold=args.threshold, nfix_crc=args.fix, mode_ac=int(args.mode_ac), device=device_index, dc_filter=args.dcfilter,
                             max_batch_samples=batch, stream=stream.cuda_stream, message_capacity=1 << 21,
-                            decode_fields=args.fields)
+                            decode_fields=args.fields, **({"sc16q11_table_bits": args.sc16q11_table_bits} if args.sc16q11_table_bits else {}))
             for _ in range(nctx)]
     for d in dems:
         d.set_timing_interval(args.timing_interval)
@@ -376,7 +378,7 @@ def main():
         # (a) one thread doing everything (orc_replay: IQ -> magnitude -> demodulator), whole passes for ~10 s
         passes, cpu_s = 0, 0.0
         while passes < 1 or (cpu_s < 10.0 and passes < 8):
-            orc = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter)
+            orc = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter, sc16q11_table_bits=args.sc16q11_table_bits)
             t0 = time.perf_counter()
             w, ws = orc.replay(iq[: ns * bps], cap=1 << 21)
             cpu_s += time.perf_counter() - t0
@@ -391,7 +393,7 @@ def main():
         if not args.dcfilter:
             nb2 = min(ns, 1 << 28) // pkg.CHUNK
             q = queue.Queue(maxsize=12)
-            conv = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
+            conv = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), sc16q11_table_bits=args.sc16q11_table_bits)
             demo = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
             cpu_t = {}
 
@@ -433,7 +435,8 @@ def main():
         O = graft.load_oracle()
         if want is None:
             ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
-            want, wstats = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter).replay(iq, cap=1 << 21)
+            want, wstats = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter,
+                                    sc16q11_table_bits=args.sc16q11_table_bits).replay(iq, cap=1 << 21)
         dem.reset()
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
         ndiff = abs(len(got) - len(want))

@@ -54,6 +54,11 @@ typedef struct msd_config {
     int32_t debug_flags;          /* kernel ablations for timing experiments (results are then incomplete): 1 stop after the
                                      preamble tests, 2 after the conversion, 4 no step B, 64 / 128 record writers without
                                      their stores / altogether */
+    int32_t sc16q11_table_bits;   /* MSD_FMT_SC16Q11 only: what a reference built with -DSC16Q11_TABLE_BITS=n does (debian/rules
+                                     sets 8 on armhf) -- convert_sc16q11_table, convert.c:264-328: magnitudes from a
+                                     2^(2n)-entry table of the top n of 11 bits of |I| and |Q|, integer sums.  1..11; 0 = the
+                                     float path (convert_sc16q11_nodc).  Ignored with MSD_CFG_DC_FILTER, as the reference's
+                                     selection does (convert.c:425-444) */
 } msd_config;
 
 /* The part of struct modesMessage (readsb.h:340-547) the demodulator determines; this is what

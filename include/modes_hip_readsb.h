@@ -53,6 +53,9 @@ void msd_cleanup_converter(struct converter_state *state); /* convert.h:45 */
 /* the GPU device the next msd_init_converter uses (default 0); the context behind a state, for callers
  * that want to demodulate with the same one (msd_demodulate_magbuf); the last error text or "" */
 void msd_converter_set_device(int device);
+/* the SC16Q11_TABLE_BITS of the build being replaced: init_converter(INPUT_SC16Q11, ..., 0, ...) then hands out the table
+ * converter (convert.c:437-438), as the reference's does.  0 (default): the float path. */
+void msd_converter_set_sc16q11_table_bits(int bits);
 msd_ctx *msd_converter_context(struct converter_state *state);
 const char *msd_converter_error(const struct converter_state *state);
 
@@ -134,6 +137,7 @@ typedef struct msd_receiver_options {
     msd_message_fn sink;    /* useModesMessage */
     void *sink_user;
     int dc_filter;          /* Modes.dc_filter (--dcfilter, readsb.c:486); fused mode only */
+    int sc16q11_table_bits; /* the SC16Q11_TABLE_BITS the host was built with (convert.c:264-328; 0: not defined) */
 } msd_receiver_options;
 
 /* What the reference's handler reaches through the global `Modes` and sdr.h (sdr_ifile.c:86,178-184,236):

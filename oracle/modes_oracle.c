@@ -35,6 +35,8 @@ struct syndrome_entry { /* struct errorinfo, crc.h:32-37 */
 struct orc_ctx {
     int format, threshold, nfix, mode_ac;
     int dc_filter; /* struct converter_state, convert.c:28-33 */
+    int q11_bits;  /* SC16Q11_TABLE_BITS of the build being restated (0: undefined, the float path) */
+    uint16_t *q11_table;
     float dc_z1_i, dc_z1_q, dc_a, dc_b;
     /* icao_filter.c:38-40 */
     uint32_t filt[2][FILTER_SLOTS];
@@ -181,6 +183,56 @@ void orc_set_dc_filter(orc_ctx *ctx, int on)
     ctx->dc_a = 1.0 - ctx->dc_b;
 }
 
+/* convert.c:264-328, a build with -DSC16Q11_TABLE_BITS=bits (debian/rules:19 sets 8 on armhf): init_sc16q11_lookup ... */
+void orc_set_sc16q11_table_bits(orc_ctx *ctx, int bits)
+{
+    free(ctx->q11_table);
+    ctx->q11_table = NULL;
+    ctx->q11_bits = 0;
+    if (bits < 1 || bits > 11)
+        return;
+    const int lose = 11 - bits;
+    ctx->q11_table = malloc(sizeof(uint16_t) * ((size_t)1 << (bits * 2)));
+    if (!ctx->q11_table)
+        return;
+    for (int i = 0; i < 2048; i += (1 << lose)) {
+        for (int q = 0; q < 2048; q += (1 << lose)) {
+            float fI = i / 2048.0, fQ = q / 2048.0;
+            float magsq = fI * fI + fQ * fQ;
+            if (magsq > 1)
+                magsq = 1;
+            float mag = sqrtf(magsq);
+            unsigned index = ((i >> lose) << bits) | (q >> lose);
+            ctx->q11_table[index] = (uint16_t)(mag * 65535.0f + 0.5f);
+        }
+    }
+    ctx->q11_bits = bits;
+}
+
+const uint16_t *orc_sc16q11_table(const orc_ctx *ctx)
+{
+    return ctx->q11_table;
+}
+
+/* ... and convert_sc16q11_table, convert.c:297-328 */
+static void convert_q11_table(const orc_ctx *ctx, const uint8_t *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
+{
+    const int bits = ctx->q11_bits, lose = 11 - bits;
+    uint64_t sum_level = 0, sum_power = 0;
+    for (unsigned k = 0; k < n; ++k) {
+        uint16_t I = abs((int16_t)((unsigned)iq[4 * k] | ((unsigned)iq[4 * k + 1] << 8))) & 2047;
+        uint16_t Q = abs((int16_t)((unsigned)iq[4 * k + 2] | ((unsigned)iq[4 * k + 3] << 8))) & 2047;
+        uint16_t v = ctx->q11_table[((I >> lose) << bits) | (Q >> lose)];
+        mag[k] = v;
+        sum_level += v;
+        sum_power += (uint32_t)v * (uint32_t)v;
+    }
+    if (ml)
+        *ml = sum_level / 65536.0 / n;
+    if (mp)
+        *mp = sum_power / 65535.0 / 65535.0 / n;
+}
+
 void orc_convert(orc_ctx *ctx, const void *iq, uint16_t *mag, unsigned n, double *ml, double *mp)
 {
     if (ctx->dc_filter) {
@@ -195,7 +247,10 @@ void orc_convert(orc_ctx *ctx, const void *iq, uint16_t *mag, unsigned n, double
         convert_s16(iq, mag, n, 32768.0f, ml, mp);
         break;
     default:
-        convert_s16(iq, mag, n, 2048.0f, ml, mp);
+        if (ctx->q11_bits) /* convert.c:437-438: the table path takes the float path's place in converters_table */
+            convert_q11_table(ctx, iq, mag, n, ml, mp);
+        else
+            convert_s16(iq, mag, n, 2048.0f, ml, mp);
         break;
     }
 }
@@ -2009,6 +2064,7 @@ void orc_destroy(orc_ctx *ctx)
     if (!ctx)
         return;
     free(ctx->buf);
+    free(ctx->q11_table);
     free(ctx);
 }
 

@@ -76,6 +76,9 @@ typedef struct orc_ctx orc_ctx;
 orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_ac);
 /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,374-423); resets its state */
 void orc_set_dc_filter(orc_ctx *ctx, int on);
+/* restate a reference built with -DSC16Q11_TABLE_BITS=bits (1..11; anything else: the float path, as without the define) */
+void orc_set_sc16q11_table_bits(orc_ctx *ctx, int bits);
+const uint16_t *orc_sc16q11_table(const orc_ctx *ctx);
 void orc_destroy(orc_ctx *ctx);
 
 /* Replay a whole capture exactly as `readsb --device-type ifile --ifile F --iformat X --throttle`

@@ -125,6 +125,10 @@ def lib():
         L.orc_create.argtypes = [C.c_int] * 4
         L.orc_set_dc_filter.restype = None
         L.orc_set_dc_filter.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_sc16q11_table_bits.restype = None
+        L.orc_set_sc16q11_table_bits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_sc16q11_table.restype = C.POINTER(C.c_uint16)
+        L.orc_sc16q11_table.argtypes = [C.c_void_p]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_replay.restype = C.c_uint64
         L.orc_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
@@ -181,12 +185,15 @@ def beast_frame(message):
 class Oracle:
     """One receiver context (its own ICAO filter, clock and counters)."""
 
-    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, dc_filter=False):
+    def __init__(self, fmt=FMT_UC8, preamble_threshold=58, nfix_crc=1, mode_ac=0, dc_filter=False, sc16q11_table_bits=0):
         self._h = lib().orc_create(fmt, preamble_threshold, nfix_crc, mode_ac)
         if not self._h:
             raise ValueError("orc_create rejected the configuration")
         if dc_filter:
             lib().orc_set_dc_filter(self._h, 1)
+        self.sc16q11_table_bits = sc16q11_table_bits
+        if sc16q11_table_bits: # a reference built with -DSC16Q11_TABLE_BITS=n (convert.c:264-328)
+            lib().orc_set_sc16q11_table_bits(self._h, sc16q11_table_bits)
         self.fmt = fmt
 
     def close(self):

@@ -117,6 +117,7 @@ class Config(C.Structure):
         ("test_arena_permille", C.c_int32),
         ("test_inline_adds", C.c_int32),
         ("debug_flags", C.c_int32),
+        ("sc16q11_table_bits", C.c_int32),
     ]
 
 

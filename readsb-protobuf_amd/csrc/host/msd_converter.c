@@ -17,6 +17,12 @@ struct converter_state {
 };
 
 static int g_device = 0;
+static int g_q11_bits = 0;
+
+void msd_converter_set_sc16q11_table_bits(int bits)
+{
+    g_q11_bits = bits >= 1 && bits <= 11 ? bits : 0;
+}
 
 void msd_converter_set_device(int device)
 {
@@ -77,6 +83,7 @@ msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_ra
     memset(&cfg, 0, sizeof cfg);
     cfg.device = g_device;
     cfg.format = fmt;
+    cfg.sc16q11_table_bits = fmt == MSD_FMT_SC16Q11 ? g_q11_bits : 0; /* #if defined(SC16Q11_TABLE_BITS), convert.c:437 */
     cfg.preamble_threshold = 58; /* the converter does not demodulate; msd_set_preamble_threshold etc. apply */
     cfg.nfix_crc = 1;
     cfg.max_batch_samples = MSD_CHUNK_SAMPLES; /* a block of MODES_MAG_BUF_SAMPLES, sdr_ifile.c:140 */

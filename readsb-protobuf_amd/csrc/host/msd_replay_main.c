@@ -92,6 +92,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--device-type") && next) { ++i; /* always ifile */ }
         else if (!strcmp(a, "--device") && next) { rx.device = atoi(next); ++i; }
         else if (!strcmp(a, "--batch-buffers") && next) { rx.batch_buffers = (unsigned)atoi(next); ++i; }
+        else if (!strcmp(a, "--sc16q11-table-bits") && next) { rx.sc16q11_table_bits = atoi(next); ++i; } /* a -DSC16Q11_TABLE_BITS=n build */
         else if (!strcmp(a, "--preamble-threshold") && next) {
             long v = strtol(next, NULL, 10); /* readsb.c:503-505 clamps to 40..400 */
             rx.preamble_threshold = (int)(v < 40 ? 40 : (v > 400 ? 400 : v));
@@ -99,7 +100,7 @@ int main(int argc, char **argv)
         } else {
             fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] [--dcfilter] "
                             "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast] [--stats] [--path fused|magbuf] "
-                            "[--device N]\n");
+                            "[--device N] [--sc16q11-table-bits N]\n");
             return 2;
         }
     }

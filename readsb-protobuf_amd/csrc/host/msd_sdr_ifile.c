@@ -167,6 +167,7 @@ bool msd_ifileOpen(void)
             return false;
         }
         msd_converter_set_device(F.rx.device);
+        msd_converter_set_sc16q11_table_bits(F.rx.sc16q11_table_bits);
         F.converter = msd_init_converter((msd_input_format_t)(F.format == MSD_FMT_UC8 ? 0 : F.format == MSD_FMT_SC16 ? 1 : 2),
                                          2400000.0, 0, &F.converter_state);
         if (!F.converter) {
@@ -182,6 +183,8 @@ bool msd_ifileOpen(void)
     cfg.preamble_threshold = F.rx.preamble_threshold;
     cfg.nfix_crc = F.rx.nfix_crc;
     cfg.mode_ac = F.rx.mode_ac;
+    if (F.format == MSD_FMT_SC16Q11 && !F.rx.dc_filter && F.mode == MSD_IFILE_FUSED)
+        cfg.sc16q11_table_bits = F.rx.sc16q11_table_bits; /* a host built with -DSC16Q11_TABLE_BITS (convert.c:437-438) */
     if (F.rx.dc_filter) {
         if (F.mode != MSD_IFILE_FUSED) { /* the stateful converters live inside msd_launch_* */
             snprintf(F.err, sizeof F.err, "ifile: --dcfilter needs the fused path");

@@ -331,6 +331,8 @@ struct msd_ctx {
     uint64_t enqueue_seq = 0;
     uint64_t launch_count = 0;
     bool dc = false;              /* MSD_CFG_DC_FILTER */
+    int q11_bits = 0;             /* msd_config.sc16q11_table_bits in effect: the batches' IQ goes through d_q11_table first */
+    uint16_t *d_q11_table = nullptr;
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
     float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
     int scan_format = 0;          /* what the scan and its follow-up kernels read: cfg.format, or MAG16 behind the DC filter */
@@ -1738,6 +1740,13 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
             return fail(c, rc, "DC filter kernel launch failed");
         }
         s.d_iq = reinterpret_cast<const uint8_t *>(s.d_dcmag);
+    } else if (c->q11_bits) { /* convert_sc16q11_table: the scan runs on its magnitudes and its integer sums are the converter's */
+        rc = msd_launch_q11_table(d_iq, nsamples, c->d_q11_table, c->q11_bits, s.d_dcmag, nullptr, c->stream);
+        if (rc) {
+            s.busy = false;
+            return fail(c, rc, "SC16Q11 table converter launch failed");
+        }
+        s.d_iq = reinterpret_cast<const uint8_t *>(s.d_dcmag);
     }
     /* a capture of N samples is floor(N/131072)+1 buffers, the last possibly empty
      * (sdr_ifile.c:192-216: EOF is only noticed by a short read) */
@@ -1870,7 +1879,7 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
-    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work);
+    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
     (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -1917,7 +1926,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     *out = nullptr;
     if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
         cfg->preamble_threshold < 1 || cfg->preamble_threshold > MSD_MAX_PREAMBLE_THRESHOLD ||
-        ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16)) {
+        ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16) || cfg->sc16q11_table_bits < 0 ||
+        cfg->sc16q11_table_bits > 11 || (cfg->sc16q11_table_bits && cfg->format != MSD_FMT_SC16Q11)) {
         snprintf(g_create_err, sizeof g_create_err, "msd_create: invalid configuration");
         return -EINVAL;
     }
@@ -1938,7 +1948,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->cfg.max_batch_samples = MSD_MAX_BATCH_SAMPLES;
     c->bps = (cfg->format == MSD_FMT_UC8 || cfg->format == MSD_FMT_MAG16) ? 2 : 4;
     c->dc = (cfg->flags & MSD_CFG_DC_FILTER) != 0;
-    c->scan_format = c->dc ? (int)MSD_FMT_MAG16 : cfg->format;
+    c->q11_bits = (!c->dc && cfg->format == MSD_FMT_SC16Q11) ? cfg->sc16q11_table_bits : 0;
+    c->scan_format = (c->dc || c->q11_bits) ? (int)MSD_FMT_MAG16 : cfg->format;
     c->scan_bps = bps_of(c->scan_format);
     if (c->dc) { /* init_converter's "DC block @ 1Hz", convert.c:479-482, at Modes.sample_rate = 2.4 MHz */
         c->dc_b = (float)exp(-2.0 * M_PI * 1.0 / 2400000.0);
@@ -2058,7 +2069,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_totals), 4 * sizeof(uint64_t)));
         if (cfg->mode_ac) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac), c->ac_arena * sizeof(msd_ac_hit)));
-            if (!c->dc && cfg->format != MSD_FMT_MAG16) /* (those scan magnitudes already) */
+            if (!c->dc && !c->q11_bits && cfg->format != MSD_FMT_MAG16) /* (those scan magnitudes already) */
                 CK(hipMalloc(reinterpret_cast<void **>(&s.d_mag), (cfg->max_batch_samples + 4096) * sizeof(uint16_t)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_ac_totals), 4 * sizeof(uint64_t)));
             CK(hipHostMalloc(reinterpret_cast<void **>(&s.h_ac_totals), 4 * sizeof(uint64_t)));
@@ -2068,10 +2079,19 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         if (c->dc) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_dcmag), c->cfg.max_batch_samples * sizeof(uint16_t) + 64));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_magsq), c->cfg.max_batch_samples * sizeof(float) + 64));
+        } else if (c->q11_bits) { /* the table converter's magnitudes: what the scan kernel reads */
+            CK(hipMalloc(reinterpret_cast<void **>(&s.d_dcmag), c->cfg.max_batch_samples * sizeof(uint16_t) + 64));
+            CK(hipMemset(s.d_dcmag, 0, c->cfg.max_batch_samples * sizeof(uint16_t) + 64));
         }
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
         for (hipEvent_t *e : evs)
             CK(hipEventCreate(e));
+    }
+    if (c->q11_bits) {
+        std::vector<uint16_t> tab((size_t)1 << (2 * c->q11_bits));
+        msd_sc16q11_table_build(c->q11_bits, tab.data());
+        CK(hipMalloc(reinterpret_cast<void **>(&c->d_q11_table), tab.size() * sizeof(uint16_t)));
+        CK(hipMemcpy(c->d_q11_table, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (c->dc) {
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_dcstate), 2 * sizeof(float)));
@@ -2462,11 +2482,13 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
     HIPCHK(c, hipMemsetAsync(s.d_sums, 0, 2 * sizeof(uint64_t), c->stream));
     if (nsamples) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
-        int rc = msd_launch_convert(c->cfg.format, c->d_stage, nsamples, c->d_lut, c->d_mag,
-                                    reinterpret_cast<unsigned long long *>(s.d_sums), c->stream);
+        int rc = c->q11_bits ? msd_launch_q11_table(c->d_stage, nsamples, c->d_q11_table, c->q11_bits, c->d_mag,
+                                                    reinterpret_cast<unsigned long long *>(s.d_sums), c->stream)
+                             : msd_launch_convert(c->cfg.format, c->d_stage, nsamples, c->d_lut, c->d_mag,
+                                                  reinterpret_cast<unsigned long long *>(s.d_sums), c->stream);
         if (rc)
             return fail(c, rc, "convert kernel launch failed");
-        if (c->cfg.format != MSD_FMT_UC8) {
+        if (c->cfg.format != MSD_FMT_UC8 && !c->q11_bits) {
             rc = msd_launch_float_means(c->cfg.format, c->d_stage, nsamples, nsamples, 1, s.d_fmeans, nullptr, c->d_fm_work, 0, c->stream);
             if (rc)
                 return fail(c, rc, "float means kernel launch failed");
@@ -2476,10 +2498,10 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
     uint64_t sums[2] = {0, 0};
     float fm[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(sums, s.d_sums, sizeof sums, hipMemcpyDeviceToHost, c->stream));
-    if (c->cfg.format != MSD_FMT_UC8 && nsamples)
+    if (c->cfg.format != MSD_FMT_UC8 && !c->q11_bits && nsamples)
         HIPCHK(c, hipMemcpyAsync(fm, s.d_fmeans, sizeof fm, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->cfg.format == MSD_FMT_UC8) {
+    if (c->cfg.format == MSD_FMT_UC8 || c->q11_bits) { /* integer sums: convert.c:104-110 and :318-326 */
         if (out_mean_level)
             *out_mean_level = (double)sums[0] / 65536.0 / (double)nsamples;
         if (out_mean_power)

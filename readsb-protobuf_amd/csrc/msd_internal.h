@@ -189,6 +189,8 @@ typedef struct msd_tables {
     uint32_t slicer[MSD_SLICER_WORDS];         /* see MSD_SL_* */
 } msd_tables;
 void msd_tables_build(msd_tables *t, int nfix_crc);
+/* the SC16Q11 table converter's lookup table (convert.c:271-295): out[1 << (2 * bits)], bits in 1..11 */
+void msd_sc16q11_table_build(int bits, uint16_t *out);
 /* two-bit correction (msd_tables.c); the caller frees the table */
 #define MSD_FIX2_HASH(syndrome, log2_slots) (((uint32_t)(syndrome) * 0x9E3779B1u) >> (32u - (log2_slots)))
 uint64_t *msd_fix2_table(const msd_tables *t, int bits, uint32_t *log2_slots);

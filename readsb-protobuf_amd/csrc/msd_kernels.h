@@ -182,6 +182,10 @@ int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, co
                   uint32_t nbuffers, uint32_t *d_noise, int noise_ready, msd_ac_hit *d_regions,
                   uint64_t region_total, msd_wg_counts *d_counts, uint64_t *d_offsets, uint64_t *d_totals,
                   msd_ac_hit *d_dense, uint64_t dense_cap, uint32_t max_wg, int phase, hipStream_t stream);
+/* SC16Q11 through the table of a -DSC16Q11_TABLE_BITS reference (convert.c:264-328): IQ -> u16 magnitudes; d_sums (or NULL)
+ * receives the level / power sums the converter entry reports */
+int msd_launch_q11_table(const void *d_iq, uint64_t nsamples, const uint16_t *d_table, int bits, uint16_t *d_mag,
+                         unsigned long long *d_sums, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
 /* --dcfilter: IQ -> DC-blocked u16 magnitudes + f32 squares, the converter state (z1_I, z1_Q, device

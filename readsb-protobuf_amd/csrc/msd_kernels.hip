@@ -3112,6 +3112,73 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+/* convert_sc16q11_table, convert.c:297-328: |I| & 2047 and |Q| & 2047 (abs of the sample as an int: -32768 -> 32768 -> 0), their
+ * top `bits` bits index the table.  Eight samples a thread; the magnitudes go to `mag`, which the scan kernel then reads as
+ * MSD_FMT_MAG16 -- its integer level / power sums are this converter's (same formulas as UC8, convert.c:318-326) -- and, for
+ * the converter entry, `sums` gets them here. */
+__global__ void __launch_bounds__(256) msd_q11_table_kernel(const uint8_t *iq, uint64_t nsamples, const uint16_t *table, int bits,
+                                                            uint16_t *mag, unsigned long long *sums /* [2] or NULL */)
+{
+    const int lose = 11 - bits;
+    const uint64_t ngroups = (nsamples + 7) / 8;
+    unsigned long long sl = 0, sp = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(iq) + 8 * g;
+        if (8 * g + 8 <= nsamples) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(src), b = *reinterpret_cast<const uint4 *>(src + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else {
+            for (int k = 0; k < 8; ++k)
+                if (8 * g + k < nsamples)
+                    w[k] = src[k];
+        }
+        uint32_t m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int I = (int)(int16_t)(w[k] & 0xffffu), Q = (int)(int16_t)(w[k] >> 16);
+            const uint32_t ai = (uint32_t)(I < 0 ? -I : I) & 2047u, aq = (uint32_t)(Q < 0 ? -Q : Q) & 2047u;
+            m[k] = 8 * g + k < nsamples ? table[((ai >> lose) << bits) | (aq >> lose)] : 0u;
+            sl += m[k];
+            sp += (unsigned long long)(m[k] * m[k]);
+        }
+        const uint4 packed = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+        if (8 * g + 8 <= nsamples) {
+            *reinterpret_cast<uint4 *>(mag + 8 * g) = packed;
+        } else {
+            for (int k = 0; k < 8; ++k)
+                if (8 * g + k < nsamples)
+                    mag[8 * g + k] = (uint16_t)m[k];
+        }
+    }
+    if (sums) {
+        for (int o = 32; o > 0; o >>= 1) {
+            sl += __shfl_down(sl, o);
+            sp += __shfl_down(sp, o);
+        }
+        if ((threadIdx.x & 63) == 0 && (sl | sp)) {
+            atomicAdd(&sums[0], sl);
+            atomicAdd(&sums[1], sp);
+        }
+    }
+}
+
+extern "C" int msd_launch_q11_table(const void *d_iq, uint64_t nsamples, const uint16_t *d_table, int bits, uint16_t *d_mag,
+                                    unsigned long long *d_sums, hipStream_t stream)
+{
+    if (!nsamples)
+        return 0;
+    if (bits < 1 || bits > 11)
+        return -22;
+    const uint64_t ngroups = (nsamples + 7) / 8;
+    uint64_t blocks = (ngroups + 255) / 256;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(msd_q11_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, static_cast<const uint8_t *>(d_iq), nsamples,
+                       d_table, bits, d_mag, d_sums);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 extern "C" int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                                   uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream)
 {

@@ -222,6 +222,22 @@ int msd_fix2_diagnose(int bits, uint32_t syndrome, int bit[2])
 }
 
 /* Checks the folding identity the kernels rely on; returns the number of mismatching slots. */
+/* init_sc16q11_lookup, convert.c:271-295: entry ((i >> lose) << bits) | (q >> lose) for i, q = 0, 2^lose, ... < 2048 */
+void msd_sc16q11_table_build(int bits, uint16_t *out)
+{
+    const int lose = 11 - bits;
+    for (int i = 0; i < 2048; i += 1 << lose)
+        for (int q = 0; q < 2048; q += 1 << lose) {
+            const float fI = (float)(i / 2048.0), fQ = (float)(q / 2048.0);
+            const float sq_i = fI * fI, sq_q = fQ * fQ;
+            float magsq = sq_i + sq_q;
+            if (magsq > 1)
+                magsq = 1;
+            const float mag = sqrtf(magsq);
+            out[((unsigned)(i >> lose) << bits) | (unsigned)(q >> lose)] = (uint16_t)(mag * 65535.0f + 0.5f);
+        }
+}
+
 int msd_tables_selftest(const msd_tables *t)
 {
     int bad = 0;
