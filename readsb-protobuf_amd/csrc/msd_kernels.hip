@@ -3116,9 +3116,24 @@ extern "C" int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t 
  * top `bits` bits index the table.  Eight samples a thread; the magnitudes go to `mag`, which the scan kernel then reads as
  * MSD_FMT_MAG16 -- its integer level / power sums are this converter's (same formulas as UC8, convert.c:318-326) -- and, for
  * the converter entry, `sums` gets them here. */
-__global__ void __launch_bounds__(256) msd_q11_table_kernel(const uint8_t *iq, uint64_t nsamples, const uint16_t *table, int bits,
-                                                            uint16_t *mag, unsigned long long *sums /* [2] or NULL */)
+template <bool LDS_TABLE>
+__global__ void __launch_bounds__(LDS_TABLE ? 1024 : 256) msd_q11_table_kernel(const uint8_t *iq, uint64_t nsamples, const uint16_t *table,
+                                                                              int bits, uint16_t *mag, unsigned long long *sums /* [2] or NULL */)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char q11_lds[];
+    const uint16_t *tab = table;
+    if (LDS_TABLE) { /* up to eight bits the table fits the LDS (128 KB): one copy per compute unit, gathers at LDS speed */
+        const uint32_t words = (1u << (2 * bits)) * 2u / 16u;
+        const uint4 *g = reinterpret_cast<const uint4 *>(table);
+        uint4 *l = reinterpret_cast<uint4 *>(q11_lds);
+        for (uint32_t i = threadIdx.x; i < (words ? words : 1u); i += blockDim.x)
+            if (words)
+                l[i] = g[i];
+            else if (i == 0)
+                *reinterpret_cast<uint2 *>(q11_lds) = *reinterpret_cast<const uint2 *>(table); /* one bit: four entries */
+        __syncthreads();
+        tab = reinterpret_cast<const uint16_t *>(q11_lds);
+    }
     const int lose = 11 - bits;
     const uint64_t ngroups = (nsamples + 7) / 8;
     unsigned long long sl = 0, sp = 0;
@@ -3138,7 +3153,7 @@ __global__ void __launch_bounds__(256) msd_q11_table_kernel(const uint8_t *iq, u
         for (int k = 0; k < 8; ++k) {
             const int I = (int)(int16_t)(w[k] & 0xffffu), Q = (int)(int16_t)(w[k] >> 16);
             const uint32_t ai = (uint32_t)(I < 0 ? -I : I) & 2047u, aq = (uint32_t)(Q < 0 ? -Q : Q) & 2047u;
-            m[k] = 8 * g + k < nsamples ? table[((ai >> lose) << bits) | (aq >> lose)] : 0u;
+            m[k] = 8 * g + k < nsamples ? tab[((ai >> lose) << bits) | (aq >> lose)] : 0u;
             sl += m[k];
             sp += (unsigned long long)(m[k] * m[k]);
         }
@@ -3171,10 +3186,30 @@ extern "C" int msd_launch_q11_table(const void *d_iq, uint64_t nsamples, const u
     if (bits < 1 || bits > 11)
         return -22;
     const uint64_t ngroups = (nsamples + 7) / 8;
+    if (bits <= 8 && ngroups >= 4096) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+                return -5;
+            cus = prop.multiProcessorCount;
+        }
+        const size_t lds = ((size_t)2 << (2 * bits)) < 16 ? 16 : ((size_t)2 << (2 * bits));
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_q11_table_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -5;
+        uint64_t blocks = (ngroups + 1023) / 1024;
+        if (blocks > (uint64_t)cus)
+            blocks = (uint64_t)cus;
+        hipLaunchKernelGGL(msd_q11_table_kernel<true>, dim3((uint32_t)blocks), dim3(1024), lds, stream, static_cast<const uint8_t *>(d_iq),
+                           nsamples, d_table, bits, d_mag, d_sums);
+        return hipGetLastError() == hipSuccess ? 0 : -5;
+    }
     uint64_t blocks = (ngroups + 255) / 256;
     if (blocks > 8192)
         blocks = 8192;
-    hipLaunchKernelGGL(msd_q11_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, static_cast<const uint8_t *>(d_iq), nsamples,
+    hipLaunchKernelGGL(msd_q11_table_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, stream, static_cast<const uint8_t *>(d_iq), nsamples,
                        d_table, bits, d_mag, d_sums);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
