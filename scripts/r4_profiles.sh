@@ -71,7 +71,7 @@ for cfg in "uc8:" "sc16:--format sc16 --samples 268435456" "modeac:--mode-ac --f
 done
 
 : > $O/configs.txt
-for f in "" "--fix 1" "--fix 2" "--fields" "--mode-ac --fix 1" "--format sc16 --samples 268435456" "--format sc16q11 --samples 268435456" "--format sc16 --samples 268435456 --mode-ac --fix 1"; do
+for f in "" "--fix 1" "--fix 2" "--fields" "--mode-ac --fix 1" "--format sc16 --samples 268435456" "--format sc16q11 --samples 268435456" "--format sc16q11 --samples 268435456 --sc16q11-table-bits 8" "--format sc16 --samples 268435456 --mode-ac --fix 1"; do
   echo -n "bench.py $f : " >> $O/configs.txt
   timeout 600 python bench.py --no-cpu-baseline --no-also --check $f 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'scan_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'msgs', d['messages_per_step'], 'diff', d.get('message_set_diff_vs_oracle'))" >> $O/configs.txt
 done

@@ -38,10 +38,11 @@ for case in range(first, first + ncases):
     d = torch.from_numpy(iq).to("cuda:0")
     with_fields = int(rng.integers(0, 2))
     dc = bool(rng.integers(0, 8) == 0) and n <= 12 * 131072  # the DC block runs at ~0.06 GS/s: short captures only
+    q11 = int(rng.choice([0, 0, 7, 8, 11])) if fmt_name == "sc16q11" and not dc else 0  # a -DSC16Q11_TABLE_BITS build (convert.c:264-328)
     dem = pkg.Demodulator(fmt=fmt, preamble_threshold=thr, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19,
-                          decode_fields=bool(with_fields), dc_filter=dc)
+                          decode_fields=bool(with_fields), dc_filter=dc, **({"sc16q11_table_bits": q11} if q11 else {}))
     desc = (f"case {case}: {fmt_name} n={n} batch={batch // 131072} nfix={nfix} ac={mode_ac} gpu_resolve={gpu_resolve} "
-            f"fields={with_fields} dc={int(dc)} thr={thr} {kw}")
+            f"fields={with_fields} dc={int(dc)} thr={thr} q11_table_bits={q11} {kw}")
     if with_fields:
         parts, fparts, bps = [], [], dem.bytes_per_sample
         for off in list(range(0, n, batch)) or [0]:
@@ -51,10 +52,10 @@ for case in range(first, first + ncases):
             parts.append(mm)
             fparts.append(ff)
         got, gfields = np.concatenate(parts), np.concatenate(fparts)
-        want, wfields, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc).replay_fields(iq, cap=1 << 19)
+        want, wfields, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc, sc16q11_table_bits=q11).replay_fields(iq, cap=1 << 19)
     else:
         got = pkg.replay_device(dem, d.data_ptr(), n, batch)
-        want, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc).replay(iq, cap=1 << 19)
+        want, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc, sc16q11_table_bits=q11).replay(iq, cap=1 << 19)
     try:
         assert_same(got, dem.stats(), want, wstats)
         if with_fields:
