@@ -390,8 +390,11 @@ int msd_get_buffer_means(const msd_ctx *ctx, double *means, size_t cap);
 void msd_fields_to_float(const msd_fields *fields, msd_fields_float *out);
 
 /* ---- iq_convert_fn-shaped converter (convert.h:33-38): host buffers in, host buffers out,
- * bit-identical u16 magnitudes and means for UC8 / SC16 / SC16Q11 without DC filter.
- * `format` is taken from the context.  Either out pointer may be NULL (convert.c:104-110). ---- */
+ * bit-identical u16 magnitudes and means for UC8 / SC16 / SC16Q11 (and the SC16Q11 table of
+ * msd_config.sc16q11_table_bits).  `format` is taken from the context.  Either out pointer may be NULL
+ * (convert.c:104-110).  A MSD_CFG_DC_FILTER context converts with the 1 Hz DC block (convert.c:113-213,
+ * 374-423): the filter state is the context's and runs on from call to call, as struct converter_state
+ * does -- use such a context as a converter only, msd_launch_* of the same context advances the same state. ---- */
 int msd_convert(msd_ctx *ctx, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
                 double *out_mean_level, double *out_mean_power);
 

@@ -41,12 +41,13 @@ typedef void (*msd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned ns
 #endif
 
 /* init_converter (convert.h:40-43, convert.c:446-491): returns the converter for `format` and a state
- * for it, or NULL (no GPU; filter_dc != 0 -- the stateful DC-blocking converters only exist inside
- * the stream interface, MSD_CFG_DC_FILTER; unknown format).  The returned function converts on the
- * GPU and writes magnitudes and means bit-identical to convert_uc8_nodc / convert_sc16_nodc /
- * convert_sc16q11_nodc (convert.c:63-111,215-253,332-370); either out pointer may be NULL
- * (convert.c:104-110).  It is void like the reference's: after a device failure the magnitudes are
- * zero and msd_converter_error(state) says why. */
+ * for it, or NULL (no GPU; unknown format; filter_dc with a sample_rate other than 2.4 MHz).  The returned
+ * function converts on the GPU and writes magnitudes and means bit-identical to convert_uc8_nodc /
+ * convert_sc16_nodc / convert_sc16q11_nodc (convert.c:63-111,215-253,332-370) -- convert_sc16q11_table
+ * (:264-328) after msd_converter_set_sc16q11_table_bits -- or, with filter_dc, to the convert_*_generic
+ * functions (:113-213,374-423), whose DC estimate lives in the state and runs on from call to call like
+ * the reference's.  Either out pointer may be NULL (convert.c:104-110).  It is void like the reference's:
+ * after a device failure the magnitudes are zero and msd_converter_error(state) says why. */
 msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_rate, int filter_dc,
                                      struct converter_state **out_state);
 void msd_cleanup_converter(struct converter_state *state); /* convert.h:45 */

@@ -63,7 +63,6 @@ static void convert_on_gpu(void *iq_data, uint16_t *mag_data, unsigned nsamples,
 msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_rate, int filter_dc,
                                      struct converter_state **out_state)
 {
-    (void)sample_rate; /* only the DC filter's time constant depends on it (convert.c:479-482) */
     if (!out_state)
         return NULL;
     *out_state = NULL;
@@ -74,8 +73,8 @@ msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_ra
     case 2: fmt = MSD_FMT_SC16Q11; break; /* INPUT_SC16Q11 */
     default: return NULL;                 /* "no suitable converter", convert.c:466-470 */
     }
-    if (filter_dc)
-        return NULL; /* the DC-blocking converters keep state across calls: MSD_CFG_DC_FILTER + msd_launch_* */
+    if (filter_dc && sample_rate != 2400000.0)
+        return NULL; /* the DC block's constant is worked out for Modes.sample_rate = 2.4 MHz (convert.c:479-482) */
     struct converter_state *st = calloc(1, sizeof *st);
     if (!st)
         return NULL;
@@ -83,7 +82,9 @@ msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_ra
     memset(&cfg, 0, sizeof cfg);
     cfg.device = g_device;
     cfg.format = fmt;
-    cfg.sc16q11_table_bits = fmt == MSD_FMT_SC16Q11 ? g_q11_bits : 0; /* #if defined(SC16Q11_TABLE_BITS), convert.c:437 */
+    if (filter_dc) /* convert_*_generic: the state (z1_I, z1_Q) is the context's, carried from call to call (convert.c:28-33) */
+        cfg.flags |= MSD_CFG_DC_FILTER;
+    cfg.sc16q11_table_bits = (fmt == MSD_FMT_SC16Q11 && !filter_dc) ? g_q11_bits : 0; /* #if defined(SC16Q11_TABLE_BITS), convert.c:437 */
     cfg.preamble_threshold = 58; /* the converter does not demodulate; msd_set_preamble_threshold etc. apply */
     cfg.nfix_crc = 1;
     cfg.max_batch_samples = MSD_CHUNK_SAMPLES; /* a block of MODES_MAG_BUF_SAMPLES, sdr_ifile.c:140 */

@@ -161,15 +161,10 @@ bool msd_ifileOpen(void)
     if (F.mode == MSD_IFILE_MAGBUF) {
         /* the literal drop-in: the converter comes from init_converter's twin (sdr_ifile.c:150-153) and
          * keeps its own state; the demodulator's context is created below, as for the fused path */
-        if (F.rx.dc_filter) {
-            snprintf(F.err, sizeof F.err, "ifile: --dcfilter needs the fused path");
-            msd_ifileClose();
-            return false;
-        }
         msd_converter_set_device(F.rx.device);
         msd_converter_set_sc16q11_table_bits(F.rx.sc16q11_table_bits);
         F.converter = msd_init_converter((msd_input_format_t)(F.format == MSD_FMT_UC8 ? 0 : F.format == MSD_FMT_SC16 ? 1 : 2),
-                                         2400000.0, 0, &F.converter_state);
+                                         2400000.0, F.rx.dc_filter, &F.converter_state);
         if (!F.converter) {
             snprintf(F.err, sizeof F.err, "ifile: can't initialize sample converter");
             msd_ifileClose();
@@ -185,14 +180,9 @@ bool msd_ifileOpen(void)
     cfg.mode_ac = F.rx.mode_ac;
     if (F.format == MSD_FMT_SC16Q11 && !F.rx.dc_filter && F.mode == MSD_IFILE_FUSED)
         cfg.sc16q11_table_bits = F.rx.sc16q11_table_bits; /* a host built with -DSC16Q11_TABLE_BITS (convert.c:437-438) */
-    if (F.rx.dc_filter) {
-        if (F.mode != MSD_IFILE_FUSED) { /* the stateful converters live inside msd_launch_* */
-            snprintf(F.err, sizeof F.err, "ifile: --dcfilter needs the fused path");
-            msd_ifileClose();
-            return false;
-        }
-        cfg.flags |= MSD_CFG_DC_FILTER; /* init_converter(..., Modes.dc_filter, ...), sdr_ifile.c:150-153 */
-    }
+    if (F.rx.dc_filter && F.mode == MSD_IFILE_FUSED)
+        cfg.flags |= MSD_CFG_DC_FILTER; /* init_converter(..., Modes.dc_filter, ...), sdr_ifile.c:150-153 (the literal drop-in's
+                                           converter above has it; its demodulator gets magnitudes) */
     cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * nbuf;
     int rc = msd_create(&cfg, &F.ctx);
     if (rc) {

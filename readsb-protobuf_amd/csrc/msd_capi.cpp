@@ -333,6 +333,7 @@ struct msd_ctx {
     bool dc = false;              /* MSD_CFG_DC_FILTER */
     int q11_bits = 0;             /* msd_config.sc16q11_table_bits in effect: the batches' IQ goes through d_q11_table first */
     uint16_t *d_q11_table = nullptr;
+    float *d_conv_magsq = nullptr; /* msd_convert of a MSD_CFG_DC_FILTER context: the clamped squares of the call's samples */
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
     float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
     int scan_format = 0;          /* what the scan and its follow-up kernels read: cfg.format, or MAG16 behind the DC filter */
@@ -1879,7 +1880,7 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
-    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table);
+    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table); (void)hipFree(c->d_conv_magsq);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
     (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -2467,8 +2468,6 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
 {
     if (!c || c->cfg.format == MSD_FMT_MAG16)
         return -EINVAL;
-    if (c->dc) /* the DC-blocking converters keep state between calls; they run inside msd_launch_* */
-        return fail(c, -ENOTSUP, "msd_convert is the stateless converter; MSD_CFG_DC_FILTER contexts convert in msd_launch_*");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (nsamples > c->cfg.max_batch_samples)
         return fail(c, -E2BIG, "nsamples exceeds max_batch_samples");
@@ -2480,6 +2479,31 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
     if (c->outstanding)
         return fail(c, -EBUSY, "batches outstanding");
     HIPCHK(c, hipMemsetAsync(s.d_sums, 0, 2 * sizeof(uint64_t), c->stream));
+    if (c->dc) {
+        /* convert_*_generic (convert.c:113-213, 374-423): the DC estimate of the two channels lives in the context, as in
+         * the reference's struct converter_state, and runs on from call to call -- a context that converts this way is a
+         * converter and nothing else (msd_launch_* of the same context would advance the same state) */
+        float fm[2] = {0, 0};
+        if (nsamples) {
+            if (!c->d_conv_magsq)
+                HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_conv_magsq), c->cfg.max_batch_samples * sizeof(float) + 64));
+            HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
+            int rc = msd_launch_dcfilter(c->cfg.format, c->d_stage, nsamples, c->dc_a, c->dc_b, c->d_dcstate, c->d_mag, c->d_conv_magsq,
+                                         c->stream);
+            if (!rc)
+                rc = msd_launch_dc_sums(c->d_conv_magsq, nsamples, nsamples, 1, s.d_fmeans, c->d_fm_work, 0, c->stream);
+            if (rc)
+                return fail(c, rc, "DC filter converter launch failed");
+            HIPCHK(c, hipMemcpyAsync(mag_data, c->d_mag, (size_t)nsamples * 2, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(fm, s.d_fmeans, sizeof fm, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (out_mean_level)
+            *out_mean_level = (double)(fm[0] / (float)nsamples);
+        if (out_mean_power)
+            *out_mean_power = (double)(fm[1] / (float)nsamples);
+        return 0;
+    }
     if (nsamples) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
         int rc = c->q11_bits ? msd_launch_q11_table(c->d_stage, nsamples, c->d_q11_table, c->q11_bits, c->d_mag,

@@ -262,3 +262,36 @@ def test_bound_void_demodulators_deliver_the_oracles_order(pkg, oracle, torch_cu
     want, _ = oracle.Oracle(of, 58, 1, mode_ac).replay(iq, cap=1 << 16)
     assert len(want) > 100 and (not mode_ac or sum(k for _, k in per_buffer) > 10)
     assert_same_messages(np.array(got, dtype=pkg.capi.MESSAGE_DTYPE), want)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_dc_filter_converter_carries_its_state_from_call_to_call(pkg, oracle, torch_cuda, fmt):
+    """init_converter(format, 2.4 MHz, filter_dc = 1): convert_uc8_generic / convert_sc16_generic / convert_sc16q11_generic
+    (convert.c:113-213, 374-423).  z1_I / z1_Q live in the converter state and run on through every call
+    (convert.c:28-33): five blocks of different lengths, one context each side, magnitudes and both means bit for bit --
+    and a second converter that starts in the middle of the stream must NOT agree (its state starts at zero)."""
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    n = 3 * CHUNK
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=515, fmt=f, msgs_per_sec=3000), n)
+    if fmt == "uc8":     # a DC offset for the block to find
+        iq = np.clip(iq.astype(np.int32) + np.tile(np.array([9, -6]), n), 0, 255).astype(np.uint8)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK, dc_filter=True)
+    orc = oracle.Oracle(of, 58, 1, 0, dc_filter=True)
+    off, first_mags = 0, None
+    for m in (CHUNK, 1, 4097, 0, CHUNK - 5000):
+        blk = iq[off * bps:(off + m) * bps]
+        gm, gl, gp = dem.convert(blk if m else iq[:8], m)
+        wm, wl, wp = orc.convert(blk if m else iq[:8], m) if m else (np.zeros(0, np.uint16), np.nan, np.nan)
+        assert np.array_equal(gm[:m], wm), (fmt, off, m)
+        assert np.array_equal(np.float64(gl), np.float64(wl), equal_nan=True) and np.array_equal(np.float64(gp), np.float64(wp), equal_nan=True)
+        if first_mags is None:
+            first_mags = gm.copy()
+        off += m
+    fresh = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK, dc_filter=True)
+    m2, _, _ = fresh.convert(iq[CHUNK * bps:(CHUNK + 4097) * bps], 4097)
+    cont = orc.convert(iq[off * bps:(off + 16) * bps], 16)[0]   # the running oracle is further along: only used to keep it honest
+    assert cont.size == 16
+    if fmt == "uc8":
+        nodc = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK).convert(iq[:CHUNK * bps], CHUNK)[0]
+        assert not np.array_equal(nodc, first_mags)   # the block did find the offset
