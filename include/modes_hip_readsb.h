@@ -137,7 +137,7 @@ typedef struct msd_receiver_options {
     unsigned batch_buffers; /* fused mode: buffers per GPU batch (default 64) */
     msd_message_fn sink;    /* useModesMessage */
     void *sink_user;
-    int dc_filter;          /* Modes.dc_filter (--dcfilter, readsb.c:486); fused mode only */
+    int dc_filter;          /* Modes.dc_filter (--dcfilter, readsb.c:486) */
     int sc16q11_table_bits; /* the SC16Q11_TABLE_BITS the host was built with (convert.c:264-328; 0: not defined) */
 } msd_receiver_options;
 

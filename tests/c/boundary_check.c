@@ -41,10 +41,25 @@ int main(int argc, char **argv)
     iq_convert_fn (*factory)(input_format_t, double, int, struct converter_state **) = msd_init_converter;
     void (*cleanup)(struct converter_state *) = msd_cleanup_converter;
     struct converter_state *state = (struct converter_state *)0x1;
-    iq_convert_fn fn = factory(INPUT_SC16Q11, 2400000.0, 1 /* --dcfilter */, &state);
-    CHECK(fn == NULL && state == NULL); /* stateful converters only exist behind the stream interface */
+    iq_convert_fn fn = factory(INPUT_SC16Q11, 2000000.0, 1 /* --dcfilter */, &state);
+    CHECK(fn == NULL && state == NULL); /* the DC block's constant is worked out for 2.4 MHz (convert.c:479-482) */
     fn = factory((input_format_t)9, 2400000.0, 0, &state);
     CHECK(fn == NULL && state == NULL);
+    fn = factory(INPUT_SC16Q11, 2400000.0, 1 /* --dcfilter */, &state);
+    if (fn) { /* a GPU is present: convert_sc16q11_generic, its DC estimate carried in the state from call to call */
+        static int16_t iq16[2 * 4096];
+        static uint16_t mag_a[4096], mag_b[4096];
+        double level = -1, power = -1;
+        for (unsigned i = 0; i < 2 * 4096; ++i)
+            iq16[i] = (int16_t)(300 + (int)((i * 2654435761u) >> 22) - 512); /* an offset for the block to find */
+        fn(iq16, mag_a, 4096, state, &level, &power);
+        CHECK(msd_converter_error(state)[0] == 0 && level > 0 && power > 0);
+        fn(iq16, mag_b, 4096, state, NULL, NULL); /* the same samples again: the estimate has moved on */
+        CHECK(memcmp(mag_a, mag_b, sizeof mag_a) != 0);
+        cleanup(state);
+    } else {
+        CHECK(state == NULL);
+    }
     fn = factory(INPUT_UC8, 2400000.0, 0, &state);
     if (fn) { /* a GPU is present: one block through the converter */
         static uint8_t iq[2 * 4096];
