@@ -2105,17 +2105,28 @@ __global__ void __launch_bounds__(FMK_THREADS, MSD_FM_OCC) msd_fm_functions_kern
                 if (!__ballot(c0 != c1)) { /* no lane's elements care about the parity: the block adds its total */
                     f0 = f1 = wave_last(wave_incl_scan(min(c0, 1u << 25)));
                 } else {
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { /* ordered composition: (lanes .. L-d) then (L-d+1 .. L) */
-                        const uint32_t p0 = __shfl_up(c0, d, 64), p1 = __shfl_up(c1, d, 64);
-                        if (lane >= d) {
-                            const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);
-                            c0 = min(n0, FS_SAT);
-                            c1 = min(n1, FS_SAT);
-                        }
-                    }
-                    f0 = (uint32_t)__shfl((int)c0, 63, 64);
-                    f1 = (uint32_t)__shfl((int)c1, 63, 64);
+                    /* Only the composition of all 64 lanes is wanted: a tree -- lanes 2d-1 mod 2d take in the lane d below them
+                     * (DPP row_shr 1, 2, 4, 8), then lane 31 the row below and lane 63 lane 31 (row_bcast 15 / 31) -- with
+                     * (earlier lanes) first, (this lane's) second in every step.  Six DPP pairs and no LDS round trip, where
+                     * the scan through __shfl_up was twelve ds_bpermute, each waited for; the other lanes compute along and
+                     * are not looked at (a missing source reads 0 = the identity). */
+#define FM_COMPOSE(CTRL, RMASK)                                                                                         \
+    {                                                                                                                   \
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c0, CTRL, RMASK, 0xf, false);                 \
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c1, CTRL, RMASK, 0xf, false);                 \
+        const uint32_t n0 = p0 + ((p0 & 1u) ? c1 : c0), n1 = p1 + (((1u + p1) & 1u) ? c1 : c0);                        \
+        c0 = min(n0, FS_SAT);                                                                                           \
+        c1 = min(n1, FS_SAT);                                                                                           \
+    }
+                    FM_COMPOSE(0x111, 0xf) /* row_shr:1 */
+                    FM_COMPOSE(0x112, 0xf) /* row_shr:2 */
+                    FM_COMPOSE(0x114, 0xf) /* row_shr:4 */
+                    FM_COMPOSE(0x118, 0xf) /* row_shr:8 */
+                    FM_COMPOSE(0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */
+                    FM_COMPOSE(0x143, 0xc) /* row_bcast:31 into rows 2 and 3 */
+#undef FM_COMPOSE
+                    f0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, 63);
+                    f1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, 63);
                 }
                 if (lane == 0) {
                     W.f0[s][blk] = f0;

@@ -10,7 +10,7 @@ lib.msd_fm_work_bytes.restype = ctypes.c_size_t
 lib.msd_fm_work_bytes.argtypes = [ctypes.c_uint32]
 lib.msd_launch_float_means.restype = ctypes.c_int
 lib.msd_launch_float_means.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 amp = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
 tail = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # samples cut off the last buffer
@@ -22,7 +22,7 @@ d_iq = torch.from_numpy(iq).cuda()
 d_out = torch.zeros(2 * nb, dtype=torch.float32, device="cuda")
 work = torch.zeros(lib.msd_fm_work_bytes(nb), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-rc = lib.msd_launch_float_means(1, d_iq.data_ptr(), n, L, nb, d_out.data_ptr(), None, work.data_ptr(), None)
+rc = lib.msd_launch_float_means(1, d_iq.data_ptr(), n, L, nb, d_out.data_ptr(), None, work.data_ptr(), 0, None)
 torch.cuda.synchronize()
 print("rc", rc)
 got = d_out.cpu().numpy().reshape(nb, 2)
