@@ -29,26 +29,34 @@ def test_pacer_releases_buffers_at_the_sample_rate(pkg):
     """First buffer at once, every later one samples / rate after its predecessor, deadlines absolute: a consumer
     that dawdles between two buffers does not push the later ones back (clock_nanosleep TIMER_ABSTIME)."""
     L = host_lib(pkg)
-    p = Pacer()
-    rate, block = 2.4e6, 131072  # one buffer = 54.6 ms
-    L.msd_pacer_start(C.byref(p), rate)
-    t0 = time.monotonic()
-    release = []
-    for i in range(6):
-        L.msd_pacer_wait(C.byref(p), block)
-        release.append(time.monotonic() - t0)
-        if i == 2:
-            time.sleep(0.03)  # a slow consumer, shorter than a buffer
-    period = block / rate
-    assert release[0] < 0.02
-    for i in range(1, 6):
-        assert release[i] >= i * period - 1e-3, (i, release)
-        assert release[i] < i * period + 0.03, (i, release)
-    # a ragged last block moves the deadline by its own length only
-    L.msd_pacer_wait(C.byref(p), 1000)
-    t1 = time.monotonic()
-    L.msd_pacer_wait(C.byref(p), 0)
-    assert time.monotonic() - t1 < 0.02
+    rate, block = 2.4e6, 4 * 131072  # four buffers a step = 218 ms: the tolerances below survive a busy test host
+    period, slack = block / rate, 0.1
+
+    def attempt():
+        p = Pacer()
+        L.msd_pacer_start(C.byref(p), rate)
+        t0 = time.monotonic()
+        release = []
+        for i in range(5):
+            L.msd_pacer_wait(C.byref(p), block)
+            release.append(time.monotonic() - t0)
+            if i == 2:
+                time.sleep(0.15)  # a slow consumer, shorter than a step (and longer than the slack)
+        # a ragged last block moves the deadline by its own length only
+        L.msd_pacer_wait(C.byref(p), 1000)
+        t1 = time.monotonic()
+        L.msd_pacer_wait(C.byref(p), 0)
+        return release, time.monotonic() - t1
+
+    # never early -- on any attempt; on time within the slack -- on one attempt of three (the host may be busy)
+    for _ in range(3):
+        release, ragged = attempt()
+        for i in range(1, 5):
+            assert release[i] >= i * period - 1e-3, (i, release)
+        if release[0] < slack and ragged < slack and all(release[i] < i * period + slack for i in range(1, 5)):
+            break
+    else:
+        raise AssertionError(("late", release, ragged))
 
 
 def test_pacer_carries_nanoseconds_into_seconds(pkg):
