@@ -1,0 +1,58 @@
+"""The HIP path against the second reading of the reference (tests/indep_demod.py: numpy / plain Python, written from
+the reference's sources without looking at oracle/modes_oracle.c) -- directly, not through the oracle: ordered message
+list (timestamps, bytes, address, CRC, score, phase, corrected bits, signal level as the same double) and the demodulator
+counters, Mode S and Mode A/C, three sample formats, both resolve stages."""
+import numpy as np
+import pytest
+
+import indep_demod as D
+import indep_signal as S
+from helpers import fmt_ids
+from test_indep_demod import CORPUS, assert_second_reading_agrees
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["gpu-resolve", "host-resolve"])
+def resolve_stage(request, monkeypatch):
+    monkeypatch.setenv("MSD_GPU_RESOLVE", "1" if request.param == "gpu-resolve" else "0")
+    return request.param
+
+
+def hip_and_second_reading(pkg, oracle, torch, fmt, iq, threshold=58, nfix=1, mode_ac=True, batch=4 * 131072):
+    raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = raw.size // (2 if fmt == "uc8" else 4)
+    f, _ = fmt_ids(pkg, oracle, fmt)
+    dem = pkg.Demodulator(fmt=f, preamble_threshold=threshold, nfix_crc=nfix, mode_ac=1 if mode_ac else 0,
+                          max_batch_samples=batch, message_capacity=1 << 17)
+    got = pkg.replay_device(dem, torch.from_numpy(raw).to("cuda:0").data_ptr(), n, batch)
+    want, wstats = D.Receiver(fmt, threshold, nfix, mode_ac).replay(raw.tobytes())
+    assert_second_reading_agrees(want, wstats, got, dem.stats())
+    return got
+
+
+@pytest.mark.parametrize("case", sorted(CORPUS))
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_numpy_corpus(pkg, oracle, torch_cuda, resolve_stage, fmt, case):
+    iq, _ = S.capture(201 + sorted(CORPUS).index(case), 9 * 131072 + 555, fmt=fmt, **CORPUS[case])
+    hip_and_second_reading(pkg, oracle, torch_cuda, fmt, iq)
+
+
+@pytest.mark.parametrize("threshold,nfix", [(40, 1), (58, 0), (75, 1), (400, 0)])
+def test_thresholds_and_no_fix(pkg, oracle, torch_cuda, resolve_stage, threshold, nfix):
+    iq, _ = S.capture(34, 6 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04)
+    hip_and_second_reading(pkg, oracle, torch_cuda, "uc8", iq, threshold=threshold, nfix=nfix, mode_ac=False)
+
+
+@pytest.mark.parametrize("fmt", ["UC8", "SC16", "SC16Q11"])
+def test_generator_of_the_benchmark(pkg, oracle, torch_cuda, resolve_stage, fmt):
+    """the benchmark's content model and seed: 24 buffers in three batches"""
+    cfg = pkg.siggen.make_cfg(seed=10901, fmt=getattr(pkg.siggen, fmt), ac_per_sec=1500)
+    iq = pkg.siggen.generate(cfg, 24 * 131072 + 4096)
+    got = hip_and_second_reading(pkg, oracle, torch_cuda, fmt.lower(), iq, batch=8 * 131072)
+    assert len(got) > 1500
+
+
+def test_capture_that_ends_on_a_buffer_boundary(pkg, oracle, torch_cuda, resolve_stage):
+    iq, _ = S.capture(6, 4 * 131072, fmt="uc8", ac_per_sec=2000.0)
+    hip_and_second_reading(pkg, oracle, torch_cuda, "uc8", iq)

@@ -1,0 +1,110 @@
+"""Two readings of the reference against each other: oracle/modes_oracle.c (the checker of every parity test) and
+tests/indep_demod.py (numpy / plain Python, written from demod_2400.c, mode_s.c, crc.c, icao_filter.c, convert.c and
+mode_ac.c without looking at the oracle).  Same capture in, same ordered message list and the same demodulator counters
+out -- bit for bit, floats included.  The reference cannot be built in this image, so this does not pin the oracle
+to the reference; it does say that the oracle is not one person's single misreading.  CPU only; the GPU leg
+(HIP path against this second reading directly, not through the oracle) is tests/test_gpu_indep_demod.py."""
+import numpy as np
+import pytest
+
+import indep_demod as D
+import indep_signal as S
+
+OFMT = {"uc8": "FMT_UC8", "sc16": "FMT_SC16", "sc16q11": "FMT_SC16Q11"}
+INT_STATS = ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted",
+             "demod_preamblePhase", "demod_bestPhase", "demod_modeac", "strong_signal_count", "noise_power_count",
+             "signal_power_count")
+FLOAT_STATS = ("noise_power_sum", "signal_power_sum", "peak_signal_power")
+
+
+def assert_second_reading_agrees(got, gstats, want, wstats):
+    """got: indep_demod's list of dicts; want: a MESSAGE_DTYPE array (the oracle's, or the HIP path's)"""
+    assert len(got) == len(want), (len(got), len(want))
+    for i, (g, w) in enumerate(zip(got, want)):
+        nb = int(w["msgbits"]) // 8
+        for k in ("timestampMsg", "sysTimestampMsg", "msgtype", "msgbits", "addr", "correctedbits"):
+            assert g[k] == int(w[k]), (i, k, g, w)
+        assert g["msg"][:nb] == bytes(w["msg"][:nb]), (i, g, w)
+        if g["msgtype"] != 32:  # Mode S: what demodulate2400 itself decides and measures
+            for k in ("score", "bestphase", "crc", "iid"):
+                assert g[k] == int(w[k]), (i, k, g, w)
+            assert g["signalLevel"] == float(w["signalLevel"]), (i, g, w)  # the same double, not a tolerance
+    for k in INT_STATS:
+        assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
+    for k in FLOAT_STATS:
+        assert np.array_equal(np.float64(gstats[k]), np.float64(wstats[k]), equal_nan=True), (k, gstats[k], wstats[k])
+
+
+def both(oracle, fmt, raw, threshold=58, nfix=1, mode_ac=False):
+    raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    got, gstats = D.Receiver(fmt, threshold, nfix, mode_ac).replay(raw.tobytes())
+    want, wstats = oracle.Oracle(getattr(oracle, OFMT[fmt]), threshold, nfix, 1 if mode_ac else 0).replay(raw, cap=1 << 18)
+    assert_second_reading_agrees(got, gstats, want, wstats)
+    return got
+
+
+CORPUS = {
+    "plain": dict(),
+    "carrier_plus_minus_50kHz": dict(freq_offset_hz=50e3),
+    "dc_offset": dict(dc=(0.06, -0.04)),
+    "clipped": dict(clip_gain=1.6),
+    "echo_750ns": dict(echo=(9, 0.35, 1.0)),
+    "dense_noisy": dict(frames_per_sec=12000.0, noise=0.06, n_aircraft=400),
+    "mode_ac": dict(ac_per_sec=3000.0),
+    "random_bytes": dict(random_bytes=True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CORPUS))
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_numpy_corpus(oracle, fmt, case):
+    """the independent corpus (tests/indep_signal.py), Mode A/C on, --fix"""
+    iq, _ = S.capture(101 + sorted(CORPUS).index(case), 4 * 131072 + 1234, fmt=fmt, **CORPUS[case])
+    got = both(oracle, fmt, iq, nfix=1, mode_ac=True)
+    if case not in ("random_bytes",):
+        assert len(got) > 50
+
+
+@pytest.mark.parametrize("threshold", [40, 58, 75, 400])
+@pytest.mark.parametrize("nfix", [0, 1])
+def test_thresholds_and_no_fix(oracle, threshold, nfix):
+    iq, _ = S.capture(33, 3 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04)
+    both(oracle, "uc8", iq, threshold=threshold, nfix=nfix)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_capture_that_ends_on_a_buffer_boundary(oracle, fmt):
+    """the reader then hands over one more, empty buffer (sdr_ifile.c:200-216): its means are 0 / 0 and the noise power
+    statistic is a NaN from there on -- in both readings"""
+    iq, _ = S.capture(5, 2 * 131072, fmt=fmt, ac_per_sec=2000.0)
+    both(oracle, fmt, iq, mode_ac=True)
+
+
+@pytest.mark.parametrize("seed", [10901, 10920])
+@pytest.mark.parametrize("fmt", ["UC8", "SC16", "SC16Q11"])
+def test_generator_of_the_benchmark(pkg, oracle, fmt, seed):
+    """the benchmark's own content model (csrc/msd_siggen.c), five buffers of it"""
+    cfg = pkg.siggen.make_cfg(seed=seed, fmt=getattr(pkg.siggen, fmt), ac_per_sec=1500)
+    iq = pkg.siggen.generate(cfg, 5 * 131072 + 4096)
+    got = both(oracle, fmt.lower(), iq, mode_ac=True)
+    assert len(got) > 300 and {m["msgtype"] for m in got} >= {0, 4, 5, 11, 17, 20, 32}
+
+
+def test_a_long_quiet_stretch_flips_the_filter(oracle):
+    """more than 60 s between two messages of an aircraft that only ever sent DF4: the first table is wiped at the second
+    flip (icao_filter.c:150-164), so the second one is rejected -- unless the squitter in between re-announced it.
+    Synthetic magnitudes would need 150 M samples; the filter is driven directly instead."""
+    f = D.IcaoFilter()
+    f.expire(0)            # first backgroundTasks(): active = b
+    f.add(0x4840D6)
+    f.expire(59999)
+    assert f.test(0x4840D6)
+    f.expire(60000)        # active = a (wiped); b still holds it
+    assert f.test(0x4840D6)
+    f.expire(120000)       # active = b, wiped
+    assert not f.test(0x4840D6)
+    o = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0)
+    assert o.filter_test(0x4840D6) == 0
+    o.filter_add(0x4840D6)
+    assert o.filter_test(0x4840D6) == 1 and o.filter_test(0x4840D7) == 0
+    assert D.IcaoFilter.hash(0x4840D6) == D.IcaoFilter.hash(0x4840D6 | 0xFF000000)  # three bytes only
