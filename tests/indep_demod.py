@@ -8,7 +8,7 @@ second witness there is.)  Slow (Python loop over preamble hits): meant for capt
 Scope: ifile replay of a UC8 / SC16 / SC16Q11 capture through convert_*_nodc, demodulate2400, scoreModesMessage,
 decodeModesMessage's CRC / address / filter part, modesChecksum + single-bit repair (--fix, the default) or none
 (--no-fix), the ICAO filter with its two tables, and demodulate2400AC + decodeModeAMessage's acceptance -- the ordered
-message list and the demodulator counters of stats.h:61-80.  --aggressive (two-bit tables) is not restated here."""
+message list and the demodulator counters of stats.h:61-80, for --no-fix, --fix and --aggressive."""
 import numpy as np
 
 BUF = 131072           # MODES_MAG_BUF_SAMPLES (readsb.h)
@@ -89,12 +89,44 @@ def _single_bit_syndromes():
 SINGLE = _single_bit_syndromes()
 
 
+_tables = {}
+
+
 def error_table(bits, nfix):
-    """prepareErrorTable(bits, 1, 1), crc.c:184-350: syndrome -> wrong bit, the DF bits 0..4 left out (:214)."""
+    """prepareErrorTable, crc.c:184-350, as modesChecksumInit calls it (:353-383): syndrome -> tuple of wrong bits.
+    --fix: (bits, 1, 1) -- every single wrong bit but the DF's five (:214).  --aggressive: (bits, 2, 4) -- one and two
+    wrong bits; every syndrome that two of those patterns share is dropped altogether (:231-251), and so is every one
+    that a pattern of three or four wrong bits also produces (flagCollisions, :150-177, :254-283)."""
     if nfix == 0:
         return None
-    assert nfix == 1, "--aggressive is not restated here"
-    return {SINGLE[i + 112 - bits]: i for i in range(5, bits)}
+    if (bits, nfix) in _tables:
+        return _tables[(bits, nfix)]
+    off = 112 - bits
+    pos = np.arange(5, bits)
+    s1 = np.array([SINGLE[i + off] for i in pos], dtype=np.int64)
+    table = {int(s): (int(i),) for s, i in zip(s1, pos)}
+    if nfix >= 2:
+        ii, jj = np.triu_indices(len(pos), k=1)        # i < j
+        s2 = s1[ii] ^ s1[jj]
+        every = np.concatenate([s1, s2])
+        uniq, counts = np.unique(every, return_counts=True)
+        shared = set(uniq[counts > 1].tolist())
+        table = {s: b for s, b in table.items() if s not in shared}
+        for s, i, j in zip(s2.tolist(), pos[ii].tolist(), pos[jj].tolist()):
+            if s not in shared:
+                table[s] = (i, j)
+        keys = np.array(sorted(table), dtype=np.int64)
+        flagged = set()
+        # three wrong bits i < j < k, four wrong bits i < j < k < l: a pair (i, j) with a single k > j or a pair (k, l), k > j
+        for a in range(0, len(s2), 256):
+            sa, ja = s2[a: a + 256, None], jj[a: a + 256, None]
+            t3 = (sa ^ s1[None, :])[np.arange(len(pos))[None, :] > ja]
+            t4 = (sa ^ s2[None, :])[ii[None, :] > ja]
+            for t in (t3, t4):
+                flagged.update(t[np.isin(t, keys)].tolist())
+        table = {s: b for s, b in table.items() if s not in flagged}
+    _tables[(bits, nfix)] = table
+    return table
 
 
 # ---------------------------------------------------------------------------------------------- icao_filter.c
@@ -227,7 +259,7 @@ class Receiver:
         table = self.tab56 if bits == 56 else self.tab112
         if table is None or syndrome not in table:
             return None
-        return [table[syndrome]]
+        return list(table[syndrome])
 
     @staticmethod
     def correct_aa(addr, ei):  # mode_s.c:266-281

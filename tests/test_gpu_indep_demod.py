@@ -38,9 +38,9 @@ def test_numpy_corpus(pkg, oracle, torch_cuda, resolve_stage, fmt, case):
     hip_and_second_reading(pkg, oracle, torch_cuda, fmt, iq)
 
 
-@pytest.mark.parametrize("threshold,nfix", [(40, 1), (58, 0), (75, 1), (400, 0)])
-def test_thresholds_and_no_fix(pkg, oracle, torch_cuda, resolve_stage, threshold, nfix):
-    iq, _ = S.capture(34, 6 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04)
+@pytest.mark.parametrize("threshold,nfix", [(40, 1), (58, 0), (75, 1), (400, 0), (58, 2), (40, 2)])
+def test_thresholds_no_fix_and_aggressive(pkg, oracle, torch_cuda, resolve_stage, threshold, nfix):
+    iq, _ = S.capture(34, 6 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04, flip_fraction=0.2)
     hip_and_second_reading(pkg, oracle, torch_cuda, "uc8", iq, threshold=threshold, nfix=nfix, mode_ac=False)
 
 

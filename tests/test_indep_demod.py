@@ -66,10 +66,34 @@ def test_numpy_corpus(oracle, fmt, case):
 
 
 @pytest.mark.parametrize("threshold", [40, 58, 75, 400])
-@pytest.mark.parametrize("nfix", [0, 1])
-def test_thresholds_and_no_fix(oracle, threshold, nfix):
-    iq, _ = S.capture(33, 3 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04)
-    both(oracle, "uc8", iq, threshold=threshold, nfix=nfix)
+@pytest.mark.parametrize("nfix", [0, 1, 2])
+def test_thresholds_no_fix_and_aggressive(oracle, threshold, nfix):
+    iq, _ = S.capture(33, 3 * 131072 + 77, fmt="uc8", frames_per_sec=4000.0, noise=0.04, flip_fraction=0.2)
+    got = both(oracle, "uc8", iq, threshold=threshold, nfix=nfix)
+    if threshold != 400:
+        assert max(m["correctedbits"] for m in got) == nfix  # the repairs the option allows really happen
+
+
+@pytest.mark.parametrize("bits", [56, 112])
+def test_two_bit_tables_of_both_readings(oracle, bits):
+    """prepareErrorTable(bits, 2, 4) twice: every entry of this reading's table is the oracle's answer, and the oracle
+    has no answer where this table has none (every one- and two-bit pattern, a sample of three-bit ones, random ones)"""
+    import itertools
+    table = D.error_table(bits, 2)
+    o = oracle.Oracle(oracle.FMT_UC8, 58, 2, 0)
+    single = D.SINGLE[112 - bits:]
+    syns = set(single) | {a ^ b for a, b in itertools.combinations(single, 2)}
+    rng = np.random.default_rng(bits)
+    tri = list(itertools.combinations(single[5:], 3))
+    syns |= {a ^ b ^ c for a, b, c in (tri[i] for i in rng.integers(0, len(tri), 5000))}
+    syns |= {int(x) for x in rng.integers(1, 1 << 24, 5000)}
+    syns.discard(0)
+    for s in syns:
+        n, wrong = o.diagnose(s, bits)
+        if s in table:
+            assert n == len(table[s]) and tuple(wrong[:n]) == table[s], (hex(s), n, wrong, table[s])
+        else:
+            assert n == -1, (hex(s), n, wrong)
 
 
 @pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
