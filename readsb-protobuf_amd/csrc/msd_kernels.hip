@@ -134,7 +134,8 @@ constexpr int SC = 64;                /* tries with a known DF per round: one pe
                                          that would need more is retried with half the hits */
 constexpr int LUT_STRIDE = MSD_LUT_STRIDE;
 
-static_assert(WT_MAX == 1024 || WT_MAX == 2048, "each lane scans one or two runs of 16 consecutive positions");
+static_assert(WT_MAX == 1024 || WT_MAX == 2048 || WT_MAX == 4096, "each lane scans one, two or four runs of 16 consecutive positions");
+static_assert(WT_MAX <= 8192, "a position inside a tile has 13 bits in the hit and slot words");
 static_assert(FRONT % 8 == 0, "whole load groups");
 static_assert(MSD_CHUNK_SAMPLES % WT_MAX == 0, "a tile never straddles two buffers");
 
