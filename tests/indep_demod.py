@@ -5,7 +5,7 @@ readings of demod_2400.c / mode_s.c / crc.c / icao_filter.c / convert.c and not 
 (The reference itself cannot be built in this image -- readsb.h:86 needs protobuf-c -- so this is the closest thing to a
 second witness there is.)  Slow (Python loop over preamble hits): meant for captures of a few buffers.
 
-Scope: ifile replay of a UC8 / SC16 / SC16Q11 capture through convert_*_nodc, demodulate2400, scoreModesMessage,
+Scope: ifile replay of a UC8 / SC16 / SC16Q11 capture through convert_*_nodc or (--dcfilter) convert_*_generic, demodulate2400, scoreModesMessage,
 decodeModesMessage's CRC / address / filter part, modesChecksum + single-bit repair (--fix, the default) or none
 (--no-fix), the ICAO filter with its two tables, and demodulate2400AC + decodeModeAMessage's acceptance -- the ordered
 message list and the demodulator counters of stats.h:61-80, for --no-fix, --fix and --aggressive."""
@@ -25,27 +25,51 @@ def uc8_table():
     return (mag * np.float32(65535.0) + np.float32(0.5)).astype(np.float32).astype(np.uint16)  # [hi byte][lo byte], symmetric
 
 
-def convert(fmt, raw):
-    """-> (uint16 magnitudes, per-sample level terms, per-sample power terms); the terms are what the converter sums
-    (convert.c:63-111 integers for UC8; :215-253 / :332-370 floats for the 16-bit formats)."""
-    if fmt == "uc8":
+def dc_block(f, sample_rate=2.4e6):
+    """convert.c:135-139 (and :187-191, :396-400) with the state of init_converter (:478-482): a one-pole DC estimate
+    per channel, z = fI * dc_a + z * dc_b in float arithmetic, one sample after the other through the whole stream."""
+    import math
+    dc_b = np.float32(math.exp(-2.0 * math.pi * 1.0 / sample_rate))
+    dc_a = np.float32(1.0 - float(dc_b))
+    out = np.empty_like(f)
+    for ch in range(2):
+        a = (f[:, ch] * dc_a).astype(np.float32)
+        z = np.float32(0.0)
+        zs = np.empty(len(a), dtype=np.float32)
+        for i in range(len(a)):
+            z = a[i] + z * dc_b  # np.float32 scalars: two roundings, as in C without contraction
+            zs[i] = z
+        out[:, ch] = f[:, ch] - zs
+    return out
+
+
+def convert(fmt, raw, dc=False):
+    """-> (uint16 magnitudes, per-sample level terms, per-sample power terms, float sums?); the terms are what the
+    converter sums (convert.c:63-111 integers for UC8 without --dcfilter; floats for every other converter)."""
+    if fmt == "uc8" and not dc:
         b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 2)
         mag = uc8_table()[b[:, 1], b[:, 0]]  # uc8_lookup[le16 of the pair]: high byte = second byte
-        return mag, mag.astype(np.uint64), mag.astype(np.uint64) * mag.astype(np.uint64)
-    s = np.frombuffer(raw, dtype="<i2").reshape(-1, 2).astype(np.float32)
-    f = s / np.float32(32768.0 if fmt == "sc16" else 2048.0)
+        return mag, mag.astype(np.uint64), mag.astype(np.uint64) * mag.astype(np.uint64), False
+    if fmt == "uc8":  # convert_uc8_generic, convert.c:113-162
+        s = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 2).astype(np.float32)
+        f = ((s - np.float32(127.5)) / np.float32(127.5)).astype(np.float32)
+    else:
+        s = np.frombuffer(raw, dtype="<i2").reshape(-1, 2).astype(np.float32)
+        f = s / np.float32(32768.0 if fmt == "sc16" else 2048.0)
+    if dc:
+        f = dc_block(f)
     magsq = (f[:, 0] * f[:, 0]).astype(np.float32) + (f[:, 1] * f[:, 1]).astype(np.float32)
     magsq = np.minimum(magsq.astype(np.float32), np.float32(1.0))
     magf = np.sqrt(magsq, dtype=np.float32)
     mag = (magf * np.float32(65535.0) + np.float32(0.5)).astype(np.float32).astype(np.uint16)
-    return mag, magf, magsq
+    return mag, magf, magsq, True
 
 
-def buffer_means(fmt, level_terms, power_terms):
+def buffer_means(float_sums, level_terms, power_terms):
     n = len(level_terms)
     if n == 0:
         return float("nan"), float("nan")  # 0 / 0 in every converter: the empty buffer behind a capture that ends on a buffer boundary
-    if fmt == "uc8":
+    if not float_sums:
         sl, sp = int(level_terms.sum(dtype=np.uint64)), int(power_terms.sum(dtype=np.uint64))
         return sl / 65536.0 / n, sp / 65535.0 / 65535.0 / n
     # float accumulators, one addition per sample, in order
@@ -239,8 +263,8 @@ def msg_bits_by_type(df):
 
 
 class Receiver:
-    def __init__(self, fmt="uc8", threshold=58, nfix=1, mode_ac=False, startup_time=0):
-        self.fmt, self.threshold, self.mode_ac = fmt, threshold, mode_ac
+    def __init__(self, fmt="uc8", threshold=58, nfix=1, mode_ac=False, startup_time=0, dc_filter=False):
+        self.fmt, self.threshold, self.mode_ac, self.dc_filter = fmt, threshold, mode_ac, dc_filter
         self.tab56, self.tab112 = error_table(56, nfix), error_table(112, nfix)
         self.filter = IcaoFilter()
         self.startup_time = startup_time
@@ -509,7 +533,7 @@ class Receiver:
         bps = 2 if self.fmt == "uc8" else 4
         raw = bytes(raw)
         nsamples = len(raw) // bps
-        mag, lvl, pwr = convert(self.fmt, raw[: nsamples * bps])
+        mag, lvl, pwr, float_sums = convert(self.fmt, raw[: nsamples * bps], self.dc_filter)
         tail = np.zeros(OVERLAP, dtype=np.uint16)  # calloc'ed overlap buffer, fifo.c:47
         counter = 0
         while True:
@@ -517,7 +541,7 @@ class Receiver:
             data = np.concatenate([tail, mag[counter: counter + n]])
             sample_ts = int(counter * 12e6 / 2.4e6)
             sys_ts = sample_ts // 12000 + self.startup_time
-            mean_level, mean_power = buffer_means(self.fmt, lvl[counter: counter + n], pwr[counter: counter + n])
+            mean_level, mean_power = buffer_means(float_sums, lvl[counter: counter + n], pwr[counter: counter + n])
             tail = data[len(data) - OVERLAP:]
             self.demodulate(data, n, sample_ts, sys_ts, mean_power)
             if self.mode_ac:

@@ -19,14 +19,14 @@ def resolve_stage(request, monkeypatch):
     return request.param
 
 
-def hip_and_second_reading(pkg, oracle, torch, fmt, iq, threshold=58, nfix=1, mode_ac=True, batch=4 * 131072):
+def hip_and_second_reading(pkg, oracle, torch, fmt, iq, threshold=58, nfix=1, mode_ac=True, batch=4 * 131072, dc_filter=False):
     raw = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     n = raw.size // (2 if fmt == "uc8" else 4)
     f, _ = fmt_ids(pkg, oracle, fmt)
     dem = pkg.Demodulator(fmt=f, preamble_threshold=threshold, nfix_crc=nfix, mode_ac=1 if mode_ac else 0,
-                          max_batch_samples=batch, message_capacity=1 << 17)
+                          max_batch_samples=batch, message_capacity=1 << 17, dc_filter=dc_filter)
     got = pkg.replay_device(dem, torch.from_numpy(raw).to("cuda:0").data_ptr(), n, batch)
-    want, wstats = D.Receiver(fmt, threshold, nfix, mode_ac).replay(raw.tobytes())
+    want, wstats = D.Receiver(fmt, threshold, nfix, mode_ac, dc_filter=dc_filter).replay(raw.tobytes())
     assert_second_reading_agrees(want, wstats, got, dem.stats())
     return got
 
@@ -56,3 +56,10 @@ def test_generator_of_the_benchmark(pkg, oracle, torch_cuda, resolve_stage, fmt)
 def test_capture_that_ends_on_a_buffer_boundary(pkg, oracle, torch_cuda, resolve_stage):
     iq, _ = S.capture(6, 4 * 131072, fmt="uc8", ac_per_sec=2000.0)
     hip_and_second_reading(pkg, oracle, torch_cuda, "uc8", iq)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_dc_blocking_converters(pkg, oracle, torch_cuda, resolve_stage, fmt):
+    """--dcfilter: the filter state runs through the stream, across buffers and batches"""
+    iq, _ = S.capture(78, 3 * 131072 + 3000, fmt=fmt, dc=(0.05, -0.03), ac_per_sec=1500.0)
+    hip_and_second_reading(pkg, oracle, torch_cuda, fmt, iq, batch=2 * 131072, dc_filter=True)

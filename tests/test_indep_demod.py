@@ -35,10 +35,11 @@ def assert_second_reading_agrees(got, gstats, want, wstats):
         assert np.array_equal(np.float64(gstats[k]), np.float64(wstats[k]), equal_nan=True), (k, gstats[k], wstats[k])
 
 
-def both(oracle, fmt, raw, threshold=58, nfix=1, mode_ac=False):
+def both(oracle, fmt, raw, threshold=58, nfix=1, mode_ac=False, dc_filter=False):
     raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
-    got, gstats = D.Receiver(fmt, threshold, nfix, mode_ac).replay(raw.tobytes())
-    want, wstats = oracle.Oracle(getattr(oracle, OFMT[fmt]), threshold, nfix, 1 if mode_ac else 0).replay(raw, cap=1 << 18)
+    got, gstats = D.Receiver(fmt, threshold, nfix, mode_ac, dc_filter=dc_filter).replay(raw.tobytes())
+    want, wstats = oracle.Oracle(getattr(oracle, OFMT[fmt]), threshold, nfix, 1 if mode_ac else 0,
+                                 dc_filter=dc_filter).replay(raw, cap=1 << 18)
     assert_second_reading_agrees(got, gstats, want, wstats)
     return got
 
@@ -102,6 +103,14 @@ def test_capture_that_ends_on_a_buffer_boundary(oracle, fmt):
     statistic is a NaN from there on -- in both readings"""
     iq, _ = S.capture(5, 2 * 131072, fmt=fmt, ac_per_sec=2000.0)
     both(oracle, fmt, iq, mode_ac=True)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_dc_blocking_converters(oracle, fmt):
+    """--dcfilter: convert_*_generic, the filter state carried through the stream, a receiver with a DC offset"""
+    iq, _ = S.capture(77, 2 * 131072 + 3000, fmt=fmt, dc=(0.05, -0.03), ac_per_sec=1500.0)
+    got = both(oracle, fmt, iq, mode_ac=True, dc_filter=True)
+    assert len(got) > 50
 
 
 @pytest.mark.parametrize("seed", [10901, 10920])
