@@ -1,6 +1,7 @@
 """Randomised parity sweep (not collected by pytest): python tests/fuzz_parity.py [cases] [first_seed]
 Each case draws a traffic model, a format, a batch size and the resolve path at random and compares the
-HIP path with the oracle message for message and counter for counter."""
+HIP path with the oracle message for message and counter for counter; captures of up to eight buffers also with the
+second reading of the reference (tests/indep_demod.py), directly."""
 import os
 import sys
 
@@ -10,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g  # noqa: E402
 from tests.test_gpu_parity import assert_same  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import indep_demod  # noqa: E402  (the second reading of the reference: a third witness for the short captures)
+from test_indep_demod import assert_second_reading_agrees  # noqa: E402
 
 pkg = g.load_package()
 orc = g.load_oracle()
@@ -61,7 +65,12 @@ for case in range(first, first + ncases):
         if with_fields:
             for name in gfields.dtype.names:
                 assert np.array_equal(gfields[name], wfields[name]), "field " + name
-        print("ok  ", desc, "msgs", len(want), "passes", dem.timing()["resolve_passes"], "fallback", dem.timing()["resolve_fallback"])
+        second = ""
+        if nbuf <= 8 and not q11:
+            smsgs, sstats = indep_demod.Receiver(fmt_name, thr, nfix, bool(mode_ac), dc_filter=dc).replay(iq.tobytes())
+            assert_second_reading_agrees(smsgs, sstats, got, dem.stats())
+            second = " second-reading ok"
+        print("ok  ", desc, "msgs", len(want), "passes", dem.timing()["resolve_passes"], "fallback", dem.timing()["resolve_fallback"], second)
     except AssertionError as e:
         bad += 1
         print("FAIL", desc, str(e)[:200])

@@ -464,8 +464,14 @@ class Receiver:
             return  # (its noise level would be a NaN turned into an unsigned; the loop does not run)
         f32 = np.float32
         x = [int(v) for v in m] + [0] * 8
-        noise_stddev = math.sqrt(mean_power - mean_level * mean_level)
-        noise_level = int((mean_power + noise_stddev) * 65535 + 0.5)
+        var = mean_power - mean_level * mean_level
+        if var >= 0:
+            noise_level = int((mean_power + math.sqrt(var)) * 65535 + 0.5)
+        else:
+            # sqrt of a negative number (a buffer of one or two samples whose float mean of squares was rounded below the
+            # square of the mean): a NaN, and (unsigned) of a NaN is undefined in C.  The reference's x86-64 build turns it
+            # into 0 (cvttsd2si gives 0x8000000000000000, the low half is kept) -- which is what is restated here.
+            noise_level = 0
 
         def pulse(s):
             """rising edge, quiet third sample, 6 dB above the noise (:581-594) -> level or None"""
@@ -533,15 +539,20 @@ class Receiver:
         bps = 2 if self.fmt == "uc8" else 4
         raw = bytes(raw)
         nsamples = len(raw) // bps
-        mag, lvl, pwr, float_sums = convert(self.fmt, raw[: nsamples * bps], self.dc_filter)
+        whole = convert(self.fmt, raw[: nsamples * bps], True) if self.dc_filter else None  # the filter runs through the stream
         tail = np.zeros(OVERLAP, dtype=np.uint16)  # calloc'ed overlap buffer, fifo.c:47
         counter = 0
         while True:
             n = min(BUF, nsamples - counter)
-            data = np.concatenate([tail, mag[counter: counter + n]])
+            if whole is not None:
+                mag, lvl, pwr, float_sums = (whole[0][counter: counter + n], whole[1][counter: counter + n],
+                                             whole[2][counter: counter + n], whole[3])
+            else:  # every other converter is a function of the sample alone: one buffer at a time
+                mag, lvl, pwr, float_sums = convert(self.fmt, raw[counter * bps: (counter + n) * bps], False)
+            data = np.concatenate([tail, mag])
             sample_ts = int(counter * 12e6 / 2.4e6)
             sys_ts = sample_ts // 12000 + self.startup_time
-            mean_level, mean_power = buffer_means(float_sums, lvl[counter: counter + n], pwr[counter: counter + n])
+            mean_level, mean_power = buffer_means(float_sums, lvl, pwr)
             tail = data[len(data) - OVERLAP:]
             self.demodulate(data, n, sample_ts, sys_ts, mean_power)
             if self.mode_ac:

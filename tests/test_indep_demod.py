@@ -113,6 +113,16 @@ def test_dc_blocking_converters(oracle, fmt):
     assert len(got) > 50
 
 
+@pytest.mark.parametrize("fmt", ["sc16", "sc16q11", "uc8"])
+@pytest.mark.parametrize("extra", [1, 2, 7])
+def test_last_buffer_of_a_few_samples_with_mode_ac(oracle, fmt, extra):
+    """A float mean of squares can round below the square of the float mean when a buffer holds one or two samples:
+    demodulate2400AC takes the square root of a negative number and casts the NaN to unsigned (demod_2400.c:530-531,
+    undefined in C; 0 on the reference's x86-64 build).  Found by the fuzzer's third witness (case 200103)."""
+    iq, _ = S.capture(9, 131072 + extra, fmt=fmt, ac_per_sec=3000.0)
+    both(oracle, fmt, iq, mode_ac=True)
+
+
 @pytest.mark.parametrize("seed", [10901, 10920])
 @pytest.mark.parametrize("fmt", ["UC8", "SC16", "SC16Q11"])
 def test_generator_of_the_benchmark(pkg, oracle, fmt, seed):
