@@ -159,11 +159,17 @@ class IcaoFilter:
     EMPTY = 0xFFFFFFFF
     TTL = 60000
 
-    def __init__(self):
+    def __init__(self, literal=False):
         self.a = [self.EMPTY] * self.SIZE
         self.b = [self.EMPTY] * self.SIZE
         self.active = self.a
         self.next_flip = 0
+        # What the tables hold, as sets: a short cut for test() once a table is crowded (30 000 aircraft fill it, and a
+        # miss then walks all 8192 slots).  Sound because entries are only ever wiped table by table and add() stores
+        # the second copy only after the first: an address is found on its probe path iff the table holds it.
+        # literal=True always walks the table (tests compare the two).
+        self.literal = literal
+        self.held = {id(self.a): set(), id(self.b): set()}
 
     @staticmethod
     def hash(a):
@@ -188,6 +194,7 @@ class IcaoFilter:
                 return
         if t[h] == self.EMPTY:
             t[h] = addr
+            self.held[id(t)].add(addr)
         h0 = h = self.hash(addr & 0xFFFF)
         while t[h] != self.EMPTY and (t[h] & 0xFFFF) != (addr & 0xFFFF):
             h = (h + 1) & (self.SIZE - 1)
@@ -197,6 +204,8 @@ class IcaoFilter:
             t[h] = addr
 
     def test(self, addr):
+        if not self.literal:
+            return addr in self.held[id(self.a)] or addr in self.held[id(self.b)]
         for t in (self.a, self.b):
             h0 = h = self.hash(addr)
             while t[h] != self.EMPTY and t[h] != addr:
@@ -210,10 +219,14 @@ class IcaoFilter:
     def expire(self, now):
         if now >= self.next_flip:
             if self.active is self.a:
+                del self.held[id(self.b)]
                 self.b = [self.EMPTY] * self.SIZE
+                self.held[id(self.b)] = set()
                 self.active = self.b
             else:
+                del self.held[id(self.a)]
                 self.a = [self.EMPTY] * self.SIZE
+                self.held[id(self.a)] = set()
                 self.active = self.a
             self.next_flip = now + self.TTL
 
@@ -263,10 +276,10 @@ def msg_bits_by_type(df):
 
 
 class Receiver:
-    def __init__(self, fmt="uc8", threshold=58, nfix=1, mode_ac=False, startup_time=0, dc_filter=False):
+    def __init__(self, fmt="uc8", threshold=58, nfix=1, mode_ac=False, startup_time=0, dc_filter=False, literal_filter=False):
         self.fmt, self.threshold, self.mode_ac, self.dc_filter = fmt, threshold, mode_ac, dc_filter
         self.tab56, self.tab112 = error_table(56, nfix), error_table(112, nfix)
-        self.filter = IcaoFilter()
+        self.filter = IcaoFilter(literal=literal_filter)
         self.startup_time = startup_time
         self.ifile_now = startup_time
         self.stats = dict(demod_preambles=0, demod_rejected_bad=0, demod_rejected_unknown_icao=0, demod_accepted=[0, 0, 0],

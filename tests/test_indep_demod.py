@@ -133,6 +133,31 @@ def test_generator_of_the_benchmark(pkg, oracle, fmt, seed):
     assert len(got) > 300 and {m["msgtype"] for m in got} >= {0, 4, 5, 11, 17, 20, 32}
 
 
+def test_crowded_filter_and_the_short_cut_of_its_membership_test(pkg, oracle):
+    """30 000 aircraft: the 8192-slot table (two entries per address) is full after the first seconds and
+    icaoFilterAdd gives up (icao_filter.c:73-76).  The second reading walking the table literally, its set short cut and
+    the oracle agree."""
+    cfg = pkg.siggen.make_cfg(seed=31, msgs_per_sec=12000, n_aircraft=30000, noise_fs=0.005)
+    iq = pkg.siggen.generate(cfg, 6 * 131072 + 4096)
+    got = both(oracle, "uc8", iq)
+    lit = D.Receiver("uc8", 58, 1, False, literal_filter=True)
+    msgs, stats = lit.replay(iq.tobytes())
+    assert [m["timestampMsg"] for m in msgs] == [m["timestampMsg"] for m in got] and len(got) > 500
+    rng = np.random.default_rng(3)
+    fast = D.IcaoFilter()
+    slow = D.IcaoFilter(literal=True)
+    for k, a in enumerate(rng.integers(1, 1 << 24, 9000).tolist()):
+        fast.add(a)
+        slow.add(a)
+        if k == 4000:
+            fast.expire(0)
+            slow.expire(0)
+    assert fast.a == slow.a and fast.b == slow.b
+    assert D.IcaoFilter.EMPTY not in slow.b  # 5000 addresses after the flip: the active table is full, later adds gave up
+    for a in rng.integers(1, 1 << 24, 300).tolist() + [x for x in slow.a[:200] if x != D.IcaoFilter.EMPTY]:
+        assert fast.test(a) == slow.test(a)
+
+
 def test_a_long_quiet_stretch_flips_the_filter(oracle):
     """more than 60 s between two messages of an aircraft that only ever sent DF4: the first table is wiped at the second
     flip (icao_filter.c:150-164), so the second one is rejected -- unless the squitter in between re-announced it.
