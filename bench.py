@@ -122,7 +122,9 @@ def run_also(extra):
             "kernel_ms": scan, "kernels_behind_the_scan_ms": rest, "frac": d["roofline"]["frac"],
             "traffic": d["roofline"]["traffic"], "traffic_of_kernels_behind_the_scan": d["roofline"].get("traffic_of_kernels_behind_the_scan"),
             "messages_per_step": d["messages_per_step"],
-            "message_set_diff_vs_oracle": d.get("message_set_diff_vs_oracle"), "resolve_stage": d.get("resolve_stage")}
+            "message_set_diff_vs_oracle": d.get("message_set_diff_vs_oracle"),
+            "message_set_diff_vs_second_reading": (d.get("message_set_diff_vs_second_reading") or {}).get("diff"),
+            "resolve_stage": d.get("resolve_stage")}
 
 
 def main():
@@ -455,6 +457,40 @@ def main():
         out["messages_checked"] = int(len(want))
         if ndiff:
             raise SystemExit("bench: GPU messages differ from the oracle: " + json.dumps(out))
+        # ---- a third witness on the head of the capture: the second reading of the reference (tests/indep_demod.py, numpy /
+        # plain Python, written from the reference's sources without the oracle), against the GPU's list directly.  Reported,
+        # never fatal: the oracle above is the gate. ----
+        if not args.sc16q11_table_bits:
+            try:
+                tdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests")
+                if tdir not in sys.path:
+                    sys.path.insert(0, tdir)
+                import indep_demod
+                nb = 128
+                head = min(n, nb * pkg.CHUNK + 4096)
+                w0 = time.perf_counter()
+                smsgs, _ = indep_demod.Receiver(args.format, args.threshold, args.fix, bool(args.mode_ac),
+                                                dc_filter=args.dcfilter).replay(iq[: head * bps].tobytes())
+                # whole buffers only: the short last buffer of the head sees another end of the stream than the capture's
+                limit = (head // pkg.CHUNK) * pkg.CHUNK * 5
+                smsgs = [x for x in smsgs if x["timestampMsg"] < limit]
+                ghead = got[got["timestampMsg"] < limit]
+                sdiff = abs(len(smsgs) - len(ghead))
+                for x, y in zip(smsgs, ghead):
+                    nbytes = int(y["msgbits"]) // 8
+                    same = (x["timestampMsg"] == int(y["timestampMsg"]) and x["msgtype"] == int(y["msgtype"]) and
+                            x["addr"] == int(y["addr"]) and x["correctedbits"] == int(y["correctedbits"]) and
+                            x["msg"][:nbytes] == bytes(y["msg"][:nbytes]))
+                    if same and x["msgtype"] != 32:
+                        same = (x["score"] == int(y["score"]) and x["bestphase"] == int(y["bestphase"]) and
+                                x["crc"] == int(y["crc"]) and x["signalLevel"] == float(y["signalLevel"]))
+                    sdiff += 0 if same else 1
+                out["message_set_diff_vs_second_reading"] = {
+                    "diff": sdiff, "messages": len(smsgs), "buffers": head // pkg.CHUNK, "seconds": round(time.perf_counter() - w0, 1),
+                    "what": "tests/indep_demod.py on the first buffers of the same capture, compared with the GPU's list (not the "
+                            "oracle's): timestamps, bytes, address, repaired bits, score, phase, CRC, signal level as the same double"}
+            except Exception as e:  # noqa: BLE001
+                out["message_set_diff_vs_second_reading"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dcfilter:
         # ---- the drop-in figure: the same capture handed over in host memory (what --ifile sees, sdr_ifile.c:192-216) -- upload
         # over PCIe + kernels + records home, batches in flight, page-locked buffers.  Reported beside `value`, never as it. ----
