@@ -176,3 +176,14 @@ def test_a_long_quiet_stretch_flips_the_filter(oracle):
     o.filter_add(0x4840D6)
     assert o.filter_test(0x4840D6) == 1 and o.filter_test(0x4840D7) == 0
     assert D.IcaoFilter.hash(0x4840D6) == D.IcaoFilter.hash(0x4840D6 | 0xFF000000)  # three bytes only
+
+
+def test_pulse_train_of_preambles(oracle):
+    """the adversarial capture of tests/test_gpu_adversarial.py (36 % of the positions are preamble hits, five trial
+    phases each): one buffer and a bit, both readings"""
+    from test_gpu_adversarial import pulse_train
+    n = 131072 + 5000
+    got, gstats = D.Receiver("uc8", 58, 1, True).replay(pulse_train(n, 7).tobytes())
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 1).replay(pulse_train(n, 7), cap=1 << 16)
+    assert gstats["demod_preambles"] > 0.3 * n
+    assert_second_reading_agrees(got, gstats, want, wstats)
