@@ -47,8 +47,10 @@ typedef struct msd_config {
     /* ---- tuning and test settings of THIS context (0 = default); nothing in the library reads the environment ---- */
     int32_t resolve_threads;      /* host threads of the buffer-parallel resolve when a batch is resolved on the host;
                                      0 = an eighth of the CPUs, 4..64 */
-    int32_t test_arena_permille;  /* tests: candidate arenas at this many thousandths of their size (provokes the
-                                     overflow path, a batch rescanned in pieces) */
+    int32_t test_arena_permille;  /* candidate arenas at this many thousandths of their base size (one hit per 8 samples,
+                                     one live try per 16, of a region of the scan); 0 = the default, 4000.
+                                     Tests provoke the overflow path (a batch rescanned in pieces) with small values; a
+                                     receiver short of device memory can run at 1000 */
     int32_t test_inline_adds;     /* tests: at most this many entries in a buffer's short add list (< MSD_RB_ADD_INLINE);
                                      0 = all of them */
     int32_t debug_flags;          /* kernel ablations for timing experiments (results are then incomplete): 1 stop after the

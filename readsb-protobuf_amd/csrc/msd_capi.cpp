@@ -2022,11 +2022,20 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     }
 
     const uint64_t B = c->cfg.max_batch_samples;
+    /* Candidate arenas.  Base size: one hit per 8 samples, one live try per 16 -- eight times the benchmark capture's
+     * density, and all that round 1's 8 GB budget allowed.  Default since round 4: four times the base, one hit per 2
+     * samples and one try per 4 (13.8 GB per context at 128 Mi-sample batches, of 288): a burst of pulse trains that fills a
+     * tenth of every buffer with preambles of five trial phases each stays on the fast path instead of sending the
+     * whole batch through rerun_in_pieces (profiles/r04_density.txt: 74 against 1.2 GS/s).  What overflows even these is
+     * rescanned in pieces as before -- nothing is ever truncated. */
     uint64_t hit_want = B / 8, try_want = B / 16;
-    if (cfg->test_arena_permille > 0) { /* test setting: provoke the overflow path */
+    if (cfg->test_arena_permille > 0) { /* explicit size in thousandths of the base (tests: provoke the overflow path) */
         const uint64_t pm = (uint64_t)cfg->test_arena_permille;
         hit_want = hit_want * pm / 1000;
         try_want = try_want * pm / 1000;
+    } else {
+        hit_want *= 4;
+        try_want *= 4;
     }
     c->hit_arena = hit_want > MIN_HIT_ARENA ? hit_want : MIN_HIT_ARENA;
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;

@@ -29,9 +29,14 @@ def resolve_stage(request, monkeypatch):
     return request.param
 
 
+@pytest.mark.parametrize("arenas", ["base-size", "default"])
 @pytest.mark.parametrize("noise_seed", [None, 7])
 @pytest.mark.parametrize("nfix,mode_ac", [(0, 0), (1, 1)])
-def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, noise_seed, nfix, mode_ac):
+def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, monkeypatch, noise_seed, nfix, mode_ac, arenas):
+    """base-size: arenas of one hit per 8 and one live try per 16 samples (msd_config.test_arena_permille = 1000) -- they
+    overflow, the batch is rescanned in pieces; default (four times that): these short batches fit and stay on the GPU"""
+    if arenas == "base-size":
+        monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "1000")
     n = 12 * 131072 + 4321
     iq = pulse_train(n, noise_seed)
     f, of = fmt_ids(pkg, oracle, "uc8")
@@ -42,11 +47,15 @@ def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, noise_
     assert wstats["demod_preambles"] > 0.3 * n  # it is as dense as advertised
     assert_same(got, dem.stats(), want, wstats)
     t = dem.timing()
-    assert t["reruns"] > 0 or t["resolve_fallback"] > 0  # the arenas did overflow; nothing was cut short
+    if arenas == "base-size":
+        assert t["reruns"] > 0 or t["resolve_fallback"] > 0  # the arenas did overflow; nothing was cut short
 
 
-def test_pulse_train_inside_ordinary_traffic(pkg, oracle, torch_cuda, resolve_stage):
+@pytest.mark.parametrize("arenas", ["base-size", "default"])
+def test_pulse_train_inside_ordinary_traffic(pkg, oracle, torch_cuda, resolve_stage, monkeypatch, arenas):
     """three buffers of the pulse train in the middle of an ordinary capture: the batches around them are untouched"""
+    if arenas == "base-size":
+        monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "1000")
     n = 24 * 131072
     iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=515), n).copy()
     a, b = 9 * 131072 + 1000, 12 * 131072 + 500
