@@ -2024,7 +2024,7 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     const uint64_t B = c->cfg.max_batch_samples;
     /* Candidate arenas.  Base size: one hit per 8 samples, one live try per 16 -- eight times the benchmark capture's
      * density, and all that round 1's 8 GB budget allowed.  Default since round 4: four times the base, one hit per 2
-     * samples and one try per 4 (13.8 GB per context at 128 Mi-sample batches, of 288): a burst of pulse trains that fills a
+     * samples and one try per 4 (14.5 GB per context at 128 Mi-sample batches, of 288): a burst of pulse trains that fills a
      * tenth of every buffer with preambles of five trial phases each stays on the fast path instead of sending the
      * whole batch through rerun_in_pieces (profiles/r04_density.txt: 74 against 1.2 GS/s).  What overflows even these is
      * rescanned in pieces as before -- nothing is ever truncated. */
