@@ -289,6 +289,31 @@ def test_dropped_samples_between_batches(pkg, oracle, torch_cuda, drop):
         dem.note_dropped(1)  # the capture is over
 
 
+@pytest.mark.parametrize("drop", [(1 << 32) - 6 * 131072 - 100, (1 << 32) + 12345, (1 << 36) + 3, (1 << 43) + 131071])
+def test_sample_clock_beyond_32_bits(pkg, oracle, torch_cuda, drop):
+    """A live receiver passes 2^32 samples after half an hour.  The sample clock is a 64-bit counter turned into 12 MHz
+    ticks by a double expression (sdr_ifile.c:187, sdr_rtlsdr.c: `sampleCounter * 12e6 / sample_rate`, inexact once the
+    product leaves 53 bits): a gap of that size in front of the second batch (the first drop makes the clock cross 2^32
+    inside the batch behind it), compared with the oracle fed the same way."""
+    from helpers import oracle_live_feed
+    C = pkg.CHUNK
+    n = 14 * C + 777
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=77, msgs_per_sec=7000, n_aircraft=25), n)
+    cuts = [0, 3 * C, 9 * C, n]
+    drops = [0, drop, 5]
+    segs = [iq[2 * a: 2 * b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want, wstats = oracle_live_feed(oracle.Oracle(oracle.FMT_UC8, 58, 1, 0), segs, drops)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=6 * C, message_capacity=1 << 16)
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if drops[i]:
+            dem.note_dropped(drops[i])
+        dem.launch_device(d_iq.data_ptr() + 2 * a, b - a, last=b == n)
+    got = np.concatenate([dem.collect() for _ in range(3)])
+    assert len(want) > 100 and int(want["timestampMsg"].max()) > 5 * drop
+    assert_same(got, dem.stats(), want, wstats)
+
+
 def test_preamble_threshold_change_applies_to_later_batches(pkg, oracle, torch_cuda):
     """msd_set_preamble_threshold (demod_2400.c:285-290 raises the threshold to 75 while samples were
     dropped recently): batches launched before the call keep the old value."""
