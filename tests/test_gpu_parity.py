@@ -314,6 +314,23 @@ def test_sample_clock_beyond_32_bits(pkg, oracle, torch_cuda, drop):
     assert_same(got, dem.stats(), want, wstats)
 
 
+def test_more_batches_than_prediction_generations(pkg, oracle, torch_cuda):
+    """The prediction table of a pipeline slot is never wiped between batches: its entries carry one of 255 generations
+    (msd_pred_impl.h).  1100 batches of two buffers -- 275 per slot -- take every slot's generation round once, with new
+    aircraft in every batch (30 000 of them), so stale entries of the generation that comes back would be believed."""
+    import os
+    if os.environ.get("MSD_GPU_RESOLVE") == "0":
+        pytest.skip("the host resolver keeps no prediction table")
+    C = pkg.CHUNK
+    n = 2200 * C + 4096
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=255, msgs_per_sec=3000, n_aircraft=30000, noise_fs=0.01), n)
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 20)
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=2 * C, message_capacity=1 << 20)
+    got = pkg.replay_device(dem, torch_cuda.from_numpy(iq).to("cuda:0").data_ptr(), n, 2 * C)
+    assert len(want) > 100000
+    assert_same(got, dem.stats(), want, wstats)
+
+
 def test_preamble_threshold_change_applies_to_later_batches(pkg, oracle, torch_cuda):
     """msd_set_preamble_threshold (demod_2400.c:285-290 raises the threshold to 75 while samples were
     dropped recently): batches launched before the call keep the old value."""
