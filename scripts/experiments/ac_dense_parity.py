@@ -1,5 +1,8 @@
+"""Dense Mode A/C (30 000 to 400 000 replies per second, mostly overlapping) through the HIP path and the oracle, both
+resolve stages, UC8 and SC16: python scripts/experiments/ac_dense_parity.py (GPU box)."""
 import sys, os
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import __graft_entry__ as g
 from test_gpu_parity import assert_same

@@ -1,5 +1,5 @@
 import sys, importlib, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 pkg = importlib.import_module("readsb-protobuf_amd")
 iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=9, msgs_per_sec=5000), 6 * 131072 + 5)
 d = torch.from_numpy(iq).to("cuda:0")
