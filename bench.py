@@ -101,7 +101,7 @@ def pin_to_gpu_local_cpus(torch, local_rank, world, gpu_of=None):
         os.sched_setaffinity(0, mine)
         return {"gpu": bdf, "cpus": "%d-%d (%d of the %d local to the GPU, slice %d of %d)" % (mine[0], mine[-1], len(mine), len(allowed), j, k),
                 "cpu_list": mine}
-    except (OSError, ValueError, AttributeError):
+    except Exception:  # noqa: BLE001 -- placement is an optimisation: whatever sysfs or the device query says, the run goes on
         return None
 
 
