@@ -575,3 +575,41 @@ class Receiver:
             if n < BUF:  # a short (or empty) read is the end of the file
                 break
         return self.messages, self.stats
+
+    # ---- a live receiver's feed: rtlsdrCallback's sample clock, which runs on over blocks dropped for want of a free
+    # buffer (sdr_rtlsdr.c:279-301), the MAGBUF_DISCONTINUOUS buffer behind such a gap with zeros for its look-behind
+    # (fifo.c:179-185), --ifile's system clock (sdr_ifile.c:190).  segments: raw IQ, all but the last whole buffers;
+    # drops[i]: samples lost in front of segment i.  The last segment ends like a file.
+    def live_feed(self, segments, drops):
+        assert not self.dc_filter
+        bps = 2 if self.fmt == "uc8" else 4
+        tail = np.zeros(OVERLAP, dtype=np.uint16)
+        counter = 0
+        for si, (seg, drop) in enumerate(zip(segments, drops)):
+            raw = bytes(seg)
+            nsamples = len(raw) // bps
+            last = si == len(segments) - 1
+            assert last or nsamples % BUF == 0
+            counter += drop
+            discontinuous = drop > 0
+            off = 0
+            while True:
+                n = min(BUF, nsamples - off)
+                if n == 0 and not last:
+                    break
+                mag, lvl, pwr, float_sums = convert(self.fmt, raw[off * bps: (off + n) * bps], False)
+                data = np.concatenate([np.zeros(OVERLAP, dtype=np.uint16) if discontinuous else tail, mag])
+                discontinuous = False
+                sample_ts = int(counter * 12e6 / 2.4e6)
+                sys_ts = sample_ts // 12000 + self.startup_time
+                mean_level, mean_power = buffer_means(float_sums, lvl, pwr)
+                tail = data[len(data) - OVERLAP:]
+                self.demodulate(data, n, sample_ts, sys_ts, mean_power)
+                if self.mode_ac:
+                    self.demodulate_ac(data, n, sample_ts, sys_ts, mean_level, mean_power)
+                self.filter.expire(self.ifile_now)
+                counter += n
+                off += n
+                if n < BUF:
+                    break
+        return self.messages, self.stats

@@ -63,3 +63,24 @@ def test_dc_blocking_converters(pkg, oracle, torch_cuda, resolve_stage, fmt):
     """--dcfilter: the filter state runs through the stream, across buffers and batches"""
     iq, _ = S.capture(78, 3 * 131072 + 3000, fmt=fmt, dc=(0.05, -0.03), ac_per_sec=1500.0)
     hip_and_second_reading(pkg, oracle, torch_cuda, fmt, iq, batch=2 * 131072, dc_filter=True)
+
+
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", False), ("sc16", True)])
+@pytest.mark.parametrize("drop", [1, 131072 + 17, (1 << 32) + 12345])
+def test_live_feed_with_dropped_samples(pkg, oracle, torch_cuda, resolve_stage, fmt, mode_ac, drop):
+    """msd_note_dropped between batches in flight: the HIP path against the second reading's live feed"""
+    C, bps = 131072, 2 if fmt == "uc8" else 4
+    n = 9 * C + 999
+    f, _ = fmt_ids(pkg, oracle, fmt)
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=401, fmt=f, msgs_per_sec=7000, n_aircraft=25, ac_per_sec=1000), n)
+    cuts, drops = [0, 2 * C, 6 * C, n], [0, drop, 3 * drop + 1]
+    want, wstats = D.Receiver(fmt, 58, 1, mode_ac).live_feed([iq[bps * a: bps * b].tobytes() for a, b in zip(cuts[:-1], cuts[1:])], drops)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, mode_ac=int(mode_ac), max_batch_samples=4 * C, message_capacity=1 << 16)
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if drops[i]:
+            dem.note_dropped(drops[i])
+        dem.launch_device(d_iq.data_ptr() + bps * a, b - a, last=b == n)
+    got = np.concatenate([dem.collect() for _ in range(3)])
+    assert len(want) > 100
+    assert_second_reading_agrees(want, wstats, got, dem.stats())

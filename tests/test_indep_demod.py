@@ -187,3 +187,21 @@ def test_pulse_train_of_preambles(oracle):
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 1).replay(pulse_train(n, 7), cap=1 << 16)
     assert gstats["demod_preambles"] > 0.3 * n
     assert_second_reading_agrees(got, gstats, want, wstats)
+
+
+@pytest.mark.parametrize("fmt,mode_ac", [("uc8", False), ("sc16", True)])
+@pytest.mark.parametrize("drop", [1, 131072 + 17, (1 << 32) + 12345])
+def test_live_feed_with_dropped_samples(pkg, oracle, fmt, mode_ac, drop):
+    """gaps in the stream: the sample clock runs on, the buffer behind a gap has no look-behind -- both readings"""
+    from helpers import oracle_live_feed
+    C, bps = 131072, 2 if fmt == "uc8" else 4
+    n = 9 * C + 999
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=400, fmt=getattr(pkg.siggen, fmt.upper()), msgs_per_sec=7000,
+                                                 n_aircraft=25, ac_per_sec=1000), n)
+    cuts, drops = [0, 2 * C, 6 * C, n], [0, drop, 3 * drop + 1]
+    segs = [iq[bps * a: bps * b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want, wstats = oracle_live_feed(oracle.Oracle(getattr(oracle, OFMT[fmt]), 58, 1, int(mode_ac)), segs, drops,
+                                    bytes_per_sample=bps)
+    got, gstats = D.Receiver(fmt, 58, 1, mode_ac).live_feed([s.tobytes() for s in segs], drops)
+    assert len(got) > 100
+    assert_second_reading_agrees(got, gstats, want, wstats)
