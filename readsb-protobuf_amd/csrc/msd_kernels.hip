@@ -33,6 +33,7 @@
 #include <cstdlib>
 
 #include "msd_internal.h"
+#include "msd_dc_chain_asm.h"
 #include "msd_kernels.h"
 
 /* Candidate arenas (hits, tries): written once by the scan, read once by the next kernel.  MSD_ARENA_NT=1 marks the
@@ -2374,14 +2375,15 @@ __global__ void __launch_bounds__(128) msd_fm_apply_kernel(const uint8_t *iq, ui
 /* --dcfilter: the "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11).
  * Per channel z = f * dc_a + z * dc_b runs through the WHOLE stream (the converter state survives
  * the calls, convert.c:476-477), and a float recurrence cannot be re-associated bit-exactly, so this is
- * one dependent chain per channel: ~2 x 12 cycles per sample on one lane, about 100 Msamples/s -- 40x
+ * one dependent chain per channel: two dependent instructions per sample, 4.2 cycles each for a lone wavefront
+ * (scripts/micro/dep_chain.hip), plus the LDS traffic that feeds them: 130 Msamples/s measured (round 4; 65 before) -- 50x
  * real time for one receiver, and what this option costs.  One workgroup walks the batch in blocks:
  *   wavefronts 1-3  block k+1: samples -> f * dc_a for both channels, into LDS
  *   wavefront 0     block k:   lanes 0 (I) and 1 (Q) run the two chains in lock step, z into LDS
  *   wavefronts 1-3  block k-1: f - z, clamp, sqrt -> u16 magnitudes (what the scan kernel then reads as
  *                              MSD_FMT_MAG16) and the f32 squares for the per-buffer sums
  * (sum_level / sum_power restart with every buffer: msd_float_means_kernel<MSD_FMT_MAGSQ>). */
-constexpr int DC_BLK = 1536, DC_THREADS = 256, DC_WORKERS = DC_THREADS - 64;
+constexpr int DC_BLK = 1920, DC_THREADS = 1024, DC_WORKERS = DC_THREADS - 64; /* (1920 / 1024: no faster, the chain is what takes the time) */
 
 template <int FMT>
 __device__ __forceinline__ void dc_sample(const uint8_t *iq, uint64_t g, float &fi, float &fq)
@@ -2403,7 +2405,7 @@ __global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t 
                                                                   float dc_b, float *state /* z1_I, z1_Q */,
                                                                   uint16_t *mag, float *magsq_out)
 {
-    __shared__ __attribute__((aligned(16))) float tv[2][2][DC_BLK]; /* [block parity][channel] f * dc_a */
+    __shared__ __attribute__((aligned(16))) float tv[2][2][DC_BLK + 16]; /* [block parity][channel] f * dc_a (+ 16: the chain loop's last, unused prefetch) */
     __shared__ __attribute__((aligned(16))) float zv[2][2][DC_BLK]; /* [block parity][channel] z */
     const int tid = threadIdx.x;
     const uint64_t nblk = (nsamples + DC_BLK - 1) / DC_BLK;
@@ -2439,40 +2441,25 @@ __global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t 
         } else if (tid < 2 && k >= 1 && k <= nblk) { /* block k - 1: the two chains */
             const uint64_t base = (k - 1) * DC_BLK;
             const uint32_t cnt = nsamples - base < (uint64_t)DC_BLK ? (uint32_t)(nsamples - base) : (uint32_t)DC_BLK;
-            const float4 *t4 = reinterpret_cast<const float4 *>(tv[(k - 1) & 1][tid]);
-            float4 *z4 = reinterpret_cast<float4 *>(zv[(k - 1) & 1][tid]);
             /* z = t + z * dc_b as two plain instructions (separately rounded product and sum, like the
-             * reference's SSE2 build; nothing for the compiler to contract or reorder) */
+             * reference's SSE2 build; nothing for the compiler to contract or reorder).  Whole blocks of 32 samples go
+             * through the hand-scheduled loop of msd_dc_chain_asm.h (round 4: the compiler's schedule of the same loop
+             * waited for an LDS access after every fourth step, 11-13 ns per sample against 7-8), the rest one by one. */
 #define DC_STEP(T, OUT)                                                                                      \
     asm volatile("v_mul_f32 %0, %1, %3\n\tv_add_f32 %0, %2, %0" : "=&v"(OUT) : "v"(z), "v"(T), "v"(dc_b)); \
     z = OUT; /* a rename, not a move: the next step reads OUT's register */
-            float4 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                x[u] = t4[u];
-            for (uint32_t i = 0; i < cnt; i += 16) { /* the next 16 values are on their way while these are used */
-                float4 nx[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    nx[u] = t4[((i + 16) >> 2) + u < DC_BLK / 4 ? ((i + 16) >> 2) + u : 0];
-                if (i + 16 <= cnt) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float4 o;
-                        DC_STEP(x[u].x, o.x) DC_STEP(x[u].y, o.y) DC_STEP(x[u].z, o.z) DC_STEP(x[u].w, o.w)
-                        z4[(i >> 2) + u] = o;
-                    }
-                } else {
-                    const float *tt = tv[(k - 1) & 1][tid];
-                    float *zz = zv[(k - 1) & 1][tid];
-                    for (uint32_t j = i; j < cnt; ++j) {
-                        const float t = tt[j];
-                        DC_STEP(t, zz[j])
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    x[u] = nx[u];
+            const float *tt = tv[(k - 1) & 1][tid];
+            float *zz = zv[(k - 1) & 1][tid];
+            uint32_t done = 0;
+            if (cnt >= 32u) {
+                uint32_t ta = (uint32_t)(uintptr_t)tt, za = (uint32_t)(uintptr_t)zz;
+                uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cnt / 32u));
+                done = 32u * (cnt / 32u);
+                MSD_DC_CHAIN_ASM(z, dc_b, ta, za, nn);
+            }
+            for (uint32_t j = done; j < cnt; ++j) {
+                const float t = tt[j];
+                DC_STEP(t, zz[j])
             }
 #undef DC_STEP
         }
