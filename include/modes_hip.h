@@ -106,8 +106,8 @@ typedef struct msd_message {
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums
                                    run through the stream strictly in order -- one dependent float chain per channel
-                                   -- which bounds it at 0.064 Gsamples/s measured (27x real time for one receiver;
-                                   one host core runs the same recurrence about ten times faster).  It exists so
+                                   -- which bounds it at 0.13 Gsamples/s measured (55x real time for one receiver;
+                                   one host core runs the same recurrence about five times faster).  It exists so
                                    that the option is there behind the same stream interface; not with
                                    MSD_FMT_MAG16 */
 

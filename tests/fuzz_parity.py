@@ -41,7 +41,7 @@ for case in range(first, first + ncases):
     iq = pkg.siggen.generate(cfg, n)
     d = torch.from_numpy(iq).to("cuda:0")
     with_fields = int(rng.integers(0, 2))
-    dc = bool(rng.integers(0, 8) == 0) and n <= 12 * 131072  # the DC block runs at ~0.06 GS/s: short captures only
+    dc = bool(rng.integers(0, 8) == 0) and n <= 12 * 131072  # the DC block runs at ~0.13 GS/s: short captures only
     q11 = int(rng.choice([0, 0, 7, 8, 11])) if fmt_name == "sc16q11" and not dc else 0  # a -DSC16Q11_TABLE_BITS build (convert.c:264-328)
     dem = pkg.Demodulator(fmt=fmt, preamble_threshold=thr, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 19,
                           decode_fields=bool(with_fields), dc_filter=dc, **({"sc16q11_table_bits": q11} if q11 else {}))
