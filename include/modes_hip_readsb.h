@@ -1,7 +1,8 @@
 /*
  * modes_hip_readsb.h -- the reference-shaped host boundary of the MI355X Mode S receive path
  * (libmsd_host.so, plain C): the three interfaces readsb's hot path sits behind, with the
- * reference's own signatures, so that a readsb maintainer binds them by name:
+ * reference's own signatures, so that a readsb maintainer binds them by name (included behind the
+ * reference's convert.h / fifo.h, the declarations below use the reference's own types):
  *
  *   converter          convert.h:27-45   struct converter_state, iq_convert_fn, init_converter,
  *                                        cleanup_converter
@@ -63,6 +64,13 @@ const char *msd_converter_error(const struct converter_state *state);
 /* ------------------------------------------------------------------------------------------ */
 /* mag_buf FIFO (fifo.h:57-120)                                                               */
 /* ------------------------------------------------------------------------------------------ */
+#ifdef FIFO_H /* the reference's fifo.h is in scope: `struct msd_mag_buf` IS its `struct mag_buf`, so that msd_fifo_* and
+               * msd_demodulate2400[AC] are assignable to pointers of the reference's own function types without a cast
+               * (tests/c/boundary_ref_bind.c; the two layouts are compared field by field in boundary_ref_layout.c) */
+#define msd_mag_buf mag_buf
+typedef mag_buf_flags msd_mag_buf_flags;
+#define MSD_MAGBUF_DISCONTINUOUS MAGBUF_DISCONTINUOUS
+#else
 typedef enum {
     MSD_MAGBUF_DISCONTINUOUS = 1, /* fifo.h:30-32 */
 } msd_mag_buf_flags;
@@ -81,6 +89,7 @@ struct msd_mag_buf {
     unsigned dropped;
     struct msd_mag_buf *next;
 };
+#endif
 
 /* Same calls, same meaning as fifo.h:80-120.  Two defects of fifo.c are not reproduced (SURVEY.md
  * 8(b)): every enqueued buffer is delivered, in order, however deep the queue (fifo.c:192-197 never

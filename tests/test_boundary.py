@@ -20,6 +20,24 @@ def build_check(tmp_path):
     return exe
 
 
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "fifo.h")), reason="the reference tree exists in the build container only")
+def test_boundary_is_pinned_on_the_references_own_header_text(pkg, tmp_path):
+    """convert.h, fifo.h and demod_2400.h are self-contained (fifo.h:57-120, convert.h:27-45, demod_2400.h:37-38): one
+    translation unit compares `struct msd_mag_buf` with the reference's `struct mag_buf` field by field (and the flag,
+    format and threshold values), the other assigns every replacement entry point to a pointer of the reference's
+    declared type without a cast under -Werror and runs the FIFO through those pointers."""
+    for name, libs in (("boundary_ref_layout", []),
+                       ("boundary_ref_bind", ["-L" + CSRC, "-lmsd_host", "-lmodes_hip", "-Wl,-rpath," + CSRC, "-lpthread", "-lm"])):
+        exe = str(tmp_path / name)
+        subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + REF,
+                               os.path.join(ROOT, "tests", "c", name + ".c"), "-o", exe] + libs)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and " ok" in out.stdout, (name, out.returncode, out.stdout + out.stderr)
+
+
 def test_boundary_compiles_against_reference_style_declarations_and_runs(pkg, tmp_path):
     exe = build_check(tmp_path)
     capture = tmp_path / "tiny.uc8"
