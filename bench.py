@@ -148,7 +148,10 @@ def main():
     dev = torch.device("cuda", device_index)
     pinned = None if args.no_pin else pin_to_gpu_local_cpus(torch, local_rank, world, gpu_of)
     reduce_dev = dev
-    if world > 1:
+    # MSD_BENCH_FORCE_DIST=1: one rank takes the N > 1 branch (process group, barrier, reductions, gather), so that the RCCL
+    # leg of this script has run on a one-GPU box before it runs on eight (tests/test_gpu_bench_rccl_one_rank.py)
+    distributed = world > 1 or os.environ.get("MSD_BENCH_FORCE_DIST", "") not in ("", "0")
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -227,7 +230,7 @@ def main():
         return counts.get(k - 1, 0)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +261,7 @@ def main():
     my_ms_per_step = elapsed * 1e3 / max(1, args.steps)
     per_rank = [{"rank": rank, "ms_per_step": my_ms_per_step, "seed": seed, "device": device_index, "messages": nmsg,
                  "cpus": (pinned or {}).get("cpu_list")}]
-    if world > 1:  # every rank's own time, capture and placement, beside the MAX / SUM the contract asks for
+    if distributed:  # every rank's own time, capture and placement, beside the MAX / SUM the contract asks for
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
@@ -360,7 +363,7 @@ def main():
         "settle_ms_per_pass": settle_log,  # untimed single passes before the warm-up, by half second (rank 0)
         "host_placement": ({k: v for k, v in pinned.items() if k != "cpu_list"} if pinned else "process affinity left as found"),
         "ranks": [{k: (("%d-%d" % (v[0], v[-1])) if k == "cpus" and v else v) for k, v in r.items()} for r in per_rank],
-        "dist_backend": args.dist_backend if world > 1 else None,
+        "dist_backend": args.dist_backend if distributed else None,
         "host_threads_per_rank": "2 busy (caller: polls events, replays filter changes, queues kernels; helper: copies the "
                                  "records, power statistics) + an idle pool for the host resolver",
         "resolve_stage": ("gpu, %.2f passes per batch, %d batches handed to the host resolver"
@@ -533,7 +536,7 @@ def main():
         out["also"] = [run_also(["--format", "sc16", "--samples", str(1 << 28)]), run_also(["--mode-ac", "--fix", "1"])]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -160,7 +160,10 @@ __device__ __forceinline__ void swap16(uint32_t &a, uint32_t &b)
     asm("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-template <bool PRE>
+/* VAR 0: the high product takes the shifted low product as its C operand, the compiler's order; 1: the same, all three
+ * low products of a block issued first, then the shifts, then the three high products, then the verdicts (the order
+ * pinned with scheduling barriers); 2: low and high products independent, value = (D_high << 8) + D_low on the vector ALU */
+template <bool PRE, int VAR>
 __device__ __forceinline__ void tests_mfma(const uint16_t *mags, int lane, const FirConsts &C, uint32_t (&pl)[NH][3])
 {
     const int n = lane & 15, g = lane >> 4;
@@ -174,16 +177,53 @@ __device__ __forceinline__ void tests_mfma(const uint16_t *mags, int lane, const
             const int m35 = col[32];
             const v4i B = {(int)(raw.x ^ 0x80808080u), (int)(raw.y ^ 0x80808080u), (int)(raw.z ^ 0x80808080u), (int)(raw.w ^ 0x80808080u)};
             uint32_t x = 0;
+            if (VAR == 0) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][0], B, C.cinit[t], 0, 0, 0);
-                int l3;
-                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(l3) : "v"(m35), "v"(C.mu), "v"(lo[3]));
-                const v4i q = {lo[0] >> 8, lo[1] >> 8, lo[2] >> 8, l3 >> 8};
-                const v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][1], B, q, 0, 0, 0);
+                for (int t = 0; t < 3; ++t) {
+                    v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][0], B, C.cinit[t], 0, 0, 0);
+                    const int l3 = __mul24(m35, C.mu) + lo[3]; /* (not inline asm: hipcc pads no MFMA hazard in front of an asm statement) */
+                    const v4i q = {lo[0] >> 8, lo[1] >> 8, lo[2] >> 8, l3 >> 8};
+                    const v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][1], B, q, 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    x = __builtin_amdgcn_alignbit(x, (uint32_t)hi[c], 31);
+                    for (int c = 0; c < 4; ++c)
+                        x = __builtin_amdgcn_alignbit(x, (uint32_t)hi[c], 31);
+                }
+            } else if (VAR == 1) {
+                v4i lo[3], hi[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    lo[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][0], B, C.cinit[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int l3 = __mul24(m35, C.mu) + lo[t][3];
+                    const v4i q = {lo[t][0] >> 8, lo[t][1] >> 8, lo[t][2] >> 8, l3 >> 8};
+                    hi[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][1], B, q, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        x = __builtin_amdgcn_alignbit(x, (uint32_t)hi[t][c], 31);
+            } else {
+                v4i lo[3], hi[3];
+                const v4i zero = {0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    lo[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][0], B, C.cinit[t], 0, 0, 0);
+                    hi[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[t][1], B, zero, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int l3 = __mul24(m35, C.mu) + lo[t][3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int v = (hi[t][c] << 8) + (c == 3 ? l3 : lo[t][c]);
+                        x = __builtin_amdgcn_alignbit(x, (uint32_t)v, 31);
+                    }
+                }
             }
             X[b] = x; /* bits 11..8: test 0 of rows 4 g .. 4 g + 3, 7..4: test 1, 3..0: test 2 */
         }
@@ -228,7 +268,9 @@ __device__ __forceinline__ void tests_mfma(const uint16_t *mags, int lane, const
     }
 }
 
-/* MODE 0: vector ALU, 1: matrix pipe + VALU pre-check, 2: matrix pipe, tests only (no pre-check: what the pipe costs) */
+/* MODE 0: vector ALU, 1: matrix pipe + VALU pre-check, 2: matrix pipe, tests only (no pre-check: what the pipe costs),
+ * 3 / 4: mode 2 in the orders VAR 1 / 2, 5: mode 1 in the order VAR 1, 6: 24 independent MFMAs per run and nothing else
+ * (the pipe's issue rate) */
 template <int MODE>
 __global__ void __launch_bounds__(1024) fir_kernel(const uint16_t *in, uint32_t *out, int iters, FirParams F, int waves_per_wg)
 {
@@ -250,8 +292,25 @@ __global__ void __launch_bounds__(1024) fir_kernel(const uint16_t *in, uint32_t 
         uint32_t pl[NH][3];
         if (MODE == 0)
             tests_valu(mags, lane, F.thr, pl);
-        else
-            tests_mfma<MODE == 1>(mags, lane, C, pl);
+        else if (MODE == 6) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(mags + 16 * lane + 8 * (it & 7));
+            const v4i B = {(int)raw.x, (int)raw.y, (int)raw.z, (int)raw.w};
+            v4i d[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                d[k] = C.cinit[k % 3];
+#pragma unroll
+            for (int r = 0; r < 2 * 24 / 6; ++r)
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    d[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(C.a[k % 3][k / 3], B, d[k], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    pl[h][t] = (uint32_t)(d[3 * h + t][0] ^ d[3 * h + t][1] ^ d[3 * h + t][2] ^ d[3 * h + t][3]);
+        } else
+            tests_mfma<MODE == 1 || MODE == 5, MODE == 3 || MODE == 5 ? 1 : MODE == 4 ? 2 : 0>(mags, lane, C, pl);
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -315,6 +374,21 @@ static int run(const uint16_t *d_in, uint32_t *d_out, int wgs, int waves, int it
     return 0;
 }
 
+static int run_mode(int mode, const uint16_t *d_in, uint32_t *d_out, int wgs, int waves, int iters, FirParams F, float *ms)
+{
+    switch (mode) {
+    case 0: return run<0>(d_in, d_out, wgs, waves, iters, F, ms);
+    case 1: return run<1>(d_in, d_out, wgs, waves, iters, F, ms);
+    case 2: return run<2>(d_in, d_out, wgs, waves, iters, F, ms);
+    case 3: return run<3>(d_in, d_out, wgs, waves, iters, F, ms);
+    case 4: return run<4>(d_in, d_out, wgs, waves, iters, F, ms);
+    case 5: return run<5>(d_in, d_out, wgs, waves, iters, F, ms);
+    default: return run<6>(d_in, d_out, wgs, waves, iters, F, ms);
+    }
+}
+static const char *const MODE_NAMES[7] = {"vector ALU (MSD_TESTS_V2)", "matrix pipe + VALU pre-check", "matrix pipe, tests only", "tests only, phased order",
+                                          "tests only, independent products", "phased order + VALU pre-check", "48 bare MFMAs per tile"};
+
 int main(int argc, char **argv)
 {
     const int wgs = argc > 1 ? atoi(argv[1]) : 256;
@@ -358,30 +432,44 @@ int main(int argc, char **argv)
                 printf("thr %d: w = %d does not fit a signed byte -- vector-ALU form only\n", thr, F.w);
                 continue;
             }
-            for (int mode = 0; mode < 3; ++mode) {
+            for (int mode = 0; mode < 6; ++mode) {
                 float ms;
                 CK(hipMemset(d_out, 0, h_out.size() * 4));
-                if (mode == 0 ? run<0>(d_in, d_out, wgs, waves, 1, F, &ms) : mode == 1 ? run<1>(d_in, d_out, wgs, waves, 1, F, &ms) : run<2>(d_in, d_out, wgs, waves, 1, F, &ms))
+                if (run_mode(mode, d_in, d_out, wgs, waves, 1, F, &ms))
                     return 1;
                 CK(hipMemcpy(h_out.data(), d_out, h_out.size() * 4, hipMemcpyDeviceToHost));
                 long bad = 0, npos = 0, npass = 0;
+                long by_q[16] = {0}, by_lg[4] = {0}, by_h[2] = {0}, by_t[3] = {0};
                 const int shift = mode == 0 ? 0 : SHIFT;
                 for (size_t wv = 0; wv < nw; ++wv)
                     for (int h = 0; h < NH; ++h)
                         for (int l = 0; l < 64; ++l)
                             for (int q = 0; q < 16; ++q) {
                                 const int j = 1024 * h + 16 * l + shift + q;
-                                const int want = ref_verdicts(h_in.data() + wv * MAGS_N, j, thr, mode != 2);
+                                const int want = ref_verdicts(h_in.data() + wv * MAGS_N, j, thr, mode < 2 || mode == 5);
                                 int got = 0;
                                 for (int t = 0; t < 3; ++t)
                                     got |= (int)((h_out[((wv * NH + h) * 64 + l) * 3 + t] >> (15 - q)) & 1u) << t;
                                 /* (iteration 0 adds it = 0 to the planes: acc = planes) */
                                 bad += got != want;
+                                if (got != want) {
+                                    ++by_q[q];
+                                    ++by_lg[l >> 4];
+                                    ++by_h[h];
+                                    for (int t = 0; t < 3; ++t)
+                                        by_t[t] += ((got ^ want) >> t) & 1;
+                                }
                                 npass += want != 0;
                                 ++npos;
                             }
                 printf("parity  data %-44s thr %3d (u %2d w %3d)  %-28s: %ld of %ld positions differ (%ld pass)\n", dnames[dk], thr, F.u, F.w,
-                       mode == 0 ? "vector ALU (MSD_TESTS_V2)" : mode == 1 ? "matrix pipe + VALU pre-check" : "matrix pipe, tests only", bad, npos, npass);
+                       MODE_NAMES[mode], bad, npos, npass);
+                if (bad && total_bad == 0) {
+                    printf("   first failing case, mismatches by q:");
+                    for (int q = 0; q < 16; ++q)
+                        printf(" %ld", by_q[q]);
+                    printf("\n   by lane >> 4: %ld %ld %ld %ld   by run: %ld %ld   by test: %ld %ld %ld\n", by_lg[0], by_lg[1], by_lg[2], by_lg[3], by_h[0], by_h[1], by_t[0], by_t[1], by_t[2]);
+                }
                 total_bad += bad;
             }
         }
@@ -399,11 +487,11 @@ int main(int argc, char **argv)
     FirParams F = {58, 16, 29, 15};
     const double clk = prop.clockRate * 1e3;
     for (int wv : {16, 12, 8, 4}) {
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
                 float ms;
-                if (mode == 0 ? run<0>(d_in, d_out, wgs, wv, timing_iters, F, &ms) : mode == 1 ? run<1>(d_in, d_out, wgs, wv, timing_iters, F, &ms) : run<2>(d_in, d_out, wgs, wv, timing_iters, F, &ms))
+                if (run_mode(mode, d_in, d_out, wgs, wv, timing_iters, F, &ms))
                     return 1;
                 if (ms < best)
                     best = ms;
@@ -414,7 +502,7 @@ int main(int argc, char **argv)
             const double cyc = best * 1e-3 * clk / groups_per_simd;
             const double per_128mi = best * (134217728.0 / ((double)wgs * wv * timing_iters * WT));
             printf("timing  %2d waves/CU  %-28s: %.4f ms for %d tiles per wavefront = %.1f SIMD cycles per 64 positions; tests of a 128 Mi-sample launch on %d CUs: %.4f ms\n",
-                   wv, mode == 0 ? "vector ALU (MSD_TESTS_V2)" : mode == 1 ? "matrix pipe + VALU pre-check" : "matrix pipe, tests only", best, timing_iters, cyc, wgs, per_128mi);
+                   wv, MODE_NAMES[mode], best, timing_iters, cyc, wgs, per_128mi);
         }
     }
     return 0;

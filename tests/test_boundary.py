@@ -12,11 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "readsb-protobuf_amd", "csrc")
 
 
-def build_check(tmp_path):
+def build_check(tmp_path, libdir=CSRC):
     exe = str(tmp_path / "boundary_check")
     subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "boundary_check.c"), "-o", exe, "-L" + CSRC, "-lmsd_host",
-                           "-lmodes_hip", "-Wl,-rpath," + CSRC, "-lpthread", "-lm"])
+                           os.path.join(ROOT, "tests", "c", "boundary_check.c"), "-o", exe, "-L" + libdir, "-lmsd_host",
+                           "-lmodes_hip", "-Wl,-rpath," + libdir, "-lpthread", "-lm"])
     return exe
 
 
@@ -39,7 +39,7 @@ def test_boundary_is_pinned_on_the_references_own_header_text(pkg, tmp_path):
 
 
 def test_boundary_compiles_against_reference_style_declarations_and_runs(pkg, tmp_path):
-    exe = build_check(tmp_path)
+    exe = build_check(tmp_path, os.path.dirname(pkg.capi.LIB_PATH))   # (a sanitizer build when tests/test_sanitizers.py runs this)
     capture = tmp_path / "tiny.uc8"
     np.full(2 * 4096, 127, dtype=np.uint8).tofile(capture)
     out = subprocess.run([exe, str(capture)], capture_output=True, text=True, timeout=120)

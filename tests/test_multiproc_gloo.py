@@ -48,3 +48,29 @@ def test_two_ranks_independent_captures():
 
 def test_reduce_is_identity_without_process_group(pkg):
     assert pkg.sharding.reduce_job(1.25, 7, 100) == (1.25, 7, 100)
+
+
+def _one_rank_group(port, q):
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    q.put(pkg.sharding.reduce_job(1.25, 7, 100))
+    dist.destroy_process_group()
+
+
+def test_a_group_of_one_rank_goes_through_the_collectives(pkg):
+    """bench.py's MSD_BENCH_FORCE_DIST leg: with a process group of one rank the reductions still run (and give the rank's own numbers)."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_group, args=(port, q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(60)
+    assert got == (1.25, 7, 100) and p.exitcode == 0
