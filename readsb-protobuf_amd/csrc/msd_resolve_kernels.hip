@@ -244,14 +244,15 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
     S.nsamples = P.nsamples;
     constexpr uint32_t PER = MSD_POWER_PER, NW = RT / 64;
     constexpr uint32_t BPS = (FMT == MSD_FMT_SC16 || FMT == MSD_FMT_SC16Q11) ? 4 : 2;
-    static_assert(MSD_RB_MSG_CAP <= 128 * NW, "two records per lane");
+    constexpr uint32_t QN = (MSD_RB_MSG_CAP + 64 * NW - 1) / (64 * NW); /* records per lane: two for eight wavefronts, four for four */
+    static_assert(QN == 2 || QN == 4, "two or four records per lane");
     const int lane = tid & 63;
     const uint32_t wave = (uint32_t)(tid >> 6);
     if (wave >= nm)
         return;
-    uint32_t rpos[2], rlen[2];
+    uint32_t rpos[QN], rlen[QN];
 #pragma unroll
-    for (uint32_t q = 0; q < 2; ++q) {
+    for (uint32_t q = 0; q < QN; ++q) {
         const uint32_t m = wave + ((uint32_t)lane + 64u * q) * NW;
         const msd_acc rec = acc[m < nm ? m : wave];
         rpos[q] = rec.pos;
@@ -263,11 +264,16 @@ __device__ inline void power_of_accepted(const MsdResolveParams &P, const msd_ac
         bool inside = true;
 #pragma unroll
         for (uint32_t u = 0; u < PER; ++u) {
-            const uint32_t q = q0 + u; /* < 128 + PER: past the last record the lengths are zero */
-            const uint32_t p0 = __builtin_amdgcn_readlane(rpos[0], q & 63u), p1 = __builtin_amdgcn_readlane(rpos[1], q & 63u);
-            const uint32_t l0 = __builtin_amdgcn_readlane(rlen[0], q & 63u), l1 = __builtin_amdgcn_readlane(rlen[1], q & 63u);
-            pos[u] = q < 64u ? p0 : p1;
-            len[u] = q < 64u ? l0 : (q < 128u ? l1 : 0u);
+            const uint32_t q = q0 + u; /* < 64 QN + PER: past the last record the lengths are zero */
+            uint32_t pu = 0, lu = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < QN; ++k) {
+                const uint32_t pk = __builtin_amdgcn_readlane(rpos[k], q & 63u), lk = __builtin_amdgcn_readlane(rlen[k], q & 63u);
+                pu = (q >> 6) == k ? pk : pu;
+                lu = (q >> 6) == k ? lk : lu;
+            }
+            pos[u] = q < 64u * QN ? pu : __builtin_amdgcn_readlane(rpos[QN - 1], q & 63u);
+            len[u] = lu;
             const int64_t rel0 = (int64_t)pos[u] - (int64_t)MSD_OVERLAP + 19;
             inside = inside && rel0 >= 0 && rel0 + (int64_t)len[u] <= (int64_t)S.nsamples;
         }
@@ -567,18 +573,21 @@ __global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const 
         /* the sums of the wavefronts in front of mine, chunk by chunk: every wavefront runs the same 40-entry scan in
          * its lanes (eight lanes a chunk; both counts in one word, neither reaches 2^16) and picks its two numbers per
          * chunk out with v_readlane */
-        static_assert(RT / 64 == 8 && MAXC * 8 <= 64, "one lane per chunk and wavefront");
+        constexpr int NWV = RT / 64; /* wavefronts per workgroup: 8, or 4 for the slim workgroup that fits beside a scan workgroup */
+        static_assert((NWV == 8 || NWV == 4) && MAXC * NWV <= 64, "one lane per chunk and wavefront");
         uint32_t cw_incl, cw_excl;
         {
-            const uint32_t x = (tid & 63) < MAXC * 8 ? (&sh_cw[0][0])[tid & 63] : 0u;
+            const uint32_t x = (tid & 63) < MAXC * NWV ? (&sh_cw[0][0])[tid & 63] : 0u;
             uint32_t incl = x;
             {
                 const uint32_t u1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false); /* row_shr:1 */
-                incl += (tid & 7) >= 1 ? u1 : 0u;
+                incl += (tid & (NWV - 1)) >= 1 ? u1 : 0u;
                 const uint32_t u2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
-                incl += (tid & 7) >= 2 ? u2 : 0u;
-                const uint32_t u4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
-                incl += (tid & 7) >= 4 ? u4 : 0u;
+                incl += (tid & (NWV - 1)) >= 2 ? u2 : 0u;
+                if (NWV == 8) {
+                    const uint32_t u4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+                    incl += (tid & 7) >= 4 ? u4 : 0u;
+                }
             }
             cw_incl = incl;
             cw_excl = incl - x;
@@ -589,7 +598,7 @@ __global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const 
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             keep_d[c] = ~0u;
-            const uint32_t tot = __builtin_amdgcn_readlane(cw_incl, 8 * c + 7), mine = __builtin_amdgcn_readlane(cw_excl, 8 * c + wave);
+            const uint32_t tot = __builtin_amdgcn_readlane(cw_incl, NWV * c + NWV - 1), mine = __builtin_amdgcn_readlane(cw_excl, NWV * c + wave);
             const uint32_t ch = tot & 0xffffu, ct = tot >> 16; /* hits with tries / tries of the chunk ... */
             const uint32_t bh = mine & 0xffffu, bt = mine >> 16; /* ... and of the wavefronts in front of mine */
             const uint64_t v = s0 + (uint64_t)c * RT + tid;
