@@ -52,6 +52,7 @@ def parse():
                     help="diff the GPU message list against the oracle even without the CPU baseline leg (it is on by "
                          "default whenever the baseline replays the whole capture)")
     ap.add_argument("--no-check", action="store_true", help="skip the message-set diff against the oracle")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the replay-tool runs of the literal mag_buf path (about 15 s, 10 of them in real time)")
     ap.add_argument("--mode-ac", action="store_true", help="BASELINE configs[4]: Mode A/C demodulator on, 500 replies/s")
     ap.add_argument("--fields", action="store_true",
                     help="MSD_CFG_DECODE_FIELDS: also decode header and extended squitter fields of every message")
@@ -528,6 +529,74 @@ def main():
             del bufs
         except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
             out["pcie_inclusive"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dcfilter:
+        # ---- one lone capture, start to finish: the steady-state figure above is K passes chained by msd_restart(); a single
+        # file costs the pipeline's fill and drain as well ----
+        try:
+            lone = []
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_steps(1)
+                torch.cuda.synchronize()
+                lone.append((time.perf_counter() - t0) * 1e3)
+            out["single_capture_ms"] = {"value": round(min(lone), 3), "all": [round(x, 3) for x in lone], "samples": n,
+                                        "msamples_per_s": round(n / min(lone) / 1e3, 1),
+                                        "what": "msd_restart, every batch of the capture launched and collected, device idle before and after"}
+        except Exception as e:  # noqa: BLE001
+            out["single_capture_ms"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_dropin and args.format == "uc8" and not args.dcfilter:
+        # ---- the path north_star names: "keeping the sdr.h / fifo.h mag_buf interface so it drops in behind --ifile" -- the
+        # replay tool (readsb's part: option keys, hooks, the ifile handler) on a 10 s capture file (BASELINE configs[0]: 24 M
+        # samples), once through the literal mag_buf path (iq_convert_fn per 131072-sample block, FIFO, demodulate2400(struct
+        # mag_buf *) on the consumer thread; readsb.c:820-855, sdr_ifile.c:164-237), once through the fused path, and the
+        # mag_buf path again in real time (--throttle, sdr_ifile.c:218-226): per-buffer latency and missed deadlines ----
+        import subprocess
+        import tempfile
+        exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "msd_replay")
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        cap = os.path.join(tmpdir, "msd_bench_capture_%d.uc8" % os.getpid())
+        dropin = {"capture": "first %d samples (10 s at 2.4 MSPS) of the benchmark capture, as a file" % min(n, 24_000_000)}
+        try:
+            iq[: 2 * min(n, 24_000_000)].tofile(cap)
+            base_args = [exe, "--ifile", cap, "--iformat", "uc8", "--no-output", "--timing", "--device", str(device_index),
+                         "--preamble-threshold", str(args.threshold)] + (["--fix"] if args.fix == 1 else ["--aggressive"] if args.fix == 2 else ["--no-fix"]) + \
+                        (["--modeac"] if args.mode_ac else [])
+
+            def replay(extra, timeout):
+                best = None
+                for rep in range(1 if "--throttle" in extra else 3):
+                    res = subprocess.run(base_args + extra, capture_output=True, text=True, timeout=timeout)
+                    line = [l for l in res.stderr.splitlines() if l.startswith("{")]
+                    if res.returncode != 0 or not line:
+                        return {"error": (res.stderr or "no timing line")[-300:]}
+                    d = json.loads(line[-1])
+                    if best is None or d["wall_s"] < best["wall_s"]:
+                        best = d
+                return best
+            m = replay(["--path", "magbuf"], 600)
+            dropin["magbuf"] = m if "error" in m else {
+                "value": m["msamples_per_s"], "unit": "Msamples/s", "wall_s": m["wall_s"], "buffers": m["buffers"], "messages": m["messages"],
+                "demodulate2400_us_per_buffer": {"p50": m["demod_us_p50"], "p99": m["demod_us_p99"], "max": m["demod_us_max"]},
+                "iq_convert_fn_us_per_buffer": {"p50": m["convert_us_p50"], "p99": m["convert_us_p99"]},
+                "what": "msd_replay --path magbuf: reader thread (read, iq_convert_fn on the GPU, fifo_enqueue) + consumer thread "
+                        "(fifo_dequeue, demodulate2400(struct mag_buf *) on the GPU, fifo_release), best of 3"}
+            f = replay(["--path", "fused"], 600)
+            dropin["fused"] = f if "error" in f else {"value": f["msamples_per_s"], "unit": "Msamples/s", "wall_s": f["wall_s"], "messages": f["messages"],
+                                                      "what": "msd_replay --path fused: the same handler, 64 buffers per msd_launch_host, best of 3"}
+            t = replay(["--path", "magbuf", "--throttle"], 120)
+            dropin["magbuf_throttle"] = t if "error" in t else {
+                "wall_s": t["wall_s"], "buffers": t["buffers"], "deadline_misses": t["deadline_misses"], "buffer_period_ms": round(131072 / 2400.0, 2),
+                "release_to_messages_us": {"p50": t["latency_us_p50"], "p99": t["latency_us_p99"], "max": t["latency_us_max"]},
+                "what": "the same path paced like a live receiver (--throttle): from fifo_enqueue of a buffer to its last message at the sink"}
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+            dropin["error"] = repr(e)[:200]
+        finally:
+            try:
+                os.unlink(cap)
+            except OSError:
+                pass
+        out["dropin_magbuf"] = dropin
     if rank == 0 and world == 1 and not args.no_also and not args.no_cpu_baseline and args.format == "uc8" and \
             not (args.mode_ac or args.fields or args.dcfilter or args.fix) and n == 1 << 29:
         # BASELINE configs[2] and configs[4] at full size, after the clock stopped, each against the oracle

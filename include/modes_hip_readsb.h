@@ -184,6 +184,22 @@ void msd_ifileSetOptionKeys(int name_key, int format_key, int throttle_key, int 
 void msd_ifileSetHooks(const msd_ifile_hooks *hooks);
 void msd_ifileSetReceiver(const msd_receiver_options *opt);
 int msd_ifileGetStats(msd_stats *st);
+/* What the last msd_ifileRun cost, on the host's clock (CLOCK_MONOTONIC).  "Buffer" = one 131072-sample block of the
+ * reader loop (sdr_ifile.c:192-216).  MSD_IFILE_MAGBUF: convert_us is the iq_convert_fn call (upload, conversion,
+ * magnitudes and means back), demod_us the demodulate2400-shaped call on the consumer thread (readsb.c:846-851).
+ * MSD_IFILE_FUSED with --throttle: demod_us is msd_launch_host + msd_collect of the buffer.  latency_us: from the moment
+ * a buffer was released to the demodulator (fifo_enqueue / the pacer's deadline) to its last message handed to the sink;
+ * deadline_misses: buffers that were not through by the time the next one was due (one buffer period = 54.6 ms at
+ * 2.4 MSPS) -- meaningful under --throttle only.  Percentiles over at most the first 65536 buffers. */
+typedef struct msd_ifile_timing {
+    uint64_t buffers, samples;
+    double wall_s;
+    double convert_us_p50, convert_us_p99;
+    double demod_us_p50, demod_us_p99, demod_us_max;
+    double latency_us_p50, latency_us_p99, latency_us_max;
+    uint64_t deadline_misses;
+} msd_ifile_timing;
+int msd_ifileGetTiming(msd_ifile_timing *t);
 const char *msd_ifileLastError(void);
 
 #ifdef __cplusplus

@@ -40,6 +40,13 @@ static void print_net_raw(const msd_message *mm, void *user)
     g_count++;
 }
 
+static void count_only(const msd_message *mm, void *user)
+{
+    (void)mm;
+    (void)user;
+    g_count++;
+}
+
 static void write_beast(const msd_message *mm, void *user)
 {
     uint8_t frame[MSD_BEAST_MAX];
@@ -63,7 +70,7 @@ int main(int argc, char **argv)
     rx.batch_buffers = 64;
     rx.sink = print_raw;
     rx.sink_user = stdout;
-    int want_stats = 0;
+    int want_stats = 0, want_timing = 0;
 
     const msd_ifile_hooks hooks = {host_should_exit, NULL, host_at_eof, NULL};
     msd_ifileSetOptionKeys(OptIfileName, OptIfileFormat, OptIfileThrottle, OptIfilePath);
@@ -86,6 +93,8 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--dcfilter")) rx.dc_filter = 1; /* readsb.c:486 */
         else if (!strcmp(a, "--mlat")) g_mlat = 1;
         else if (!strcmp(a, "--stats")) want_stats = 1;
+        else if (!strcmp(a, "--timing")) want_timing = 1; /* one JSON line on stderr: what the run cost (msd_ifileGetTiming) */
+        else if (!strcmp(a, "--no-output")) rx.sink = count_only;
         else if (!strcmp(a, "--net-raw")) rx.sink = print_net_raw;
         else if (!strcmp(a, "--beast")) rx.sink = write_beast;
         else if (!strcmp(a, "--raw") || !strcmp(a, "--quiet")) { /* this tool only has the raw dump */ }
@@ -99,7 +108,7 @@ int main(int argc, char **argv)
             ++i;
         } else {
             fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] [--dcfilter] "
-                            "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast] [--stats] [--path fused|magbuf] "
+                            "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast|--no-output] [--stats] [--timing] [--throttle] [--path fused|magbuf] "
                             "[--device N] [--sc16q11-table-bits N]\n");
             return 2;
         }
@@ -115,6 +124,15 @@ int main(int argc, char **argv)
     clock_gettime(CLOCK_MONOTONIC, &run1);
     if (want_stats) /* how long the reader ran: in signal time under --throttle (sdr_ifile.c:218-226) */
         fprintf(stderr, "run_seconds %.3f\n", (double)(run1.tv_sec - run0.tv_sec) + 1e-9 * (double)(run1.tv_nsec - run0.tv_nsec));
+    if (want_timing) {
+        msd_ifile_timing t;
+        if (msd_ifileGetTiming(&t) == 0)
+            fprintf(stderr, "{\"buffers\": %" PRIu64 ", \"samples\": %" PRIu64 ", \"messages\": %" PRIu64 ", \"wall_s\": %.6f, \"msamples_per_s\": %.1f, "
+                            "\"convert_us_p50\": %.1f, \"convert_us_p99\": %.1f, \"demod_us_p50\": %.1f, \"demod_us_p99\": %.1f, \"demod_us_max\": %.1f, "
+                            "\"latency_us_p50\": %.1f, \"latency_us_p99\": %.1f, \"latency_us_max\": %.1f, \"deadline_misses\": %" PRIu64 "}\n",
+                    t.buffers, t.samples, g_count, t.wall_s, t.wall_s > 0 ? (double)t.samples / t.wall_s * 1e-6 : 0.0, t.convert_us_p50, t.convert_us_p99,
+                    t.demod_us_p50, t.demod_us_p99, t.demod_us_max, t.latency_us_p50, t.latency_us_p99, t.latency_us_max, t.deadline_misses);
+    }
     if (msd_ifileLastError()[0])
         fprintf(stderr, "%s\n", msd_ifileLastError());
     if (!g_exit) { /* readsb.c:279-281: a reader that returns without the exit flag set is an abnormal exit */

@@ -6,6 +6,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +28,7 @@ static struct {
     msd_receiver_options rx;
     msd_ctx *ctx;
     char err[256];
-    volatile int exit_flag;
+    atomic_int exit_flag; /* the reader tells the consumer thread that the queue has been drained (ThreadSanitizer found the plain int it was) */
     /* magbuf mode: the converter of msd_init_converter (convert.h:40-43) and its state, like sdr_ifile.c:58-68 */
     msd_iq_convert_fn converter;
     struct converter_state *converter_state;
@@ -35,7 +36,91 @@ static struct {
     pthread_mutex_t mu;
     pthread_cond_t idle;
     int in_flight;
+    /* msd_ifileGetTiming: per-buffer clocks of the last run (reader writes release_ns / convert_us of buffer k before it
+     * hands the buffer over, the consumer reads them after it took it: ordered by the FIFO's mutex) */
+    struct run_clock {
+        uint64_t buffers, samples, misses;
+        double wall_s;
+        uint64_t *release_ns; /* [TIMING_CAP] */
+        float *convert_us, *demod_us, *latency_us;
+        uint64_t nconv, ndemod;
+    } T;
 } F;
+
+enum { TIMING_CAP = 65536 };
+
+static uint64_t now_ns(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+static void timing_reset(void)
+{
+    struct run_clock *T = &F.T;
+    if (!T->release_ns) {
+        T->release_ns = calloc(TIMING_CAP, sizeof *T->release_ns);
+        T->convert_us = calloc(TIMING_CAP, sizeof *T->convert_us);
+        T->demod_us = calloc(TIMING_CAP, sizeof *T->demod_us);
+        T->latency_us = calloc(TIMING_CAP, sizeof *T->latency_us);
+    }
+    T->buffers = T->samples = T->misses = T->nconv = T->ndemod = 0;
+    T->wall_s = 0;
+}
+
+/* buffer k (in delivery order) is through: its demodulate call took `demod_ns`, its messages are with the sink now */
+static void timing_done(uint64_t k, uint64_t demod_ns, uint64_t now, uint64_t samples)
+{
+    struct run_clock *T = &F.T;
+    T->buffers++;
+    T->samples += samples;
+    if (!T->release_ns || k >= TIMING_CAP)
+        return;
+    const uint64_t lat = now - T->release_ns[k];
+    T->demod_us[k] = (float)(demod_ns * 1e-3);
+    T->latency_us[k] = (float)(lat * 1e-3);
+    T->ndemod = k + 1;
+    if ((double)lat > (double)MSD_CHUNK_SAMPLES * 1e9 / 2400000.0)
+        T->misses++;
+}
+
+static int cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+static void percentiles(float *v, uint64_t n, double *p50, double *p99, double *pmax)
+{
+    *p50 = *p99 = 0;
+    if (pmax)
+        *pmax = 0;
+    if (!n)
+        return;
+    qsort(v, n, sizeof *v, cmp_float);
+    *p50 = v[n / 2];
+    *p99 = v[(n * 99) / 100 < n ? (n * 99) / 100 : n - 1];
+    if (pmax)
+        *pmax = v[n - 1];
+}
+
+int msd_ifileGetTiming(msd_ifile_timing *t)
+{
+    struct run_clock *T = &F.T;
+    if (!t || !T->release_ns)
+        return -EINVAL;
+    memset(t, 0, sizeof *t);
+    t->buffers = T->buffers;
+    t->samples = T->samples;
+    t->wall_s = T->wall_s;
+    t->deadline_misses = T->misses;
+    percentiles(T->convert_us, T->nconv, &t->convert_us_p50, &t->convert_us_p99, NULL);
+    percentiles(T->demod_us, T->ndemod, &t->demod_us_p50, &t->demod_us_p99, &t->demod_us_max);
+    percentiles(T->latency_us, T->ndemod, &t->latency_us_p50, &t->latency_us_p99, &t->latency_us_max);
+    T->nconv = T->ndemod = 0; /* (sorted in place: one reading per run) */
+    return 0;
+}
 
 /* what describes the host program rather than a run: survives msd_ifileInitConfig */
 static struct {
@@ -209,16 +294,20 @@ static size_t read_fully(char *dst, size_t want)
 static void *magbuf_consumer(void *arg)
 {
     (void)arg;
+    uint64_t k = 0;
     for (;;) {
         struct msd_mag_buf *buf = msd_fifo_dequeue(100);
         if (!buf) {
-            if (F.exit_flag)
+            if (atomic_load(&F.exit_flag))
                 break;
             continue;
         }
+        const uint64_t t0 = now_ns();
         int rc = msd_demodulate_magbuf(F.ctx, buf->data, buf->validLength, buf->overlap, buf->sampleTimestamp,
                                        buf->sysTimestamp, buf->mean_level, buf->mean_power, F.rx.sink,
                                        F.rx.sink_user);
+        const uint64_t t1 = now_ns();
+        timing_done(k++, t1 - t0, t1, buf->validLength - buf->overlap);
         msd_fifo_release(buf);
         pthread_mutex_lock(&F.mu); /* (F.err is written by the reader thread too: under the lock) */
         if (rc)
@@ -237,12 +326,12 @@ static void run_magbuf(void)
         return;
     }
     pthread_t consumer;
-    F.exit_flag = 0;
+    atomic_store(&F.exit_flag, 0);
     pthread_mutex_init(&F.mu, NULL);
     pthread_cond_init(&F.idle, NULL);
     F.in_flight = 0;
     pthread_create(&consumer, NULL, magbuf_consumer, NULL);
-    uint64_t sample_counter = 0;
+    uint64_t sample_counter = 0, kbuf = 0;
     bool eof = false;
     msd_pacer pacer;
     msd_pacer_start(&pacer, 2400000.0); /* Modes.sample_rate, readsb.c:195 */
@@ -259,8 +348,13 @@ static void run_magbuf(void)
         if (got < want)
             eof = true;
         const unsigned samples = (unsigned)(got / F.bytes_per_sample);
+        const uint64_t c0 = now_ns();
         F.converter(F.readbuf, &out->data[out->overlap], samples, F.converter_state, &out->mean_level,
                     &out->mean_power); /* sdr_ifile.c:214 */
+        if (kbuf < TIMING_CAP) {
+            F.T.convert_us[kbuf] = (float)((now_ns() - c0) * 1e-3);
+            F.T.nconv = kbuf + 1;
+        }
         out->validLength = out->overlap + samples;
         out->flags = 0;
         pthread_mutex_lock(&F.mu);
@@ -270,6 +364,9 @@ static void run_magbuf(void)
         pthread_mutex_unlock(&F.mu);
         if (F.throttle)
             msd_pacer_wait(&pacer, samples); /* sdr_ifile.c:218-226: wait until this buffer may be released */
+        if (kbuf < TIMING_CAP)
+            F.T.release_ns[kbuf] = now_ns();
+        ++kbuf;
         msd_fifo_enqueue(out);
         /* The converter owns a GPU context of its own (msd_init_converter), the consumer demodulates on F.ctx:
          * the next block is read and converted while this one is demodulated, as the reference's reader and
@@ -279,7 +376,7 @@ static void run_magbuf(void)
         sample_counter += samples;
     }
     msd_fifo_drain();
-    F.exit_flag = 1;
+    atomic_store(&F.exit_flag, 1);
     pthread_join(consumer, NULL);
     msd_fifo_destroy();
 }
@@ -317,9 +414,14 @@ static void run_fused(void)
             int rc = 0;
             if (F.throttle) {
                 msd_pacer_wait(&pacer, samples);
+                const uint64_t t0 = now_ns();
+                if (k - 1 < TIMING_CAP)
+                    F.T.release_ns[k - 1] = t0;
                 rc = msd_launch_host(F.ctx, buf, samples, eof ? 1 : 0);
                 if (!rc)
                     rc = msd_collect(F.ctx, F.rx.sink, F.rx.sink_user);
+                const uint64_t t1 = now_ns();
+                timing_done(k - 1, t1 - t0, t1, samples);
                 if (rc) {
                     snprintf(F.err, sizeof F.err, "submit: %s", msd_last_error(F.ctx));
                     goto out;
@@ -354,10 +456,20 @@ void msd_ifileRun(void)
 {
     if (F.fd < 0 || !F.ctx)
         return;
+    timing_reset();
+    const uint64_t w0 = now_ns();
     if (F.mode == MSD_IFILE_MAGBUF)
         run_magbuf();
     else
         run_fused();
+    F.T.wall_s = (double)(now_ns() - w0) * 1e-9;
+    if (!F.T.samples) { /* the unthrottled fused loop does not clock single buffers */
+        msd_stats st;
+        if (msd_get_stats(F.ctx, &st) == 0) {
+            F.T.buffers = st.buffers;
+            F.T.samples = st.samples_processed;
+        }
+    }
     if (G.hooks.at_eof)
         G.hooks.at_eof(); /* Modes.exit = 1, sdr_ifile.c:236 */
 }

@@ -1742,7 +1742,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
         }
         s.d_iq = reinterpret_cast<const uint8_t *>(s.d_dcmag);
     } else if (c->q11_bits) { /* convert_sc16q11_table: the scan runs on its magnitudes and its integer sums are the converter's */
-        rc = msd_launch_q11_table(d_iq, nsamples, c->d_q11_table, c->q11_bits, s.d_dcmag, nullptr, c->stream);
+        rc = msd_launch_q11_table(d_iq, nsamples, c->d_q11_table, c->q11_bits, s.d_dcmag, nullptr, c->cu_count, c->stream);
         if (rc) {
             s.busy = false;
             return fail(c, rc, "SC16Q11 table converter launch failed");
@@ -2516,7 +2516,7 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
     if (nsamples) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
         int rc = c->q11_bits ? msd_launch_q11_table(c->d_stage, nsamples, c->d_q11_table, c->q11_bits, c->d_mag,
-                                                    reinterpret_cast<unsigned long long *>(s.d_sums), c->stream)
+                                                    reinterpret_cast<unsigned long long *>(s.d_sums), c->cu_count, c->stream)
                              : msd_launch_convert(c->cfg.format, c->d_stage, nsamples, c->d_lut, c->d_mag,
                                                   reinterpret_cast<unsigned long long *>(s.d_sums), c->stream);
         if (rc)

@@ -185,7 +185,7 @@ int msd_launch_ac(const MsdScanParams *p, int format, const uint64_t *d_sums, co
 /* SC16Q11 through the table of a -DSC16Q11_TABLE_BITS reference (convert.c:264-328): IQ -> u16 magnitudes; d_sums (or NULL)
  * receives the level / power sums the converter entry reports */
 int msd_launch_q11_table(const void *d_iq, uint64_t nsamples, const uint16_t *d_table, int bits, uint16_t *d_mag,
-                         unsigned long long *d_sums, hipStream_t stream);
+                         unsigned long long *d_sums, int cu_count, hipStream_t stream);
 int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const uint16_t *d_lut,
                        uint16_t *d_mag, unsigned long long *d_sums, hipStream_t stream);
 /* --dcfilter: IQ -> DC-blocked u16 magnitudes + f32 squares, the converter state (z1_I, z1_Q, device

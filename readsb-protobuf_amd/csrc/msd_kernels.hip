@@ -3178,32 +3178,28 @@ __global__ void __launch_bounds__(LDS_TABLE ? 1024 : 256) msd_q11_table_kernel(c
 }
 
 extern "C" int msd_launch_q11_table(const void *d_iq, uint64_t nsamples, const uint16_t *d_table, int bits, uint16_t *d_mag,
-                                    unsigned long long *d_sums, hipStream_t stream)
+                                    unsigned long long *d_sums, int cu_count, hipStream_t stream)
 {
     if (!nsamples)
         return 0;
     if (bits < 1 || bits > 11)
         return -22;
     const uint64_t ngroups = (nsamples + 7) / 8;
-    if (bits <= 8 && ngroups >= 4096) {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-                return -5;
-            cus = prop.multiProcessorCount;
-        }
+    /* the table in the LDS (one copy per compute unit, up to 128 KB at 8 bits) where the device grants that much to a
+     * workgroup; otherwise -- a smaller or a shared part, or the attribute call refused -- the instantiation that reads it
+     * through the caches.  cu_count is the context's (the device the stream belongs to), not a process-wide guess. */
+    if (bits <= 8 && ngroups >= 4096 && cu_count > 0) {
         const size_t lds = ((size_t)2 << (2 * bits)) < 16 ? 16 : ((size_t)2 << (2 * bits));
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_q11_table_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return -5;
-        uint64_t blocks = (ngroups + 1023) / 1024;
-        if (blocks > (uint64_t)cus)
-            blocks = (uint64_t)cus;
-        hipLaunchKernelGGL(msd_q11_table_kernel<true>, dim3((uint32_t)blocks), dim3(1024), lds, stream, static_cast<const uint8_t *>(d_iq),
-                           nsamples, d_table, bits, d_mag, d_sums);
-        return hipGetLastError() == hipSuccess ? 0 : -5;
+                                (int)lds) == hipSuccess) {
+            uint64_t blocks = (ngroups + 1023) / 1024;
+            if (blocks > (uint64_t)cu_count)
+                blocks = (uint64_t)cu_count;
+            hipLaunchKernelGGL(msd_q11_table_kernel<true>, dim3((uint32_t)blocks), dim3(1024), lds, stream, static_cast<const uint8_t *>(d_iq),
+                               nsamples, d_table, bits, d_mag, d_sums);
+            return hipGetLastError() == hipSuccess ? 0 : -5;
+        }
+        (void)hipGetLastError(); /* refused: not an error of this launch */
     }
     uint64_t blocks = (ngroups + 255) / 256;
     if (blocks > 8192)
