@@ -54,7 +54,7 @@ typedef struct msd_config {
                                      Tests provoke the overflow path (a batch rescanned in pieces) with small values; a
                                      receiver short of device memory can run at 1000 */
     int32_t test_inline_adds;     /* tests: at most this many entries in a buffer's short add list (< MSD_RB_ADD_INLINE);
-                                     0 = all of them */
+                                     0 = all of them, negative = none (every add through the long list) */
     int32_t debug_flags;          /* kernel ablations for timing experiments (results are then incomplete): 1 stop after the
                                      preamble tests, 2 after the conversion, 4 no step B, 64 / 128 record writers without
                                      their stores / altogether */
@@ -99,9 +99,6 @@ typedef struct msd_message {
 #define MSD_CFG_REPASS_AUX (1 << 14)       /* repeated resolve passes on the high-priority side stream */
 #define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records fetched with a copy instead of written by the kernels */
 #define MSD_CFG_TRACE (1 << 16)            /* per-batch host timings on stderr (experiments) */
-#define MSD_CFG_DEFER_TAILS (1 << 17)      /* side streams: the float sums' apply walk and the Mode A/C gather head the batch's
-                                              resolve chain instead of following its scan (measured: 2 % slower, the chain
-                                              has no slack either) */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums

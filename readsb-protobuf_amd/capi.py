@@ -67,7 +67,7 @@ CFG_DECODE_FIELDS = 1
 CFG_DC_FILTER = 2
 CFG_HOST_RESOLVE, CFG_CHAIN_IN_ORDER, CFG_CHAIN_SIDE_STREAMS, CFG_NO_LEAN, CFG_NO_RESOLVE_AHEAD = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 CFG_POWER_KERNEL, CFG_POWER_IN_RESOLVE, CFG_EMIT_KERNEL, CFG_WAIT_INPUTS_ON_STREAM = 1 << 9, 1 << 10, 1 << 11, 1 << 12
-CFG_NO_HELPER, CFG_REPASS_AUX, CFG_RECORDS_DMA, CFG_TRACE, CFG_DEFER_TAILS = 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17
+CFG_NO_HELPER, CFG_REPASS_AUX, CFG_RECORDS_DMA, CFG_TRACE = 1 << 13, 1 << 14, 1 << 15, 1 << 16
 
 
 def layout_from_environment():
@@ -89,8 +89,7 @@ def layout_from_environment():
     if e("MSD_EMIT_FUSED", "1") == "0":
         flags |= CFG_EMIT_KERNEL
     for name, bit in (("MSD_WAIT_INPUTS_ON_STREAM", CFG_WAIT_INPUTS_ON_STREAM), ("MSD_NO_HELPER", CFG_NO_HELPER),
-                      ("MSD_REPASS_AUX", CFG_REPASS_AUX), ("MSD_RESOLVE_TRACE", CFG_TRACE),
-                      ("MSD_DEFER_TAILS", CFG_DEFER_TAILS)):
+                      ("MSD_REPASS_AUX", CFG_REPASS_AUX), ("MSD_RESOLVE_TRACE", CFG_TRACE)):
         if e(name) is not None:
             flags |= bit
     if e("MSD_RECORDS_DMA", "0") not in ("0", ""):

@@ -219,11 +219,6 @@ struct Slot {
     void *d_fm_work = nullptr;       /* 16-bit IQ, --dcfilter: the float-sum kernels' hand-over (msd_fm_work_bytes) */
     msd_ac_hit *d_ac_regions = nullptr; /* Mode A/C: the candidate kernel's region slices and counts, gathered into d_ac */
     msd_wg_counts *d_ac_counts = nullptr;
-    /* MSD_CFG_DEFER_TAILS: latency-bound tail kernels of the batch -- the float sums' apply walk, the Mode A/C gather -- that
-     * were left off the scan stream: gpu_begin() puts them at the head of the batch's resolve chain (side streams), where
-     * they run beside the next batch's kernels instead of in front of its scan. */
-    bool fm_apply_pending = false, ac_gather_pending = false;
-    int ac_format_pending = 0;
     uint32_t *d_rec_off = nullptr;   /* [max_buffers + 2] records in front of each buffer's (power kernel) */
     uint32_t *d_buf_first = nullptr; /* [max_buffers + 2] start of each buffer's hits in d_hits (gather kernel) */
     bool buf_first_valid = false;
@@ -656,19 +651,13 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
     } else if (s.timed) {
         HIPCHK(c, hipEventRecord(s.ev_scan, c->stream));
     }
-    /* what may wait for the head of the batch's resolve chain (see Slot::fm_apply_pending; MSD_CFG_DEFER_TAILS): only a batch
-     * whose totals and sums nobody reads before its first resolve pass (lean), resolved on side streams; Mode A/C needs the
-     * sums at once.  Off by default: 37 us of apply walk / 10 us of gather leave the scan stream, but the chain they now head
-     * has to be through before the scan after next, and it is not -- SC16 198.6 against 203.4, Mode A/C 251.0 against 256.7 */
-    const bool defer_tails = pipelined && s.lean && s.gpu_resolve && !c->chain_inline && (c->cfg.flags & MSD_CFG_DEFER_TAILS);
-    s.fm_apply_pending = s.ac_gather_pending = false;
     if (fm && s.nbuffers) {
-        const int fm_phase = defer_tails && !c->cfg.mode_ac && msd_fm_deferrable(s.d_fm_work, MSD_CHUNK_SAMPLES, s.nbuffers) ? 1 : 0;
-        s.fm_apply_pending = fm_phase == 1;
-        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, s.d_fm_work, fm_phase, c->stream)
+        /* (the apply walk and the Mode A/C gather stay on the scan stream: deferred to the head of the batch's resolve chain
+         * they were 2 % slower, LABLOG R4.5; the variant is scripts/experiments/r4_defer_tails.patch) */
+        int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, s.d_fm_work, 0, c->stream)
                       : msd_launch_float_means(format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
                                                nwg && msd_scan_tile(format) == 1024 ? s.d_tile_sums : nullptr,
-                                               s.d_fm_work, fm_phase, c->stream);
+                                               s.d_fm_work, 0, c->stream);
         if (rc)
             return fail(c, rc, "float means kernel launch failed");
     }
@@ -687,12 +676,10 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
             p.have_prev = s.have_prev && s.d_mag_prev;
             p.ragged = reinterpret_cast<const uint8_t *>(s.d_mag + (s.nsamples & ~7ull)); /* zeros behind the last sample */
         }
-        s.ac_gather_pending = defer_tails && host_noise == nullptr;
-        s.ac_format_pending = ac_format;
         int rc = msd_launch_ac(&p, ac_format, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise,
                                host_noise != nullptr ? 1 : ((s.dc || (s.mag_pass && fm)) ? 2 : 0), /* (16-bit IQ: the float sums, whatever the pass reads) */
                                s.d_ac_regions, c->ac_arena, s.d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac,
-                               c->ac_arena, c->ac_max_wg, s.ac_gather_pending ? 1 : 0, c->stream);
+                               c->ac_arena, c->ac_max_wg, 0, c->stream);
         if (rc)
             return fail(c, rc, "Mode A/C kernel launch failed");
     }
@@ -1114,29 +1101,6 @@ void apply_dropped(msd_ctx *c, Slot &s)
     s.dropped_before = 0;
 }
 
-/* the batch's tail kernels enqueue() left out (Slot::fm_apply_pending), on `stream`, which is behind the batch's kernels */
-int launch_deferred_tails(msd_ctx *c, Slot &s, hipStream_t stream)
-{
-    if (s.fm_apply_pending) {
-        s.fm_apply_pending = false;
-        const int rc = s.dc ? msd_launch_dc_sums(s.d_magsq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans, s.d_fm_work, 2, stream)
-                            : msd_launch_float_means(c->scan_format, s.d_iq, s.nsamples, MSD_CHUNK_SAMPLES, s.nbuffers, s.d_fmeans,
-                                                     nullptr, s.d_fm_work, 2, stream);
-        if (rc)
-            return fail(c, rc, "float means apply kernel launch failed");
-    }
-    if (s.ac_gather_pending) {
-        s.ac_gather_pending = false;
-        MsdScanParams p{};
-        p.nsamples = s.nsamples; /* all the gather's launch geometry depends on */
-        const int rc = msd_launch_ac(&p, s.ac_format_pending, s.d_sums, s.d_fmeans, s.nbuffers, c->d_noise, 0, s.d_ac_regions, c->ac_arena,
-                                     s.d_ac_counts, c->d_ac_offsets, s.d_ac_totals, s.d_ac, c->ac_arena, c->ac_max_wg, 2, stream);
-        if (rc)
-            return fail(c, rc, "Mode A/C gather kernel launch failed");
-    }
-    return 0;
-}
-
 int gpu_begin(msd_ctx *c, Slot &s, int format)
 {
     apply_dropped(c, s);
@@ -1165,9 +1129,6 @@ int gpu_begin(msd_ctx *c, Slot &s, int format)
         if (&nx != &s && nx.busy && nx.launch_seq == s.launch_seq + 1 && nx.ev_scanned && nx.nsamples >= MSD_CHUNK_SAMPLES)
             HIPCHK(c, hipStreamWaitEvent(ks, nx.ev_scanned, 0));
     }
-    rc = launch_deferred_tails(c, s, ks);
-    if (rc)
-        return rc;
     rc = gpu_queue_pass(c, s, ks, true);
     if (!rc) {
         HIPCHK(c, hipEventRecord(s.ev_resolve, ks));
@@ -2141,6 +2102,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         c->records_dma = (cfg->flags & MSD_CFG_RECORDS_DMA) != 0;
         if (cfg->test_inline_adds > 0 && (uint32_t)cfg->test_inline_adds < MSD_RB_ADD_INLINE)
             c->inline_adds = (uint32_t)cfg->test_inline_adds;
+        else if (cfg->test_inline_adds < 0)
+            c->inline_adds = 0; /* every add through the long list */
     }
     /* (every layout: UC8 / magnitudes in order, 16-bit IQ and Mode A/C with the chain on side streams) */
     c->lean_ok = c->gpu_resolve && !c->dc && !(cfg->flags & MSD_CFG_NO_LEAN);

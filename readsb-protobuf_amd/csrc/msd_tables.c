@@ -221,7 +221,6 @@ int msd_fix2_diagnose(int bits, uint32_t syndrome, int bit[2])
     }
 }
 
-/* Checks the folding identity the kernels rely on; returns the number of mismatching slots. */
 /* init_sc16q11_lookup, convert.c:271-295: entry ((i >> lose) << bits) | (q >> lose) for i, q = 0, 2^lose, ... < 2048 */
 void msd_sc16q11_table_build(int bits, uint16_t *out)
 {
@@ -238,6 +237,7 @@ void msd_sc16q11_table_build(int bits, uint16_t *out)
         }
 }
 
+/* Checks the folding identity the kernels rely on; returns the number of mismatching slots. */
 int msd_tables_selftest(const msd_tables *t)
 {
     int bad = 0;

@@ -40,11 +40,9 @@ def test_bounded_slice_of_the_randomised_sweep():
 @pytest.mark.parametrize("env", [{"MSD_CHAIN_INLINE": "0"}, {"MSD_CHAIN_INLINE": "1"}, {"MSD_EMIT_FUSED": "0"},
                                  {"MSD_NO_HELPER": "1"}, {"MSD_LEAN": "0"}, {"MSD_RESOLVE_AHEAD": "0"},
                                  {"MSD_POWER_FUSED": "0", "MSD_CHAIN_INLINE": "1"}, {"MSD_POWER_FUSED": "1", "MSD_CHAIN_INLINE": "0"},
-                                 {"MSD_WAIT_INPUTS_ON_STREAM": "1"}, {"MSD_LEAN": "0", "MSD_RESOLVE_AHEAD": "0", "MSD_POWER_FUSED": "0"},
-                                 {"MSD_DEFER_TAILS": "1", "MSD_CHAIN_INLINE": "0"}],
+                                 {"MSD_WAIT_INPUTS_ON_STREAM": "1"}, {"MSD_LEAN": "0", "MSD_RESOLVE_AHEAD": "0", "MSD_POWER_FUSED": "0"}],
                          ids=["side-streams", "in-order", "record-kernel", "no-helper", "gather-kernel", "no-resolve-ahead",
-                              "power-kernel-in-order", "power-in-resolve-side-streams", "stream-waits-for-inputs", "round-2-layout",
-                              "tails-head-the-chain"])
+                              "power-kernel-in-order", "power-in-resolve-side-streams", "stream-waits-for-inputs", "round-2-layout"])
 @pytest.mark.parametrize("mode", ["uc8", "uc8-ac-fix", "sc16"])
 def test_every_stream_layout_gives_the_same_messages(pkg, oracle, torch_cuda, monkeypatch, env, mode):
     """The stream layouts of DESIGN.md 4.6 (chain in order with the records written by the next scan, chain on

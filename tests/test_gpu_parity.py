@@ -232,12 +232,14 @@ def test_gpu_resolve_overlaps_and_new_aircraft(pkg, oracle, torch_cuda, resolve_
                         n_aircraft=aircraft, msgs_per_sec=6000, overlap_permille=overlap, flip_permille=50)
 
 
-def test_gpu_resolve_long_add_lists(pkg, oracle, torch_cuda, resolve_stage, monkeypatch):
+@pytest.mark.parametrize("inline_adds", ["40", "-1"], ids=["forty-inline", "none-inline"])
+def test_gpu_resolve_long_add_lists(pkg, oracle, torch_cuda, resolve_stage, monkeypatch, inline_adds):
     """More unique addresses in one buffer than a per-buffer report holds inline (232; 40 here, the
-    synthetic traffic peaks near 150): the complete add lists are fetched instead."""
+    synthetic traffic peaks near 150 -- or none at all: msd_config.test_inline_adds < 0): the complete add
+    lists are fetched instead."""
     if resolve_stage != "gpu-resolve":
         pytest.skip("GPU resolve only")
-    monkeypatch.setenv("MSD_RESOLVE_INLINE_ADDS", "40")
+    monkeypatch.setenv("MSD_RESOLVE_INLINE_ADDS", inline_adds)
     got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, 8 * 131072, seed=12, nfix=0, n_aircraft=1000,
                         msgs_per_sec=8000, overlap_permille=0)
     assert dem.timing()["resolve_long_lists"] >= 1, dem.timing()
