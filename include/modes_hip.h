@@ -63,6 +63,10 @@ typedef struct msd_config {
                                      2^(2n)-entry table of the top n of 11 bits of |I| and |Q|, integer sums.  1..11; 0 = the
                                      float path (convert_sc16q11_nodc).  Ignored with MSD_CFG_DC_FILTER, as the reference's
                                      selection does (convert.c:425-444) */
+    int32_t reserved0;            /* 0 */
+    double sample_rate;           /* MSD_CFG_DC_FILTER: Modes.sample_rate for the DC block's constant, dc_b = exp(-2 pi / rate),
+                                     convert.c:479-482 (init_converter's argument; readsb.c:195 sets 2.4e6).  0 = 2 400 000.
+                                     The demodulator itself is demodulate2400: its timestamps assume 2.4 MSPS whatever this says */
 } msd_config;
 
 /* The part of struct modesMessage (readsb.h:340-547) the demodulator determines; this is what
@@ -382,6 +386,10 @@ void msd_host_free(msd_ctx *ctx, void *p);
 /* The counters of everything collected so far (the order-sensitive power statistics of the last batch are summed on
  * a helper thread after msd_collect() has returned: this call waits for them). */
 int msd_get_stats(const msd_ctx *ctx, msd_stats *st);
+/* The size of the context's candidate arenas in thousandths of the base size: 4000 by default, 1000 when msd_create ran
+ * out of device memory at the default size and fell back to the base size (it retries once), or what
+ * msd_config.test_arena_permille asked for. */
+int msd_arena_permille(const msd_ctx *ctx);
 int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
 /* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
  * fifo.h:70-71): 2 doubles per buffer, up to cap buffers; returns the number of buffers. */

@@ -42,7 +42,8 @@ typedef void (*msd_iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned ns
 #endif
 
 /* init_converter (convert.h:40-43, convert.c:446-491): returns the converter for `format` and a state
- * for it, or NULL (no GPU; unknown format; filter_dc with a sample_rate other than 2.4 MHz).  The returned
+ * for it, or NULL (no GPU; unknown format; filter_dc without a sample_rate).  With filter_dc the DC block's constant is
+ * exp(-2 pi / sample_rate) for whatever rate the host passes (convert.c:479-482), not only Modes.sample_rate.  The returned
  * function converts on the GPU and writes magnitudes and means bit-identical to convert_uc8_nodc /
  * convert_sc16_nodc / convert_sc16q11_nodc (convert.c:63-111,215-253,332-370) -- convert_sc16q11_table
  * (:264-328) after msd_converter_set_sc16q11_table_bits -- or, with filter_dc, to the convert_*_generic
@@ -55,9 +56,12 @@ void msd_cleanup_converter(struct converter_state *state); /* convert.h:45 */
 /* the GPU device the next msd_init_converter uses (default 0); the context behind a state, for callers
  * that want to demodulate with the same one (msd_demodulate_magbuf); the last error text or "" */
 void msd_converter_set_device(int device);
-/* the SC16Q11_TABLE_BITS of the build being replaced: init_converter(INPUT_SC16Q11, ..., 0, ...) then hands out the table
- * converter (convert.c:437-438), as the reference's does.  0 (default): the float path. */
-void msd_converter_set_sc16q11_table_bits(int bits);
+/* the SC16Q11_TABLE_BITS of the build being replaced -- a compile-time constant of the reference, so a property of the
+ * host program here too: the one process-wide setting of this layer (with the device number above), read when a converter
+ * is made and kept in its state from then on.  init_converter(INPUT_SC16Q11, ..., 0, ...) then hands out the table converter
+ * (convert.c:437-438), as the reference's does.  0 (default): the float path.  Returns 0, or -EINVAL for a value outside
+ * 0..11 (nothing changes then; msd_ifileOpen and the replay tool report it). */
+int msd_converter_set_sc16q11_table_bits(int bits);
 msd_ctx *msd_converter_context(struct converter_state *state);
 const char *msd_converter_error(const struct converter_state *state);
 

@@ -117,6 +117,8 @@ class Config(C.Structure):
         ("test_inline_adds", C.c_int32),
         ("debug_flags", C.c_int32),
         ("sc16q11_table_bits", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("sample_rate", C.c_double),
     ]
 
 
@@ -181,6 +183,7 @@ EXPORTS = [
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
+    "msd_arena_permille",
 ]
 
 _lib = None
@@ -291,6 +294,10 @@ class Demodulator:
             self.close()
         except Exception:
             pass
+
+    def arena_permille(self):
+        """Candidate arenas in thousandths of the base size: 4000, or 1000 after msd_create's out-of-memory retry."""
+        return int(lib().msd_arena_permille(self._h))
 
     @property
     def bytes_per_sample(self):

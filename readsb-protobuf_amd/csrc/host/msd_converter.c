@@ -19,9 +19,12 @@ struct converter_state {
 static int g_device = 0;
 static int g_q11_bits = 0;
 
-void msd_converter_set_sc16q11_table_bits(int bits)
+int msd_converter_set_sc16q11_table_bits(int bits)
 {
-    g_q11_bits = bits >= 1 && bits <= 11 ? bits : 0;
+    if (bits < 0 || bits > 11)
+        return -EINVAL; /* (used to become 0, the float path, silently -- while the fused path refused the same value) */
+    g_q11_bits = bits;
+    return 0;
 }
 
 void msd_converter_set_device(int device)
@@ -73,8 +76,8 @@ msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_ra
     case 2: fmt = MSD_FMT_SC16Q11; break; /* INPUT_SC16Q11 */
     default: return NULL;                 /* "no suitable converter", convert.c:466-470 */
     }
-    if (filter_dc && sample_rate != 2400000.0)
-        return NULL; /* the DC block's constant is worked out for Modes.sample_rate = 2.4 MHz (convert.c:479-482) */
+    if (filter_dc && !(sample_rate >= 1.0))
+        return NULL; /* dc_b = exp(-2 pi / sample_rate), convert.c:479-482, needs a rate */
     struct converter_state *st = calloc(1, sizeof *st);
     if (!st)
         return NULL;
@@ -82,8 +85,10 @@ msd_iq_convert_fn msd_init_converter(msd_input_format_t format, double sample_ra
     memset(&cfg, 0, sizeof cfg);
     cfg.device = g_device;
     cfg.format = fmt;
-    if (filter_dc) /* convert_*_generic: the state (z1_I, z1_Q) is the context's, carried from call to call (convert.c:28-33) */
+    if (filter_dc) { /* convert_*_generic: the state (z1_I, z1_Q) is the context's, carried from call to call (convert.c:28-33) */
         cfg.flags |= MSD_CFG_DC_FILTER;
+        cfg.sample_rate = sample_rate; /* the DC block's constant follows the caller's rate, as init_converter's does */
+    }
     cfg.sc16q11_table_bits = (fmt == MSD_FMT_SC16Q11 && !filter_dc) ? g_q11_bits : 0; /* #if defined(SC16Q11_TABLE_BITS), convert.c:437 */
     cfg.preamble_threshold = 58; /* the converter does not demodulate; msd_set_preamble_threshold etc. apply */
     cfg.nfix_crc = 1;

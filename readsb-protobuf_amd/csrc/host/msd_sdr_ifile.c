@@ -247,7 +247,11 @@ bool msd_ifileOpen(void)
         /* the literal drop-in: the converter comes from init_converter's twin (sdr_ifile.c:150-153) and
          * keeps its own state; the demodulator's context is created below, as for the fused path */
         msd_converter_set_device(F.rx.device);
-        msd_converter_set_sc16q11_table_bits(F.rx.sc16q11_table_bits);
+        if (msd_converter_set_sc16q11_table_bits(F.rx.sc16q11_table_bits)) {
+            snprintf(F.err, sizeof F.err, "ifile: SC16Q11 table bits %d outside 0..11", F.rx.sc16q11_table_bits);
+            msd_ifileClose();
+            return false;
+        }
         F.converter = msd_init_converter((msd_input_format_t)(F.format == MSD_FMT_UC8 ? 0 : F.format == MSD_FMT_SC16 ? 1 : 2),
                                          2400000.0, F.rx.dc_filter, &F.converter_state);
         if (!F.converter) {

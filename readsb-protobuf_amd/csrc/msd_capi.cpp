@@ -1881,7 +1881,7 @@ void msd_array_sink(const msd_message *mm, void *state)
     st->count++;
 }
 
-int msd_create(const msd_config *cfg, msd_ctx **out)
+static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_memory)
 {
     if (!cfg || !out)
         return -EINVAL;
@@ -1889,7 +1889,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     if (cfg->format < MSD_FMT_UC8 || cfg->format > MSD_FMT_MAG16 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
         cfg->preamble_threshold < 1 || cfg->preamble_threshold > MSD_MAX_PREAMBLE_THRESHOLD ||
         ((cfg->flags & MSD_CFG_DC_FILTER) && cfg->format == MSD_FMT_MAG16) || cfg->sc16q11_table_bits < 0 ||
-        cfg->sc16q11_table_bits > 11 || (cfg->sc16q11_table_bits && cfg->format != MSD_FMT_SC16Q11)) {
+        cfg->sc16q11_table_bits > 11 || (cfg->sc16q11_table_bits && cfg->format != MSD_FMT_SC16Q11) ||
+        !(cfg->sample_rate >= 0.0) || (cfg->sample_rate > 0.0 && cfg->sample_rate < 1.0)) {
         snprintf(g_create_err, sizeof g_create_err, "msd_create: invalid configuration");
         return -EINVAL;
     }
@@ -1913,8 +1914,8 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     c->q11_bits = (!c->dc && cfg->format == MSD_FMT_SC16Q11) ? cfg->sc16q11_table_bits : 0;
     c->scan_format = (c->dc || c->q11_bits) ? (int)MSD_FMT_MAG16 : cfg->format;
     c->scan_bps = bps_of(c->scan_format);
-    if (c->dc) { /* init_converter's "DC block @ 1Hz", convert.c:479-482, at Modes.sample_rate = 2.4 MHz */
-        c->dc_b = (float)exp(-2.0 * M_PI * 1.0 / 2400000.0);
+    if (c->dc) { /* init_converter's "DC block @ 1Hz", convert.c:479-482, at its sample_rate argument (Modes.sample_rate = 2.4 MHz) */
+        c->dc_b = (float)exp(-2.0 * M_PI * 1.0 / (cfg->sample_rate > 0.0 ? cfg->sample_rate : 2400000.0));
         c->dc_a = (float)(1.0 - c->dc_b);
     }
 
@@ -1923,6 +1924,9 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
         hipError_t e_ = (call);                                               \
         if (e_ != hipSuccess) {                                               \
             snprintf(g_create_err, sizeof g_create_err, "msd_create: %s: %s", #call, hipGetErrorString(e_)); \
+            if (e_ == hipErrorOutOfMemory)                                    \
+                *out_of_memory = true;                                        \
+            (void)hipGetLastError();                                          \
             destroy(c);                                                       \
             return -EIO;                                                      \
         }                                                                     \
@@ -2160,6 +2164,30 @@ int msd_create(const msd_config *cfg, msd_ctx **out)
     msd_resolver_reset(&c->resolver);
     *out = c;
     return 0;
+}
+
+int msd_create(const msd_config *cfg, msd_ctx **out)
+{
+    bool oom = false;
+    int rc = create_context(cfg, out, &oom);
+    if (rc && oom && cfg->test_arena_permille == 0) {
+        /* The default candidate arenas are four times the base size (108 bytes per sample of max_batch_samples over
+         * the four pipeline slots).  On a smaller or a shared GPU that may not fit where the base size does: one more
+         * try at the base size -- the only price is an earlier arena overflow (a batch rescanned in pieces) on captures
+         * that are mostly preamble -- and the context says so (msd_arena_permille). */
+        msd_config smaller = *cfg;
+        smaller.test_arena_permille = 1000;
+        oom = false;
+        rc = create_context(&smaller, out, &oom);
+    }
+    return rc;
+}
+
+int msd_arena_permille(const msd_ctx *ctx)
+{
+    if (!ctx)
+        return -EINVAL;
+    return ctx->cfg.test_arena_permille > 0 ? ctx->cfg.test_arena_permille : 4000;
 }
 
 void msd_destroy(msd_ctx *ctx)

@@ -43,7 +43,7 @@ def dc_block(f, sample_rate=2.4e6):
     return out
 
 
-def convert(fmt, raw, dc=False):
+def convert(fmt, raw, dc=False, sample_rate=2.4e6):
     """-> (uint16 magnitudes, per-sample level terms, per-sample power terms, float sums?); the terms are what the
     converter sums (convert.c:63-111 integers for UC8 without --dcfilter; floats for every other converter)."""
     if fmt == "uc8" and not dc:
@@ -57,7 +57,7 @@ def convert(fmt, raw, dc=False):
         s = np.frombuffer(raw, dtype="<i2").reshape(-1, 2).astype(np.float32)
         f = s / np.float32(32768.0 if fmt == "sc16" else 2048.0)
     if dc:
-        f = dc_block(f)
+        f = dc_block(f, sample_rate)
     magsq = (f[:, 0] * f[:, 0]).astype(np.float32) + (f[:, 1] * f[:, 1]).astype(np.float32)
     magsq = np.minimum(magsq.astype(np.float32), np.float32(1.0))
     magf = np.sqrt(magsq, dtype=np.float32)

@@ -86,3 +86,13 @@ def test_bad_configuration_is_rejected(pkg):
             setattr(cfg, k, v)
         assert lib.msd_create(C.byref(cfg), C.byref(h)) == -errno.EINVAL
     assert lib.msd_create(None, C.byref(h)) == -errno.EINVAL
+
+
+def test_sc16q11_table_bits_outside_the_range_are_refused(pkg):
+    """The reference's SC16Q11_TABLE_BITS is a compile-time constant; the setter that stands for it says -EINVAL for a value
+    no build could have (it used to fall back to the float path silently, while msd_create refused the same value)."""
+    host = C.CDLL(os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "libmsd_host.so"))
+    host.msd_converter_set_sc16q11_table_bits.restype = C.c_int
+    assert host.msd_converter_set_sc16q11_table_bits(12) == -errno.EINVAL
+    assert host.msd_converter_set_sc16q11_table_bits(-1) == -errno.EINVAL
+    assert host.msd_converter_set_sc16q11_table_bits(8) == 0 and host.msd_converter_set_sc16q11_table_bits(0) == 0

@@ -295,3 +295,23 @@ def test_dc_filter_converter_carries_its_state_from_call_to_call(pkg, oracle, to
     if fmt == "uc8":
         nodc = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=CHUNK).convert(iq[:CHUNK * bps], CHUNK)[0]
         assert not np.array_equal(nodc, first_mags)   # the block did find the offset
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["uc8", "sc16"])
+def test_dc_filter_converter_at_another_sample_rate(pkg, torch_cuda, fmt):
+    """init_converter derives dc_b = exp(-2 pi / sample_rate) from whatever rate it is given (convert.c:479-482), not only
+    from Modes.sample_rate: msd_config.sample_rate = 2.0 MHz against the second reading's converter at that rate (numpy
+    float32, tests/indep_demod.py) -- magnitudes bit for bit -- and the 2.4 MHz converter must differ from it."""
+    import indep_demod
+    f = pkg.FMT_UC8 if fmt == "uc8" else pkg.FMT_SC16
+    bps = 2 if fmt == "uc8" else 4
+    n = 20000
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=616, fmt=f, msgs_per_sec=3000), n)
+    if fmt == "uc8":
+        iq = np.clip(iq.astype(np.int32) + np.tile(np.array([11, -7]), n), 0, 255).astype(np.uint8)
+    got = pkg.Demodulator(fmt=f, max_batch_samples=CHUNK, dc_filter=True, sample_rate=2.0e6).convert(iq[:n * bps], n)[0][:n]
+    want = indep_demod.convert(fmt, iq[:n * bps].tobytes(), dc=True, sample_rate=2.0e6)[0]
+    assert np.array_equal(got, want)
+    at_2400 = pkg.Demodulator(fmt=f, max_batch_samples=CHUNK, dc_filter=True).convert(iq[:n * bps], n)[0][:n]
+    assert np.array_equal(at_2400, indep_demod.convert(fmt, iq[:n * bps].tobytes(), dc=True)[0]) and not np.array_equal(at_2400, got)
