@@ -382,6 +382,12 @@ int msd_decode_fields_device(msd_ctx *ctx, const msd_message *msgs, size_t n, ms
 int msd_launch_host(msd_ctx *ctx, const void *h_iq, uint64_t nsamples, int last);
 int msd_host_alloc(msd_ctx *ctx, size_t bytes, void **out); /* page-locked host memory */
 void msd_host_free(msd_ctx *ctx, void *p);
+/* Page-lock memory the host program owns already -- the mag_buf FIFO's sample arrays (fifo.c:74-77 allocates them with
+ * malloc), the reader's block buffer -- so that the copies behind msd_convert / msd_demodulate_magbuf are DMA transfers
+ * instead of staged ones (a 256 KB block: 100 -> 50 us, and two threads' copies no longer queue behind one staging
+ * buffer).  Optional: unregistered memory works, slower.  Unregister before the memory is freed. */
+int msd_host_register(msd_ctx *ctx, void *p, size_t bytes);
+void msd_host_unregister(msd_ctx *ctx, void *p);
 
 /* The counters of everything collected so far (the order-sensitive power statistics of the last batch are summed on
  * a helper thread after msd_collect() has returned: this call waits for them). */

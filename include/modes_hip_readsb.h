@@ -107,6 +107,8 @@ struct msd_mag_buf *msd_fifo_acquire(uint32_t timeout_ms);                      
 void msd_fifo_enqueue(struct msd_mag_buf *buf);                                      /* fifo.h:111 */
 struct msd_mag_buf *msd_fifo_dequeue(uint32_t timeout_ms);                           /* fifo.h:117 */
 void msd_fifo_release(struct msd_mag_buf *buf);                                      /* fifo.h:120 */
+/* (not in fifo.h) where all the buffers' samples lie, for a host that wants to page-lock them (msd_host_register) */
+void msd_fifo_memory(void **base, size_t *bytes);
 
 /* ------------------------------------------------------------------------------------------ */
 /* "ifile" SDR front-end (sdr.c:41-50,78-98; sdr_ifile.c)                                     */

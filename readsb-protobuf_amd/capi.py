@@ -183,7 +183,7 @@ EXPORTS = [
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
-    "msd_arena_permille",
+    "msd_arena_permille", "msd_host_register", "msd_host_unregister",
 ]
 
 _lib = None

@@ -58,6 +58,16 @@ static void wait_for(const bool *stop, const unsigned *len, uint32_t ms)
             break;
 }
 
+void msd_fifo_memory(void **base, size_t *bytes)
+{
+    pthread_mutex_lock(&Q.mu);
+    if (base)
+        *base = Q.ready ? Q.samples : NULL;
+    if (bytes)
+        *bytes = Q.ready ? (size_t)Q.count * Q.size * sizeof *Q.samples : 0;
+    pthread_mutex_unlock(&Q.mu);
+}
+
 /* A buffer index back onto the unused stack (mutex held).  A buffer that is already there, or that is still
  * queued, is a caller bug (double release / release of a queued buffer): ignored instead of growing the stack
  * past its allocation. */

@@ -329,6 +329,12 @@ static void run_magbuf(void)
         snprintf(F.err, sizeof F.err, "Out of memory allocating FIFO");
         return;
     }
+    /* page-lock what the two threads hand to the GPU: the FIFO's sample arrays and the block buffer (msd_host_register) */
+    void *fifo_mem = NULL;
+    size_t fifo_bytes = 0;
+    msd_fifo_memory(&fifo_mem, &fifo_bytes);
+    const bool fifo_pinned = fifo_mem && msd_host_register(F.ctx, fifo_mem, fifo_bytes) == 0;
+    const bool read_pinned = msd_host_register(F.ctx, F.readbuf, F.readbuf_bytes) == 0;
     pthread_t consumer;
     atomic_store(&F.exit_flag, 0);
     pthread_mutex_init(&F.mu, NULL);
@@ -382,6 +388,10 @@ static void run_magbuf(void)
     msd_fifo_drain();
     atomic_store(&F.exit_flag, 1);
     pthread_join(consumer, NULL);
+    if (read_pinned)
+        msd_host_unregister(F.ctx, F.readbuf);
+    if (fifo_pinned)
+        msd_host_unregister(F.ctx, fifo_mem);
     msd_fifo_destroy();
 }
 

@@ -2414,6 +2414,23 @@ void msd_host_free(msd_ctx *c, void *p)
     }
 }
 
+int msd_host_register(msd_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+void msd_host_unregister(msd_ctx *c, void *p)
+{
+    if (c && p) {
+        (void)hipSetDevice(c->cfg.device);
+        (void)hipHostUnregister(p);
+    }
+}
+
 int msd_submit_host(msd_ctx *c, const void *h_iq, uint64_t nsamples, int last, msd_message_fn sink,
                     void *user)
 {
