@@ -204,6 +204,8 @@ typedef struct msd_ifile_timing {
     double demod_us_p50, demod_us_p99, demod_us_max;
     double latency_us_p50, latency_us_p99, latency_us_max;
     uint64_t deadline_misses;
+    double reader_wait_s, consumer_wait_s; /* MSD_IFILE_MAGBUF: time the reader spent waiting for a free buffer (fifo_acquire)
+                                              and the consumer for a filled one (fifo_dequeue): who is the bottleneck */
 } msd_ifile_timing;
 int msd_ifileGetTiming(msd_ifile_timing *t);
 const char *msd_ifileLastError(void);

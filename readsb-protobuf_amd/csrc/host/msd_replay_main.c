@@ -129,9 +129,11 @@ int main(int argc, char **argv)
         if (msd_ifileGetTiming(&t) == 0)
             fprintf(stderr, "{\"buffers\": %" PRIu64 ", \"samples\": %" PRIu64 ", \"messages\": %" PRIu64 ", \"wall_s\": %.6f, \"msamples_per_s\": %.1f, "
                             "\"convert_us_p50\": %.1f, \"convert_us_p99\": %.1f, \"demod_us_p50\": %.1f, \"demod_us_p99\": %.1f, \"demod_us_max\": %.1f, "
-                            "\"latency_us_p50\": %.1f, \"latency_us_p99\": %.1f, \"latency_us_max\": %.1f, \"deadline_misses\": %" PRIu64 "}\n",
+                            "\"latency_us_p50\": %.1f, \"latency_us_p99\": %.1f, \"latency_us_max\": %.1f, \"deadline_misses\": %" PRIu64 ", "
+                            "\"reader_wait_s\": %.6f, \"consumer_wait_s\": %.6f}\n",
                     t.buffers, t.samples, g_count, t.wall_s, t.wall_s > 0 ? (double)t.samples / t.wall_s * 1e-6 : 0.0, t.convert_us_p50, t.convert_us_p99,
-                    t.demod_us_p50, t.demod_us_p99, t.demod_us_max, t.latency_us_p50, t.latency_us_p99, t.latency_us_max, t.deadline_misses);
+                    t.demod_us_p50, t.demod_us_p99, t.demod_us_max, t.latency_us_p50, t.latency_us_p99, t.latency_us_max, t.deadline_misses,
+                    t.reader_wait_s, t.consumer_wait_s);
     }
     if (msd_ifileLastError()[0])
         fprintf(stderr, "%s\n", msd_ifileLastError());

@@ -44,6 +44,7 @@ static struct {
         uint64_t *release_ns; /* [TIMING_CAP] */
         float *convert_us, *demod_us, *latency_us;
         uint64_t nconv, ndemod;
+        uint64_t reader_wait_ns, consumer_wait_ns;
     } T;
 } F;
 
@@ -66,6 +67,7 @@ static void timing_reset(void)
         T->latency_us = calloc(TIMING_CAP, sizeof *T->latency_us);
     }
     T->buffers = T->samples = T->misses = T->nconv = T->ndemod = 0;
+    T->reader_wait_ns = T->consumer_wait_ns = 0;
     T->wall_s = 0;
 }
 
@@ -115,6 +117,8 @@ int msd_ifileGetTiming(msd_ifile_timing *t)
     t->samples = T->samples;
     t->wall_s = T->wall_s;
     t->deadline_misses = T->misses;
+    t->reader_wait_s = (double)T->reader_wait_ns * 1e-9;
+    t->consumer_wait_s = (double)T->consumer_wait_ns * 1e-9;
     percentiles(T->convert_us, T->nconv, &t->convert_us_p50, &t->convert_us_p99, NULL);
     percentiles(T->demod_us, T->ndemod, &t->demod_us_p50, &t->demod_us_p99, &t->demod_us_max);
     percentiles(T->latency_us, T->ndemod, &t->latency_us_p50, &t->latency_us_p99, &t->latency_us_max);
@@ -300,7 +304,9 @@ static void *magbuf_consumer(void *arg)
     (void)arg;
     uint64_t k = 0;
     for (;;) {
+        const uint64_t w0 = now_ns();
         struct msd_mag_buf *buf = msd_fifo_dequeue(100);
+        F.T.consumer_wait_ns += now_ns() - w0;
         if (!buf) {
             if (atomic_load(&F.exit_flag))
                 break;
@@ -346,7 +352,9 @@ static void run_magbuf(void)
     msd_pacer pacer;
     msd_pacer_start(&pacer, 2400000.0); /* Modes.sample_rate, readsb.c:195 */
     while (!eof && !host_wants_exit()) {
+        const uint64_t a0 = now_ns();
         struct msd_mag_buf *out = msd_fifo_acquire(100);
+        F.T.reader_wait_ns += now_ns() - a0;
         if (!out)
             continue;
         if (G.hooks.monitor)

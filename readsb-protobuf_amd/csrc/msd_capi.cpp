@@ -195,6 +195,9 @@ struct Slot {
     msd_region_counts *d_rcounts = nullptr;
     msd_wg_totals *d_rwgt = nullptr;
     uint32_t lean_k = 0, lean_hcap = 0, lean_tcap = 0, lean_nreg = 0; /* regions per buffer, slice capacities, regions */
+    /* the slot's own arena sizes: the context's (msd_config) to begin with; grow_and_rescan() enlarges the region slices of
+     * a slot whose batch overflowed them, lean_gather_now() the dense lists if somebody on the host wants such a batch */
+    uint64_t rhit_arena = 0, rtry_arena = 0, dense_hits = 0, dense_tries = 0;
     uint64_t *d_powr = nullptr; /* [buffer][MSD_RB_MSG_CAP] signal power of the accepted messages */
     uint8_t *h_ctl = nullptr; /* pinned, read by the kernels in place: ts[2n] u64 | valid[n] | snap_idx[n] | todo[n] */
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
@@ -267,6 +270,7 @@ struct msd_ctx {
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
+    double want_hits_per_sample = 0, want_tries_per_sample = 0; /* region slices a slot should have at its next launch (grow_and_rescan) */
     msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
     msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
     uint32_t max_wg = 0, max_buffers = 0;  /* max_wg: most regions a scan is split into */
@@ -507,6 +511,37 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         nwg = (nb_data ? nb_data : 1) * lean_k;
         tpw = lean_tpr;
         s.lean = true;
+        /* another slot's batch overflowed its region slices and got bigger ones (grow_and_rescan): this slot follows before
+         * it meets the same traffic -- it is idle now, its last batch has been collected; a failed allocation leaves it as it is */
+        const uint64_t want_h = (uint64_t)(c->want_hits_per_sample * (double)s.nsamples), want_t = (uint64_t)(c->want_tries_per_sample * (double)s.nsamples);
+        if ((want_h > s.rhit_arena || want_t > s.rtry_arena) && want_t < (1ull << 30)) {
+            size_t free_b = 0, total_b = 0;
+            const uint64_t grow_b = (want_h > s.rhit_arena ? (want_h - s.rhit_arena) * sizeof(msd_hit) : 0) +
+                                    (want_t > s.rtry_arena ? (want_t - s.rtry_arena) * sizeof(msd_try) : 0);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && grow_b + (1ull << 30) <= free_b) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (want_h > s.rhit_arena) {
+                    msd_hit *nh = nullptr;
+                    if (hipMalloc(reinterpret_cast<void **>(&nh), want_h * sizeof(msd_hit)) == hipSuccess) {
+                        (void)hipFree(s.d_rhits);
+                        s.d_rhits = nh;
+                        s.rhit_arena = want_h;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
+                if (want_t > s.rtry_arena) {
+                    msd_try *nt = nullptr;
+                    if (hipMalloc(reinterpret_cast<void **>(&nt), want_t * sizeof(msd_try)) == hipSuccess) {
+                        (void)hipFree(s.d_rtries);
+                        s.d_rtries = nt;
+                        s.rtry_arena = want_t;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+        }
     }
 
     if (s.nsamples & 7u) { /* the last, partially filled 8-sample group: a zero-padded private copy */
@@ -538,7 +573,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         p.hits = s.lean ? s.d_rhits : c->d_region_hits;
         p.tries = s.lean ? s.d_rtries : c->d_region_tries;
         /* a tile can never produce more than one hit per position and five tries per hit */
-        uint64_t hcap = c->hit_arena / nwg, tcap = c->try_arena / nwg;
+        uint64_t hcap = (s.lean ? s.rhit_arena : c->hit_arena) / nwg, tcap = (s.lean ? s.rtry_arena : c->try_arena) / nwg;
         if (hcap > (uint64_t)tpw * tile)
             hcap = (uint64_t)tpw * tile;
         if (tcap > (uint64_t)tpw * tile * 5)
@@ -635,7 +670,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
                 s.tail_dst = nullptr; /* the scan's first wavefront copies it */
         } else {
             rc = msd_launch_gather(c->d_counts, c->d_wg_totals, nwg, s.d_totals, c->d_region_hits, c->d_region_tries, p.hcap, p.tcap,
-                                   s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers,
+                                   s.d_hits, s.dense_hits, s.d_tries, s.dense_tries, s.d_sums, s.nbuffers,
                                    gather_publishes ? s.h_totals : nullptr, gather_publishes ? s.h_sums : nullptr, nullptr, 0,
                                    tail_here ? s.d_iq + (s.nsamples - TAIL_SAMPLES) * bps_of(format) : nullptr,
                                    tail_here ? s.tail_dst : nullptr, tail_here ? (uint32_t)(TAIL_SAMPLES * bps_of(format)) : 0,
@@ -1179,12 +1214,103 @@ void means_from_sums(msd_ctx *c, const Slot &s)
  * over the slot's region slices, synchronously.  Totals land in h_totals; the sums were published already. */
 int lean_gather_now(msd_ctx *c, Slot &s)
 {
+    /* the first resolve pass has published the batch's totals: a slot whose region slices were enlarged may hold more
+     * than the dense lists were made for */
+    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
+    if (H > s.dense_hits || Tn > s.dense_tries) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (H > s.dense_hits) {
+            (void)hipFree(s.d_hits);
+            s.d_hits = nullptr;
+            s.dense_hits = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_hits), (H + H / 8) * sizeof(msd_hit)));
+            s.dense_hits = H + H / 8;
+        }
+        if (Tn > s.dense_tries) {
+            (void)hipFree(s.d_tries);
+            s.d_tries = nullptr;
+            s.dense_tries = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_tries), (Tn + Tn / 8) * sizeof(msd_try)));
+            s.dense_tries = Tn + Tn / 8;
+        }
+    }
     int rc = msd_launch_gather(s.d_rcounts, s.d_rwgt, s.lean_nreg, s.d_totals, s.d_rhits, s.d_rtries, s.lean_hcap, s.lean_tcap,
-                               s.d_hits, c->hit_arena, s.d_tries, c->try_arena, s.d_sums, s.nbuffers, s.h_totals, nullptr,
+                               s.d_hits, s.dense_hits, s.d_tries, s.dense_tries, s.d_sums, s.nbuffers, s.h_totals, nullptr,
                                nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 1, c->stream);
     if (rc)
         return fail(c, rc, "gather kernel launch failed");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* A lean batch overflowed the region slices of its slot (an interference storm, a pulse train: a large share of all
+ * positions look like preambles).  The scan counts on past the end of a slice, so the region counts say exactly what
+ * every region needed: the slot gets slices the densest region fits (plus an eighth), the batch is scanned again into
+ * them and stays on the GPU resolve -- one extra scan instead of the whole batch in pieces through the host resolver
+ * (rerun_in_pieces: 0.09-0.7 GS/s on such input).  The slot keeps the bigger slices; the other slots follow at their
+ * next launch (enqueue: c->want_*).  0: rescanned, the first resolve pass has to be begun again; 1: not possible (no
+ * device memory for it, or it was the Mode A/C arena): the old way; < 0: error. */
+int grow_and_rescan(msd_ctx *c, Slot &s, int format)
+{
+    if (!s.lean || !s.lean_nreg || !s.d_rcounts)
+        return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<msd_region_counts> rc(s.lean_nreg);
+    HIPCHK(c, hipMemcpy(rc.data(), s.d_rcounts, rc.size() * sizeof(msd_region_counts), hipMemcpyDeviceToHost));
+    uint64_t mh = 0, mt = 0;
+    for (const msd_region_counts &r : rc) {
+        mh = r.nhits > mh ? r.nhits : mh;
+        mt = r.ntries > mt ? r.ntries : mt;
+    }
+    if (mh <= s.lean_hcap && mt <= s.lean_tcap)
+        return 1; /* the Mode S slices held: it was the Mode A/C arena */
+    uint64_t hcap = mh + mh / 8 + 64, tcap = mt + mt / 8 + 64;
+    hcap = hcap > s.lean_hcap ? hcap : s.lean_hcap;
+    tcap = tcap > s.lean_tcap ? tcap : s.lean_tcap;
+    const uint64_t need_h = hcap * s.lean_nreg, need_t = tcap * s.lean_nreg;
+    if (need_t >= (1ull << 30) || hcap >= (1ull << 32) || tcap >= (1ull << 32))
+        return 1; /* try indices are 30 bits of the hit record */
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+        return 1;
+    const uint64_t grow_b = (need_h > s.rhit_arena ? (need_h - s.rhit_arena) * sizeof(msd_hit) : 0) +
+                            (need_t > s.rtry_arena ? (need_t - s.rtry_arena) * sizeof(msd_try) : 0);
+    if (grow_b + (1ull << 30) > free_b)
+        return 1;
+    if (need_h > s.rhit_arena) {
+        msd_hit *nh = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&nh), need_h * sizeof(msd_hit)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        (void)hipFree(s.d_rhits);
+        s.d_rhits = nh;
+        s.rhit_arena = need_h;
+    }
+    if (need_t > s.rtry_arena) {
+        msd_try *nt = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&nt), need_t * sizeof(msd_try)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        (void)hipFree(s.d_rtries);
+        s.d_rtries = nt;
+        s.rtry_arena = need_t;
+    }
+    /* what the other slots should have before they meet the same traffic: per sample of a batch */
+    const double per_h = (double)s.rhit_arena / (double)(s.nsamples ? s.nsamples : 1), per_t = (double)s.rtry_arena / (double)(s.nsamples ? s.nsamples : 1);
+    c->want_hits_per_sample = per_h > c->want_hits_per_sample ? per_h : c->want_hits_per_sample;
+    c->want_tries_per_sample = per_t > c->want_tries_per_sample ? per_t : c->want_tries_per_sample;
+    HIPCHK(c, hipMemsetAsync(s.d_totals, 0, 4 * sizeof(uint64_t), c->stream)); /* the overflow flag the first scan raised */
+    s.h_totals[2] = 0;
+    if (c->pending_emit == &s)
+        c->pending_emit = nullptr;
+    const int erc = enqueue(c, s, format, nullptr, true);
+    if (erc)
+        return erc < 0 ? erc : -EIO;
+    if (!s.lean)
+        return 1;
+    c->timing.reruns++;
     return 0;
 }
 
@@ -1511,6 +1637,17 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
     if (s.gpu_resolve) {
         rc = (ts_override || skip_resolve) ? 1 : finish_gpu(c, s, format, sink, user);
         s.resolve_inflight = false;
+        if (rc == 2 && s.lean) { /* the region slices overflowed: bigger ones, one more scan, and the GPU resolve again */
+            const int g = grow_and_rescan(c, s, format);
+            if (g < 0)
+                return g;
+            if (g == 0) {
+                s.ahead_done = false;
+                s.ahead_verdict = 0;
+                rc = finish_gpu(c, s, format, sink, user);
+                s.resolve_inflight = false;
+            }
+        }
         if (rc < 0)
             return rc;
         if (s.lean) {
@@ -2025,6 +2162,8 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
     for (Slot &s : c->slots) {
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
+        s.dense_hits = c->hit_arena;
+        s.dense_tries = c->try_arena;
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
         if (cfg->format != MSD_FMT_UC8 || (cfg->flags & MSD_CFG_DC_FILTER))
@@ -2115,6 +2254,8 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
         for (Slot &s : c->slots) {
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rhits), c->hit_arena * sizeof(msd_hit)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rtries), c->try_arena * sizeof(msd_try)));
+            s.rhit_arena = c->hit_arena;
+            s.rtry_arena = c->try_arena;
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rcounts), c->max_wg * sizeof(msd_region_counts)));
             CK(hipMalloc(reinterpret_cast<void **>(&s.d_rwgt), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
             CK(hipMemset(s.d_totals, 0, 4 * sizeof(uint64_t)));

@@ -1,8 +1,9 @@
 """A capture built to hurt: a periodic pulse train (found by random search over short periodic UC8 patterns, the
 preamble tests of the second reading as the objective) in which 36 % of all positions pass the preamble tests and every
 one of them asks for all five trial phases -- 24 x the hit density of the benchmark capture, far beyond what the candidate
-arenas are sized for.  The batch must be rescanned in pieces (never truncated), and the result must still be the
-oracle's, message for message and counter for counter."""
+arenas are sized for.  The batch must be scanned again -- into bigger region slices on the GPU resolve path, in pieces
+through the host resolver where that is not possible -- never truncated, and the result must still be the oracle's, message
+for message and counter for counter."""
 import numpy as np
 import pytest
 
@@ -49,6 +50,10 @@ def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, monkey
     t = dem.timing()
     if arenas == "base-size":
         assert t["reruns"] > 0 or t["resolve_fallback"] > 0  # the arenas did overflow; nothing was cut short
+        if resolve_stage == "gpu-resolve" and not mode_ac:
+            # ... and the batch stayed on the GPU: its slot got region slices the densest region fits, one more scan, the
+            # GPU resolve again (grow_and_rescan) -- no batch went through the host resolver
+            assert t["reruns"] > 0 and t["resolve_fallback"] == 0, t
 
 
 @pytest.mark.parametrize("arenas", ["base-size", "default"])
