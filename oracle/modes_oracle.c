@@ -34,6 +34,7 @@ struct syndrome_entry { /* struct errorinfo, crc.h:32-37 */
 
 struct orc_ctx {
     int format, threshold, nfix, mode_ac;
+    int recently_dropped; /* Modes.stats_15min.samples_dropped != 0 (demod_2400.c:285-290): a live receiver's state, set by the caller */
     int dc_filter; /* struct converter_state, convert.c:28-33 */
     int q11_bits;  /* SC16Q11_TABLE_BITS of the build being restated (0: undefined, the float path) */
     uint16_t *q11_table;
@@ -175,6 +176,11 @@ static void convert_dc(orc_ctx *ctx, const uint8_t *iq, uint16_t *mag, unsigned 
 }
 
 /* --dcfilter (readsb.c:486): init_converter's "DC block @ 1Hz" (convert.c:479-482) at 2.4 MHz */
+void orc_set_recently_dropped(orc_ctx *ctx, int on)
+{
+    ctx->recently_dropped = on != 0;
+}
+
 void orc_set_dc_filter(orc_ctx *ctx, int on)
 {
     ctx->dc_filter = on;
@@ -1793,8 +1799,12 @@ static void demod_mode_s(orc_ctx *ctx, const uint16_t *m, unsigned valid_length,
             continue; /* demod_2400.c:276 */
 
         int32_t base_noise = pa[5] + pa[8] + pa[16] + pa[17] + pa[18];
-        /* samples_dropped is always 0 for ifile input, so demod_2400.c:286-288 is inert */
-        int32_t ref_level = (int32_t)((uint32_t)base_noise * (uint32_t)ctx->threshold);
+        /* demod_2400.c:285-290: "reduce number of preamble detections if we recently dropped samples" -- the threshold is
+         * max(PREAMBLE_THRESHOLD_PIZERO, Modes.preambleThreshold) while the 15-minute statistics hold dropped samples.  Never
+         * the case for ifile input; a live feed's host says so through orc_set_recently_dropped (the product's host calls
+         * msd_set_preamble_threshold with the same maximum: the statistics window is the host program's) */
+        const int thr = ctx->recently_dropped && ctx->threshold < 75 ? 75 : ctx->threshold;
+        int32_t ref_level = (int32_t)((uint32_t)base_noise * (uint32_t)thr);
         ref_level >>= 5;
 
         ts.best = NULL;

@@ -75,6 +75,10 @@ typedef struct orc_ctx orc_ctx;
 
 orc_ctx *orc_create(int format, int preamble_threshold, int nfix_crc, int mode_ac);
 /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,374-423); resets its state */
+/* Modes.stats_15min.samples_dropped != 0 from now on / no longer: demodulate2400 then tests preambles against
+ * max(PREAMBLE_THRESHOLD_PIZERO = 75, threshold) (demod_2400.c:285-290).  The 15-minute window belongs to the host program
+ * (stats.c); for --ifile input it never holds anything. */
+void orc_set_recently_dropped(orc_ctx *ctx, int on);
 void orc_set_dc_filter(orc_ctx *ctx, int on);
 /* restate a reference built with -DSC16Q11_TABLE_BITS=bits (1..11; anything else: the float path, as without the define) */
 void orc_set_sc16q11_table_bits(orc_ctx *ctx, int bits);

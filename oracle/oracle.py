@@ -125,6 +125,8 @@ def lib():
         L.orc_create.argtypes = [C.c_int] * 4
         L.orc_set_dc_filter.restype = None
         L.orc_set_dc_filter.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_recently_dropped.restype = None
+        L.orc_set_recently_dropped.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_sc16q11_table_bits.restype = None
         L.orc_set_sc16q11_table_bits.argtypes = [C.c_void_p, C.c_int]
         L.orc_sc16q11_table.restype = C.POINTER(C.c_uint16)
@@ -207,6 +209,10 @@ class Oracle:
     @property
     def bytes_per_sample(self):
         return 2 if self.fmt == FMT_UC8 else 4
+
+    def set_recently_dropped(self, on):
+        """Modes.stats_15min.samples_dropped != 0 (demod_2400.c:285-290) for the buffers demodulated from now on."""
+        lib().orc_set_recently_dropped(self._h, 1 if on else 0)
 
     def replay_fields(self, iq, cap):
         """replay() that also decodes the header fields: returns (messages, fields, stats)."""

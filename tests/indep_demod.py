@@ -278,6 +278,7 @@ def msg_bits_by_type(df):
 class Receiver:
     def __init__(self, fmt="uc8", threshold=58, nfix=1, mode_ac=False, startup_time=0, dc_filter=False, literal_filter=False):
         self.fmt, self.threshold, self.mode_ac, self.dc_filter = fmt, threshold, mode_ac, dc_filter
+        self.recently_dropped = False  # Modes.stats_15min.samples_dropped != 0 (demod_2400.c:285-290); the host program's to set
         self.tab56, self.tab112 = error_table(56, nfix), error_table(112, nfix)
         self.filter = IcaoFilter(literal=literal_filter)
         self.startup_time = startup_time
@@ -415,7 +416,7 @@ class Receiver:
         pa = lambda d: x[d: d + mlen]
         pre = (pa(1) > pa(7)) & (pa(12) > pa(14)) & (pa(12) > pa(15))
         base_noise = pa(5) + pa(8) + pa(16) + pa(17) + pa(18)
-        ref = (base_noise * self.threshold) >> 5
+        ref = (base_noise * (max(75, self.threshold) if self.recently_dropped else self.threshold)) >> 5  # demod_2400.c:285-292
         d23, s14, d1011 = pa(2) - pa(3), pa(1) + pa(4), pa(10) - pa(11)
         common = s14 - d23 + pa(9) + pa(12)
         t0 = pre & (common - d1011 >= ref)

@@ -360,6 +360,36 @@ def test_preamble_threshold_change_applies_to_later_batches(pkg, oracle, torch_c
         dem.set_preamble_threshold(0)
 
 
+def test_threshold_while_samples_were_dropped_recently(pkg, oracle, torch_cuda):
+    """demod_2400.c:285-290: while Modes.stats_15min.samples_dropped is not zero, preambles are tested against
+    max(PREAMBLE_THRESHOLD_PIZERO = 75, Modes.preambleThreshold).  The 15-minute window is the host program's; the boundary
+    contract is that the host calls msd_set_preamble_threshold(max(75, threshold)) when the window fills and the configured
+    value again when it empties.  The oracle and the second reading model the flag itself: a whole capture under each
+    state, and the product's two settings must equal them -- for a configured threshold below 75 and for one above it
+    (which the flag must not lower)."""
+    import indep_demod
+    C = pkg.CHUNK
+    n = 6 * C + 999
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=77, msgs_per_sec=9000, n_aircraft=40), n)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    for configured in (58, 90):
+        per_state = []
+        for dropped in (False, True):
+            orc = oracle.Oracle(oracle.FMT_UC8, configured, 1, 0)
+            orc.set_recently_dropped(dropped)
+            want, wstats = orc.replay(iq, cap=1 << 16)
+            second = indep_demod.Receiver("uc8", configured, 1, False)
+            second.recently_dropped = dropped
+            smsgs, sstats = second.replay(iq.tobytes())
+            assert len(smsgs) == len(want) and sstats["demod_preambles"] == wstats["demod_preambles"]
+            dem = pkg.Demodulator(nfix_crc=1, preamble_threshold=configured, max_batch_samples=4 * C, message_capacity=1 << 16)
+            dem.set_preamble_threshold(max(75, configured) if dropped else configured)   # the host's side of the contract
+            got = pkg.replay_device(dem, d_iq.data_ptr(), n, 4 * C)
+            assert_same(got, dem.stats(), want, wstats)
+            per_state.append(len(want))
+        assert (per_state[0] != per_state[1]) == (configured < 75)
+
+
 @pytest.mark.parametrize("fmt,mode_ac", [("uc8", 0), ("uc8", 1), ("sc16", 0)])
 def test_aggressive_two_bit_correction(pkg, oracle, torch_cuda, fmt, mode_ac):
     """--aggressive (Modes.nfix_crc = 2, readsb.c:542): DF17/18 with two wrong bits are corrected against the

@@ -205,3 +205,19 @@ def test_live_feed_with_dropped_samples(pkg, oracle, fmt, mode_ac, drop):
     got, gstats = D.Receiver(fmt, 58, 1, mode_ac).live_feed([s.tobytes() for s in segs], drops)
     assert len(got) > 100
     assert_second_reading_agrees(got, gstats, want, wstats)
+
+
+def test_threshold_while_samples_were_dropped_recently(pkg, oracle):
+    """demod_2400.c:285-290 in both restatements: with Modes.stats_15min.samples_dropped set the preamble tests use
+    max(75, threshold) -- equal to a receiver configured with that maximum, and no change for a threshold above 75."""
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=77, msgs_per_sec=9000, n_aircraft=40), 3 * 131072)
+    for configured in (58, 90):
+        orc = oracle.Oracle(oracle.FMT_UC8, configured, 1, 0)
+        orc.set_recently_dropped(True)
+        want, wstats = orc.replay(iq, cap=1 << 16)
+        plain, pstats = oracle.Oracle(oracle.FMT_UC8, max(75, configured), 1, 0).replay(iq, cap=1 << 16)
+        assert np.array_equal(want, plain) and wstats["demod_preambles"] == pstats["demod_preambles"]
+        second = D.Receiver("uc8", configured, 1, False)
+        second.recently_dropped = True
+        msgs, sstats = second.replay(iq.tobytes())
+        assert_second_reading_agrees(msgs, sstats, want, wstats)
