@@ -71,12 +71,6 @@ __device__ __forceinline__ void arena_store16(const uint4 v, uint4 *p)
                            27.9 M -> 20.9 M, SQ_LDS_IDX_ACTIVE 50.9 M -> 43.5 M cycles per 64 Mi-sample launch, the launch itself
                            0.2617 -> 0.2596 ms per 128 Mi samples (profiles/r04_pmc_counters.txt) */
 #endif
-#ifndef MSD_TESTS_SPARSE
-#define MSD_TESTS_SPARSE 0 /* 1: the three threshold tests only for the positions that pass the pre-check (one in six on noise), as
-                              the reference's `continue` has it (demod_2400.c:276-278): pre-check planes -> the survivors' positions
-                              compacted into the candidate scratch -> dense rounds of 64 survivors, taps gathered from the LDS ->
-                              verdict bits ORed back into their owners' planes (LABLOG R5.5) */
-#endif
 #ifndef MSD_PRIO_CONV
 #define MSD_PRIO_CONV 0
 #endif
@@ -959,81 +953,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                     }
 #endif
                 }
-#if MSD_TESTS_SPARSE
-                uint32_t p0, p1, p2;
-                {
-                    /* the pre-check of the run's 1024 positions: samples pa[1], pa[7], pa[12], pa[14], pa[15] = mags[p + 3 .. p + 17] */
-                    int sm[40];
-#pragma unroll
-                    for (int k = 1; k <= 16; ++k) {
-                        asm("v_and_b32 %0, 0xffff, %1" : "=v"(sm[2 * k]) : "v"(v[k]));
-                        asm("v_lshrrev_b32 %0, 16, %1" : "=v"(sm[2 * k + 1]) : "v"(v[k]));
-                    }
-                    uint32_t pp = 0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int pre = (sm[q + 9] - sm[q + 3]) & (sm[q + 16] - sm[q + 14]) & (sm[q + 17] - sm[q + 14]);
-                        pp = __builtin_amdgcn_alignbit(pp, (uint32_t)pre, 31);
-                    }
-                    {
-                        const uint64_t first = a0 + 1024ull * h + 16ull * lane;
-                        if (first + 16 > batch_end) {
-                            const int keep = first >= batch_end ? 0 : (int)(batch_end - first);
-                            pp &= keep ? ~((1u << (16 - keep)) - 1u) : 0u;
-                        }
-                    }
-                    /* the survivors' positions (in the run), in order, into the candidate scratch -- free until the rounds begin --,
-                     * and a zeroed pair of verdict words per lane: [test 1 | test 0] planes, [test 2] plane, position q at bit 15 - q */
-                    uint16_t *plist = reinterpret_cast<uint16_t *>(X.w + W_TRYL);
-                    uint32_t *pverd = reinterpret_cast<uint32_t *>(X.w + W_TRYL + 2048);
-                    static_assert(W_BYTES - W_TRYL >= 2048 + 512, "1024 positions and 64 verdict pairs fit the candidate scratch");
-                    const uint32_t npre = (uint32_t)__popc(pp);
-                    const uint32_t pincl = wave_incl_scan(npre);
-                    const uint32_t N1 = wave_last(pincl);
-                    *reinterpret_cast<uint2 *>(pverd + 2 * lane) = make_uint2(0u, 0u);
-                    {
-                        uint32_t x = pp, k = pincl - npre;
-                        while (__ballot(x != 0)) { /* as many turns as the busiest lane has survivors (about seven on noise) */
-                            if (x) {
-                                const int bit = 31 - __clz((int)x);
-                                x &= ~(1u << bit);
-                                plist[k++] = (uint16_t)(16 * lane + 15 - bit);
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    const int thr = P.threshold, m32 = -32;
-                    for (uint32_t r0 = 0; r0 < N1; r0 += 64u) { /* wave-uniform */
-                        const uint32_t j = r0 + (uint32_t)lane;
-                        const bool live = j < N1;
-                        const uint32_t pos = plist[live ? j : 0u];
-                        const uint16_t *pa = mags + 1024 * h + pos + 2; /* pa[d] = mags[p + 2 + d] */
-                        const int a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4], a5 = pa[5], a8 = pa[8], a9 = pa[9], a10 = pa[10], a11 = pa[11],
-                                  a12 = pa[12], a16 = pa[16], a17 = pa[17], a18 = pa[18];
-                        const int base_noise = a5 + a8 + a16 + a17 + a18;
-                        int refm;
-                        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(refm) : "v"(base_noise), "v"(thr), "v"(m32));
-                        refm >>= 5;
-                        const int diff_2_3 = a2 - a3, diff_10_11 = a10 - a11;
-                        const int b = refm - (a1 + a4 + a12);
-                        const int r1 = b + diff_2_3 - a9;
-                        const uint32_t g0 = (uint32_t)(r1 + diff_10_11) >> 31, g1 = (uint32_t)(r1 - diff_10_11) >> 31;
-                        const uint32_t g2 = (uint32_t)(b - diff_2_3 - diff_2_3 - diff_10_11) >> 31;
-                        const uint32_t sh = 15u - (pos & 15u);
-                        const uint32_t w01 = (g0 | (g1 << 16)) << sh, w2 = g2 << sh;
-                        if (live && w01)
-                            atomicOr(&pverd[2 * (pos >> 4)], w01);
-                        if (live && w2)
-                            atomicOr(&pverd[2 * (pos >> 4) + 1], w2);
-                    }
-                    wave_lds_sync();
-                    const uint2 vd = *reinterpret_cast<const uint2 *>(pverd + 2 * lane);
-                    p0 = vd.x & 0xffffu;
-                    p1 = vd.x >> 16;
-                    p2 = vd.y;
-                    wave_lds_sync(); /* the next run's list goes where this one's was */
-                }
-#elif MSD_TESTS_V2
+#if MSD_TESTS_V2
                 /* All 38 samples this run's 16 positions touch, unpacked once -- through opaque instructions, so that
                  * the compiler cannot fold the unpacking back into SDWA operands: on gfx950 a wave64 instruction with
                  * an SDWA / DPP / SGPR operand, a compare, a carry, a multiply or any three-operand integer form
@@ -1056,17 +976,6 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                      *   test 0: common - diff_10_11 >= ref  <=>  (ref - 1) - common + diff_10_11 < 0, and so on. */
 #define PA(d) (sm[q + 2 + (d)])
                     const int pre = (PA(7) - PA(1)) & (PA(14) - PA(12)) & (PA(15) - PA(12));
-#ifdef MSD_TESTS_ABLATE /* timing experiment only (wrong results): the three tests for one position in MSD_TESTS_ABLATE, the
-                           pre-check for all -- what the tests phase would cost if only the pre-check's survivors (one in
-                           six) were tested, before the cost of finding them */
-                    if (q % MSD_TESTS_ABLATE) {
-                        p0 = __builtin_amdgcn_alignbit(p0, (uint32_t)pre & 0u, 31);
-                        p1 = __builtin_amdgcn_alignbit(p1, (uint32_t)pre & 0u, 31);
-                        p2 = __builtin_amdgcn_alignbit(p2, (uint32_t)pre & 0u, 31);
-                        asm volatile("" :: "v"(pre)); /* the pre-check itself stays */
-                        continue;
-                    }
-#endif
                     const int base_noise = PA(5) + PA(8) + PA(16) + PA(17) + PA(18);
                     int refm;
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(refm) : "v"(base_noise), "v"(thr), "v"(m32));
