@@ -270,6 +270,8 @@ struct msd_ctx {
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
+    const uint16_t *magbuf_host = nullptr; /* msd_demodulate_magbuf: the caller's mag_buf.data while its finish() runs */
+    uint64_t magbuf_valid = 0;
     double want_hits_per_sample = 0, want_tries_per_sample = 0; /* region slices a slot should have at its next launch (grow_and_rescan) */
     msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
     msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
@@ -1747,6 +1749,25 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         if (rc)
             return rc;
         memcpy(s.h_req, c->out_req.data(), nm * sizeof(uint64_t));
+        if (c->magbuf_host) {
+            /* msd_demodulate_magbuf: the caller's magnitudes are in host memory already -- the sums of squares of the few
+             * accepted messages (demod_2400.c:386-399: m[j + 19 + k], k < msglen * 12 / 5) cost less here than a request
+             * upload, a kernel, a download and a synchronisation (35 us of a 165 us call) */
+            for (size_t i = 0; i < nm; ++i) {
+                const uint64_t rq = c->out_req[i];
+                const uint64_t first = (rq >> 16) + 19;
+                uint64_t len = rq & 0xffffu, acc = 0;
+                if (first >= c->magbuf_valid)
+                    len = 0;
+                else if (first + len > c->magbuf_valid)
+                    len = c->magbuf_valid - first; /* silence behind the buffer's last sample, as stream_mag has it */
+                for (uint64_t k = 0; k < len; ++k) {
+                    const uint64_t x = c->magbuf_host[first + k];
+                    acc += x * x;
+                }
+                s.h_pow[i] = acc;
+            }
+        } else {
         /* its own stream: the copy stream may already be busy downloading the next batch's lists */
         HIPCHK(c, hipMemcpyAsync(s.d_req, s.h_req, nm * sizeof(uint64_t), hipMemcpyHostToDevice, c->aux_stream));
         MsdScanParams p{};
@@ -1757,6 +1778,7 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             return fail(c, rc, "power kernel launch failed");
         HIPCHK(c, hipMemcpyAsync(s.h_pow, s.d_pow, nm * sizeof(uint64_t), hipMemcpyDeviceToHost, c->aux_stream));
         HIPCHK(c, hipStreamSynchronize(c->aux_stream));
+        }
     }
     msd_resolve_power(&c->resolver, s.nbuffers, c->valid.data(), c->means.data(), c->out_msgs.data(), sizeof(msd_message),
                       c->out_req.data(), c->out_buf.data(), s.h_pow, sizeof(uint64_t), nm);
@@ -2742,7 +2764,10 @@ int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength
     }
     const uint64_t ts[2] = {sampleTimestamp, sysTimestamp};
     const double means[2] = {mean_level, mean_power};
+    c->magbuf_host = data;
+    c->magbuf_valid = validLength;
     rc = finish(c, s, MSD_FMT_MAG16, sink, user, ts, means, 0);
+    c->magbuf_host = nullptr;
     /* the stream interface's tail ring was borrowed: a following msd_submit_* starts afresh */
     c->have_prev = false;
     c->tail_cur = 0;
