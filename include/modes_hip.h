@@ -421,6 +421,18 @@ int msd_convert(msd_ctx *ctx, const void *iq_data, uint16_t *mag_data, unsigned 
 int msd_demodulate_magbuf(msd_ctx *ctx, const uint16_t *data, unsigned validLength, unsigned overlap,
                           uint64_t sampleTimestamp, uint64_t sysTimestamp, double mean_level,
                           double mean_power, msd_message_fn sink, void *user);
+/* Several consecutive turns of that loop in one GPU batch -- what a consumer that finds n buffers queued can do instead of
+ * n calls (readsb.c:820-855 takes them one at a time; the results are the same, the round trips are paid once).  The
+ * buffers must follow one another in the stream: buffer k + 1's overlap region is the end of buffer k's data (what
+ * fifo_enqueue writes, fifo.c:170-182) -- a MAGBUF_DISCONTINUOUS buffer starts a call of its own --, all but the last hold
+ * 131072 new samples, and n x 131072 <= msd_config.max_batch_samples.  Messages are delivered in order. */
+typedef struct msd_magbuf_view {
+    const uint16_t *data;
+    unsigned validLength, overlap;
+    uint64_t sampleTimestamp, sysTimestamp;
+    double mean_level, mean_power;
+} msd_magbuf_view;
+int msd_demodulate_magbufs(msd_ctx *ctx, const msd_magbuf_view *bufs, unsigned n, msd_message_fn sink, void *user);
 
 #ifdef __cplusplus
 }

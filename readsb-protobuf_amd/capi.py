@@ -183,7 +183,7 @@ EXPORTS = [
     "msd_get_timing", "msd_get_buffer_means", "msd_convert", "msd_demodulate_magbuf", "msd_array_sink",
     "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
-    "msd_arena_permille", "msd_host_register", "msd_host_unregister",
+    "msd_arena_permille", "msd_host_register", "msd_host_unregister", "msd_demodulate_magbufs",
 ]
 
 _lib = None
@@ -431,6 +431,21 @@ class Demodulator:
         return self._run(lambda fn, st: lib().msd_demodulate_magbuf(
             self._h, data.ctypes.data, valid_length, overlap, sample_timestamp, sys_timestamp, mean_level,
             mean_power, fn, st))
+
+
+class MagbufView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("validLength", C.c_uint), ("overlap", C.c_uint), ("sampleTimestamp", C.c_uint64),
+                ("sysTimestamp", C.c_uint64), ("mean_level", C.c_double), ("mean_power", C.c_double)]
+
+
+def demodulate_magbufs(demod, bufs):
+    """msd_demodulate_magbufs: bufs = [(data, valid_length, overlap, sample_timestamp, sys_timestamp, mean_level, mean_power), ...]
+    of consecutive buffers, one GPU batch."""
+    keep = [np.ascontiguousarray(b[0], dtype=np.uint16) for b in bufs]
+    views = (MagbufView * len(bufs))()
+    for i, b in enumerate(bufs):
+        views[i] = MagbufView(keep[i].ctypes.data, b[1], b[2], b[3], b[4], b[5], b[6])
+    return demod._run(lambda fn, st: lib().msd_demodulate_magbufs(demod._h, views, len(bufs), fn, st))
 
 
 def replay_device(demod, dptr, nsamples, batch_samples):

@@ -49,6 +49,7 @@ static struct {
 } F;
 
 enum { TIMING_CAP = 65536 };
+static void warm_up(void);
 
 static uint64_t now_ns(void)
 {
@@ -276,14 +277,38 @@ bool msd_ifileOpen(void)
     if (F.rx.dc_filter && F.mode == MSD_IFILE_FUSED)
         cfg.flags |= MSD_CFG_DC_FILTER; /* init_converter(..., Modes.dc_filter, ...), sdr_ifile.c:150-153 (the literal drop-in's
                                            converter above has it; its demodulator gets magnitudes) */
-    cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * nbuf;
+    cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * (F.mode == MSD_IFILE_MAGBUF ? 8u /* MAGBUF_BATCH */ : nbuf);
     int rc = msd_create(&cfg, &F.ctx);
     if (rc) {
         snprintf(F.err, sizeof F.err, "ifile: msd_create failed: %s", strerror(-rc));
         msd_ifileClose();
         return false;
     }
+    warm_up();
     return true;
+}
+
+/* The first launch of every kernel loads its code object (8 ms for the first demodulate call, as much again for the
+ * converter): one block of silence through the path the run will take, here, where a receiver opens its device -- not in
+ * the first buffer's latency.  msd_reset() puts filter, clocks, counters and the DC block's state back to the start. */
+static void warm_up(void)
+{
+    const size_t n = MSD_CHUNK_SAMPLES;
+    char *iq = calloc(n, F.bytes_per_sample);
+    uint16_t *mag = calloc(n + MSD_OVERLAP, sizeof *mag);
+    if (iq && mag) {
+        if (F.mode == MSD_IFILE_MAGBUF) {
+            double level = 0, power = 0;
+            F.converter(iq, mag + MSD_OVERLAP, (unsigned)n, F.converter_state, &level, &power);
+            (void)msd_reset(msd_converter_context(F.converter_state));
+            (void)msd_demodulate_magbuf(F.ctx, mag, (unsigned)(n + MSD_OVERLAP), MSD_OVERLAP, 0, 0, level, power, NULL, NULL);
+        } else if (msd_launch_host(F.ctx, iq, n, 0) == 0) {
+            (void)msd_collect(F.ctx, NULL, NULL);
+        }
+        (void)msd_reset(F.ctx);
+    }
+    free(iq);
+    free(mag);
 }
 
 static size_t read_fully(char *dst, size_t want)
@@ -298,31 +323,65 @@ static size_t read_fully(char *dst, size_t want)
     return got;
 }
 
-/* the reference's main-thread consumer loop (readsb.c:820-855) for the mag_buf mode */
+/* the reference's main-thread consumer loop (readsb.c:820-855) for the mag_buf mode.  readsb demodulates one buffer per turn;
+ * when this consumer finds several queued (a file replay: the reader is ahead) it hands up to MAGBUF_BATCH consecutive ones
+ * to the GPU in one call -- the same messages in the same order, the round trips paid once (msd_demodulate_magbufs).  A
+ * paced feed (--throttle, a live receiver) never has more than one waiting, and gets the one-buffer latency. */
+enum { MAGBUF_BATCH = 8 };
+
 static void *magbuf_consumer(void *arg)
 {
     (void)arg;
     uint64_t k = 0;
+    struct msd_mag_buf *held = NULL; /* dequeued, but it has to start a call of its own */
     for (;;) {
-        const uint64_t w0 = now_ns();
-        struct msd_mag_buf *buf = msd_fifo_dequeue(100);
-        F.T.consumer_wait_ns += now_ns() - w0;
-        if (!buf) {
-            if (atomic_load(&F.exit_flag))
+        struct msd_mag_buf *bufs[MAGBUF_BATCH];
+        msd_magbuf_view views[MAGBUF_BATCH];
+        unsigned n = 0;
+        if (held) {
+            bufs[n++] = held;
+            held = NULL;
+        } else {
+            const uint64_t w0 = now_ns();
+            struct msd_mag_buf *buf = msd_fifo_dequeue(100);
+            F.T.consumer_wait_ns += now_ns() - w0;
+            if (!buf) {
+                if (atomic_load(&F.exit_flag))
+                    break;
+                continue;
+            }
+            bufs[n++] = buf;
+        }
+        while (n < MAGBUF_BATCH && !F.throttle && bufs[n - 1]->validLength - bufs[n - 1]->overlap == MSD_CHUNK_SAMPLES) {
+            struct msd_mag_buf *nb = msd_fifo_dequeue(0); /* only what is there already */
+            if (!nb)
                 break;
-            continue;
+            if (nb->flags & MSD_MAGBUF_DISCONTINUOUS) { /* its overlap region is silence, not the end of the buffer before it */
+                held = nb;
+                break;
+            }
+            bufs[n++] = nb;
+        }
+        for (unsigned i = 0; i < n; ++i) {
+            views[i].data = bufs[i]->data;
+            views[i].validLength = bufs[i]->validLength;
+            views[i].overlap = bufs[i]->overlap;
+            views[i].sampleTimestamp = bufs[i]->sampleTimestamp;
+            views[i].sysTimestamp = bufs[i]->sysTimestamp;
+            views[i].mean_level = bufs[i]->mean_level;
+            views[i].mean_power = bufs[i]->mean_power;
         }
         const uint64_t t0 = now_ns();
-        int rc = msd_demodulate_magbuf(F.ctx, buf->data, buf->validLength, buf->overlap, buf->sampleTimestamp,
-                                       buf->sysTimestamp, buf->mean_level, buf->mean_power, F.rx.sink,
-                                       F.rx.sink_user);
+        int rc = msd_demodulate_magbufs(F.ctx, views, n, F.rx.sink, F.rx.sink_user);
         const uint64_t t1 = now_ns();
-        timing_done(k++, t1 - t0, t1, buf->validLength - buf->overlap);
-        msd_fifo_release(buf);
+        for (unsigned i = 0; i < n; ++i) {
+            timing_done(k++, (t1 - t0) / n, t1, bufs[i]->validLength - bufs[i]->overlap);
+            msd_fifo_release(bufs[i]);
+        }
         pthread_mutex_lock(&F.mu); /* (F.err is written by the reader thread too: under the lock) */
         if (rc)
             snprintf(F.err, sizeof F.err, "demodulate: %s", msd_last_error(F.ctx));
-        F.in_flight--;
+        F.in_flight -= (int)n;
         pthread_cond_signal(&F.idle);
         pthread_mutex_unlock(&F.mu);
     }

@@ -270,8 +270,8 @@ struct msd_ctx {
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
-    const uint16_t *magbuf_host = nullptr; /* msd_demodulate_magbuf: the caller's mag_buf.data while its finish() runs */
-    uint64_t magbuf_valid = 0;
+    const msd_magbuf_view *magbuf_views = nullptr; /* msd_demodulate_magbufs: the caller's buffers while its finish() runs */
+    unsigned magbuf_nviews = 0;
     double want_hits_per_sample = 0, want_tries_per_sample = 0; /* region slices a slot should have at its next launch (grow_and_rescan) */
     msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
     msd_wg_totals *d_wg_totals = nullptr;  /* per workgroup of the scan kernel */
@@ -1749,20 +1749,27 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
         if (rc)
             return rc;
         memcpy(s.h_req, c->out_req.data(), nm * sizeof(uint64_t));
-        if (c->magbuf_host) {
-            /* msd_demodulate_magbuf: the caller's magnitudes are in host memory already -- the sums of squares of the few
+        if (c->magbuf_views) {
+            /* msd_demodulate_magbuf[s]: the caller's magnitudes are in host memory already -- the sums of squares of the few
              * accepted messages (demod_2400.c:386-399: m[j + 19 + k], k < msglen * 12 / 5) cost less here than a request
-             * upload, a kernel, a download and a synchronisation (35 us of a 165 us call) */
+             * upload, a kernel, a download and a synchronisation (35 us of a 165 us call).  Position -> buffer: the batch
+             * is the buffers' new samples one after the other; a message may run on into the next buffer's. */
             for (size_t i = 0; i < nm; ++i) {
                 const uint64_t rq = c->out_req[i];
-                const uint64_t first = (rq >> 16) + 19;
-                uint64_t len = rq & 0xffffu, acc = 0;
-                if (first >= c->magbuf_valid)
-                    len = 0;
-                else if (first + len > c->magbuf_valid)
-                    len = c->magbuf_valid - first; /* silence behind the buffer's last sample, as stream_mag has it */
+                const int64_t first = (int64_t)(rq >> 16) - (int64_t)MSD_OVERLAP + 19; /* index into the batch's new samples */
+                const uint64_t len = rq & 0xffffu;
+                uint64_t acc = 0;
                 for (uint64_t k = 0; k < len; ++k) {
-                    const uint64_t x = c->magbuf_host[first + k];
+                    const int64_t idx = first + (int64_t)k;
+                    uint64_t x = 0;
+                    if (idx < 0) {
+                        if (idx >= -(int64_t)MSD_OVERLAP)
+                            x = c->magbuf_views[0].data[(int64_t)MSD_OVERLAP + idx];
+                    } else {
+                        const uint64_t b = (uint64_t)idx / MSD_CHUNK_SAMPLES, o = (uint64_t)idx % MSD_CHUNK_SAMPLES;
+                        if (b < c->magbuf_nviews && o + MSD_OVERLAP < c->magbuf_views[b].validLength)
+                            x = c->magbuf_views[b].data[MSD_OVERLAP + o];
+                    }
                     acc += x * x;
                 }
                 s.h_pow[i] = acc;
@@ -2719,59 +2726,83 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
     return 0;
 }
 
-int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength, unsigned overlap,
-                          uint64_t sampleTimestamp, uint64_t sysTimestamp, double mean_level,
-                          double mean_power, msd_message_fn sink, void *user)
+int msd_demodulate_magbufs(msd_ctx *c, const msd_magbuf_view *bufs, unsigned n, msd_message_fn sink, void *user)
 {
-    if (!c || !data)
+    if (!c || !bufs || !n)
         return -EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (overlap != MSD_OVERLAP || validLength < overlap || validLength - overlap > MSD_CHUNK_SAMPLES)
-        return fail(c, -EINVAL, "mag_buf geometry must be overlap=326, at most 131072 new samples");
+    if ((uint64_t)n * MSD_CHUNK_SAMPLES > c->cfg.max_batch_samples || n > c->max_buffers)
+        return fail(c, -E2BIG, "more mag_bufs than max_batch_samples holds");
+    for (unsigned k = 0; k < n; ++k) {
+        const msd_magbuf_view &b = bufs[k];
+        if (!b.data || b.overlap != MSD_OVERLAP || b.validLength < b.overlap || b.validLength - b.overlap > MSD_CHUNK_SAMPLES ||
+            (k + 1 < n && b.validLength - b.overlap != MSD_CHUNK_SAMPLES))
+            return fail(c, -EINVAL, "mag_buf geometry must be overlap=326, 131072 new samples (the last one: at most)");
+    }
     if (c->outstanding)
         return fail(c, -EBUSY, "batches outstanding");
     if (!c->d_stage)
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), c->cfg.max_batch_samples * 4 + 64));
-    const unsigned mlen = validLength - overlap;
     Slot &s = c->slots[0];
-    /* data[0..326) -> the two-sample-padded "previous tail"; data[326..) -> the batch */
+    /* the first buffer's data[0..326) -> the two-sample-padded "previous tail"; every buffer's data[326..) -> the batch */
     uint8_t *tail = c->d_tail[0];
     HIPCHK(c, hipMemsetAsync(tail, 0, (size_t)(TAIL_SAMPLES - MSD_OVERLAP) * 2, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tail + (size_t)(TAIL_SAMPLES - MSD_OVERLAP) * 2, data, (size_t)MSD_OVERLAP * 2,
+    HIPCHK(c, hipMemcpyAsync(tail + (size_t)(TAIL_SAMPLES - MSD_OVERLAP) * 2, bufs[0].data, (size_t)MSD_OVERLAP * 2,
                              hipMemcpyHostToDevice, c->stream));
-    if (mlen)
-        HIPCHK(c, hipMemcpyAsync(c->d_stage, data + overlap, (size_t)mlen * 2, hipMemcpyHostToDevice, c->stream));
+    uint64_t total = 0;
+    std::vector<uint64_t> ts(2 * (size_t)n);
+    std::vector<double> means(2 * (size_t)n);
+    std::vector<uint32_t> noise(n);
+    for (unsigned k = 0; k < n; ++k) {
+        const msd_magbuf_view &b = bufs[k];
+        const unsigned mlen = b.validLength - b.overlap;
+        if (mlen)
+            HIPCHK(c, hipMemcpyAsync(c->d_stage + (size_t)k * MSD_CHUNK_SAMPLES * 2, b.data + b.overlap, (size_t)mlen * 2,
+                                     hipMemcpyHostToDevice, c->stream));
+        total += mlen;
+        ts[2 * k] = b.sampleTimestamp;
+        ts[2 * k + 1] = b.sysTimestamp;
+        means[2 * k] = b.mean_level;
+        means[2 * k + 1] = b.mean_power;
+        /* demod_2400.c:530-531 from the caller's mag_buf.mean_level / .mean_power */
+        const double noise_stddev = sqrt(b.mean_power - b.mean_level * b.mean_level);
+        noise[k] = mlen ? (uint32_t)((b.mean_power + noise_stddev) * 65535 + 0.5) : 0u;
+    }
     s.busy = true;
     s.d_iq = c->d_stage;
     s.d_prev = tail;
     s.have_prev = 1;
     s.threshold = c->cfg.preamble_threshold;
     s.dropped_before = 0;
-    s.gpu_resolve = false; /* one buffer with the caller's clock and means: the host resolver */
+    s.gpu_resolve = false; /* the caller's clocks and means: the host resolver */
     s.resolve_inflight = false;
     s.dc = false;
     s.batch_first = 0;
-    s.nsamples = mlen;
-    s.nbuffers = 1;
+    s.nsamples = total;
+    s.nbuffers = n;
     s.last = 1;
-    /* demod_2400.c:530-531 from the caller's mag_buf.mean_level / .mean_power */
-    const double noise_stddev = sqrt(mean_power - mean_level * mean_level);
-    const uint32_t host_noise = mlen ? (uint32_t)((mean_power + noise_stddev) * 65535 + 0.5) : 0u;
-    int rc = enqueue(c, s, MSD_FMT_MAG16, c->cfg.mode_ac ? &host_noise : nullptr);
+    int rc = enqueue(c, s, MSD_FMT_MAG16, c->cfg.mode_ac ? noise.data() : nullptr);
     if (rc) {
         s.busy = false;
         return rc;
     }
-    const uint64_t ts[2] = {sampleTimestamp, sysTimestamp};
-    const double means[2] = {mean_level, mean_power};
-    c->magbuf_host = data;
-    c->magbuf_valid = validLength;
-    rc = finish(c, s, MSD_FMT_MAG16, sink, user, ts, means, 0);
-    c->magbuf_host = nullptr;
+    c->magbuf_views = bufs;
+    c->magbuf_nviews = n;
+    rc = finish(c, s, MSD_FMT_MAG16, sink, user, ts.data(), means.data(), 0);
+    c->magbuf_views = nullptr;
+    c->magbuf_nviews = 0;
     /* the stream interface's tail ring was borrowed: a following msd_submit_* starts afresh */
     c->have_prev = false;
     c->tail_cur = 0;
     return rc;
+}
+
+int msd_demodulate_magbuf(msd_ctx *c, const uint16_t *data, unsigned validLength, unsigned overlap,
+                          uint64_t sampleTimestamp, uint64_t sysTimestamp, double mean_level,
+                          double mean_power, msd_message_fn sink, void *user)
+{
+    const msd_magbuf_view one = {data, validLength, overlap, sampleTimestamp, sysTimestamp, mean_level, mean_power};
+    return msd_demodulate_magbufs(c, &one, 1, sink, user);
 }
 
 } /* extern "C" */

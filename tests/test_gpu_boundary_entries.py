@@ -129,6 +129,43 @@ def test_magbuf_entry_from_python(pkg, oracle, torch_cuda, fmt, mode_ac, nfix):
         assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
 
 
+@pytest.mark.parametrize("fmt,mode_ac,nfix,group", [("uc8", 1, 1, 3), ("sc16", 0, 1, 8), ("uc8", 0, 0, 5)])
+def test_several_magbufs_in_one_call(pkg, oracle, torch_cuda, fmt, mode_ac, nfix, group):
+    """msd_demodulate_magbufs: what a consumer that finds several buffers queued hands over at once (the ifile handler's
+    mag_buf mode does, readsb's own loop takes them one by one): groups of `group` consecutive buffers -- the last group
+    short, the last buffer ragged -- with the caller's clocks and means per buffer, against the oracle and against the
+    one-buffer-per-call feed; the signal levels come from the caller's host magnitudes, across buffer boundaries too."""
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    n = 11 * CHUNK + 2345
+    cfg = pkg.siggen.make_cfg(seed=91, fmt=f, msgs_per_sec=4000, n_aircraft=40, ac_per_sec=1500 if mode_ac else 0)
+    iq = pkg.siggen.generate(cfg, n)
+    conv = pkg.Demodulator(fmt=f, nfix_crc=nfix, max_batch_samples=CHUNK)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=group * CHUNK, message_capacity=1 << 16)
+    overlap = pkg.capi.OVERLAP
+    carry = np.zeros(overlap, dtype=np.uint16)
+    bufs, counter = [], 0
+    for b in range(n // CHUNK + 1):
+        m = min(CHUNK, n - b * CHUNK)
+        mag, level, power = conv.convert(iq[b * CHUNK * bps:(b * CHUNK + m) * bps] if m else np.zeros(16, np.uint8), m)
+        data = np.concatenate([carry, mag])
+        bufs.append((data, overlap + m, overlap, counter * 5, counter * 5 // 12000, level, power))
+        carry = data[-overlap:]
+        counter += m
+    got = np.concatenate([pkg.capi.demodulate_magbufs(dem, bufs[i:i + group]) for i in range(0, len(bufs), group)])
+    want, wstats = oracle.Oracle(of, 58, nfix, mode_ac).replay(iq, cap=1 << 16)
+    assert len(want) > 300
+    assert_same_messages(got, want)
+    gstats = dem.stats()
+    for k in ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_modeac",
+              "demod_preamblePhase", "demod_bestPhase"):
+        assert gstats[k] == wstats[k], (k, gstats[k], wstats[k])
+    one_by_one, _ = magbuf_feed(pkg, oracle, fmt, iq, n, nfix, mode_ac)
+    assert np.array_equal(got, one_by_one)
+    with pytest.raises(pkg.MsdError):           # more buffers than the context was made for
+        pkg.capi.demodulate_magbufs(dem, bufs[:group + 1])
+
+
 @pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
 def test_sequential_float_sums_on_structured_inputs(pkg, oracle, torch_cuda, fmt):
     """convert.c:228-252's sums are float and sequential; the kernel evaluates them block-parallel with
