@@ -103,6 +103,9 @@ typedef struct msd_message {
 #define MSD_CFG_REPASS_AUX (1 << 14)       /* repeated resolve passes on the high-priority side stream */
 #define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records fetched with a copy instead of written by the kernels */
 #define MSD_CFG_TRACE (1 << 16)            /* per-batch host timings on stderr (experiments) */
+#define MSD_CFG_NO_ARENA_GROWTH (1 << 17)  /* a batch that overflows the region slices of its slot is not given bigger ones and
+                                              scanned again (grow_and_rescan): it goes through rerun_in_pieces and the host
+                                              resolver at once, as before round 5 and as a device without spare memory does */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums

@@ -1254,7 +1254,7 @@ int lean_gather_now(msd_ctx *c, Slot &s)
  * device memory for it, or it was the Mode A/C arena): the old way; < 0: error. */
 int grow_and_rescan(msd_ctx *c, Slot &s, int format)
 {
-    if (!s.lean || !s.lean_nreg || !s.d_rcounts)
+    if (!s.lean || !s.lean_nreg || !s.d_rcounts || (c->cfg.flags & MSD_CFG_NO_ARENA_GROWTH))
         return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<msd_region_counts> rc(s.lean_nreg);

@@ -41,8 +41,12 @@ int main(int argc, char **argv)
     iq_convert_fn (*factory)(input_format_t, double, int, struct converter_state **) = msd_init_converter;
     void (*cleanup)(struct converter_state *) = msd_cleanup_converter;
     struct converter_state *state = (struct converter_state *)0x1;
-    iq_convert_fn fn = factory(INPUT_SC16Q11, 2000000.0, 1 /* --dcfilter */, &state);
-    CHECK(fn == NULL && state == NULL); /* the DC block's constant is worked out for 2.4 MHz (convert.c:479-482) */
+    iq_convert_fn fn = factory(INPUT_SC16Q11, 0.0, 1 /* --dcfilter */, &state);
+    CHECK(fn == NULL && state == NULL); /* the DC block's constant exp(-2 pi / sample_rate) needs a rate (convert.c:479-482) */
+    fn = factory(INPUT_SC16Q11, 2000000.0, 1, &state); /* ... any rate, as the reference's factory takes it */
+    if (fn)
+        cleanup(state);
+    state = (struct converter_state *)0x1;
     fn = factory((input_format_t)9, 2400000.0, 0, &state);
     CHECK(fn == NULL && state == NULL);
     fn = factory(INPUT_SC16Q11, 2400000.0, 1 /* --dcfilter */, &state);

@@ -30,14 +30,18 @@ def resolve_stage(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("arenas", ["base-size", "default"])
+@pytest.mark.parametrize("arenas", ["base-size", "base-size-no-growth", "default"])
 @pytest.mark.parametrize("noise_seed", [None, 7])
 @pytest.mark.parametrize("nfix,mode_ac", [(0, 0), (1, 1)])
 def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, monkeypatch, noise_seed, nfix, mode_ac, arenas):
     """base-size: arenas of one hit per 8 and one live try per 16 samples (msd_config.test_arena_permille = 1000) -- they
-    overflow, the batch is rescanned in pieces; default (four times that): these short batches fit and stay on the GPU"""
-    if arenas == "base-size":
+    overflow: the slot's slices grow and the batch is scanned again (no-growth, MSD_CFG_NO_ARENA_GROWTH: rescanned in
+    pieces and resolved on the host, the path a device without spare memory takes); default (four times that): these
+    short batches fit and stay on the GPU"""
+    if arenas.startswith("base-size"):
         monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "1000")
+    if arenas == "base-size-no-growth":
+        monkeypatch.setenv("MSD_ARENA_GROWTH", "0")
     n = 12 * 131072 + 4321
     iq = pulse_train(n, noise_seed)
     f, of = fmt_ids(pkg, oracle, "uc8")
@@ -48,9 +52,11 @@ def test_pulse_train_of_preambles(pkg, oracle, torch_cuda, resolve_stage, monkey
     assert wstats["demod_preambles"] > 0.3 * n  # it is as dense as advertised
     assert_same(got, dem.stats(), want, wstats)
     t = dem.timing()
-    if arenas == "base-size":
+    if arenas.startswith("base-size"):
         assert t["reruns"] > 0 or t["resolve_fallback"] > 0  # the arenas did overflow; nothing was cut short
-        if resolve_stage == "gpu-resolve" and not mode_ac:
+        if arenas == "base-size-no-growth" and resolve_stage == "gpu-resolve":
+            assert t["resolve_fallback"] > 0, t
+        if arenas == "base-size" and resolve_stage == "gpu-resolve" and not mode_ac:
             # ... and the batch stayed on the GPU: its slot got region slices the densest region fits, one more scan, the
             # GPU resolve again (grow_and_rescan) -- no batch went through the host resolver
             assert t["reruns"] > 0 and t["resolve_fallback"] == 0, t

@@ -89,11 +89,16 @@ def test_every_stream_layout_gives_the_same_messages(pkg, oracle, torch_cuda, mo
         assert_same(np.concatenate(got[cap]), stats[cap], want, wstats)
 
 
-def test_overflowing_batch_in_the_middle_of_a_pipelined_stream(pkg, oracle, torch_cuda, monkeypatch):
+@pytest.mark.parametrize("growth", ["bigger-slices-and-one-more-scan", "in-pieces-through-the-host"])
+def test_overflowing_batch_in_the_middle_of_a_pipelined_stream(pkg, oracle, torch_cuda, monkeypatch, growth):
     """Four batches in flight, the third one an interference storm that overflows its candidate arenas (lean layout:
-    only its first resolve pass tells, possibly a msd_collect early -- the resolve passes run one batch ahead).  It is
-    rescanned in pieces and resolved on the host; the batches around it stay on the GPU, and what the pieces' scans
-    note must not leak into the slot's next prediction table."""
+    only its first resolve pass tells, possibly a msd_collect early -- the resolve passes run one batch ahead).  Round 5:
+    its slot gets region slices the densest region fits, the batch is scanned once more and stays on the GPU resolve
+    (grow_and_rescan; the other slots follow before they meet the same traffic).  With MSD_CFG_NO_ARENA_GROWTH -- or on a
+    device without room for the slices -- it is rescanned in pieces and resolved on the host as before; the batches
+    around it stay on the GPU, and what the pieces' scans note must not leak into the slot's next prediction table."""
+    if growth == "in-pieces-through-the-host":
+        monkeypatch.setenv("MSD_ARENA_GROWTH", "0")
     C, nb = pkg.CHUNK, 96
     n = 5 * nb * C + 4321
     iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=777, msgs_per_sec=5000, n_aircraft=400), n).copy()
@@ -107,7 +112,7 @@ def test_overflowing_batch_in_the_middle_of_a_pipelined_stream(pkg, oracle, torc
     dem = pkg.Demodulator(fmt=pkg.FMT_UC8, nfix_crc=1, max_batch_samples=nb * C, message_capacity=1 << 18)
     got = pkg.replay_device(dem, d.data_ptr(), n, nb * C)
     t = dem.timing()
-    assert t["reruns"] >= 1 and t["resolve_fallback"] >= 1, t
+    assert t["reruns"] >= 1 and (t["resolve_fallback"] >= 1) == (growth == "in-pieces-through-the-host"), t
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 18)
     assert len(want) > 1000
     assert_same(got, dem.stats(), want, wstats)
