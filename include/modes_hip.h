@@ -415,6 +415,12 @@ void msd_fields_to_float(const msd_fields *fields, msd_fields_float *out);
  * does -- use such a context as a converter only, msd_launch_* of the same context advances the same state. ---- */
 int msd_convert(msd_ctx *ctx, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
                 double *out_mean_level, double *out_mean_power);
+/* The same in two halves, for a reader that wants to read its next block while this one is converted: _begin queues
+ * upload, conversion and the download into mag_data and returns; _end waits and hands out the means.  One conversion in
+ * flight per context (-EBUSY); iq_data and mag_data must stay valid (and should be page-locked: msd_host_register) until
+ * _end has returned. */
+int msd_convert_begin(msd_ctx *ctx, const void *iq_data, uint16_t *mag_data, unsigned nsamples);
+int msd_convert_end(msd_ctx *ctx, double *out_mean_level, double *out_mean_power);
 
 /* ---- demodulate2400 / demodulate2400AC-shaped entry (demod_2400.h:37-38) on one magnitude
  * buffer laid out like struct mag_buf (fifo.h:57-73): data[0..overlap) is the previous buffer's

@@ -419,7 +419,20 @@ static void run_magbuf(void)
     bool eof = false;
     msd_pacer pacer;
     msd_pacer_start(&pacer, 2400000.0); /* Modes.sample_rate, readsb.c:195 */
-    while (!eof && !host_wants_exit()) {
+    /* The reference's reader reads a block, converts it, hands it over (sdr_ifile.c:192-216).  Here the conversion runs on
+     * the GPU, so the next block is read while it does (msd_convert_begin / _end on the converter's own context; two block
+     * buffers): same order, same converter state from block to block, same buffers out.  --throttle keeps the plain order:
+     * a paced reader has nothing to gain and would hold a block back. */
+    msd_ctx *conv_ctx = msd_converter_context(F.converter_state);
+    const size_t want = (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample;
+    char *rb[2] = {F.readbuf, NULL};
+    bool rb1_pinned = false;
+    if (!F.throttle && conv_ctx && posix_memalign((void **)&rb[1], 64, want) == 0)
+        rb1_pinned = msd_host_register(F.ctx, rb[1], want) == 0;
+    const bool overlap_read = rb[1] != NULL;
+    size_t got = read_fully(rb[0], want);
+    unsigned cur = 0;
+    while (!host_wants_exit()) {
         const uint64_t a0 = now_ns();
         struct msd_mag_buf *out = msd_fifo_acquire(100);
         F.T.reader_wait_ns += now_ns() - a0;
@@ -429,16 +442,30 @@ static void run_magbuf(void)
             G.hooks.monitor(); /* sdrMonitor(), sdr_ifile.c:184 */
         out->sampleTimestamp = (uint64_t)(sample_counter * 12e6 / 2400000.0); /* sdr_ifile.c:187 */
         out->sysTimestamp = out->sampleTimestamp / 12000U;                    /* startup_time = 0 */
-        const size_t want = (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample;
-        const size_t got = read_fully(F.readbuf, want);
         if (got < want)
             eof = true;
         const unsigned samples = (unsigned)(got / F.bytes_per_sample);
         const uint64_t c0 = now_ns();
-        F.converter(F.readbuf, &out->data[out->overlap], samples, F.converter_state, &out->mean_level,
-                    &out->mean_power); /* sdr_ifile.c:214 */
+        size_t got_next = 0;
+        if (overlap_read) {
+            const bool begun = msd_convert_begin(conv_ctx, rb[cur], &out->data[out->overlap], samples) == 0;
+            if (!eof)
+                got_next = read_fully(rb[cur ^ 1], want); /* ... while the GPU converts this one */
+            if (!begun) {
+                F.converter(rb[cur], &out->data[out->overlap], samples, F.converter_state, &out->mean_level, &out->mean_power);
+            } else if (msd_convert_end(conv_ctx, &out->mean_level, &out->mean_power)) {
+                pthread_mutex_lock(&F.mu);
+                snprintf(F.err, sizeof F.err, "%s", msd_last_error(conv_ctx));
+                pthread_mutex_unlock(&F.mu);
+            }
+        } else {
+            F.converter(rb[0], &out->data[out->overlap], samples, F.converter_state, &out->mean_level,
+                        &out->mean_power); /* sdr_ifile.c:214 */
+            if (!eof)
+                got_next = read_fully(rb[0], want);
+        }
         if (kbuf < TIMING_CAP) {
-            F.T.convert_us[kbuf] = (float)((now_ns() - c0) * 1e-3);
+            F.T.convert_us[kbuf] = (float)((now_ns() - c0) * 1e-3); /* (with the next block's read inside it when they overlap) */
             F.T.nconv = kbuf + 1;
         }
         out->validLength = out->overlap + samples;
@@ -460,6 +487,16 @@ static void run_magbuf(void)
          * the messages do not depend on how far the reader gets ahead; msd_fifo_acquire() holds it back once
          * all twelve buffers are in use. */
         sample_counter += samples;
+        if (eof)
+            break;
+        got = got_next;
+        if (overlap_read)
+            cur ^= 1u;
+    }
+    if (rb[1]) {
+        if (rb1_pinned)
+            msd_host_unregister(F.ctx, rb[1]);
+        free(rb[1]);
     }
     msd_fifo_drain();
     atomic_store(&F.exit_flag, 1);

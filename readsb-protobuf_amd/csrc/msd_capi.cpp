@@ -270,6 +270,9 @@ struct msd_ctx {
     msd_hit *d_region_hits = nullptr;
     msd_try *d_region_tries = nullptr;
     uint64_t hit_arena = 0, try_arena = 0;
+    uint64_t *h_conv = nullptr; /* msd_convert_begin / _end: the sums of the conversion in flight (page-locked) */
+    bool conv_pending = false;
+    unsigned conv_n = 0;
     const msd_magbuf_view *magbuf_views = nullptr; /* msd_demodulate_magbufs: the caller's buffers while its finish() runs */
     unsigned magbuf_nviews = 0;
     double want_hits_per_sample = 0, want_tries_per_sample = 0; /* region slices a slot should have at its next launch (grow_and_rescan) */
@@ -2008,6 +2011,8 @@ void destroy(msd_ctx *c)
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table); (void)hipFree(c->d_conv_magsq);
+    if (c->h_conv)
+        (void)hipHostFree(c->h_conv);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
     (void)hipFree(c->d_ac_offsets);
     (void)hipFree(c->d_noise);
@@ -2650,27 +2655,32 @@ int msd_get_buffer_means(const msd_ctx *c, double *means, size_t cap)
     return (int)n;
 }
 
-int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
-                double *out_mean_level, double *out_mean_power)
+int msd_convert_begin(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned nsamples)
 {
     if (!c || c->cfg.format == MSD_FMT_MAG16)
         return -EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (nsamples > c->cfg.max_batch_samples)
         return fail(c, -E2BIG, "nsamples exceeds max_batch_samples");
+    if (c->conv_pending)
+        return fail(c, -EBUSY, "a conversion is in flight: msd_convert_end() first");
     if (!c->d_stage)
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_stage), c->cfg.max_batch_samples * 4 + 64));
     if (!c->d_mag)
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_mag), c->cfg.max_batch_samples * 2 + 64));
+    if (!c->h_conv) { /* where the sums come home: page-locked, so that nothing of this call waits for the device */
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_conv), 4 * sizeof(uint64_t)));
+    }
     Slot &s = c->slots[0];
     if (c->outstanding)
         return fail(c, -EBUSY, "batches outstanding");
+    memset(c->h_conv, 0, 4 * sizeof(uint64_t));
+    float *h_fm = reinterpret_cast<float *>(c->h_conv + 2);
     HIPCHK(c, hipMemsetAsync(s.d_sums, 0, 2 * sizeof(uint64_t), c->stream));
     if (c->dc) {
         /* convert_*_generic (convert.c:113-213, 374-423): the DC estimate of the two channels lives in the context, as in
          * the reference's struct converter_state, and runs on from call to call -- a context that converts this way is a
          * converter and nothing else (msd_launch_* of the same context would advance the same state) */
-        float fm[2] = {0, 0};
         if (nsamples) {
             if (!c->d_conv_magsq)
                 HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_conv_magsq), c->cfg.max_batch_samples * sizeof(float) + 64));
@@ -2682,13 +2692,10 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
             if (rc)
                 return fail(c, rc, "DC filter converter launch failed");
             HIPCHK(c, hipMemcpyAsync(mag_data, c->d_mag, (size_t)nsamples * 2, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(fm, s.d_fmeans, sizeof fm, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_fm, s.d_fmeans, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (out_mean_level)
-            *out_mean_level = (double)(fm[0] / (float)nsamples);
-        if (out_mean_power)
-            *out_mean_power = (double)(fm[1] / (float)nsamples);
+        c->conv_pending = true;
+        c->conv_n = nsamples;
         return 0;
     }
     if (nsamples) {
@@ -2706,13 +2713,27 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
         }
         HIPCHK(c, hipMemcpyAsync(mag_data, c->d_mag, (size_t)nsamples * 2, hipMemcpyDeviceToHost, c->stream));
     }
-    uint64_t sums[2] = {0, 0};
-    float fm[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(sums, s.d_sums, sizeof sums, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_conv, s.d_sums, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (c->cfg.format != MSD_FMT_UC8 && !c->q11_bits && nsamples)
-        HIPCHK(c, hipMemcpyAsync(fm, s.d_fmeans, sizeof fm, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_fm, s.d_fmeans, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->conv_pending = true;
+    c->conv_n = nsamples;
+    return 0;
+}
+
+int msd_convert_end(msd_ctx *c, double *out_mean_level, double *out_mean_power)
+{
+    if (!c)
+        return -EINVAL;
+    if (!c->conv_pending)
+        return fail(c, -EINVAL, "no conversion in flight");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->conv_pending = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->cfg.format == MSD_FMT_UC8 || c->q11_bits) { /* integer sums: convert.c:104-110 and :318-326 */
+    const unsigned nsamples = c->conv_n;
+    const uint64_t *sums = c->h_conv;
+    const float *fm = reinterpret_cast<const float *>(c->h_conv + 2);
+    if (!c->dc && (c->cfg.format == MSD_FMT_UC8 || c->q11_bits)) { /* integer sums: convert.c:104-110 and :318-326 */
         if (out_mean_level)
             *out_mean_level = (double)sums[0] / 65536.0 / (double)nsamples;
         if (out_mean_power)
@@ -2724,6 +2745,15 @@ int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned ns
             *out_mean_power = (double)(fm[1] / (float)nsamples);
     }
     return 0;
+}
+
+int msd_convert(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsigned nsamples,
+                double *out_mean_level, double *out_mean_power)
+{
+    int rc = msd_convert_begin(c, iq_data, mag_data, nsamples);
+    if (!rc)
+        rc = msd_convert_end(c, out_mean_level, out_mean_power);
+    return rc;
 }
 
 int msd_demodulate_magbufs(msd_ctx *c, const msd_magbuf_view *bufs, unsigned n, msd_message_fn sink, void *user)
