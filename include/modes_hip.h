@@ -389,6 +389,9 @@ void msd_host_free(msd_ctx *ctx, void *p);
  * malloc), the reader's block buffer -- so that the copies behind msd_convert / msd_demodulate_magbuf are DMA transfers
  * instead of staged ones (a 256 KB block: 100 -> 50 us, and two threads' copies no longer queue behind one staging
  * buffer).  Optional: unregistered memory works, slower.  Unregister before the memory is freed. */
+/* A thread's first HIP call pays for the runtime's per-thread set-up (milliseconds): a thread that will call into a
+ * context can pay it before its first buffer arrives. */
+int msd_thread_attach(msd_ctx *ctx);
 int msd_host_register(msd_ctx *ctx, void *p, size_t bytes);
 void msd_host_unregister(msd_ctx *ctx, void *p);
 

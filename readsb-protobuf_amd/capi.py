@@ -186,7 +186,7 @@ EXPORTS = [
     "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
     "msd_arena_permille", "msd_host_register", "msd_host_unregister", "msd_demodulate_magbufs",
-    "msd_convert_begin", "msd_convert_end",
+    "msd_convert_begin", "msd_convert_end", "msd_thread_attach",
 ]
 
 _lib = None

@@ -343,6 +343,7 @@ static void *magbuf_consumer(void *arg)
     (void)arg;
     uint64_t k = 0;
     struct msd_mag_buf *held = NULL; /* dequeued, but it has to start a call of its own */
+    (void)msd_thread_attach(F.ctx); /* this thread's first HIP call, before the first buffer is there */
     for (;;) {
         struct msd_mag_buf *bufs[MAGBUF_BATCH];
         msd_magbuf_view views[MAGBUF_BATCH];

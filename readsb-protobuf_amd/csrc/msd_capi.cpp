@@ -2589,6 +2589,16 @@ void msd_host_free(msd_ctx *c, void *p)
     }
 }
 
+int msd_thread_attach(msd_ctx *c)
+{
+    if (!c)
+        return -EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    (void)hipStreamQuery(c->stream);
+    (void)hipGetLastError();
+    return 0;
+}
+
 int msd_host_register(msd_ctx *c, void *p, size_t bytes)
 {
     if (!c || !p || !bytes)
