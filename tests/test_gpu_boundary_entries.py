@@ -352,3 +352,25 @@ def test_dc_filter_converter_at_another_sample_rate(pkg, torch_cuda, fmt):
     assert np.array_equal(got, want)
     at_2400 = pkg.Demodulator(fmt=f, max_batch_samples=CHUNK, dc_filter=True).convert(iq[:n * bps], n)[0][:n]
     assert np.array_equal(at_2400, indep_demod.convert(fmt, iq[:n * bps].tobytes(), dc=True)[0]) and not np.array_equal(at_2400, got)
+
+
+@pytest.mark.gpu
+def test_convert_in_two_halves(pkg, oracle, torch_cuda):
+    """msd_convert_begin / msd_convert_end (what the ifile handler's reader uses to read its next block while the GPU
+    converts): the same magnitudes and means as msd_convert; one conversion in flight per context; _end without _begin and a
+    second _begin are refused."""
+    import errno
+    L = pkg.capi.lib()
+    f, of = fmt_ids(pkg, oracle, "sc16")
+    n = 50000
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=5, fmt=f, msgs_per_sec=3000), n)
+    dem = pkg.Demodulator(fmt=f, max_batch_samples=CHUNK)
+    want_mag, want_level, want_power = dem.convert(iq, n)
+    mag = np.zeros(n, dtype=np.uint16)
+    level, power = C.c_double(), C.c_double()
+    assert L.msd_convert_end(dem._h, C.byref(level), C.byref(power)) == -errno.EINVAL
+    assert L.msd_convert_begin(dem._h, iq.ctypes.data, mag.ctypes.data, n) == 0
+    assert L.msd_convert_begin(dem._h, iq.ctypes.data, mag.ctypes.data, n) == -errno.EBUSY
+    assert L.msd_convert_end(dem._h, C.byref(level), C.byref(power)) == 0
+    assert np.array_equal(mag, want_mag[:n]) and level.value == want_level and power.value == want_power
+    assert L.msd_thread_attach(dem._h) == 0
