@@ -485,6 +485,38 @@ void gpu_params(const msd_ctx *c, const Slot &s, MsdResolveParams &rp);
 
 bool gpu_eligible(const msd_ctx *c, const Slot &s);
 
+/* The arenas of the layouts without region slices (a batch that is not lean: msd_submit_*-sized batches of fewer than four
+ * buffers, the mag_buf entry, MSD_CFG_NO_LEAN / MSD_CFG_HOST_RESOLVE contexts, the pieces of rerun_in_pieces), made at
+ * first use. */
+int ensure_dense(msd_ctx *c, Slot &s)
+{
+    if (!c->d_region_hits)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
+    if (!c->d_region_tries)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
+    if (!s.d_hits || s.dense_hits < c->hit_arena) {
+        if (s.d_hits) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(s.d_hits);
+            s.d_hits = nullptr;
+        }
+        s.dense_hits = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
+        s.dense_hits = c->hit_arena;
+    }
+    if (!s.d_tries || s.dense_tries < c->try_arena) {
+        if (s.d_tries) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(s.d_tries);
+            s.d_tries = nullptr;
+        }
+        s.dense_tries = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
+        s.dense_tries = c->try_arena;
+    }
+    return 0;
+}
+
 int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pipelined = false)
 {
     const uint64_t tile = msd_scan_tile(format);
@@ -549,6 +581,11 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         }
     }
 
+    if (!s.lean && nwg) {
+        const int erc = ensure_dense(c, s);
+        if (erc)
+            return erc;
+    }
     if (s.nsamples & 7u) { /* the last, partially filled 8-sample group: a zero-padded private copy */
         const size_t bps = (format == MSD_FMT_UC8 || format == MSD_FMT_MAG16) ? 2 : 4;
         HIPCHK(c, hipMemsetAsync(s.d_ragged, 0, 64, c->stream));
@@ -764,6 +801,11 @@ int ensure_ac_host(msd_ctx *c, Slot &s, size_t nac)
  * Synchronous and slow on purpose; nothing is ever dropped. */
 int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
 {
+    {
+        const int erc = ensure_dense(c, s); /* before the pieces copy the slot: they share its dense lists */
+        if (erc)
+            return erc;
+    }
     const uint64_t total_buffers = s.nbuffers;
     for (uint64_t pieces = 2;; pieces *= 2) {
         uint64_t piece = ((s.nsamples + pieces - 1) / pieces + MSD_CHUNK_SAMPLES - 1) / MSD_CHUNK_SAMPLES *
@@ -1221,7 +1263,7 @@ int lean_gather_now(msd_ctx *c, Slot &s)
 {
     /* the first resolve pass has published the batch's totals: a slot whose region slices were enlarged may hold more
      * than the dense lists were made for */
-    const uint64_t H = s.h_totals[0], Tn = s.h_totals[1];
+    const uint64_t H = s.h_totals[0] ? s.h_totals[0] : 1, Tn = s.h_totals[1] ? s.h_totals[1] : 1; /* (never a null list) */
     if (H > s.dense_hits || Tn > s.dense_tries) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (H > s.dense_hits) {
@@ -1714,7 +1756,9 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
             HIPCHK(c, hipMemcpyAsync(s.h_hits, s.d_hits, H * sizeof(msd_hit), hipMemcpyDeviceToHost, c->aux_stream));
         if (Tn && !overflowed)
             HIPCHK(c, hipMemcpyAsync(s.h_tries, s.d_tries, Tn * sizeof(msd_try), hipMemcpyDeviceToHost, c->aux_stream));
-        if (c->cfg.mode_ac) {
+        if (c->cfg.mode_ac && !overflowed) { /* (rerun_in_pieces has stitched the pieces' Mode A/C lists on the host already; the
+                                                device holds the last piece's only -- round 5's fuzzer, drawing arena sizes,
+                                                found a reply six buffers early: this copy used to run in both cases) */
             const uint64_t nac = s.h_ac_totals[0];
             rc = ensure_ac_host(c, s, nac);
             if (rc)
@@ -2177,8 +2221,9 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
     c->try_arena = try_want > MIN_TRY_ARENA ? try_want : MIN_TRY_ARENA;
     c->max_wg = (uint32_t)c->cu_count * MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU;
     c->max_buffers = (uint32_t)(B / MSD_CHUNK_SAMPLES) + 2u;
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_hits), c->hit_arena * sizeof(msd_hit)));
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_region_tries), c->try_arena * sizeof(msd_try)));
+    /* (the arenas of the layouts without region slices -- c->d_region_*, the slots' dense lists d_hits / d_tries: 60 of the
+     * 108 bytes per sample -- are made when a batch first takes such a layout: ensure_dense(); a context that only ever
+     * runs the lean pipelined path, the default, never allocates them) */
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_counts), c->max_wg * sizeof(msd_region_counts)));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_wg_totals), (size_t)c->cu_count * MSD_SCAN_WGS_PER_CU * sizeof(msd_wg_totals)));
     if (cfg->mode_ac) {
@@ -2194,10 +2239,6 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
         CK(hipMemset(t, 0, (size_t)TAIL_SAMPLES * 4));
     }
     for (Slot &s : c->slots) {
-        CK(hipMalloc(reinterpret_cast<void **>(&s.d_hits), c->hit_arena * sizeof(msd_hit)));
-        CK(hipMalloc(reinterpret_cast<void **>(&s.d_tries), c->try_arena * sizeof(msd_try)));
-        s.dense_hits = c->hit_arena;
-        s.dense_tries = c->try_arena;
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_totals), 4 * sizeof(uint64_t)));
         CK(hipMalloc(reinterpret_cast<void **>(&s.d_buf_first), (c->max_buffers + 2) * sizeof(uint32_t)));
         if (cfg->format != MSD_FMT_UC8 || (cfg->flags & MSD_CFG_DC_FILTER))

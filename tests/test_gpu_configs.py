@@ -116,3 +116,23 @@ def test_overflowing_batch_in_the_middle_of_a_pipelined_stream(pkg, oracle, torc
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 18)
     assert len(want) > 1000
     assert_same(got, dem.stats(), want, wstats)
+
+
+def test_mode_ac_replies_of_a_batch_rescanned_in_pieces(pkg, oracle, torch_cuda, monkeypatch):
+    """Found by the fuzzer once it drew arena sizes (case 500110): a GPU-resolve context whose batch overflows its slices and
+    -- growth off, or no memory for it -- is rescanned in pieces.  The pieces' Mode A/C lists are stitched on the host; the
+    fallback then copied the device's list (the last piece's, with piece-relative positions) over them: a reply of the second
+    piece came out six buffers early.  Ordinary traffic with Mode A/C replies in every piece."""
+    monkeypatch.setenv("MSD_ARENA_SCALE_PERMILLE", "50")
+    monkeypatch.setenv("MSD_ARENA_GROWTH", "0")
+    n = 11 * pkg.CHUNK
+    cfg = pkg.siggen.make_cfg(seed=500110, msgs_per_sec=12000, n_aircraft=800, overlap_permille=10, flip_permille=200, noise_fs=0.02, ac_per_sec=4000)
+    iq = pkg.siggen.generate(cfg, n)
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(fmt=pkg.FMT_UC8, preamble_threshold=40, nfix_crc=1, mode_ac=1, max_batch_samples=64 * pkg.CHUNK, message_capacity=1 << 18)
+    got = pkg.replay_device(dem, d.data_ptr(), n, 64 * pkg.CHUNK)
+    t = dem.timing()
+    assert t["reruns"] >= 1 and t["resolve_fallback"] >= 1, t
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 40, 1, 1).replay(iq, cap=1 << 18)
+    assert (want["msgtype"] == 32).sum() > 20
+    assert_same(got, dem.stats(), want, wstats)
