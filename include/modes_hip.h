@@ -42,9 +42,12 @@ typedef struct msd_config {
                                    correction of DF17/18 against the (2, 4) tables of crc.c:374-379) */
     int32_t mode_ac;            /* --modeac, readsb.c:509-512 */
     int32_t flags;              /* MSD_CFG_* */
-    uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk.  Device memory of a context: about 108 bytes
-                                   per sample of this (candidate arenas of four pipeline slots; 14.5 GB at 128 Mi samples),
-                                   a quarter of that with test_arena_permille = 1000 */
+    uint64_t max_batch_samples; /* largest msd_submit_* call; 0 = one chunk.  Device memory of a context: about 48 bytes
+                                   per sample of this (the region slices of four pipeline slots; 6.4 GB at 128 Mi samples)
+                                   on the default path -- batches of four buffers or more through msd_launch_*, resolved on
+                                   the GPU; the layouts without region slices (small batches, the mag_buf entry, the host
+                                   resolver, MSD_CFG_NO_LEAN) add 60 bytes per sample when first used; a quarter of either
+                                   with test_arena_permille = 1000; slices that overflow grow (msd_timing.reruns) */
     void *stream;               /* hipStream_t to launch on; NULL = the context creates one */
     /* ---- tuning and test settings of THIS context (0 = default); nothing in the library reads the environment ---- */
     int32_t resolve_threads;      /* host threads of the buffer-parallel resolve when a batch is resolved on the host;

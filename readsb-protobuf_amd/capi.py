@@ -247,6 +247,19 @@ def lib():
         L.msd_demodulate_magbuf.restype = C.c_int
         L.msd_demodulate_magbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64,
                                             C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.msd_demodulate_magbufs.restype = C.c_int
+        L.msd_demodulate_magbufs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        L.msd_convert_begin.restype = C.c_int
+        L.msd_convert_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+        L.msd_convert_end.restype = C.c_int
+        L.msd_convert_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for name in ("msd_thread_attach", "msd_arena_permille"):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.msd_host_register.restype = C.c_int
+        L.msd_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.msd_host_unregister.restype = None
+        L.msd_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -368,6 +368,9 @@ def test_convert_in_two_halves(pkg, oracle, torch_cuda):
     want_mag, want_level, want_power = dem.convert(iq, n)
     mag = np.zeros(n, dtype=np.uint16)
     level, power = C.c_double(), C.c_double()
+    L.msd_convert_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+    L.msd_convert_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.msd_thread_attach.argtypes = [C.c_void_p]
     assert L.msd_convert_end(dem._h, C.byref(level), C.byref(power)) == -errno.EINVAL
     assert L.msd_convert_begin(dem._h, iq.ctypes.data, mag.ctypes.data, n) == 0
     assert L.msd_convert_begin(dem._h, iq.ctypes.data, mag.ctypes.data, n) == -errno.EBUSY
