@@ -134,5 +134,6 @@ def test_mode_ac_replies_of_a_batch_rescanned_in_pieces(pkg, oracle, torch_cuda,
     t = dem.timing()
     assert t["reruns"] >= 1 and t["resolve_fallback"] >= 1, t
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 40, 1, 1).replay(iq, cap=1 << 18)
-    assert (want["msgtype"] == 32).sum() > 20
+    ac = want[want["msgtype"] == 32]
+    assert len(ac) >= 5 and (ac["timestampMsg"] >= 6 * pkg.CHUNK * 5).any()   # replies in the second piece too
     assert_same(got, dem.stats(), want, wstats)
