@@ -1120,7 +1120,10 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
 template <int FMT, bool FIX2 /* --aggressive: two-bit correction tables in global memory */,
           bool EMIT /* the wavefronts also write the previous batch's message records (P.emit): an instantiation of its
                        own, because the call alone costs the tile loop 7 us per launch in spills */>
-__global__ void __launch_bounds__(NT, (MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3) / 4) msd_scan_kernel(const MsdScanParams P)
+#ifndef MSD_SCAN_OCC
+#define MSD_SCAN_OCC ((MSD_SCAN_WAVES * MSD_SCAN_WGS_PER_CU + 3) / 4) /* wavefronts per SIMD the register budget is held to */
+#endif
+__global__ void __launch_bounds__(NT, MSD_SCAN_OCC) msd_scan_kernel(const MsdScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *syn = reinterpret_cast<uint32_t *>(smem + OFF_SYN);

@@ -42,6 +42,9 @@ namespace {
 #ifndef MSD_RESOLVE_SEG
 #define MSD_RESOLVE_SEG 1280
 #endif
+#ifndef MSD_RESOLVE_PRIO
+#define MSD_RESOLVE_PRIO 0 /* s_setprio of the resolve wavefronts: matters only where they share a SIMD with scan wavefronts (LABLOG R5.7) */
+#endif
 constexpr int RT = MSD_RESOLVE_WG;   /* threads per workgroup (one workgroup per buffer) */
 constexpr int SEG = MSD_RESOLVE_SEG; /* hits staged per segment */
 constexpr uint32_t VACANT = 0xFFFFFFFFu;
@@ -368,6 +371,8 @@ __global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const 
 
     const int tid = threadIdx.x;
     const uint32_t wave = uni((uint32_t)tid >> 6);
+    if (MSD_RESOLVE_PRIO)
+        __builtin_amdgcn_s_setprio(MSD_RESOLVE_PRIO);
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = wall_clock64();
 #if MSD_RESOLVE_TIMING
