@@ -551,7 +551,7 @@ int enqueue(msd_ctx *c, Slot &s, int format, const uint32_t *host_noise, bool pi
         /* another slot's batch overflowed its region slices and got bigger ones (grow_and_rescan): this slot follows before
          * it meets the same traffic -- it is idle now, its last batch has been collected; a failed allocation leaves it as it is */
         const uint64_t want_h = (uint64_t)(c->want_hits_per_sample * (double)s.nsamples), want_t = (uint64_t)(c->want_tries_per_sample * (double)s.nsamples);
-        if ((want_h > s.rhit_arena || want_t > s.rtry_arena) && want_t < (1ull << 30)) {
+        if ((want_h > s.rhit_arena + s.rhit_arena / 64 || want_t > s.rtry_arena + s.rtry_arena / 64) && want_t < (1ull << 30)) { /* (not for a rounding's worth) */
             size_t free_b = 0, total_b = 0;
             const uint64_t grow_b = (want_h > s.rhit_arena ? (want_h - s.rhit_arena) * sizeof(msd_hit) : 0) +
                                     (want_t > s.rtry_arena ? (want_t - s.rtry_arena) * sizeof(msd_try) : 0);
