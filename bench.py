@@ -584,6 +584,16 @@ def main():
             f = replay(["--path", "fused"], 600)
             dropin["fused"] = f if "error" in f else {"value": f["msamples_per_s"], "unit": "Msamples/s", "wall_s": f["wall_s"], "messages": f["messages"],
                                                       "what": "msd_replay --path fused: the same handler, 64 buffers per msd_launch_host, best of 3"}
+            # the same two paths over 1024 buffers: the per-buffer cost without the run's first calls
+            if n >= 1 << 27:
+                iq[: 2 << 27].tofile(cap)
+                ms_, fs_ = replay(["--path", "magbuf"], 600), replay(["--path", "fused"], 600)
+                dropin["steady_state_1024_buffers"] = {
+                    "magbuf": ms_ if "error" in ms_ else {"value": ms_["msamples_per_s"], "unit": "Msamples/s", "wall_s": ms_["wall_s"],
+                                                          "demodulate2400_us_per_buffer_p50": ms_["demod_us_p50"],
+                                                          "iq_convert_fn_us_per_buffer_p50": ms_["convert_us_p50"]},
+                    "fused": fs_ if "error" in fs_ else {"value": fs_["msamples_per_s"], "unit": "Msamples/s", "wall_s": fs_["wall_s"]}}
+                iq[: 2 * min(n, 24_000_000)].tofile(cap)
             t = replay(["--path", "magbuf", "--throttle"], 120)
             dropin["magbuf_throttle"] = t if "error" in t else {
                 "wall_s": t["wall_s"], "buffers": t["buffers"], "deadline_misses": t["deadline_misses"], "buffer_period_ms": round(131072 / 2400.0, 2),
