@@ -2175,11 +2175,14 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
         destroy(c);
         return -EDOM; /* the folded UC8 table would not reproduce the reference's */
     }
-    CK(hipMalloc(reinterpret_cast<void **>(&c->d_lut), sizeof c->tables->uc8_folded));
+    static_assert(offsetof(msd_tables, uc8_scan) == sizeof(((msd_tables *)nullptr)->uc8_folded) &&
+                  sizeof(((msd_tables *)nullptr)->uc8_folded) == MSD_LUT_SCAN_OFFSET * sizeof(uint16_t),
+                  "the scan kernel's table lies directly behind the folded one");
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_lut), sizeof c->tables->uc8_folded + sizeof c->tables->uc8_scan));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_crc), sizeof c->tables->crc_byte));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_syn56), sizeof c->tables->syn56 + 16));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_syn112), sizeof c->tables->syn112 + 16));
-    CK(hipMemcpy(c->d_lut, c->tables->uc8_folded, sizeof c->tables->uc8_folded, hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_lut, c->tables->uc8_folded, sizeof c->tables->uc8_folded + sizeof c->tables->uc8_scan, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_crc, c->tables->crc_byte, sizeof c->tables->crc_byte, hipMemcpyHostToDevice));
     CK(hipMalloc(reinterpret_cast<void **>(&c->d_slicer), sizeof c->tables->slicer));
     CK(hipMemcpy(c->d_slicer, c->tables->slicer, sizeof c->tables->slicer, hipMemcpyHostToDevice));

@@ -180,8 +180,36 @@ typedef struct msd_acc {
 #define MSD_SL_PERM (MSD_SL_QOFF + 8u) /* bytes [5][32] */
 #define MSD_SLICER_WORDS (MSD_SL_PERM + 40u)
 #define MSD_LUT_STRIDE 136u /* folded UC8 table row pitch in u16 (bank spread) */
+/* The scan kernel's own copy of the folded table (round 5): a row pitch of 256 entries makes the folded byte pair
+ * fold(Q) << 8 | fold(I) the index itself -- three full-rate instructions per two samples where the 136-entry pitch needs
+ * two bit-field extracts, a multiply and a shifted add per sample.  With rows 512 bytes apart the same columns of every
+ * row would meet in the same bytes of a cache line (a quiet band reads the first few columns of the first few rows), so
+ * row r keeps column c at c ^ MSD_LUT_SCAN_SWZ(r): an XOR of both samples' indices at once, no carries.  The table
+ * lies behind uc8_folded in the same device allocation (MSD_LUT_SCAN_OFFSET entries in). */
+#ifndef MSD_LUT_SCAN256
+#define MSD_LUT_SCAN256 1
+#endif
+#ifndef MSD_LUT_SCAN_SWZ_BITS
+#define MSD_LUT_SCAN_SWZ_BITS 4u /* row bits that take part */
+#endif
+#ifndef MSD_LUT_SCAN_SWZ_SHIFT
+#define MSD_LUT_SCAN_SWZ_SHIFT 3u /* ... and the column bit they start at (8 entries = 16 bytes per step) */
+#endif
+#define MSD_LUT_SCAN_SWZ(row) ((((uint32_t)(row)) & ((1u << MSD_LUT_SCAN_SWZ_BITS) - 1u)) << MSD_LUT_SCAN_SWZ_SHIFT)
+#ifndef MSD_LUT_SCAN_TILED
+#define MSD_LUT_SCAN_TILED 0 /* experiment: 128-byte lines of 16 columns x 4 rows instead of rows of 256 entries */
+#endif
+#if MSD_LUT_SCAN_TILED == 2 /* lines of 8 x 8 */
+#define MSD_LUT_SCAN_INDEX(row, col) ((((uint32_t)(row) >> 3) << 10) | (((uint32_t)(col) >> 3) << 6) | (((uint32_t)(row) & 7u) << 3) | ((uint32_t)(col) & 7u))
+#elif MSD_LUT_SCAN_TILED
+#define MSD_LUT_SCAN_INDEX(row, col) ((((uint32_t)(row) >> 2) << 9) | ((uint32_t)(col) << 2) | ((uint32_t)(row) & 3u))
+#else
+#define MSD_LUT_SCAN_INDEX(row, col) ((uint32_t)(row) * 256u + ((uint32_t)(col) ^ MSD_LUT_SCAN_SWZ(row)))
+#endif
+#define MSD_LUT_SCAN_OFFSET (128u * MSD_LUT_STRIDE)
 typedef struct msd_tables {
     uint16_t uc8_folded[128 * MSD_LUT_STRIDE]; /* [fold(Q)][fold(I)] of convert.c:35-61 */
+    uint16_t uc8_scan[128 * 256];              /* the same, [fold(Q)][fold(I) ^ MSD_LUT_SCAN_SWZ(fold(Q))]: directly behind uc8_folded */
     uint16_t uc8_full[65536];                  /* the reference's table, for msd_tables_selftest */
     uint32_t crc_byte[256];                    /* crc.c:42-55 */
     uint32_t syn56[51], syn112[107];           /* sorted: syndrome | bit << 24 (crc.c:184-354) */

@@ -207,7 +207,8 @@ __device__ __forceinline__ uint32_t fetch_group(const MsdScanParams &P, int64_t 
     return valid;
 }
 
-template <int FMT, bool MASK = true /* false: the caller masks (mask_group) once all its groups' loads are out */>
+template <int FMT, bool MASK = true /* false: the caller masks (mask_group) once all its groups' loads are out */,
+          bool SCAN_TABLE = false /* lut is the context's device table: use the 256-pitch copy behind it (msd_internal.h) */>
 __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t valid, const uint16_t *lut,
                                               uint32_t (&mg)[8])
 {
@@ -220,6 +221,41 @@ __device__ __forceinline__ void convert_group(const RawGroup<FMT> &r, uint32_t v
             const uint32_t top = w & 0x80808080u;
             const uint32_t keep = top - (top >> 7); /* 0x7f in the bytes >= 128 */
             const uint32_t f = (w ^ ~keep) & 0x7f7f7f7fu;
+            if constexpr (SCAN_TABLE) {
+                /* the 256-pitch copy behind the folded table (msd_internal.h): the folded pair is the index.  Both samples'
+                 * columns are swizzled by one XOR (no carries between the halves), both byte offsets come out of one
+                 * addition (bit 15 of f is zero, so f + f carries nothing into the second sample's field), one AND and
+                 * one shift -- all of them full-rate forms, written as asm so that they stay that way. */
+                const unsigned char *tab = reinterpret_cast<const unsigned char *>(lut + MSD_LUT_SCAN_OFFSET);
+                uint32_t x = f, t, o0, o1;
+#if MSD_LUT_SCAN_TILED
+                {
+#if MSD_LUT_SCAN_TILED == 2
+                    const uint32_t off = (f & 0x78007800u) | ((f << 4) & 0x07800780u) | ((f >> 4) & 0x00700070u) | ((f + f) & 0x000e000eu);
+#else
+                    const uint32_t off = (f & 0x7c007c00u) | ((f & 0x007f007fu) << 3) | ((f >> 7) & 0x00060006u);
+#endif
+                    asm("v_and_b32 %0, 0xffff, %1" : "=v"(o0) : "v"(off));
+                    asm("v_lshrrev_b32 %0, 16, %1" : "=v"(o1) : "v"(off));
+                    mg[2 * k] = *reinterpret_cast<const uint16_t *>(tab + o0);
+                    mg[2 * k + 1] = *reinterpret_cast<const uint16_t *>(tab + o1);
+                    continue;
+                }
+#endif
+                if (MSD_LUT_SCAN_SWZ_BITS) {
+                    constexpr uint32_t SM = ((1u << MSD_LUT_SCAN_SWZ_BITS) - 1u) << MSD_LUT_SCAN_SWZ_SHIFT;
+                    uint32_t r;
+                    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(r) : "n"(8 - MSD_LUT_SCAN_SWZ_SHIFT), "v"(f));
+                    asm("v_and_b32 %0, %1, %2" : "=v"(r) : "n"(SM | (SM << 16)), "v"(r));
+                    asm("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(f), "v"(r));
+                }
+                asm("v_add_u32 %0, %1, %1" : "=v"(t) : "v"(x));
+                asm("v_and_b32 %0, 0x1fffe, %1" : "=v"(o0) : "v"(t));
+                asm("v_lshrrev_b32 %0, 16, %1" : "=v"(o1) : "v"(t));
+                mg[2 * k] = *reinterpret_cast<const uint16_t *>(tab + o0);
+                mg[2 * k + 1] = *reinterpret_cast<const uint16_t *>(tab + o1);
+                continue;
+            }
             mg[2 * k] = lut[((f >> 8) & 0xffu) * LUT_STRIDE + (f & 0xffu)];
             mg[2 * k + 1] = lut[(f >> 24) * LUT_STRIDE + ((f >> 16) & 0xffu)];
         }
@@ -740,6 +776,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
                                             uint32_t &tries_total)
 {
     constexpr int NH = tile_runs(FMT), WT = 1024 * NH; /* scan positions per tile */
+    constexpr bool SCAN_LUT = MSD_LUT_SCAN256 && MSD_LUT_GLOBAL; /* lut is P.lut: the 256-pitch copy lies behind it */
     constexpr int GPT = WT / 8 / 64;                   /* 8-sample load groups per lane per tile (2 per run) */
     const int lane = X.lane;
     uint16_t *mags = reinterpret_cast<uint16_t *>(X.w + W_MAGS);
@@ -812,7 +849,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
             RawGroup<FMT> r;
             const uint32_t valid = fetch_group<FMT>(P, (int64_t)a0 - FRONT + 8 * lane, r);
             uint32_t mg[8];
-            convert_group<FMT>(r, valid, lut, mg);
+            convert_group<FMT, true, SCAN_LUT>(r, valid, lut, mg);
             *reinterpret_cast<uint4 *>(mags + 8 * lane) = pack8(mg);
         }
     }
@@ -883,7 +920,7 @@ __device__ __forceinline__ void scan_region(const MsdScanParams &P, const WaveCt
         uint32_t mgs[GPT][8], mg_valid[GPT];
 #pragma unroll
         for (int k = 0; k < GPT; ++k) {
-            convert_group<FMT, false>(cur[k], cur_valid[k], lut, mgs[k]);
+            convert_group<FMT, false, SCAN_LUT>(cur[k], cur_valid[k], lut, mgs[k]);
             mg_valid[k] = cur_valid[k];
         }
 #pragma unroll

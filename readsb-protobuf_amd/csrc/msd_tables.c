@@ -57,6 +57,9 @@ void msd_tables_build(msd_tables *t, int nfix_crc)
     for (int kq = 0; kq < 128; ++kq)
         for (int ki = 0; ki < 128; ++ki)
             t->uc8_folded[kq * MSD_LUT_STRIDE + ki] = uc8_magnitude(128 + ki, 128 + kq);
+    for (int kq = 0; kq < 128; ++kq)
+        for (int ki = 0; ki < 128; ++ki)
+            t->uc8_scan[MSD_LUT_SCAN_INDEX(kq, ki)] = uc8_magnitude(128 + ki, 128 + kq);
 
     for (uint32_t b = 0; b < 256; ++b) { /* crc.c:46-57, generator 0xfff409 (crc.c:31) */
         uint32_t c = b << 16;
@@ -243,7 +246,8 @@ int msd_tables_selftest(const msd_tables *t)
     int bad = 0;
     for (int q = 0; q < 256; ++q)
         for (int i = 0; i < 256; ++i)
-            if (t->uc8_full[i + 256 * q] != t->uc8_folded[fold(q) * MSD_LUT_STRIDE + fold(i)])
+            if (t->uc8_full[i + 256 * q] != t->uc8_folded[fold(q) * MSD_LUT_STRIDE + fold(i)] ||
+                t->uc8_full[i + 256 * q] != t->uc8_scan[MSD_LUT_SCAN_INDEX(fold(q), fold(i))])
                 ++bad;
     /* slicer tables against the closed form of demod_2400.c:98-177: bit n of trial phase 4 + q is
      * correlator t % 5 at sample pa + t / 5 with t = 95 + (4 + q) + 12 n */
