@@ -196,16 +196,7 @@ typedef struct msd_acc {
 #define MSD_LUT_SCAN_SWZ_SHIFT 3u /* ... and the column bit they start at (8 entries = 16 bytes per step) */
 #endif
 #define MSD_LUT_SCAN_SWZ(row) ((((uint32_t)(row)) & ((1u << MSD_LUT_SCAN_SWZ_BITS) - 1u)) << MSD_LUT_SCAN_SWZ_SHIFT)
-#ifndef MSD_LUT_SCAN_TILED
-#define MSD_LUT_SCAN_TILED 0 /* experiment: 128-byte lines of 16 columns x 4 rows instead of rows of 256 entries */
-#endif
-#if MSD_LUT_SCAN_TILED == 2 /* lines of 8 x 8 */
-#define MSD_LUT_SCAN_INDEX(row, col) ((((uint32_t)(row) >> 3) << 10) | (((uint32_t)(col) >> 3) << 6) | (((uint32_t)(row) & 7u) << 3) | ((uint32_t)(col) & 7u))
-#elif MSD_LUT_SCAN_TILED
-#define MSD_LUT_SCAN_INDEX(row, col) ((((uint32_t)(row) >> 2) << 9) | ((uint32_t)(col) << 2) | ((uint32_t)(row) & 3u))
-#else
 #define MSD_LUT_SCAN_INDEX(row, col) ((uint32_t)(row) * 256u + ((uint32_t)(col) ^ MSD_LUT_SCAN_SWZ(row)))
-#endif
 #define MSD_LUT_SCAN_OFFSET (128u * MSD_LUT_STRIDE)
 typedef struct msd_tables {
     uint16_t uc8_folded[128 * MSD_LUT_STRIDE]; /* [fold(Q)][fold(I)] of convert.c:35-61 */
