@@ -263,7 +263,7 @@ struct msd_ctx {
     int bps = 2;
     msd_tables *tables = nullptr;
     uint16_t *d_lut = nullptr;
-    uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr, *d_slicer = nullptr;
+    uint32_t *d_crc = nullptr, *d_syn56 = nullptr, *d_syn112 = nullptr, *d_slicer = nullptr, *d_synhash = nullptr;
     uint64_t *d_fix2[2] = {nullptr, nullptr}; /* two-bit correction tables for 56 / 112 bits (nfix_crc == 2) */
     uint32_t fix2_lg[2] = {0, 0};
     /* per-workgroup candidate regions (shared by all batches: stream order serialises them) */
@@ -440,6 +440,9 @@ void fill_params(const msd_ctx *c, const Slot &s, MsdScanParams &p)
     p.syn112 = c->d_syn112;
     p.nsyn56 = c->tables->nsyn56;
     p.nsyn112 = c->tables->nsyn112;
+    p.synhash = c->d_synhash;
+    p.synh_mul56 = c->tables->synhash_mul[0];
+    p.synh_mul112 = c->tables->synhash_mul[1];
     p.fix2_56 = c->d_fix2[0];
     p.fix2_112 = c->d_fix2[1];
     p.fix2_lg56 = c->fix2_lg[0];
@@ -2052,7 +2055,7 @@ void destroy(msd_ctx *c)
             if (*e)
                 (void)hipEventDestroy(*e);
     }
-    (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer);
+    (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer); (void)hipFree(c->d_synhash);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
     (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table); (void)hipFree(c->d_conv_magsq);
     if (c->h_conv)
@@ -2188,6 +2191,8 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
     CK(hipMemcpy(c->d_slicer, c->tables->slicer, sizeof c->tables->slicer, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn56, c->tables->syn56, sizeof c->tables->syn56, hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_syn112, c->tables->syn112, sizeof c->tables->syn112, hipMemcpyHostToDevice));
+    CK(hipMalloc(reinterpret_cast<void **>(&c->d_synhash), sizeof c->tables->synhash));
+    CK(hipMemcpy(c->d_synhash, c->tables->synhash, sizeof c->tables->synhash, hipMemcpyHostToDevice));
     if (cfg->nfix_crc == 2) { /* --aggressive, crc.c:374-379 */
         for (int k = 0; k < 2; ++k) {
             uint64_t *tab = msd_fix2_table(c->tables, k ? 112 : 56, &c->fix2_lg[k]);

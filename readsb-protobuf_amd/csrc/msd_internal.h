@@ -205,6 +205,15 @@ typedef struct msd_tables {
     uint32_t crc_byte[256];                    /* crc.c:42-55 */
     uint32_t syn56[51], syn112[107];           /* sorted: syndrome | bit << 24 (crc.c:184-354) */
     uint32_t nsyn56, nsyn112;
+    /* the same entries for the scan kernel's step C (round 5): buckets of four, bucket = (syndrome * mul) >> (32 - lg), so
+     * that modesChecksumDiagnose's exact-match search (crc.c:389-412) is one 16-byte LDS read and four compares instead
+     * of a seven-step binary search; an empty slot is 0 (a zero syndrome is never looked up).  The multipliers are
+     * found at table build (no bucket holds more than four).  56-bit table first (MSD_SYNH_LG56 buckets), then the 112-bit one. */
+#define MSD_SYNH_LG56 5u
+#define MSD_SYNH_LG112 6u
+#define MSD_SYNH_WORDS (4u * ((1u << MSD_SYNH_LG56) + (1u << MSD_SYNH_LG112)))
+    uint32_t synhash[MSD_SYNH_WORDS];
+    uint32_t synhash_mul[2];
     uint32_t slicer[MSD_SLICER_WORDS];         /* see MSD_SL_* */
 } msd_tables;
 void msd_tables_build(msd_tables *t, int nfix_crc);

@@ -51,6 +51,8 @@ typedef struct MsdScanParams {
     const uint32_t *syn56;
     const uint32_t *syn112;
     uint32_t nsyn56, nsyn112;
+    const uint32_t *synhash; /* msd_tables.synhash (MSD_SYNH_WORDS dwords) and its two multipliers */
+    uint32_t synh_mul56, synh_mul112;
     const uint32_t *slicer; /* msd_tables.slicer: MSD_SLICER_WORDS dwords */
     const uint64_t *fix2_56, *fix2_112; /* --aggressive: the two-bit correction hash tables (msd_fix2_table);
                                            NULL otherwise */

@@ -147,8 +147,8 @@ static_assert(FRONT % 8 == 0, "whole load groups");
 static_assert(MSD_CHUNK_SAMPLES % WT_MAX == 0, "a tile never straddles two buffers");
 
 /* ---- dynamic LDS: tables shared by the workgroup, one private block per wavefront, the UC8 table ---- */
-constexpr int OFF_SYN = 0;                                  /* u32[160] */
-constexpr int OFF_SL = OFF_SYN + 640;                       /* u32[MSD_SLICER_WORDS] */
+constexpr int OFF_SYN = 0;                                  /* u32[MSD_SYNH_WORDS]: the single-bit syndromes in buckets of four */
+constexpr int OFF_SL = OFF_SYN + MSD_SYNH_WORDS * 4;        /* u32[MSD_SLICER_WORDS] */
 constexpr int OFF_WGC = OFF_SL + MSD_SLICER_WORDS * 4;      /* u32[WAVES][4]: the regions' counts, at the end */
 constexpr int OFF_WAVE = (OFF_WGC + WAVES * 16 + 15) & ~15;
 constexpr int W_MAGS = 0;                                   /* u16[FRONT + WT_MAX + 8] */
@@ -659,22 +659,19 @@ __device__ __forceinline__ bool candidate_round(const MsdScanParams &P, const Wa
                         slot = (slot + 1) & ((1u << lg) - 1u);
                     }
                 } else {
-                    /* modesChecksumDiagnose (crc.c:389-412): exact match in the sorted single-bit
-                     * table, or give up */
-                    const uint32_t *tab = (df == 11) ? X.syn : X.syn + 51;
-                    int lo2 = 0, hi2 = (df == 11) ? (int)P.nsyn56 : (int)P.nsyn112;
-                    while (lo2 < hi2) {
-                        const int mid = (lo2 + hi2) >> 1;
-                        const uint32_t e = tab[mid];
-                        if ((e & 0xffffffu) == syndrome) {
-                            errbit = e >> 24;
-                            alive = true;
-                            break;
-                        }
-                        if ((e & 0xffffffu) < syndrome)
-                            lo2 = mid + 1;
-                        else
-                            hi2 = mid;
+                    /* modesChecksumDiagnose (crc.c:389-412): exact match in the single-bit table, or give up.  The
+                     * table lies in buckets of four (msd_internal.h): one 16-byte read, four compares, no loop. */
+                    if (P.nsyn112) { /* wave-uniform: --no-fix has no table */
+                        const uint32_t bkt = (df == 11) ? (syndrome * P.synh_mul56) >> (32u - MSD_SYNH_LG56)
+                                                        : (4u << MSD_SYNH_LG56) / 4u + ((syndrome * P.synh_mul112) >> (32u - MSD_SYNH_LG112));
+                        const uint4 e4 = *reinterpret_cast<const uint4 *>(X.syn + 4u * bkt);
+                        const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((e[j] & 0xffffffu) == syndrome) {
+                                errbit = e[j] >> 24;
+                                alive = true;
+                            }
                     }
                 }
                 if (alive && errbit >= 8 && errbit <= 31)
@@ -1184,9 +1181,8 @@ __global__ void __launch_bounds__(NT, MSD_SCAN_OCC) msd_scan_kernel(const MsdSca
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     /* constant tables -> LDS, once per workgroup */
-    for (int i = tid; i < 160; i += NT)
-        syn[i] = (i < 51) ? (i < (int)P.nsyn56 ? P.syn56[i] : 0xffffffffu)
-                          : ((i - 51) < (int)P.nsyn112 && i < 158 ? P.syn112[i - 51] : 0xffffffffu);
+    for (int i = tid; i < (int)MSD_SYNH_WORDS; i += NT)
+        syn[i] = P.synhash[i];
     for (int i = tid; i < (int)MSD_SLICER_WORDS; i += NT)
         sl[i] = P.slicer[i];
     if (FMT == MSD_FMT_UC8 && !MSD_LUT_GLOBAL) {

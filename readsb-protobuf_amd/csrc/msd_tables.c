@@ -42,6 +42,33 @@ uint32_t msd_crc24(const msd_tables *t, const uint8_t *msg, int nbits)
 
 static void build_slicer_tables(msd_tables *t);
 
+/* msd_tables.synhash: the first odd multiplier from the golden-ratio constant on that puts no more than four of a
+ * table's syndromes into one bucket (a handful of tries: 107 keys in 64 buckets, 51 in 32). */
+static void build_syndrome_hash(msd_tables *t)
+{
+    memset(t->synhash, 0, sizeof t->synhash);
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t *src = k ? t->syn112 : t->syn56;
+        const uint32_t n = k ? t->nsyn112 : t->nsyn56, lg = k ? MSD_SYNH_LG112 : MSD_SYNH_LG56;
+        uint32_t *dst = t->synhash + (k ? 4u << MSD_SYNH_LG56 : 0u);
+        uint32_t mul = 0x9E3779B1u;
+        for (;; mul += 2) {
+            uint8_t fill[1u << MSD_SYNH_LG112] = {0};
+            int ok = 1;
+            for (uint32_t i = 0; i < n && ok; ++i)
+                ok = ++fill[((src[i] & 0xffffffu) * mul) >> (32 - lg)] <= 4;
+            if (ok)
+                break;
+        }
+        t->synhash_mul[k] = mul;
+        uint8_t fill[1u << MSD_SYNH_LG112] = {0};
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t b = ((src[i] & 0xffffffu) * mul) >> (32 - lg);
+            dst[4 * b + fill[b]++] = src[i];
+        }
+    }
+}
+
 static int cmp_u24(const void *a, const void *b)
 {
     uint32_t x = *(const uint32_t *)a & 0xffffffu, y = *(const uint32_t *)b & 0xffffffu;
@@ -89,6 +116,7 @@ void msd_tables_build(msd_tables *t, int nfix_crc)
                 t->nsyn112 = n;
         }
     }
+    build_syndrome_hash(t);
 }
 
 /* The slicer / CRC tables of the scan kernel (layout: MSD_SL_* in msd_internal.h). */
@@ -249,6 +277,20 @@ int msd_tables_selftest(const msd_tables *t)
             if (t->uc8_full[i + 256 * q] != t->uc8_folded[fold(q) * MSD_LUT_STRIDE + fold(i)] ||
                 t->uc8_full[i + 256 * q] != t->uc8_scan[MSD_LUT_SCAN_INDEX(fold(q), fold(i))])
                 ++bad;
+    /* every single-bit syndrome is found in its bucket, with its bit */
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t *src = k ? t->syn112 : t->syn56;
+        const uint32_t n = k ? t->nsyn112 : t->nsyn56, lg = k ? MSD_SYNH_LG112 : MSD_SYNH_LG56;
+        const uint32_t *tab = t->synhash + (k ? 4u << MSD_SYNH_LG56 : 0u);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t b = ((src[i] & 0xffffffu) * t->synhash_mul[k]) >> (32 - lg);
+            int found = 0;
+            for (int j = 0; j < 4; ++j)
+                found += tab[4 * b + j] == src[i];
+            if (found != 1)
+                ++bad;
+        }
+    }
     /* slicer tables against the closed form of demod_2400.c:98-177: bit n of trial phase 4 + q is
      * correlator t % 5 at sample pa + t / 5 with t = 95 + (4 + q) + 12 n */
     const uint8_t *perm = (const uint8_t *)&t->slicer[MSD_SL_PERM];
