@@ -9,6 +9,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MSD_SQRT_SIGNS
+#define MSD_SQRT_SIGNS 1
+#endif
+
 /* (b - 127.5)^2 only depends on k = b-128 (b >= 128) or 127-b (b < 128) */
 __device__ __forceinline__ uint32_t fold8(uint32_t b)
 {
@@ -23,11 +27,24 @@ __device__ __forceinline__ uint32_t fold8(uint32_t b)
 __device__ __forceinline__ float msd_sqrt_cr(float x)
 {
     const float r = __builtin_amdgcn_sqrtf(x);
-    const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
+    const uint32_t rb = __float_as_uint(r);
+    const float rm = __uint_as_float(rb - 1u), rp = __uint_as_float(rb + 1u);
+#if MSD_SQRT_SIGNS
+    /* Without compares and selects (4-cycle instructions each; shifts and adds issue in 2): the answer is rm, r = rm + 1 or
+     * rp = rm + 2 as bit patterns, and each residual contributes its sign bit.  nm = rm r - x is negative iff r is not too
+     * big (the old form's `em <= 0` chose rm; an exact zero residual is +0 under round-to-nearest, sign bit clear: rm):
+     * one step up; np = rp r - x is negative iff even r is too small (the old `ep > 0`): another step up; np < 0 implies
+     * nm < 0.  x = 0: r = 0, rm is the all-ones NaN, the fused multiply-add hands that NaN through with its sign bit,
+     * np = +0: rm + 1 wraps to 0.  scripts/micro/sqrt_check.hip compares with the compiler's correctly rounded sqrtf over
+     * zero and every float in range on the hardware; the converter tests hold zero samples and the 2^24-pair lattices. */
+    const float nm = __builtin_fmaf(rm, r, -x), np = __builtin_fmaf(rp, r, -x);
+    return __uint_as_float(rb - 1u + (__float_as_uint(nm) >> 31) + (__float_as_uint(np) >> 31));
+#else
     const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
     float y = em <= 0.0f ? rm : r;
     y = ep > 0.0f ? rp : y;
     return y;
+#endif
 }
 
 /* convert.c:215-253 / :332-370 float path: separate multiply and add (no FMA contraction), correctly rounded sqrt */
