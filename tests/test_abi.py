@@ -96,3 +96,21 @@ def test_sc16q11_table_bits_outside_the_range_are_refused(pkg):
     assert host.msd_converter_set_sc16q11_table_bits(12) == -errno.EINVAL
     assert host.msd_converter_set_sc16q11_table_bits(-1) == -errno.EINVAL
     assert host.msd_converter_set_sc16q11_table_bits(8) == 0 and host.msd_converter_set_sc16q11_table_bits(0) == 0
+
+
+@pytest.mark.parametrize("nfix_crc", [0, 1, 2])
+def test_host_built_tables_pass_their_selftest(pkg, nfix_crc):
+    """msd_tables_build + msd_tables_selftest on the host (msd_create runs the same check before it uploads anything): the
+    folded UC8 table and the scan kernel's 256-pitch swizzled copy against the reference's 65536-entry table (convert.c:35-61),
+    every single-bit syndrome in its bucket of four (crc.c:367-412), the slicer tables against the closed form of
+    demod_2400.c:98-177, the per-group syndromes against modesChecksum."""
+    lib = pkg.capi.lib()
+    buf = C.create_string_buffer(1 << 20)            # sizeof(msd_tables) is about 0.4 MB
+    lib.msd_tables_build.restype = None
+    lib.msd_tables_build.argtypes = [C.c_void_p, C.c_int]
+    lib.msd_tables_selftest.restype = C.c_int
+    lib.msd_tables_selftest.argtypes = [C.c_void_p]
+    lib.msd_tables_build(buf, nfix_crc)
+    assert lib.msd_tables_selftest(buf) == 0
+    tail = bytes(buf)[(1 << 20) - 4096:]
+    assert tail == b"\0" * 4096                       # the struct fits the buffer with room to spare
