@@ -203,6 +203,7 @@ struct Slot {
     msd_wire *d_wire = nullptr, *h_wire = nullptr; /* message records of the emit kernel and their pinned copy */
     unsigned long long *h_side = nullptr;          /* per record: power sum | signal_len << 48, for the statistics */
     msd_fields *h_fields = nullptr; /* pinned: header fields next to the records (MSD_CFG_DECODE_FIELDS) */
+    msd_fields *d_fields = nullptr; /* their device copy when the records travel by DMA (records_dma) */
     hipEvent_t ev_resolve = nullptr, ev_records = nullptr, ev_power = nullptr;
     hipEvent_t ev_scanned = nullptr; /* side-stream layout: this batch's scan + gather are done (its float sums / Mode A/C kernels follow) */
     uint64_t launch_seq = 0;         /* running number of the launch that filled the slot */
@@ -404,6 +405,8 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
     if (s.h_side) (void)hipHostFree(s.h_side);
     if (s.h_fields) (void)hipHostFree(s.h_fields);
     (void)hipFree(s.d_wire);
+    (void)hipFree(s.d_fields);
+    s.d_fields = nullptr;
     s.d_req = s.d_pow = s.h_req = s.h_pow = nullptr;
     s.h_wire = s.d_wire = nullptr;
     s.h_side = nullptr;
@@ -419,6 +422,8 @@ int ensure_req(msd_ctx *c, Slot &s, size_t n)
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_wire), cap * sizeof(msd_wire)));
         if (c->want_fields)
             HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&s.h_fields), cap * sizeof(msd_fields)));
+        if (c->want_fields && c->records_dma)
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&s.d_fields), cap * sizeof(msd_fields)));
     }
     s.req_cap = cap;
     return 0;
@@ -1138,7 +1143,8 @@ int gpu_queue_emit(msd_ctx *c, Slot &s, int format, hipStream_t ps, hipStream_t 
         HIPCHK(c, hipStreamWaitEvent(ks, s.ev_power, 0));
     }
     rc = msd_launch_emit(&rp, s.nbuffers, reinterpret_cast<const unsigned long long *>(s.d_powr), s.h_side,
-                         c->records_dma ? s.d_wire : s.h_wire, c->want_fields ? s.h_fields : nullptr,
+                         c->records_dma ? s.d_wire : s.h_wire,
+                         c->want_fields ? (c->records_dma ? s.d_fields : s.h_fields) : nullptr,
                          (uint32_t)s.req_cap, ks);
     if (rc)
         return fail(c, rc, "emit kernel launch failed");
@@ -1158,6 +1164,9 @@ int fetch_records(msd_ctx *c, Slot &s, uint32_t total)
     if (total && c->records_dma) {
         HIPCHK(c, hipMemcpyAsync(s.h_wire, s.d_wire, (size_t)total * sizeof(msd_wire), hipMemcpyDeviceToHost,
                                  c->copy_stream));
+        if (c->want_fields)
+            HIPCHK(c, hipMemcpyAsync(s.h_fields, s.d_fields, (size_t)total * sizeof(msd_fields), hipMemcpyDeviceToHost,
+                                     c->copy_stream));
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     }
     return 0;
@@ -2048,6 +2057,7 @@ void destroy(msd_ctx *c)
         if (s.ev_upload) (void)hipEventDestroy(s.ev_upload);
         (void)hipFree(s.d_upload);
         (void)hipFree(s.d_wire);
+        (void)hipFree(s.d_fields);
         if (s.h_ac_totals) (void)hipHostFree(s.h_ac_totals);
         if (s.h_ac) (void)hipHostFree(s.h_ac);
         hipEvent_t *evs[] = {&s.ev_start, &s.ev_scan, &s.ev_kernels, &s.ev_totals, &s.ev_copy0, &s.ev_copy1};
