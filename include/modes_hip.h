@@ -104,7 +104,7 @@ typedef struct msd_message {
 #define MSD_CFG_WAIT_INPUTS_ON_STREAM (1 << 12) /* the resolve stream waits for the snapshot upload, not the caller */
 #define MSD_CFG_NO_HELPER (1 << 13)        /* no helper thread: the per-message half of a batch on the calling thread */
 #define MSD_CFG_REPASS_AUX (1 << 14)       /* repeated resolve passes on the high-priority side stream */
-#define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records fetched with a copy instead of written by the kernels */
+#define MSD_CFG_RECORDS_DMA (1 << 15)      /* message records (and, with MSD_CFG_DECODE_FIELDS, the field records) fetched with a copy instead of written by the kernels; measured slower on this stack */
 #define MSD_CFG_TRACE (1 << 16)            /* per-batch host timings on stderr (experiments) */
 #define MSD_CFG_NO_ARENA_GROWTH (1 << 17)  /* a batch that overflows the region slices of its slot is not given bigger ones and
                                               scanned again (grow_and_rescan): it goes through rerun_in_pieces and the host

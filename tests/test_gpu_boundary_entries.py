@@ -50,6 +50,29 @@ def test_uc8_converter_on_all_65536_byte_pairs(pkg, oracle, torch_cuda):
     assert np.array_equal(mags, oracle.uc8_table())   # the reference's table itself, slot = I + 256 Q
 
 
+def test_scan_kernel_on_all_65536_byte_pairs(pkg, oracle, torch_cuda):
+    """The scan kernel reads its own copy of the UC8 table (256-entry pitch, swizzled columns, msd_internal.h) through
+    an index of its own: every (I, Q) byte pair through msd_scan_kernel -- eight buffers whose halves are differently
+    shuffled permutations of all 65536 pairs and the natural order -- and the buffers' exact level / power sums, the
+    counters and whatever messages the permutations happen to hold against the oracle.  One wrong table slot moves the
+    sums of the eight buffers that hold its pair."""
+    pairs = np.arange(65536, dtype=np.uint32)
+    parts = [np.random.default_rng(k).permutation(pairs) for k in range(15)] + [pairs]
+    both = np.concatenate(parts)                       # 16 x 65536 samples = 8 buffers
+    iq = np.empty(2 * both.size, dtype=np.uint8)
+    iq[0::2] = both & 0xFF
+    iq[1::2] = both >> 8
+    n = both.size
+    from test_gpu_parity import assert_same
+    d = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=8 * 131072, message_capacity=1 << 14)
+    got = dem.submit_device(d.data_ptr(), n, last=True)
+    want, wstats, wmeans = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0).replay(iq, cap=1 << 14, want_means=True)
+    assert_same(got, dem.stats(), want, wstats)
+    gm = dem.buffer_means()
+    assert len(gm) == wstats["buffers"] == 9 and np.array_equal(gm, wmeans[: len(gm)], equal_nan=True)   # (8 full buffers + the empty one an exact multiple ends with, sdr_ifile.c:199-216)
+
+
 @pytest.mark.parametrize("fmt", ["sc16", "sc16q11"])
 def test_s16_converters_on_a_lattice_of_2_24_pairs(pkg, oracle, torch_cuda, fmt):
     """convert.c:215-253 / :332-370 on 4096 x 4096 (I, Q) pairs: every value the 12-bit ADCs behind SC16Q11
