@@ -128,6 +128,87 @@ def run_also(extra):
             "resolve_stage": d.get("resolve_stage")}
 
 
+COUNTERS = ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted",
+            "demod_preamblePhase", "demod_bestPhase", "demod_modeac")
+
+
+def diff_against_oracle(got, gstats, want, wstats):
+    """Entries of the ordered message list (every field the demodulator determines) and demodulator counters that differ."""
+    ndiff = abs(len(got) - len(want))
+    m = min(len(got), len(want))
+    differs = np.zeros(m, dtype=bool)
+    for f in ("timestampMsg", "sysTimestampMsg", "signalLevel", "addr", "msgtype", "correctedbits", "score", "crc",
+              "bestphase"):
+        differs |= got[f][:m] != want[f][:m]
+    differs |= (got["msg"][:m] != want["msg"][:m]).any(axis=1)
+    return ndiff + int(differs.sum()) + sum(1 for k in COUNTERS if gstats[k] != wstats[k])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def two_thread_stream(O, pkg, iq, bps, ofmt, args, nb2, cpus=None, result=None):
+    """The reference's own two-thread structure for one stream (readsb.c:271-285 reader thread: read + convert into
+    mag_bufs; readsb.c:820-855 main thread: demodulate), buffers handed over through a 12-deep queue like fifo.c's,
+    thread CPU time taken with CLOCK_THREAD_CPUTIME_ID as util.c:102-115 does.  cpus = (reader cpu, demodulator cpu):
+    each thread pins itself like readsb.c:275,749.  Runs on the calling thread (the demodulator) + one more."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=12)
+    conv = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), sc16q11_table_bits=args.sc16q11_table_bits)
+    demo = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
+    cpu_t = {}
+
+    def pin(cpu):
+        if cpu is not None:
+            try:
+                os.sched_setaffinity(threading.get_native_id(), {cpu})
+            except OSError:
+                pass
+
+    def reader():
+        pin(cpus[0] if cpus else None)
+        c0 = time.thread_time()
+        carry = np.zeros(pkg.capi.OVERLAP, dtype=np.uint16)
+        for b in range(nb2):
+            mag, lvl, pw = conv.convert(iq[b * pkg.CHUNK * bps:(b + 1) * pkg.CHUNK * bps], pkg.CHUNK)
+            data = np.concatenate([carry, mag])
+            carry = mag[-pkg.capi.OVERLAP:]
+            q.put((b, data, lvl, pw))
+        q.put(None)
+        cpu_t["reader"] = time.thread_time() - c0
+
+    pin(cpus[1] if cpus else None)
+    th = threading.Thread(target=reader)
+    w0, c0, nm2 = time.perf_counter(), time.thread_time(), 0
+    th.start()
+    while True:
+        item = q.get()
+        if item is None:
+            break
+        b, data, lvl, pw = item
+        ts = b * pkg.CHUNK * 5
+        nm2 += len(demo.demod_buffer(data, ts, ts // 12000, lvl, pw, cap=1 << 14))
+    th.join()
+    wall2, cpu_t["demod"] = time.perf_counter() - w0, time.thread_time() - c0
+    two = {"value": round(nb2 * pkg.CHUNK / wall2 / 1e6, 2), "unit": "Msamples/s", "cores": 2,
+           "wall_s": round(wall2, 2), "reader_thread_cpu_s": round(cpu_t["reader"], 2),
+           "demod_thread_cpu_s": round(cpu_t["demod"], 2), "messages": nm2,
+           "sample": "first %d buffers of the capture, one buffer per hand-over" % nb2}
+    if cpus:
+        two["cpus"] = list(cpus)
+    if result is not None:
+        result.append(two)
+    return two
+
+
 def main():
     args = parse()
     import torch
@@ -147,6 +228,7 @@ def main():
     device_index = gpu_of(local_rank)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
+    cpus_before_pinning = sorted(os.sched_getaffinity(0))  # the N-stream CPU baseline spreads over these once the ranks are done
     pinned = None if args.no_pin else pin_to_gpu_local_cpus(torch, local_rank, world, gpu_of)
     reduce_dev = dev
     # MSD_BENCH_FORCE_DIST=1: one rank takes the N > 1 branch (process group, barrier, reductions, gather), so that the RCCL
@@ -373,11 +455,67 @@ def main():
                           else "host threads (%s)" % os.environ["MSD_RESOLVE_THREADS"]),
     }
 
+    # ---- N > 1: the evidence an N = 1 line carries, for every rank, after the clock stopped ----
+    if world > 1 and not args.no_check:
+        # every rank: its GPU's ordered message list and counters over the first 256 buffers of ITS capture (seed 10901 + rank)
+        # against the oracle on the same samples
+        O = graft.load_oracle()
+        ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
+        head = min(n, 256 * pkg.CHUNK)
+        t0 = time.perf_counter()
+        hwant, hwstats = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), dc_filter=args.dcfilter,
+                                  sc16q11_table_bits=args.sc16q11_table_bits).replay(iq[: head * bps], cap=1 << 21)
+        oracle_s = time.perf_counter() - t0
+        dem.reset()
+        hgot = pkg.replay_device(dem, d_iq.data_ptr(), head, batch)
+        mine = {"rank": rank, "seed": seed, "buffers": (head + pkg.CHUNK - 1) // pkg.CHUNK, "messages": int(len(hwant)),
+                "diff": diff_against_oracle(hgot, dem.stats(), hwant, hwstats),
+                "oracle_msamples_per_s_one_core": round(head / oracle_s / 1e6, 1)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        every = sorted(every, key=lambda x: x["rank"])
+        out["message_set_diff_vs_oracle_per_rank"] = every
+        out["message_set_diff_vs_oracle"] = int(sum(x["diff"] for x in every))
+        out["messages_checked"] = int(sum(x["messages"] for x in every))
+        if out["message_set_diff_vs_oracle"]:
+            raise SystemExit("bench: GPU messages differ from the oracle on some rank: " + json.dumps(every))
+    if world > 1 and rank == 0 and not args.no_cpu_baseline and not args.dcfilter:
+        # SURVEY.md 8(d) CPU baseline, form (b): N independent streams (captures 10901 .. 10901 + N - 1) on 2 N pinned cores,
+        # each stream the reference's reader thread + demodulator thread (readsb.c:271-285, 820-855), thread CPU time
+        # (CLOCK_THREAD_CPUTIME_ID, util.c:102-115) and wall time.  The other ranks' GPU work is over: the host's cores are free.
+        import threading
+        O = graft.load_oracle()
+        ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
+        nb2 = min(n, 1 << 27) // pkg.CHUNK
+        streams_iq = [iq] + [pkg.siggen.generate(pkg.siggen.make_cfg(seed=pkg.sharding.capture_seed(r), fmt=fmt, msgs_per_sec=args.msgs_per_sec,
+                                                                     ac_per_sec=500 if args.mode_ac else 0, noise_fs=args.noise_fs),
+                                                 nb2 * pkg.CHUNK) for r in range(1, world)]
+        avail = cpus_before_pinning if len(cpus_before_pinning) >= 2 * world else sorted(os.sched_getaffinity(0))
+        pairs = [(avail[2 * r], avail[2 * r + 1]) if len(avail) >= 2 * world else None for r in range(world)]
+        results, threads = [[] for _ in range(world)], []
+        w0 = time.perf_counter()
+        for r in range(world):
+            th = threading.Thread(target=two_thread_stream, args=(O, pkg, streams_iq[r], bps, ofmt, args, nb2, pairs[r], results[r]))
+            th.start()
+            threads.append(th)
+        for th in threads:
+            th.join()
+        wall = time.perf_counter() - w0
+        per_stream = [x[0] for x in results]
+        out["cpu_baseline"] = {"value": round(world * nb2 * pkg.CHUNK / wall / 1e6, 2), "unit": "Msamples/s", "cores": 2 * world, "kind": "port",
+                               "sample": "%d independent streams (captures of seeds 10901..%d), the first %d buffers (%.2f GiB) of each, "
+                                         "each stream a reader thread (IQ -> magnitude) and a demodulator thread as in readsb.c:271-285,"
+                                         "820-855, every thread pinned to a CPU of its own" % (world, 10900 + world, nb2, nb2 * pkg.CHUNK * bps / 2**30),
+                               "wall_s": round(wall, 2),
+                               "thread_cpu_s": {"readers": round(sum(x["reader_thread_cpu_s"] for x in per_stream), 2),
+                                                "demodulators": round(sum(x["demod_thread_cpu_s"] for x in per_stream), 2)},
+                               "host": "%d logical CPUs, %s" % (os.cpu_count() or 0, cpu_model()),
+                               "streams": per_stream}
+        os.sched_setaffinity(0, set(avail))
+
     # ---- CPU baseline: the oracle on this host, bounded sample (rank 0, N=1 only), after the clock stopped ----
     want = wstats = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import queue
-        import threading
         O = graft.load_oracle()
         ns = min(n, args.cpu_sample)
         ofmt = {"uc8": O.FMT_UC8, "sc16": O.FMT_SC16, "sc16q11": O.FMT_SC16Q11}[args.format]
@@ -392,49 +530,15 @@ def main():
         cpu_s /= passes
         if ns == n:
             want, wstats = w, ws
-        # (b) the reference's own two-thread structure (readsb.c:271-285 reader thread: read + convert into
-        # mag_bufs; readsb.c:820-855 main thread: demodulate), buffers handed over through a 12-deep queue like
-        # fifo.c's, thread CPU time taken with CLOCK_THREAD_CPUTIME_ID as util.c:102-115 does.
+        # (b) the reference's own two-thread structure, one stream (two_thread_stream above)
         two = None
         if not args.dcfilter:
-            nb2 = min(ns, 1 << 28) // pkg.CHUNK
-            q = queue.Queue(maxsize=12)
-            conv = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac), sc16q11_table_bits=args.sc16q11_table_bits)
-            demo = O.Oracle(ofmt, args.threshold, args.fix, int(args.mode_ac))
-            cpu_t = {}
-
-            def reader():
-                c0 = time.thread_time()
-                carry = np.zeros(pkg.capi.OVERLAP, dtype=np.uint16)
-                for b in range(nb2):
-                    mag, lvl, pw = conv.convert(iq[b * pkg.CHUNK * bps:(b + 1) * pkg.CHUNK * bps], pkg.CHUNK)
-                    data = np.concatenate([carry, mag])
-                    carry = mag[-pkg.capi.OVERLAP:]
-                    q.put((b, data, lvl, pw))
-                q.put(None)
-                cpu_t["reader"] = time.thread_time() - c0
-
-            th = threading.Thread(target=reader)
-            w0, c0, nm2 = time.perf_counter(), time.thread_time(), 0
-            th.start()
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                b, data, lvl, pw = item
-                ts = b * pkg.CHUNK * 5
-                nm2 += len(demo.demod_buffer(data, ts, ts // 12000, lvl, pw, cap=1 << 14))
-            th.join()
-            wall2, cpu_t["demod"] = time.perf_counter() - w0, time.thread_time() - c0
-            two = {"value": round(nb2 * pkg.CHUNK / wall2 / 1e6, 2), "unit": "Msamples/s", "cores": 2,
-                   "wall_s": round(wall2, 2), "reader_thread_cpu_s": round(cpu_t["reader"], 2),
-                   "demod_thread_cpu_s": round(cpu_t["demod"], 2), "messages": nm2,
-                   "sample": "first %d buffers of the same capture, one buffer per hand-over" % nb2}
+            two = two_thread_stream(O, pkg, iq, bps, ofmt, args, min(ns, 1 << 28) // pkg.CHUNK)
         out["cpu_baseline"] = {"value": round(ns / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                "sample": "first %d samples (%.2f GiB) of the same capture, oracle replay incl. IQ->magnitude, "
                                          "%d passes of %.1f s wall" % (ns, ns * bps / 2**30, passes, cpu_s),
                                "msgs_per_s": round(len(w) / cpu_s, 1),
-                               "host": "%d logical CPUs" % (os.cpu_count() or 0),
+                               "host": "%d logical CPUs, %s" % (os.cpu_count() or 0, cpu_model()),
                                "two_threads_like_the_reference": two}
     if rank == 0 and world == 1 and not args.no_check and (args.check or want is not None):
         # the whole capture, message for message and counter for counter, against the oracle
@@ -445,18 +549,8 @@ def main():
                                     sc16q11_table_bits=args.sc16q11_table_bits).replay(iq, cap=1 << 21)
         dem.reset()
         got = pkg.replay_device(dem, d_iq.data_ptr(), n, batch)
-        ndiff = abs(len(got) - len(want))
-        m = min(len(got), len(want))
-        differs = np.zeros(m, dtype=bool)
-        for f in ("timestampMsg", "sysTimestampMsg", "signalLevel", "addr", "msgtype", "correctedbits", "score", "crc",
-                  "bestphase"):
-            differs |= got[f][:m] != want[f][:m]
-        differs |= (got["msg"][:m] != want["msg"][:m]).any(axis=1)
-        ndiff += int(differs.sum())
         gstats = dem.stats()
-        counters = ("demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted",
-                    "demod_preamblePhase", "demod_bestPhase", "demod_modeac")
-        ndiff += sum(1 for k in counters if gstats[k] != wstats[k])
+        ndiff = diff_against_oracle(got, gstats, want, wstats)
         out["message_set_diff_vs_oracle"] = ndiff
         out["messages_checked"] = int(len(want))
         if ndiff:

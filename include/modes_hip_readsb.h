@@ -10,8 +10,19 @@
  *   "ifile" front-end  sdr.c:41-50,78-98 the five-function sdr_handler (sdr_ifile.h)
  *
  * Everything here is a thin host-C layer over the C-ABI of modes_hip.h; the signal processing runs
- * in the HIP kernels behind it.  Included after the reference's own convert.h (CONVERT_H defined)
- * the converter entry points are declared with the reference's types themselves.
+ * in the HIP kernels behind it.
+ *
+ * Binding by the reference's own types is an explicit opt-in of the including file (round 6; it used to follow the
+ * reference's include guards CONVERT_H / FIFO_H, which a rename upstream would have flipped silently):
+ *
+ *   #include "convert.h"
+ *   #include "fifo.h"
+ *   #define MSD_BIND_REFERENCE_TYPES          (or only MSD_BIND_REFERENCE_CONVERTER / MSD_BIND_REFERENCE_FIFO)
+ *   #include "modes_hip_readsb.h"
+ *
+ * The entry points are then declared with input_format_t / iq_convert_fn / struct mag_buf themselves (a missing
+ * reference header is a compile error, not another ABI surface); without the macros this header declares its own,
+ * layout-identical msd_* types (tests/c/boundary_ref_layout.c compares them field by field).
  */
 #ifndef MODES_HIP_READSB_H
 #define MODES_HIP_READSB_H
@@ -22,6 +33,15 @@
 
 #include "modes_hip.h"
 
+#ifdef MSD_BIND_REFERENCE_TYPES
+#ifndef MSD_BIND_REFERENCE_CONVERTER
+#define MSD_BIND_REFERENCE_CONVERTER 1
+#endif
+#ifndef MSD_BIND_REFERENCE_FIFO
+#define MSD_BIND_REFERENCE_FIFO 1
+#endif
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -31,7 +51,7 @@ extern "C" {
 /* ------------------------------------------------------------------------------------------ */
 struct converter_state; /* opaque, as in convert.h:27; here it carries the GPU context */
 
-#ifdef CONVERT_H /* the reference's convert.h is in scope: its own types */
+#ifdef MSD_BIND_REFERENCE_CONVERTER /* the includer has the reference's convert.h in scope and asks for its types */
 typedef input_format_t msd_input_format_t;
 typedef iq_convert_fn msd_iq_convert_fn;
 #else
@@ -68,7 +88,7 @@ const char *msd_converter_error(const struct converter_state *state);
 /* ------------------------------------------------------------------------------------------ */
 /* mag_buf FIFO (fifo.h:57-120)                                                               */
 /* ------------------------------------------------------------------------------------------ */
-#ifdef FIFO_H /* the reference's fifo.h is in scope: `struct msd_mag_buf` IS its `struct mag_buf`, so that msd_fifo_* and
+#ifdef MSD_BIND_REFERENCE_FIFO /* the includer has the reference's fifo.h in scope: `struct msd_mag_buf` IS its `struct mag_buf`, so that msd_fifo_* and
                * msd_demodulate2400[AC] are assignable to pointers of the reference's own function types without a cast
                * (tests/c/boundary_ref_bind.c; the two layouts are compared field by field in boundary_ref_layout.c) */
 #define msd_mag_buf mag_buf

@@ -2,7 +2,7 @@
  * boundary_check.c -- compile-and-run check of the reference-shaped host boundary
  * (include/modes_hip_readsb.h) from the point of view of a program written against the reference's
  * headers: the converter types are re-declared here the way convert.h:27-45 declares them (this
- * file's own text), CONVERT_H is defined, and the exports must then be usable with those types
+ * file's own text), MSD_BIND_REFERENCE_CONVERTER is defined, and the exports must then be usable with those types
  * without a cast.  Built with -Werror by tests/test_boundary.py; runs without a GPU.
  */
 #include <stdint.h>
@@ -10,7 +10,7 @@
 #include <string.h>
 
 /* --- what a readsb translation unit has in scope from its own convert.h --- */
-#define CONVERT_H
+#define MSD_BIND_REFERENCE_CONVERTER 1
 struct converter_state;
 typedef enum { INPUT_UC8 = 0, INPUT_SC16, INPUT_SC16Q11 } input_format_t;
 typedef void (*iq_convert_fn)(void *iq_data, uint16_t *mag_data, unsigned nsamples, struct converter_state *state,

@@ -1,6 +1,6 @@
 /* The binding a readsb maintainer writes, type-checked against the reference's own header text (-I/root/reference,
- * build container only): the reference's convert.h / fifo.h / demod_2400.h first, modes_hip_readsb.h behind them --
- * which then declares its entry points with the reference's types -- and every replacement assigned, WITHOUT A CAST and
+ * build container only): the reference's convert.h / fifo.h / demod_2400.h first, then MSD_BIND_REFERENCE_TYPES and
+ * modes_hip_readsb.h behind them -- which then declares its entry points with the reference's types -- and every replacement assigned, WITHOUT A CAST and
  * under -Wall -Wextra -Werror, to a pointer whose type is taken from the reference's declaration itself
  * (__typeof__(&init_converter) and so on). */
 #include <stdint.h> /* convert.h relies on its includer for uint16_t (readsb.h:61 in the reference) */
@@ -9,6 +9,7 @@
 #include "convert.h"
 #include "fifo.h"
 #include "demod_2400.h"
+#define MSD_BIND_REFERENCE_TYPES /* the explicit opt-in: the entry points below are declared with the reference's types */
 #include "modes_hip_readsb.h"
 
 /* convert.h:27-45 */

@@ -6,7 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#include "modes_hip_readsb.h" /* FIFO_H / CONVERT_H not yet defined: the library's own declarations */
+#include "modes_hip_readsb.h" /* no MSD_BIND_REFERENCE_* macro: the library's own declarations, whatever else is in scope */
 #include "fifo.h"
 #include "convert.h"
 #include "demod_2400.h"

@@ -38,6 +38,28 @@ def test_boundary_is_pinned_on_the_references_own_header_text(pkg, tmp_path):
         assert out.returncode == 0 and " ok" in out.stdout, (name, out.returncode, out.stdout + out.stderr)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "fifo.h")), reason="the reference tree exists in the build container only")
+def test_reference_types_are_bound_by_explicit_opt_in_only(tmp_path):
+    """Round 6: which types the header declares its entry points with follows the includer's
+    MSD_BIND_REFERENCE_* macros, not the reference's include guards.  Behind the reference's headers WITHOUT the macro the
+    library's own struct is declared (msd_fifo_acquire does not return a `struct mag_buf *`: -Werror refuses the
+    assignment); with the macro the same line compiles; and the converter and the FIFO opt in separately."""
+    def compiles(defs, body):
+        src = tmp_path / "optin.c"
+        src.write_text('#include <stdint.h>\n#include "convert.h"\n#include "fifo.h"\n' + defs +
+                       '\n#include "modes_hip_readsb.h"\n' + body + "\nint main(void) { return 0; }\n")
+        return subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + REF, str(src)], capture_output=True, text=True).returncode == 0
+    fifo_line = "struct mag_buf *(*const p)(uint32_t) = msd_fifo_acquire; void *use_p(void) { return (void *)p; }"
+    conv_line = "__typeof__(&init_converter) const q = msd_init_converter; void *use_q(void) { return (void *)q; }"
+    assert not compiles("", fifo_line) and not compiles("", conv_line)           # the guards FIFO_H / CONVERT_H are in scope: no effect
+    assert compiles("#define MSD_BIND_REFERENCE_TYPES", fifo_line + conv_line)
+    assert compiles("#define MSD_BIND_REFERENCE_FIFO 1", fifo_line) and not compiles("#define MSD_BIND_REFERENCE_FIFO 1", conv_line)
+    assert compiles("#define MSD_BIND_REFERENCE_CONVERTER 1", conv_line) and not compiles("#define MSD_BIND_REFERENCE_CONVERTER 1", fifo_line)
+    own = "struct msd_mag_buf *(*const p)(uint32_t) = msd_fifo_acquire; void *use_p(void) { return (void *)p; }"
+    assert compiles("", own)                                                         # the library's own types beside the reference's
+
+
 def test_boundary_compiles_against_reference_style_declarations_and_runs(pkg, tmp_path):
     exe = build_check(tmp_path, os.path.dirname(pkg.capi.LIB_PATH))   # (a sanitizer build when tests/test_sanitizers.py runs this)
     capture = tmp_path / "tiny.uc8"

@@ -47,4 +47,18 @@ def test_bench_two_ranks_one_gpu(torch_cuda):
     if all(cpus):                                                 # sysfs told: the ranks' CPU slices are disjoint
         spans = [tuple(int(x) for x in c.split("-")) for c in cpus]
         assert spans[0][1] < spans[1][0] or spans[1][1] < spans[0][0], cpus
-    assert "cpu_baseline" not in d and "also" not in d            # rank 0 at N=1 only
+    # round 6: an N > 1 line carries its own evidence -- every rank's list against the oracle on its own capture ...
+    per = d["message_set_diff_vs_oracle_per_rank"]
+    assert [x["rank"] for x in per] == [0, 1] and [x["seed"] for x in per] == [10901, 10902]
+    assert all(x["diff"] == 0 and x["messages"] > 1000 and x["buffers"] == 256 for x in per), per
+    assert per[0]["messages"] != per[1]["messages"]               # two captures, two lists
+    assert d["message_set_diff_vs_oracle"] == 0 and d["messages_checked"] == per[0]["messages"] + per[1]["messages"]
+    # ... and the CPU baseline of SURVEY.md 8(d) form (b): N two-thread streams on 2 N cores
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 4 and len(cb["streams"]) == 2 and cb["value"] > 0
+    for st in cb["streams"]:
+        assert st["cores"] == 2 and st["messages"] > 1000 and st["reader_thread_cpu_s"] > 0 and st["demod_thread_cpu_s"] > 0
+    pinned_cpus = [c for st in cb["streams"] for c in st.get("cpus", [])]
+    assert len(pinned_cpus) == len(set(pinned_cpus))              # a CPU of its own for every thread (when there are enough)
+    assert cb["thread_cpu_s"]["demodulators"] >= cb["thread_cpu_s"]["readers"]     # the demodulator is the busy thread
+    assert "also" not in d                                        # the other workloads: rank 0 at N=1 only
