@@ -4,7 +4,9 @@
  * implements: replays a capture through the GPU receive path and prints one `*hex;` line per
  * accepted message like displayModesMessage does in --raw mode (mode_s.c:1786-1798), or
  * `@<12 hex digit timestamp>hex;` with --mlat.  --net-raw prints the lines of the raw TCP output
- * instead (net_io.c:870-896, upper-case hex), --beast writes Beast binary frames (net_io.c:769-835).
+ * instead (net_io.c:870-896, upper-case hex), --beast writes Beast binary frames (net_io.c:769-835); both
+ * follow modesQueueOutput's forwarding rule (net_io.c:1263-1290: two-bit repairs only with --net-verbatim,
+ * which also sends the bytes as received).
  * Counters go to stderr with --stats.
  */
 #define _GNU_SOURCE
@@ -17,7 +19,7 @@
 #include "modes_hip_readsb.h"
 #include "msd_wire.h"
 
-static int g_mlat;
+static int g_mlat, g_net_verbatim; /* Modes.mlat, Modes.net_verbatim */
 static uint64_t g_count;
 
 static void print_raw(const msd_message *mm, void *user)
@@ -36,7 +38,12 @@ static void print_raw(const msd_message *mm, void *user)
 static void print_net_raw(const msd_message *mm, void *user)
 {
     char line[MSD_AVR_MAX];
-    fwrite(line, 1, msd_avr_line(mm, g_mlat, line), (FILE *)user);
+    /* modesQueueOutput (net_io.c:1263-1290): a message that needed two repairs only with --net-verbatim, and then -- like
+     * every message -- with the bytes as received (net_io.c:874) */
+    const size_t n = msd_avr_line_out(mm, g_mlat, g_net_verbatim, line);
+    if (!n)
+        return;
+    fwrite(line, 1, n, (FILE *)user);
     g_count++;
 }
 
@@ -50,7 +57,10 @@ static void count_only(const msd_message *mm, void *user)
 static void write_beast(const msd_message *mm, void *user)
 {
     uint8_t frame[MSD_BEAST_MAX];
-    fwrite(frame, 1, msd_beast_frame(mm, frame), (FILE *)user);
+    const size_t n = msd_beast_frame_out(mm, g_net_verbatim, frame); /* net_io.c:1278-1285, :775 */
+    if (!n)
+        return;
+    fwrite(frame, 1, n, (FILE *)user);
     g_count++;
 }
 
@@ -92,6 +102,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--modeac")) rx.mode_ac = 1;
         else if (!strcmp(a, "--dcfilter")) rx.dc_filter = 1; /* readsb.c:486 */
         else if (!strcmp(a, "--mlat")) g_mlat = 1;
+        else if (!strcmp(a, "--net-verbatim")) g_net_verbatim = 1; /* readsb.c: Modes.net_verbatim */
         else if (!strcmp(a, "--stats")) want_stats = 1;
         else if (!strcmp(a, "--timing")) want_timing = 1; /* one JSON line on stderr: what the run cost (msd_ifileGetTiming) */
         else if (!strcmp(a, "--no-output")) rx.sink = count_only;
@@ -108,7 +119,7 @@ int main(int argc, char **argv)
             ++i;
         } else {
             fprintf(stderr, "usage: msd_replay --ifile F [--iformat uc8|sc16|sc16q11] [--fix|--no-fix|--aggressive] [--dcfilter] "
-                            "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast|--no-output] [--stats] [--timing] [--throttle] [--path fused|magbuf] "
+                            "[--preamble-threshold N] [--modeac] [--mlat] [--net-raw|--beast|--no-output] [--net-verbatim] [--stats] [--timing] [--throttle] [--path fused|magbuf] "
                             "[--device N] [--sc16q11-table-bits N]\n");
             return 2;
         }

@@ -66,6 +66,16 @@ static void timing_reset(void)
         T->convert_us = calloc(TIMING_CAP, sizeof *T->convert_us);
         T->demod_us = calloc(TIMING_CAP, sizeof *T->demod_us);
         T->latency_us = calloc(TIMING_CAP, sizeof *T->latency_us);
+        if (!T->release_ns || !T->convert_us || !T->demod_us || !T->latency_us) {
+            /* all four or none: release_ns == NULL is what every user of the arrays tests (the run goes on
+             * untimed, msd_ifileGetTiming says -EINVAL) */
+            free(T->release_ns);
+            free(T->convert_us);
+            free(T->demod_us);
+            free(T->latency_us);
+            T->release_ns = NULL;
+            T->convert_us = T->demod_us = T->latency_us = NULL;
+        }
     }
     T->buffers = T->samples = T->misses = T->nconv = T->ndemod = 0;
     T->reader_wait_ns = T->consumer_wait_ns = 0;
@@ -465,7 +475,7 @@ static void run_magbuf(void)
             if (!eof)
                 got_next = read_fully(rb[0], want);
         }
-        if (kbuf < TIMING_CAP) {
+        if (F.T.release_ns && kbuf < TIMING_CAP) {
             F.T.convert_us[kbuf] = (float)((now_ns() - c0) * 1e-3); /* (with the next block's read inside it when they overlap) */
             F.T.nconv = kbuf + 1;
         }
@@ -478,7 +488,7 @@ static void run_magbuf(void)
         pthread_mutex_unlock(&F.mu);
         if (F.throttle)
             msd_pacer_wait(&pacer, samples); /* sdr_ifile.c:218-226: wait until this buffer may be released */
-        if (kbuf < TIMING_CAP)
+        if (F.T.release_ns && kbuf < TIMING_CAP)
             F.T.release_ns[kbuf] = now_ns();
         ++kbuf;
         msd_fifo_enqueue(out);
@@ -545,7 +555,7 @@ static void run_fused(void)
             if (F.throttle) {
                 msd_pacer_wait(&pacer, samples);
                 const uint64_t t0 = now_ns();
-                if (k - 1 < TIMING_CAP)
+                if (F.T.release_ns && k - 1 < TIMING_CAP)
                     F.T.release_ns[k - 1] = t0;
                 rc = msd_launch_host(F.ctx, buf, samples, eof ? 1 : 0);
                 if (!rc)

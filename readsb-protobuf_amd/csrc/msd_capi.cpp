@@ -13,6 +13,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -275,6 +276,8 @@ struct msd_ctx {
     bool conv_pending = false;
     unsigned conv_n = 0;
     const msd_magbuf_view *magbuf_views = nullptr; /* msd_demodulate_magbufs: the caller's buffers while its finish() runs */
+    const uint32_t *magbuf_noise = nullptr;        /* ... and their Mode A/C noise levels (demod_2400.c:530-531 from the caller's
+                                                      means), for a batch that has to be scanned again in pieces */
     unsigned magbuf_nviews = 0;
     double want_hits_per_sample = 0, want_tries_per_sample = 0; /* region slices a slot should have at its next launch (grow_and_rescan) */
     msd_region_counts *d_counts = nullptr; /* per region (wavefront) of the scan kernel */
@@ -847,7 +850,9 @@ int rerun_in_pieces(msd_ctx *c, Slot &s, int format)
             t.h_fmeans = s.h_fmeans + 2 * b0;
             t.mag_pass = false; /* the pieces' Mode A/C passes convert the IQ themselves */
             t.d_mag = nullptr;
-            int rc = enqueue(c, t, format, nullptr);
+            /* mag_buf batches: the pieces keep the noise levels the first pass was given -- from the caller's per-buffer
+             * mean_level / mean_power, which for the float converters are not what the integer sums of a MAG16 scan give */
+            int rc = enqueue(c, t, format, c->magbuf_noise ? c->magbuf_noise + b0 : nullptr);
             if (rc)
                 return rc;
             HIPCHK(c, hipEventSynchronize(t.ev_totals));
@@ -1336,6 +1341,7 @@ int grow_and_rescan(msd_ctx *c, Slot &s, int format)
                             (need_t > s.rtry_arena ? (need_t - s.rtry_arena) * sizeof(msd_try) : 0);
     if (grow_b + (1ull << 30) > free_b)
         return 1;
+    const bool grew_h = need_h > s.rhit_arena, grew_t = need_t > s.rtry_arena;
     if (need_h > s.rhit_arena) {
         msd_hit *nh = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&nh), need_h * sizeof(msd_hit)) != hipSuccess) {
@@ -1356,10 +1362,20 @@ int grow_and_rescan(msd_ctx *c, Slot &s, int format)
         s.d_rtries = nt;
         s.rtry_arena = need_t;
     }
-    /* what the other slots should have before they meet the same traffic: per sample of a batch */
-    const double per_h = (double)s.rhit_arena / (double)(s.nsamples ? s.nsamples : 1), per_t = (double)s.rtry_arena / (double)(s.nsamples ? s.nsamples : 1);
-    c->want_hits_per_sample = per_h > c->want_hits_per_sample ? per_h : c->want_hits_per_sample;
-    c->want_tries_per_sample = per_t > c->want_tries_per_sample ? per_t : c->want_tries_per_sample;
+    /* what the other slots should have before they meet the same traffic, per sample of a batch: from what THIS batch
+     * needed (need_h / need_t entries for its nsamples -- not the slot's whole arena, which is sized for max_batch_samples
+     * and would turn a short batch's overflow into several hits per sample for everybody), only for the arena that grew,
+     * and never more than the kernels can produce -- one hit per position, five tries per hit -- plus the eighth of
+     * head-room the slices are given above */
+    const double ns = (double)(s.nsamples ? s.nsamples : 1);
+    if (grew_h) {
+        const double per_h = std::min(1.25, (double)need_h / ns);
+        c->want_hits_per_sample = per_h > c->want_hits_per_sample ? per_h : c->want_hits_per_sample;
+    }
+    if (grew_t) {
+        const double per_t = std::min(6.25, (double)need_t / ns);
+        c->want_tries_per_sample = per_t > c->want_tries_per_sample ? per_t : c->want_tries_per_sample;
+    }
     HIPCHK(c, hipMemsetAsync(s.d_totals, 0, 4 * sizeof(uint64_t), c->stream)); /* the overflow flag the first scan raised */
     s.h_totals[2] = 0;
     if (c->pending_emit == &s)
@@ -2887,9 +2903,11 @@ int msd_demodulate_magbufs(msd_ctx *c, const msd_magbuf_view *bufs, unsigned n, 
     }
     c->magbuf_views = bufs;
     c->magbuf_nviews = n;
+    c->magbuf_noise = c->cfg.mode_ac ? noise.data() : nullptr;
     rc = finish(c, s, MSD_FMT_MAG16, sink, user, ts.data(), means.data(), 0);
     c->magbuf_views = nullptr;
     c->magbuf_nviews = 0;
+    c->magbuf_noise = nullptr;
     /* the stream interface's tail ring was borrowed: a following msd_submit_* starts afresh */
     c->have_prev = false;
     c->tail_cur = 0;
