@@ -407,11 +407,36 @@ def main():
                 "avg_launch_ms_scan_only": round(float(np.mean(ms_alone)), 4) if ms_alone else None,
                 "launch_ms_min_max": [round(min(scan_ms), 4), round(max(scan_ms), 4)] if scan_ms else None,
                 "algorithmic_bytes_per_sample": bps, "launches_timed": len(scan_ms), "launches": len(timings)}
+    # The same fraction from the profiler's side: the newest profiles/*_scan_launches.json holds every launch
+    # duration of a rocprofv3 --kernel-trace run of this workload (scripts/r6_profiles.sh; >= 30 launches, the first launch of
+    # each instantiation excluded by count).  The HIP-event figure above is un-profiled; the profiler's launches are 5-7 %
+    # longer (its own per-dispatch work); the line carries both.
+    ltag = "_%sscan_launches.json" % (kind + "_" if kind else "")
+    lfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                    if f.endswith(ltag) and (kind or not any(k in f for k in ("sc16", "modeac"))))
+    roofline["frac_rocprof"] = None
+    if lfiles and not args.dcfilter:
+        L = json.load(open(os.path.join(ROOT, "profiles", lfiles[-1])))
+        if L.get("samples_per_launch") == launch_samples and L.get("launches_kept"):
+            gbs = lambda us: launch_samples * bps / (us * 1e-6) / 1e9  # noqa: E731
+            roofline["frac_rocprof"] = {"mean": round(gbs(L["mean_us"]) / HBM_PEAK_GBS, 4), "median": round(gbs(L["median_us"]) / HBM_PEAK_GBS, 4),
+                                        "mean_us": L["mean_us"], "median_us": L["median_us"], "launches": L["launches_kept"],
+                                        "excluded": L.get("excluded"), "source": "profiles/" + lfiles[-1]}
     # what the kernel is really bound by (it is not HBM): from the latest profiles/*_binding.json, a summary of SQ counter
     # passes of this same command (scripts/r3_profiles.sh) and of the issue-rate microbenchmark
     bfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_binding.json"))
     if bfiles and args.format == "uc8" and not args.mode_ac:
-        roofline["binding"] = json.load(open(os.path.join(ROOT, "profiles", bfiles[-1])))
+        binding = json.load(open(os.path.join(ROOT, "profiles", bfiles[-1])))
+        roofline["binding"] = binding
+        # the three ceilings side by side: HBM (frac above), vector-ALU issue, the table gathers of the conversion alone
+        roofline["valu_lane_util"] = binding.get("valu_lane_util")
+        roofline["conversion_floor_ms"] = binding.get("conversion_floor_ms")
+        floor = (binding.get("conversion_floor_ms") or {}).get("value")
+        roofline["ceilings"] = {"hbm": roofline["frac"], "valu_issue": binding.get("frac"),
+                                "conversion_only_over_full_kernel": round(floor / avg_ms, 3) if floor and avg_ms == avg_ms else None,
+                                "what": "share of the launch explained by each limit: algorithmic bytes / HBM peak; vector-ALU issue cycles of the "
+                                        "measured instruction mix / kernel cycles; the kernel stopped after the conversion (one table gather per "
+                                        "sample, nothing else) / the full kernel"}
     # in the in-order layout without field decoding the scan's wavefronts also write the previous batch's message
     # records; MSD_EMIT_FUSED=0 gives them a kernel of their own and times the scan alone
     roofline["launch_includes"] = ("the previous batch's message records (35 000 x 56 B to host memory); "

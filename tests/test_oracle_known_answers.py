@@ -260,3 +260,49 @@ def test_product_two_bit_tables_equal_the_oracles(oracle, pkg):
         syns.update(int(x) for x in rng.integers(0, 1 << 24, 20000))
         for s in syns:
             assert product(s, nbits) == o.diagnose(s, nbits), (nbits, hex(s))
+
+
+# crc.c:462-495: the reference's own note on its (2, 4) table for 56-bit messages -- eleven pairs of two-bit syndromes that
+# agree in their upper 17 bits, one with the lower 7 bits zero (what a DF11's `crc & 0xffff80` would look up) and one
+# without: the reason mode_s.c:352-356 never repairs two bits in a DF11.  A published known answer for the nfix = 2 tables.
+DF11_AMBIGUOUS = [
+    (0x000C00, (44, 45), 0x000C1B, (30, 43)), (0x001400, (43, 45), 0x00141B, (30, 44)),
+    (0x001800, (43, 44), 0x00181B, (30, 45)), (0x001800, (43, 44), 0x001836, (29, 42)),
+    (0x002400, (42, 45), 0x00242D, (29, 30)), (0x002800, (42, 44), 0x002836, (29, 43)),
+    (0x003000, (42, 43), 0x003036, (29, 44)), (0x003000, (42, 43), 0x00306C, (28, 41)),
+    (0x004800, (41, 44), 0x00485A, (28, 29)), (0x005000, (41, 43), 0x00506C, (28, 42)),
+    (0x006000, (41, 42), 0x00606C, (28, 43)),
+]
+
+
+def test_df11_two_bit_ambiguity_list_of_the_reference(oracle, pkg):
+    """Every syndrome of crc.c:462-495 is in the (2, 4) table of a 56-bit message with exactly the two bits the reference
+    prints -- in the oracle's restatement of prepareErrorTable and in the product's hash table (msd_fix2_table, what the
+    scan kernel probes under --aggressive) -- and the single-bit syndromes by long division agree with both."""
+    import ctypes as C
+    lib = pkg.capi.lib()
+    lib.msd_fix2_diagnose.restype = C.c_int
+    lib.msd_fix2_diagnose.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_int * 2)]
+    o = oracle.Oracle(oracle.FMT_UC8, 58, 2, 0)
+
+    def product(syn):
+        b = (C.c_int * 2)()
+        return lib.msd_fix2_diagnose(56, syn, C.byref(b)), tuple(b)
+
+    def by_division(bits):     # crc.c:31: generator 0xfff409, remainder of the 56-bit word with those bits set
+        msg = bytearray(7)
+        for b in bits:
+            msg[b >> 3] ^= 0x80 >> (b & 7)
+        rem = 0
+        for byte in msg[:4]:
+            rem ^= byte << 16
+            for _ in range(8):
+                rem = ((rem << 1) ^ 0xFFF409) & 0xFFFFFF if rem & 0x800000 else (rem << 1) & 0xFFFFFF
+        return rem ^ int.from_bytes(msg[4:], "big")
+
+    for s1, b1, s2, b2 in DF11_AMBIGUOUS:
+        assert s1 & 0x7F == 0 and s2 & 0x7F != 0 and s1 & 0xFFFF80 == s2 & 0xFFFF80     # what makes the pair ambiguous for a DF11
+        for syn, bits in ((s1, b1), (s2, b2)):
+            assert by_division(bits) == syn
+            assert o.diagnose(syn, 56) == (2, list(bits))
+            assert product(syn) == (2, bits)
