@@ -109,6 +109,10 @@ typedef struct msd_message {
 #define MSD_CFG_NO_ARENA_GROWTH (1 << 17)  /* a batch that overflows the region slices of its slot is not given bigger ones and
                                               scanned again (grow_and_rescan): it goes through rerun_in_pieces and the host
                                               resolver at once, as before round 5 and as a device without spare memory does */
+#define MSD_CFG_DC_SEQUENTIAL (1 << 18)    /* MSD_CFG_DC_FILTER: the DC block by the in-order kernel alone (130 Msamples/s), not by the
+                                              exact parallel-in-time kernels in front of it (round 6; experiments and tests) */
+#define MSD_CFG_DC_ONE_PASS (1 << 19)      /* ... one parallel pass queued instead of 24: batches of more than two blocks are
+                                              not exact by then and take the in-order kernel behind the passes (tests of that path) */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums
@@ -406,6 +410,12 @@ int msd_get_stats(const msd_ctx *ctx, msd_stats *st);
  * msd_config.test_arena_permille asked for. */
 int msd_arena_permille(const msd_ctx *ctx);
 int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
+/* MSD_CFG_DC_FILTER: how the DC block of the most recent batch (or msd_convert call) was computed.  Waits for the
+ * context's stream.  out[0] = 1: by the exact parallel-in-time kernels; 0: they had not arrived at an exact state for every
+ * block within the passes queued (or the context is MSD_CFG_DC_SEQUENTIAL / the batch's IQ was not 16-byte aligned) and the
+ * in-order kernel did the batch; out[1] = passes that did work, out[2] = blocks that had to guess (all passes),
+ * out[3] = blocks.  -EINVAL for a context without the DC filter. */
+int msd_dc_filter_status(msd_ctx *ctx, uint32_t out[4]);
 /* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
  * fifo.h:70-71): 2 doubles per buffer, up to cap buffers; returns the number of buffers. */
 int msd_get_buffer_means(const msd_ctx *ctx, double *means, size_t cap);

@@ -68,6 +68,7 @@ CFG_DC_FILTER = 2
 CFG_HOST_RESOLVE, CFG_CHAIN_IN_ORDER, CFG_CHAIN_SIDE_STREAMS, CFG_NO_LEAN, CFG_NO_RESOLVE_AHEAD = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 CFG_POWER_KERNEL, CFG_POWER_IN_RESOLVE, CFG_EMIT_KERNEL, CFG_WAIT_INPUTS_ON_STREAM = 1 << 9, 1 << 10, 1 << 11, 1 << 12
 CFG_NO_HELPER, CFG_REPASS_AUX, CFG_RECORDS_DMA, CFG_TRACE, CFG_NO_ARENA_GROWTH = 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17
+CFG_DC_SEQUENTIAL, CFG_DC_ONE_PASS = 1 << 18, 1 << 19
 
 
 def layout_from_environment():
@@ -96,6 +97,10 @@ def layout_from_environment():
         flags |= CFG_RECORDS_DMA
     if e("MSD_ARENA_GROWTH", "1") == "0":
         flags |= CFG_NO_ARENA_GROWTH
+    if e("MSD_DC", "") == "sequential":
+        flags |= CFG_DC_SEQUENTIAL
+    elif e("MSD_DC", "") == "one_pass":
+        flags |= CFG_DC_ONE_PASS
     fields = dict(resolve_threads=int(e("MSD_RESOLVE_THREADS", "0") or 0),
                   test_arena_permille=int(e("MSD_ARENA_SCALE_PERMILLE", "0") or 0),
                   test_inline_adds=int(e("MSD_RESOLVE_INLINE_ADDS", "0") or 0),
@@ -186,7 +191,7 @@ EXPORTS = [
     "msd_collect_fields", "msd_decode_fields", "msd_fields_to_float", "msd_array_fields_sink",
     "msd_note_dropped", "msd_set_preamble_threshold", "msd_set_timing_interval", "msd_restart", "msd_decode_fields_device",
     "msd_arena_permille", "msd_host_register", "msd_host_unregister", "msd_demodulate_magbufs",
-    "msd_convert_begin", "msd_convert_end", "msd_thread_attach",
+    "msd_convert_begin", "msd_convert_end", "msd_thread_attach", "msd_dc_filter_status",
 ]
 
 _lib = None
@@ -256,6 +261,8 @@ def lib():
         for name in ("msd_thread_attach", "msd_arena_permille"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_void_p]
+        L.msd_dc_filter_status.restype = C.c_int
+        L.msd_dc_filter_status.argtypes = [C.c_void_p, C.c_void_p]
         L.msd_host_register.restype = C.c_int
         L.msd_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.msd_host_unregister.restype = None
@@ -310,6 +317,13 @@ class Demodulator:
             self.close()
         except Exception:
             pass
+
+    def dc_filter_status(self):
+        """(exact, passes, guessed, blocks) of the most recent batch's DC block: exact = 1 when the parallel-in-time kernels
+        did it, 0 when the in-order kernel behind them had to."""
+        out = (C.c_uint32 * 4)()
+        self._check(lib().msd_dc_filter_status(self._h, out))
+        return tuple(int(v) for v in out)
 
     def arena_permille(self):
         """Candidate arenas in thousandths of the base size: 4000, or 1000 after msd_create's out-of-memory retry."""

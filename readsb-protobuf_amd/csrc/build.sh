@@ -12,8 +12,9 @@ gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -c msd_fields.c -o msd_fields.o
 LICM="-mllvm -disable-machine-licm"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $LICM $MSD_EXTRA_HIPFLAGS $INC -c msd_kernels.hip -o msd_kernels.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $LICM $INC -c msd_resolve_kernels.hip -o msd_resolve_kernels.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $INC -c msd_dc_kernels.hip -o msd_dc_kernels.o
 hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC $INC -c msd_capi.cpp -o msd_capi.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o libmodes_hip.so msd_kernels.o msd_resolve_kernels.o msd_capi.o msd_tables.o msd_resolve.o msd_fields.o -lm -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC -o libmodes_hip.so msd_kernels.o msd_dc_kernels.o msd_resolve_kernels.o msd_capi.o msd_tables.o msd_resolve.o msd_fields.o -lm -lpthread
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_fifo.c -o host/msd_fifo.o
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_sdr_ifile.c -o host/msd_sdr_ifile.o
 gcc -std=c11 -O2 -g -Wall -Wextra -fPIC $INC -Ihost -c host/msd_wire.c -o host/msd_wire.o

@@ -344,6 +344,10 @@ struct msd_ctx {
     float *d_conv_magsq = nullptr; /* msd_convert of a MSD_CFG_DC_FILTER context: the clamped squares of the call's samples */
     float dc_a = 0, dc_b = 1;     /* struct converter_state, convert.c:28-33,479-482 */
     float *d_dcstate = nullptr;   /* z1_I, z1_Q on the device, carried from batch to batch */
+    void *d_dc_work = nullptr;    /* the parallel-in-time DC filter's blocks, tables and control word (msd_dcp_work_bytes) */
+    bool dc_last_parallel = false; /* the most recent DC block went through the parallel kernels (msd_dc_filter_status) */
+    uint32_t dc_last_blocks = 0;
+    int dc_passes = 24;           /* passes queued per batch (MSD_CFG_DC_ONE_PASS: 1, so that the in-order kernel behind them runs) */
     int scan_format = 0;          /* what the scan and its follow-up kernels read: cfg.format, or MAG16 behind the DC filter */
     size_t scan_bps = 2;
     msd_resolver resolver{};
@@ -1912,6 +1916,26 @@ int check_batch(msd_ctx *c, const void *p, uint64_t nsamples, int last)
     return 0;
 }
 
+/* --dcfilter: the batch's IQ -> DC-blocked magnitudes and squares, the converter state advanced; strictly in stream
+ * order on `stream`.  The parallel-in-time kernels first, the in-order kernel behind them (it returns at once when they
+ * came out exact -- they always have so far; MSD_CFG_DC_SEQUENTIAL: the in-order kernel alone). */
+int launch_dc_block(msd_ctx *c, const void *d_iq, uint64_t nsamples, uint16_t *d_mag, float *d_magsq, hipStream_t stream)
+{
+    const void *skip_if = nullptr;
+    c->dc_last_parallel = false;
+    if (c->d_dc_work && nsamples && (reinterpret_cast<uintptr_t>(d_iq) & 15u) == 0) {
+        const uint32_t L = msd_dcp_block_len(nsamples);
+        const int rc = msd_launch_dcfilter_parallel(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, d_mag, d_magsq,
+                                                    c->d_dc_work, L, c->dc_passes, stream);
+        if (rc)
+            return rc;
+        skip_if = c->d_dc_work;
+        c->dc_last_parallel = true;
+        c->dc_last_blocks = (uint32_t)((nsamples + L - 1) / L);
+    }
+    return msd_launch_dcfilter(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, d_mag, d_magsq, skip_if, stream);
+}
+
 int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
 {
     int rc = check_batch(c, d_iq, nsamples, last);
@@ -1936,8 +1960,7 @@ int launch(msd_ctx *c, const void *d_iq, uint64_t nsamples, int last)
     s.threshold = c->cfg.preamble_threshold;
     s.dc = c->dc;
     if (c->dc) { /* the converter proper: IQ -> DC-blocked magnitudes, strictly in stream order */
-        rc = msd_launch_dcfilter(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, s.d_dcmag, s.d_magsq,
-                                 c->stream);
+        rc = launch_dc_block(c, d_iq, nsamples, s.d_dcmag, s.d_magsq, c->stream);
         if (rc) {
             s.busy = false;
             return fail(c, rc, "DC filter kernel launch failed");
@@ -2083,7 +2106,7 @@ void destroy(msd_ctx *c)
     }
     (void)hipFree(c->d_lut); (void)hipFree(c->d_crc); (void)hipFree(c->d_syn56); (void)hipFree(c->d_syn112); (void)hipFree(c->d_slicer); (void)hipFree(c->d_synhash);
     (void)hipFree(c->d_fix2[0]); (void)hipFree(c->d_fix2[1]);
-    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table); (void)hipFree(c->d_conv_magsq);
+    (void)hipFree(c->d_dcstate); (void)hipFree(c->d_dc_work); (void)hipFree(c->d_fm_work); (void)hipFree(c->d_q11_table); (void)hipFree(c->d_conv_magsq);
     if (c->h_conv)
         (void)hipHostFree(c->h_conv);
     (void)hipFree(c->d_region_hits); (void)hipFree(c->d_region_tries); (void)hipFree(c->d_counts); (void)hipFree(c->d_wg_totals);
@@ -2319,6 +2342,10 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
     if (c->dc) {
         CK(hipMalloc(reinterpret_cast<void **>(&c->d_dcstate), 2 * sizeof(float)));
         CK(hipMemset(c->d_dcstate, 0, 2 * sizeof(float))); /* convert.c:476-477 */
+        if (!(cfg->flags & MSD_CFG_DC_SEQUENTIAL)) { /* 0.3 MB + 8 bytes per 64 samples of a batch */
+            CK(hipMalloc(&c->d_dc_work, msd_dcp_work_bytes(c->cfg.max_batch_samples, 0)));
+            c->dc_passes = (cfg->flags & MSD_CFG_DC_ONE_PASS) ? 1 : 24;
+        }
     }
     {
         c->trace = (cfg->flags & MSD_CFG_TRACE) != 0;
@@ -2728,6 +2755,23 @@ int msd_get_timing(const msd_ctx *c, msd_timing *t)
     return 0;
 }
 
+int msd_dc_filter_status(msd_ctx *c, uint32_t out[4])
+{
+    if (!c || !out || !c->dc)
+        return -EINVAL;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!c->d_dc_work || !c->dc_last_parallel)
+        return 0;
+    uint32_t ctl[12] = {0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(ctl, c->d_dc_work, sizeof ctl, hipMemcpyDeviceToHost));
+    out[0] = ctl[0];  /* DcpCtl.done */
+    out[1] = ctl[9] > ctl[10] ? ctl[9] : ctl[10]; /* .passes_ch */
+    out[2] = ctl[11]; /* .guessed */
+    out[3] = c->dc_last_blocks;
+    return 0;
+}
+
 int msd_get_buffer_means(const msd_ctx *c, double *means, size_t cap)
 {
     if (!c || !means)
@@ -2770,8 +2814,7 @@ int msd_convert_begin(msd_ctx *c, const void *iq_data, uint16_t *mag_data, unsig
             if (!c->d_conv_magsq)
                 HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_conv_magsq), c->cfg.max_batch_samples * sizeof(float) + 64));
             HIPCHK(c, hipMemcpyAsync(c->d_stage, iq_data, (size_t)nsamples * c->bps, hipMemcpyHostToDevice, c->stream));
-            int rc = msd_launch_dcfilter(c->cfg.format, c->d_stage, nsamples, c->dc_a, c->dc_b, c->d_dcstate, c->d_mag, c->d_conv_magsq,
-                                         c->stream);
+            int rc = launch_dc_block(c, c->d_stage, nsamples, c->d_mag, c->d_conv_magsq, c->stream);
             if (!rc)
                 rc = msd_launch_dc_sums(c->d_conv_magsq, nsamples, nsamples, 1, s.d_fmeans, c->d_fm_work, 0, c->stream);
             if (rc)

@@ -193,7 +193,16 @@ int msd_launch_convert(int format, const void *d_iq, uint32_t nsamples, const ui
 /* --dcfilter: IQ -> DC-blocked u16 magnitudes + f32 squares, the converter state (z1_I, z1_Q, device
  * memory) carried from call to call; then the sequential per-buffer float sums of those squares */
 int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
-                        uint16_t *d_mag, float *d_magsq, hipStream_t stream);
+                        uint16_t *d_mag, float *d_magsq, const void *d_skip_if, hipStream_t stream);
+/* ... the same, exact and parallel in time (msd_dc_kernels.hip): blocks of block_len samples evaluated from 64 candidate start
+ * states each, an in-order walk that is exact wherever a candidate or the monotonicity of the block's map decides, at most
+ * max_passes passes.  d_work: msd_dcp_work_bytes(nsamples, block_len); its first word is 1 when the batch came out exact,
+ * and msd_launch_dcfilter(..., d_skip_if = d_work, ...) queued behind does the batch in order when it did not.  d_iq 16-byte aligned. */
+int msd_launch_dcfilter_parallel(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
+                                 uint16_t *d_mag, float *d_magsq, void *d_work, uint32_t block_len, int max_passes, hipStream_t stream);
+size_t msd_dcp_work_bytes(uint64_t max_samples, uint32_t block_len);
+uint32_t msd_dcp_block_len(uint64_t nsamples);
+
 int msd_launch_dc_sums(const float *d_magsq, uint64_t nsamples, uint64_t buffer_len, uint32_t nbuffers, float *d_out,
                        void *d_work, int phase, hipStream_t stream);
 /* tile_sums: the scan kernel's per-1024-sample approximate sums of the same batch (buffer_len a multiple of 1024), or NULL */

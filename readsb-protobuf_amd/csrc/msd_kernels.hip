@@ -2451,8 +2451,10 @@ __device__ __forceinline__ void dc_sample(const uint8_t *iq, uint64_t g, float &
 template <int FMT>
 __global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t *iq, uint64_t nsamples, float dc_a,
                                                                   float dc_b, float *state /* z1_I, z1_Q */,
-                                                                  uint16_t *mag, float *magsq_out)
+                                                                  uint16_t *mag, float *magsq_out, const uint32_t *skip_if)
 {
+    if (skip_if && *skip_if)
+        return; /* the parallel-in-time kernels in front (msd_dc_kernels.hip) did the batch */
     __shared__ __attribute__((aligned(16))) float tv[2][2][DC_BLK + 16]; /* [block parity][channel] f * dc_a (+ 16: the chain loop's last, unused prefetch) */
     __shared__ __attribute__((aligned(16))) float zv[2][2][DC_BLK]; /* [block parity][channel] z */
     const int tid = threadIdx.x;
@@ -3287,23 +3289,24 @@ extern "C" int msd_launch_convert(int format, const void *d_iq, uint32_t nsample
 }
 
 extern "C" int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b,
-                                   float *d_state, uint16_t *d_mag, float *d_magsq, hipStream_t stream)
+                                   float *d_state, uint16_t *d_mag, float *d_magsq, const void *d_skip_if, hipStream_t stream)
 {
+    const uint32_t *skip_if = static_cast<const uint32_t *>(d_skip_if);
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
     if (nsamples == 0)
         return 0;
     switch (format) {
     case MSD_FMT_UC8:
         hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_UC8>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples, dc_a,
-                           dc_b, d_state, d_mag, d_magsq);
+                           dc_b, d_state, d_mag, d_magsq, skip_if);
         break;
     case MSD_FMT_SC16:
         hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_SC16>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples, dc_a,
-                           dc_b, d_state, d_mag, d_magsq);
+                           dc_b, d_state, d_mag, d_magsq, skip_if);
         break;
     case MSD_FMT_SC16Q11:
         hipLaunchKernelGGL(msd_dcfilter_kernel<MSD_FMT_SC16Q11>, dim3(1), dim3(DC_THREADS), 0, stream, iq, nsamples,
-                           dc_a, dc_b, d_state, d_mag, d_magsq);
+                           dc_a, dc_b, d_state, d_mag, d_magsq, skip_if);
         break;
     default:
         return -22;

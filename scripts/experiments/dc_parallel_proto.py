@@ -1,0 +1,65 @@
+import numpy as np, ctypes, sys, time
+sys.path.insert(0,'/root/repo')
+import os, subprocess
+_here = os.path.dirname(os.path.abspath(__file__))
+subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-shared', '-fPIC', os.path.join(_here, 'dc_parallel_chain.c'), '-o', '/tmp/dc_parallel_chain.so'])
+lib = ctypes.CDLL('/tmp/dc_parallel_chain.so')
+def chain(t, z0, b):
+    out = np.empty_like(t)
+    lib.chain(t.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(t)), ctypes.c_float(z0), ctypes.c_float(b))
+    return out
+b = np.float32(0.9999974); a = np.float32(2.6226044e-06)
+def ordf(x):
+    i = x.view(np.int32).astype(np.int64)
+    return np.where(i >= 0, i, -(i & 0x7fffffff))
+def unord(o):
+    o = np.asarray(o, dtype=np.int64)
+    bits = np.where(o >= 0, o, (-o) | 0x80000000).astype(np.uint32)
+    return bits.view(np.float32)
+def blocks_eval(T, S):   # T: [N, L] float32, S: [N] float32 -> end states
+    z = S.copy()
+    for j in range(T.shape[1]):
+        z = T[:, j] + z * b      # numpy float32: separately rounded
+    return z
+def run(x, L=64, z0=np.float32(0), maxpass=100, J='c', verbose=True):
+    t = (x * a).astype(np.float32)
+    n = len(t) // L * L; t = t[:n]; N = n // L
+    T = t.reshape(N, L)
+    ztrue = chain(t, z0, b)
+    Strue = np.concatenate([[z0], ztrue[L-1::L][:-1]]).astype(np.float32)
+    # prediction: double linear recurrence per block + scan
+    bd = float(b); pw = bd ** np.arange(L-1, -1, -1)
+    w = (T.astype(np.float64) * pw).sum(1); c = bd ** L
+    # sequential scan in double (stand-in for a parallel scan)
+    S = np.empty(N, np.float64); zz = float(z0)
+    for i in range(N):
+        S[i] = zz; zz = c * zz + w[i]
+    S = S.astype(np.float32); S[0] = z0
+    err0 = ordf(S) - ordf(Strue)
+    if verbose: print("pred err ulps: rms %.1f max %d" % (np.sqrt((err0.astype(float)**2).mean()), np.abs(err0).max()))
+    for p in range(maxpass):
+        E = blocks_eval(T, S)
+        e = ordf(E[:-1]) - ordf(S[1:])       # mismatch at boundary i -> i+1
+        bad = np.count_nonzero(e)
+        wrong = np.count_nonzero(ordf(S) != ordf(Strue))
+        if verbose: print("pass %d: mismatching boundaries %d, wrong starts %d, first bad %s" % (p, bad, wrong, np.flatnonzero(e)[:1]))
+        if bad == 0:
+            assert wrong == 0
+            return p
+        # Newton step: delta_{i+1} = Jf*delta_i + e_i
+        Jf = c if J == 'c' else 1.0
+        d = np.empty(N, np.float64); acc = 0.0
+        d[0] = 0
+        for i in range(N-1):
+            acc = Jf * acc + e[i]; d[i+1] = acc
+        S = unord(ordf(S) + np.rint(d).astype(np.int64))
+    return -1
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1<<21
+    for name, dc, sig in (("dc0 noise.05", 0.0, 0.05), ("dc.004", 0.004, 0.05), ("dc-.02 strong", -0.02, 0.3)):
+        I = np.clip(np.rint(127.5 + 127.5*(dc + sig*rng.standard_normal(n))), 0, 255).astype(np.float32)
+        x = ((I - np.float32(127.5)) / np.float32(127.5)).astype(np.float32)
+        for J in ('c', '1'):
+            for L in (64, 256):
+                print("==", name, "J", J, "L", L); r = run(x, L=L, J=J); print("passes", r)

@@ -1,0 +1,60 @@
+from dc_parallel_proto import *
+import sys
+def offsets(kind):
+    if kind == "r2":
+        side = [2**k for k in range(31)]
+    else:  # 1.5 ratio
+        side = [1,2,3,4,6,8,12,16,24,32,48,64,96,128,192,256,384,512,768,1024,1536,2048,3072,4096,6144,8192,12288,16384,24576,32768,49152]
+    off = sorted([-s for s in side] + [0] + side + [side[-1]*2])
+    return np.array(off, dtype=np.int64)
+def eval_tab(T, C):  # T [N,L], C [N,64] float32 -> E [N,64]
+    z = C.copy()
+    for j in range(T.shape[1]):
+        z = T[:, j:j+1] + z * b
+    return z
+def run_tab(x, L, z0=np.float32(0), kind="r2", maxpass=40, verbose=False):
+    t = (x * a).astype(np.float32); n = len(t)//L*L; t=t[:n]; N=n//L; T=t.reshape(N,L)
+    ztrue = chain(t, z0, b); Strue = np.concatenate([[z0], ztrue[L-1::L][:-1]]).astype(np.float32)
+    off = offsets(kind)
+    S = np.zeros(N, np.float32); S[0] = z0
+    for p in range(maxpass):
+        C = unord(ordf(S)[:, None] + off[None, :])        # candidates, ascending
+        E = eval_tab(T, C)
+        Cd = C.astype(np.float64); Ed = E.astype(np.float64)
+        Z = np.float32(z0); exact = True; nexact = 0; Snew = np.empty_like(S); first_inexact = None
+        for i in range(N):
+            Snew[i] = Z
+            zo = ordf(np.array([Z], np.float32))[0]
+            co = ordf(C[i])
+            k = np.searchsorted(co, zo, side='right') - 1   # co[k] <= zo
+            if k < 0: k = 0; inside = False
+            elif k >= 63: k = 62; inside = (co[63] == zo)
+            else: inside = True
+            if inside and co[k] == zo: nz = E[i, k]; ex = True
+            elif inside and k+1 <= 63 and co[k+1] == zo: nz = E[i, k+1]; ex = True
+            elif inside and E[i, k].view(np.uint32) == E[i, k+1].view(np.uint32): nz = E[i, k]; ex = True
+            else:
+                fr = (float(Z) - Cd[i, k]) / (Cd[i, k+1] - Cd[i, k])
+                nz = np.float32(Ed[i, k] + fr * (Ed[i, k+1] - Ed[i, k])); ex = False
+            if exact and not ex:
+                first_inexact = i
+            exact = exact and ex
+            if exact: nexact += 1
+            Z = nz
+        wrong = np.count_nonzero(Snew.view(np.uint32) != Strue.view(np.uint32))
+        err = np.abs(ordf(Snew) - ordf(Strue))
+        if verbose: print(p, "exact prefix", nexact, "of", N, "wrong starts", wrong, "err ulps median", np.median(err), "max", err.max())
+        S = Snew
+        if exact:
+            assert wrong == 0
+            return p + 1
+    return -1
+if __name__ == "__main__":
+    rng = np.random.default_rng(2); n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1<<22
+    cases = (("dc0", 0.0, 0.05), ("dc.004", 0.004, 0.05), ("dc-.02 strong", -0.02, 0.3), ("dc.0007", 0.0007, 0.05), ("dc.1 quiet", 0.1, 0.01), ("dc 1e-5", 1e-5, 0.05))
+    for name, dc, sig in cases:
+        I = np.clip(np.rint(127.5 + 127.5*(dc + sig*rng.standard_normal(n))), 0, 255).astype(np.float32)
+        x = ((I - np.float32(127.5)) / np.float32(127.5)).astype(np.float32)
+        for L in (16384, 65536):
+            for kind in ("r2", "r15"):
+                print(name, L, kind, "passes", run_tab(x, L, kind=kind, verbose=(kind=="r2" and L==16384)), flush=True)

@@ -26,7 +26,7 @@ asan) SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omi
 tsan) SAN="-fsanitize=thread -fno-omit-frame-pointer"; CC=/opt/rocm/lib/llvm/bin/clang ;;
 *) echo "usage: $0 asan|tsan OUTDIR" >&2; exit 2 ;;
 esac
-test -f msd_kernels.o -a -f msd_resolve_kernels.o -a -f msd_capi.o || { echo "run build.sh first (the HIP objects are reused)" >&2; exit 1; }
+test -f msd_kernels.o -a -f msd_dc_kernels.o -a -f msd_resolve_kernels.o -a -f msd_capi.o || { echo "run build.sh first (the HIP objects are reused)" >&2; exit 1; }
 INC="-I. -I../../include -Ihost"
 CF="-std=c11 -O1 -g -Wall -Wextra -fPIC $SAN $INC"
 $CC $CF -ffp-contract=off -c msd_tables.c -o "$OUT/msd_tables.o"
@@ -37,7 +37,7 @@ if [ "$MODE" = tsan ]; then
     CAPI_OBJ="$OUT/msd_capi.o"
 fi
 # (the sanitizer runtime comes from LD_PRELOAD or from the instrumented executable: the shared objects leave it undefined)
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmodes_hip.so" msd_kernels.o msd_resolve_kernels.o $CAPI_OBJ \
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmodes_hip.so" msd_kernels.o msd_dc_kernels.o msd_resolve_kernels.o $CAPI_OBJ \
     "$OUT/msd_tables.o" "$OUT/msd_resolve.o" "$OUT/msd_fields.o" -lm -lpthread
 for f in msd_fifo msd_sdr_ifile msd_wire msd_converter msd_demod; do
     $CC $CF -c host/$f.c -o "$OUT/$f.o"

@@ -1,0 +1,106 @@
+"""--dcfilter by the exact parallel-in-time kernels (msd_dc_kernels.hip, round 6) against the oracle's in-order
+convert_*_generic (convert.c:113-213, 374-423): magnitudes and both means bit for bit, the filter state carried from
+call to call, for contents that put the filter state in each of its regimes (a state near zero that changes sign and
+binade all the time; a DC offset; constant and alternating input, where the rounding of z * dc_b is systematic), and the
+two other ways through the same entry (the in-order kernel alone; one parallel pass, so that the in-order kernel behind
+it has to do the batch) as cross-checks of the switch."""
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import fmt_ids
+
+CHUNK = 131072
+pytestmark = pytest.mark.gpu
+
+
+def content(kind, fmt, n, seed):
+    rng = np.random.default_rng(seed)
+    full = {"uc8": 127.5, "sc16": 32768.0, "sc16q11": 2048.0}[fmt]
+    if kind == "noise":          # no offset: z hovers around zero
+        v = rng.standard_normal((n, 2)) * 0.05
+    elif kind == "offset":       # an RTL dongle's half LSB and more
+        v = rng.standard_normal((n, 2)) * 0.05 + np.array([0.004, -0.02])
+    elif kind == "strong":
+        v = rng.standard_normal((n, 2)) * 0.4 + np.array([-0.1, 0.3])
+    elif kind == "constant":
+        v = np.tile(np.array([0.37, -1.0]), (n, 1))
+    elif kind == "alternating":
+        v = np.where((np.arange(n) & 1)[:, None] == 1, 1.0, -1.0) * np.array([1.0, 0.5])
+    elif kind == "random":
+        v = rng.uniform(-1, 1, (n, 2))
+    elif kind == "step":         # the offset jumps in the middle of the stream
+        v = rng.standard_normal((n, 2)) * 0.05 + np.where(np.arange(n)[:, None] < n // 2, 0.01, -0.3)
+    else:
+        raise ValueError(kind)
+    if fmt == "uc8":
+        return np.clip(np.rint(127.5 + 127.5 * v), 0, 255).astype(np.uint8).reshape(-1)
+    return np.clip(np.rint(v * full), -full, full - 1).astype("<i2").reshape(-1).view(np.uint8)
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+@pytest.mark.parametrize("kind", ["noise", "offset", "strong", "constant", "alternating", "random", "step"])
+def test_parallel_dc_block_equals_the_in_order_converter(pkg, oracle, torch_cuda, fmt, kind):
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    sizes = (CHUNK, 1, 4097, 8 * CHUNK + 777, 63, 64, 65, 3 * CHUNK, 1024, 2 * CHUNK - 1)
+    n = sum(sizes)
+    iq = content(kind, fmt, n, seed=zlib.crc32((fmt + kind).encode()) & 0xffff)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=16 * CHUNK, dc_filter=True, flags=0)
+    orc = oracle.Oracle(of, 58, 1, 0, dc_filter=True)
+    off = 0
+    for m in sizes:
+        blk = iq[off * bps:(off + m) * bps]
+        gm, gl, gp = dem.convert(blk, m)
+        wm, wl, wp = orc.convert(blk, m)
+        exact, passes, guessed, blocks = dem.dc_filter_status()
+        assert exact == 1, (fmt, kind, off, m, passes, guessed, blocks)   # the parallel kernels did it, nothing fell through
+        assert np.array_equal(gm[:m], wm), (fmt, kind, off, m, int(np.flatnonzero(gm[:m] != wm)[0]))
+        assert np.array_equal(np.float64(gl), np.float64(wl), equal_nan=True), (fmt, kind, off, m)
+        assert np.array_equal(np.float64(gp), np.float64(wp), equal_nan=True), (fmt, kind, off, m)
+        off += m
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16"])
+@pytest.mark.parametrize("way", ["sequential", "one_pass"])
+def test_the_in_order_kernel_behind_the_passes(pkg, oracle, torch_cuda, fmt, way):
+    """MSD_CFG_DC_SEQUENTIAL: the in-order kernel alone.  MSD_CFG_DC_ONE_PASS: one parallel pass is queued, the batch is not
+    exact by then (status 0), the in-order kernel behind the passes does it from the untouched converter state -- the path a
+    batch takes whose passes ever run out."""
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    sizes = (2 * CHUNK, 4097, CHUNK)
+    iq = content("offset", fmt, sum(sizes), seed=77)
+    flag = pkg.capi.CFG_DC_SEQUENTIAL if way == "sequential" else pkg.capi.CFG_DC_ONE_PASS
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=2 * CHUNK, dc_filter=True, flags=flag)
+    orc = oracle.Oracle(of, 58, 1, 0, dc_filter=True)
+    off = 0
+    for m in sizes:
+        blk = iq[off * bps:(off + m) * bps]
+        gm, gl, gp = dem.convert(blk, m)
+        wm, wl, wp = orc.convert(blk, m)
+        assert dem.dc_filter_status()[0] == 0
+        assert np.array_equal(gm[:m], wm) and gl == wl and gp == wp, (fmt, way, off, m)
+        off += m
+
+
+def test_parallel_dc_block_in_the_stream_interface(pkg, oracle, torch_cuda):
+    """The same kernels in front of the scan (msd_launch_device of a MSD_CFG_DC_FILTER context): three batches of a capture
+    with a DC offset, pipelined; the message list and the per-buffer means are the oracle's, every batch came out exact."""
+    n = 20 * CHUNK + 4321
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=909, msgs_per_sec=5000, n_aircraft=40), n)
+    iq = np.clip(iq.reshape(-1, 2).astype(np.int32) + np.array([7, -4]), 0, 255).astype(np.uint8).reshape(-1)
+    d_iq = torch_cuda.from_numpy(iq).to("cuda:0")
+    dem = pkg.Demodulator(nfix_crc=1, max_batch_samples=8 * CHUNK, message_capacity=1 << 17, dc_filter=True)
+    got, off = [], 0
+    for m, last in ((8 * CHUNK, False), (8 * CHUNK, False), (n - 16 * CHUNK, True)):
+        dem.launch_device(d_iq.data_ptr() + 2 * off, m, last=last)
+        assert dem.dc_filter_status()[0] == 1
+        off += m
+    for _ in range(3):
+        got.append(dem.collect())
+    got = np.concatenate(got)
+    want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0, dc_filter=True).replay(iq, cap=1 << 17)
+    assert len(want) > 1000
+    assert got.tobytes() == want.tobytes()
