@@ -731,7 +731,9 @@ def main():
         # BASELINE configs[2] and configs[4] at full size, after the clock stopped, each against the oracle
         for d in dems:
             d.close() if hasattr(d, "close") else None
-        out["also"] = [run_also(["--format", "sc16", "--samples", str(1 << 28)]), run_also(["--mode-ac", "--fix", "1"])]
+        out["also"] = [run_also(["--format", "sc16", "--samples", str(1 << 28)]), run_also(["--mode-ac", "--fix", "1"]),
+                       # round 6: --dcfilter (convert.c:113-163), whose DC block is exact and parallel in time now (0.13 GS/s in order)
+                       run_also(["--dcfilter", "--samples", str(1 << 27)])]
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -113,6 +113,11 @@ typedef struct msd_message {
                                               exact parallel-in-time kernels in front of it (round 6; experiments and tests) */
 #define MSD_CFG_DC_ONE_PASS (1 << 19)      /* ... one parallel pass queued instead of 24: batches of more than two blocks are
                                               not exact by then and take the in-order kernel behind the passes (tests of that path) */
+#define MSD_CFG_DC_FUSED_LAUNCH (1 << 20)  /* ... all passes in ONE cooperative launch (the evaluation of pass p + 1 follows the walk of
+                                              pass p block by block, nothing is launched per pass) where the batch's blocks can be
+                                              resident together.  Exact like the default (two launches per pass, 24 queued) and
+                                              measured slower at every batch size -- the cooperative launch costs more than the
+                                              passes' launches: the switch stays off */
 #define MSD_CFG_DECODE_FIELDS 1 /* also decode the header fields of every accepted message (msd_collect_fields) */
 #define MSD_CFG_DC_FILTER 2     /* --dcfilter (readsb.c:486): the converters with the 1 Hz DC block (convert.c:113-213,
                                    374-423).  A FUNCTIONAL mode, not a fast one: the filter state and the float sums

@@ -68,7 +68,7 @@ CFG_DC_FILTER = 2
 CFG_HOST_RESOLVE, CFG_CHAIN_IN_ORDER, CFG_CHAIN_SIDE_STREAMS, CFG_NO_LEAN, CFG_NO_RESOLVE_AHEAD = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 CFG_POWER_KERNEL, CFG_POWER_IN_RESOLVE, CFG_EMIT_KERNEL, CFG_WAIT_INPUTS_ON_STREAM = 1 << 9, 1 << 10, 1 << 11, 1 << 12
 CFG_NO_HELPER, CFG_REPASS_AUX, CFG_RECORDS_DMA, CFG_TRACE, CFG_NO_ARENA_GROWTH = 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17
-CFG_DC_SEQUENTIAL, CFG_DC_ONE_PASS = 1 << 18, 1 << 19
+CFG_DC_SEQUENTIAL, CFG_DC_ONE_PASS, CFG_DC_FUSED_LAUNCH = 1 << 18, 1 << 19, 1 << 20
 
 
 def layout_from_environment():
@@ -101,6 +101,8 @@ def layout_from_environment():
         flags |= CFG_DC_SEQUENTIAL
     elif e("MSD_DC", "") == "one_pass":
         flags |= CFG_DC_ONE_PASS
+    elif e("MSD_DC", "") == "fused":
+        flags |= CFG_DC_FUSED_LAUNCH
     fields = dict(resolve_threads=int(e("MSD_RESOLVE_THREADS", "0") or 0),
                   test_arena_permille=int(e("MSD_ARENA_SCALE_PERMILLE", "0") or 0),
                   test_inline_adds=int(e("MSD_RESOLVE_INLINE_ADDS", "0") or 0),

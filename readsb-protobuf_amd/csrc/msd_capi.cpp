@@ -347,6 +347,7 @@ struct msd_ctx {
     void *d_dc_work = nullptr;    /* the parallel-in-time DC filter's blocks, tables and control word (msd_dcp_work_bytes) */
     bool dc_last_parallel = false; /* the most recent DC block went through the parallel kernels (msd_dc_filter_status) */
     uint32_t dc_last_blocks = 0;
+    bool dc_fused = false;        /* MSD_CFG_DC_FUSED_LAUNCH: the passes in one cooperative launch (measured slower) */
     int dc_passes = 24;           /* passes queued per batch (MSD_CFG_DC_ONE_PASS: 1, so that the in-order kernel behind them runs) */
     int scan_format = 0;          /* what the scan and its follow-up kernels read: cfg.format, or MAG16 behind the DC filter */
     size_t scan_bps = 2;
@@ -1926,7 +1927,7 @@ int launch_dc_block(msd_ctx *c, const void *d_iq, uint64_t nsamples, uint16_t *d
     if (c->d_dc_work && nsamples && (reinterpret_cast<uintptr_t>(d_iq) & 15u) == 0) {
         const uint32_t L = msd_dcp_block_len(nsamples);
         const int rc = msd_launch_dcfilter_parallel(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, d_mag, d_magsq,
-                                                    c->d_dc_work, L, c->dc_passes, stream);
+                                                    c->d_dc_work, L, c->dc_passes, c->dc_fused ? 1 : 0, stream);
         if (rc)
             return rc;
         skip_if = c->d_dc_work;
@@ -2345,6 +2346,7 @@ static int create_context(const msd_config *cfg, msd_ctx **out, bool *out_of_mem
         if (!(cfg->flags & MSD_CFG_DC_SEQUENTIAL)) { /* 0.3 MB + 8 bytes per 64 samples of a batch */
             CK(hipMalloc(&c->d_dc_work, msd_dcp_work_bytes(c->cfg.max_batch_samples, 0)));
             c->dc_passes = (cfg->flags & MSD_CFG_DC_ONE_PASS) ? 1 : 24;
+            c->dc_fused = (cfg->flags & MSD_CFG_DC_FUSED_LAUNCH) != 0;
         }
     }
     {

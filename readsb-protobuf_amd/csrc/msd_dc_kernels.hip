@@ -25,7 +25,19 @@
  * Nothing is verified by comparison with a tolerance: a start state is either derived exactly or it is a guess.  A batch that
  * is not exact after the passes queued falls through to msd_dcfilter_kernel (sequential, always right).
  * Afterwards msd_dcp_eval_kernel's centre lane leaves the exact state at every 64th sample and msd_dcp_out_kernel -- one LANE
- * per 64 samples -- repeats the chain from there and writes what msd_dcfilter_kernel writes: u16 magnitudes, f32 squares. */
+ * per 64 samples -- repeats the chain from there and writes what msd_dcfilter_kernel writes: u16 magnitudes, f32 squares.
+ *
+ * Two ways of running the passes.  The default: msd_dcp_eval_kernel + msd_dcp_walk_kernel per pass, 24 passes queued (those
+ * behind the one that finished return at once).  MSD_CFG_DC_FUSED_LAUNCH: msd_dcp_fused_kernel, ONE cooperative launch with the
+ * two walking workgroups and all evaluating wavefronts resident together; an evaluating wavefront starts on pass p + 1 of its
+ * block as soon as walk p has gone past it (a progress word per channel), the walk of pass p + 1 waits block by block for the
+ * tables (a counter per block), so a pass costs the longer of the two instead of their sum and nothing runs once the batch is
+ * exact.  Every wait is bounded: one that runs out gives the batch up to the in-order kernel.  A table that is out of date is
+ * still a table of true values of the same block's map, so stale reads can cost passes, never exactness; the states at every
+ * 64th sample are refreshed by a launch of their own behind it (a block is re-evaluated whenever its table's centre is not its
+ * start state: `cen`).  Exact, tested -- and slower at every batch size (3.10 against 2.85 ms per 16 Mi samples, 0.91 against
+ * 0.54 for one buffer, profiles/r06_dc_rate.txt): what the cooperative launch costs exceeds what the passes' launches and the
+ * overlap of evaluation and walk save.  The switch stays off. */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
@@ -33,7 +45,7 @@
 
 namespace {
 
-constexpr int DCP_FINE = 64; /* samples per fine block = per chunk of the evaluation = per lane of the output kernel */
+constexpr int DCP_FINE = 64; /* samples per fine block = per lane of the output kernel */
 
 struct DcpCtl {
     uint32_t done;         /* both channels exact: the output kernel runs, the sequential kernel does not */
@@ -44,7 +56,8 @@ struct DcpCtl {
     uint32_t passes_ch[2]; /* walks that did something (diagnostics) */
     uint32_t guessed;      /* blocks that had to guess, all passes (diagnostics) */
     uint32_t ndone;
-    uint32_t pad[3];
+    uint32_t prog[2];      /* fused kernel: walk w has gone past block i of channel c when prog[c] >= w (nb + 1) + i + 1 */
+    uint32_t gaveup;       /* fused kernel: a bounded wait ran out, or the passes did */
 };
 
 /* floats in their order as integers: ord(-x) = -ord(x), ord(+-0) = 0, consecutive floats are consecutive integers */
@@ -84,7 +97,9 @@ __device__ __forceinline__ float dcp_sample(const uint8_t *iq, uint64_t g, int c
  * also keeps the compiler from re-associating across steps) */
 #define DCP_STEP(Z, T, B) asm volatile("v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %2, %0" : "+v"(Z) : "v"(B), "v"(T))
 
-__global__ void msd_dcp_init_kernel(DcpCtl *ctl, uint32_t *S, uint32_t *dirty, uint32_t nb, const float *state)
+constexpr uint32_t DCP_NEVER = 0x7fc00001u; /* a NaN no start state ever is: "no table yet" in cen[] */
+
+__global__ void msd_dcp_init_kernel(DcpCtl *ctl, uint32_t *S, uint32_t *cen, uint32_t *ever, uint32_t nb, const float *state)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -96,7 +111,8 @@ __global__ void msd_dcp_init_kernel(DcpCtl *ctl, uint32_t *S, uint32_t *dirty, u
     if (i < nb) {
         for (int ch = 0; ch < 2; ++ch) {
             S[ch * nb + i] = i == 0 ? __float_as_uint(state[ch]) : 0u; /* first guess: nothing; the first pass is then the */
-            dirty[ch * nb + i] = 1u;                                   /* linear prediction F_i(0) + slope * Z              */
+            cen[ch * nb + i] = DCP_NEVER;                              /* linear prediction F_i(0) + slope * Z              */
+            ever[ch * nb + i] = 0u;
         }
     }
 }
@@ -131,32 +147,23 @@ __device__ __forceinline__ void dcp_terms(const uint8_t *iq, uint64_t g0, uint64
     }
 }
 
+/* One wavefront: block i of channel ch from 64 candidate start states around sbits; its prepared table into E, the states
+ * in front of every 64th sample on the centre candidate's chain into fine.  tbuf: 2 x DCP_GROUP floats of LDS of its own. */
 template <int FMT>
-__global__ void __launch_bounds__(256) msd_dcp_eval_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples, uint32_t L,
-                                                           float dc_a, float dc_b, const uint32_t *__restrict__ S,
-                                                           uint32_t *__restrict__ dirty, float4 *__restrict__ E,
-                                                           uint32_t *__restrict__ fine, uint32_t nb, uint64_t nfine)
+__device__ __forceinline__ void dcp_eval_block(const uint8_t *__restrict__ iq, uint64_t nsamples, uint32_t L, float dc_a, float dc_b,
+                                               uint32_t sbits, uint32_t row, uint32_t i, int ch, float4 *__restrict__ E,
+                                               uint32_t *__restrict__ fine, uint64_t nfine, float (*tbuf)[DCP_GROUP], int lane)
 {
-    __shared__ __attribute__((aligned(16))) float tbuf[4][2][DCP_GROUP]; /* [wavefront][group parity][sample of the group] */
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t w = blockIdx.x * 4u + (uint32_t)wv;
-    const uint32_t i = w >> 1;
-    const int ch = (int)(w & 1u);
-    if (i >= nb)
-        return; /* the wavefronts of a workgroup never meet: no barrier below */
-    const uint32_t row = (uint32_t)ch * nb + i;
-    if (!dirty[row])
-        return; /* evaluated around this very start state already */
     const uint64_t base = (uint64_t)i * L;
     const uint32_t cnt = nsamples - base < (uint64_t)L ? (uint32_t)(nsamples - base) : L;
-    const float zstart = __uint_as_float(dcp_unord(dcp_ord(S[row]) + dcp_offset(lane)));
+    const float zstart = __uint_as_float(dcp_unord(dcp_ord(sbits) + dcp_offset(lane)));
     float z = zstart;
     const uint32_t ngroups = (cnt + DCP_GROUP - 1) / DCP_GROUP;
     uint32_t *fine_row = fine + (uint64_t)ch * nfine + base / DCP_FINE;
     float cur[4], nxt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     dcp_terms<FMT>(iq, base, nsamples, lane, ch, dc_a, cur);
     for (uint32_t g = 0; g < ngroups; ++g) {
-        float *tb = tbuf[wv][g & 1u];
+        float *tb = tbuf[g & 1u];
         *reinterpret_cast<float4 *>(tb + 4 * lane) = make_float4(cur[0], cur[1], cur[2], cur[3]);
         if (g + 1 < ngroups) /* the next group's samples, under this group's chain (1 us of it: an HBM round trip fits) */
             dcp_terms<FMT>(iq, base + (uint64_t)(g + 1) * DCP_GROUP, nsamples, lane, ch, dc_a, nxt);
@@ -201,42 +208,101 @@ __global__ void __launch_bounds__(256) msd_dcp_eval_kernel(const uint8_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             cur[q] = nxt[q];
+        __builtin_amdgcn_wave_barrier(); /* the buffer written two groups from now is this group's: every lane is done with it */
     }
     /* The block's table, prepared for the walk: lane j owns the bracket [c_j, c_(j+1)) -- its ends, the table value at its
      * lower end and the secant across it.  A slope of -0.0 marks a bracket across which the table is flat: the block's map
-     * is monotone, so every state inside such a bracket is mapped to that very value, exactly. */
-    const float x_up = lane == 63 ? __builtin_inff() : __shfl_down(zstart, 1);
+     * is monotone, so every state inside such a bracket is mapped to that very value, exactly.
+     * A state the candidates do not reach (they span 2^30 units in the last place either side, which is not the way from a
+     * guess of one sign to a truth of the other) is extrapolated from the end candidate with the secant between that end and
+     * the centre -- at that scale the map is affine, while the end bracket itself may be flat in float: lane 63's slope for
+     * the top, and for the bottom a second slope that travels in lane 63's unused upper-end field. */
+    const float x0 = zstart, y0 = z;
+    float x_up = __shfl_down(zstart, 1);
     const float y_up = __shfl_down(z, 1);
-    const float dx = x_up - zstart, dy = y_up - z;
+    const float dx = x_up - x0, dy = y_up - y0;
     float slope = (lane < 63 && dx > 0.0f && dy > 0.0f) ? dy * __builtin_amdgcn_rcpf(dx) : 0.0f; /* (a guess's slope: any value will do) */
-    if (lane == 63)
-        slope = 1.0f;
-    if (lane < 63 && __float_as_uint(y_up) == __float_as_uint(z))
+    if (lane < 63 && __float_as_uint(y_up) == __float_as_uint(y0))
         slope = -0.0f;
-    E[(uint64_t)row * 64u + lane] = make_float4(zstart, x_up, z, slope);
-    if (lane == 0)
-        dirty[row] = 0u;
+    const float xc = __shfl(zstart, 31), yc = __shfl(z, 31);
+    const float x_lo = __shfl(zstart, 0), y_lo = __shfl(z, 0);
+    if (lane == 63) {
+        const float ex = x0 - xc, ey = y0 - yc, fx = xc - x_lo, fy = yc - y_lo;
+        slope = (ex > 0.0f && ey > 0.0f) ? ey * __builtin_amdgcn_rcpf(ex) : 1.0f;
+        x_up = (fx > 0.0f && fy > 0.0f) ? fy * __builtin_amdgcn_rcpf(fx) : 1.0f; /* the slope below c_0 */
+    }
+    E[(uint64_t)row * 64u + lane] = make_float4(x0, x_up, y0, slope);
 }
 
-constexpr int DCP_TILE = 64; /* blocks whose tables the walk holds in LDS at a time (two tiles: 128 KB) */
-
-/* One workgroup per channel; its first wavefront walks, the others fetch the next tile of tables.  S[i] becomes the start
- * state the walk arrived at (exact or guessed), dirty[i] says that it moved; the tables of blocks whose start did not move
- * stay valid.  A lone wavefront issues an instruction every five to eight cycles, so what a block costs the walk is its
- * instruction count: the tables come prepared (msd_dcp_eval_kernel's last lines), one ds_read_b128 per lane and block. */
-__global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t *S, uint32_t *dirty, const float4 *__restrict__ E, uint32_t nb)
+template <int FMT>
+__global__ void __launch_bounds__(256) msd_dcp_eval_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples, uint32_t L,
+                                                           float dc_a, float dc_b, const uint32_t *__restrict__ S,
+                                                           uint32_t *__restrict__ cen, float4 *__restrict__ E,
+                                                           uint32_t *__restrict__ fine, uint32_t nb, uint64_t nfine)
 {
-    __shared__ float4 et[2][DCP_TILE * 64];
-    __shared__ uint32_t st[2][DCP_TILE];
+    __shared__ __attribute__((aligned(16))) float tbuf[4][2][DCP_GROUP]; /* [wavefront][group parity][sample of the group] */
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * 4u + (uint32_t)wv;
+    const uint32_t i = w >> 1;
+    const int ch = (int)(w & 1u);
+    if (i >= nb)
+        return; /* the wavefronts of a workgroup never meet: no barrier below */
+    const uint32_t row = (uint32_t)ch * nb + i;
+    const uint32_t sbits = S[row];
+    if (cen[row] == sbits)
+        return; /* evaluated around this very start state already */
+    dcp_eval_block<FMT>(iq, nsamples, L, dc_a, dc_b, sbits, row, i, ch, E, fine, nfine, tbuf[wv], lane);
+    if (lane == 0)
+        cen[row] = sbits;
+}
+
+/* bounded waits of the fused kernel */
+constexpr uint32_t DCP_SPINS = 1u << 19; /* x (a load or two + s_sleep 16, about 1.4 us): most of a second */
+__device__ __forceinline__ uint32_t dcp_ld_acq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t dcp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dcp_st_rel(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* One walk of channel ch by the calling workgroup (256 threads: the first wavefront walks, the others fetch the next tile of
+ * tables into LDS), from the frontier in ctl.  S[i] becomes the start state the walk arrived at (exact or guessed).  A lone
+ * wavefront issues an instruction every five to eight cycles, so what a block costs the walk is its instruction count: the
+ * tables come prepared (dcp_eval_block's last lines), one ds_read_b128 per lane and block, and the order of the floats is
+ * the order of the states (-0 = +0), so nothing is converted.
+ * FUSED: the tables of pass `pass` are waited for block by block (ever[row] > pass), progress is published tile by tile.
+ * Returns (to every thread) false when a wait ran out. */
+template <int TILE, bool FUSED>
+__device__ __forceinline__ bool dcp_walk(DcpCtl *ctl, uint32_t *S, const float4 *E, const uint32_t *ever, uint32_t nb, int ch, uint32_t pass,
+                                         float4 (*et)[TILE * 64], uint32_t (*st)[TILE], uint32_t *sh_fail)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x;
-    if (ctl->done || ctl->done_ch[ch])
-        return;
     const uint32_t i0 = ctl->frontier[ch];
     uint32_t zb = ctl->zfront[ch]; /* wave-uniform */
-    const uint32_t ntiles = (nb - i0 + DCP_TILE - 1) / DCP_TILE;
+    const uint32_t ntiles = (nb - i0 + TILE - 1) / TILE;
+    if (tid == 0)
+        *sh_fail = 0u;
+    if (FUSED && tid == 0)
+        dcp_st_rel(&ctl->prog[ch], pass * (nb + 1u) + i0); /* the blocks in front of the frontier are final */
+    __syncthreads();
     auto fetch = [&](uint32_t t, int first, int nthr) { /* tile t into its buffer, by threads first ... first + nthr - 1 */
-        const uint32_t r0 = i0 + t * DCP_TILE, rows = nb - r0 < (uint32_t)DCP_TILE ? nb - r0 : (uint32_t)DCP_TILE;
+        const uint32_t r0 = i0 + t * TILE, rows = nb - r0 < (uint32_t)TILE ? nb - r0 : (uint32_t)TILE;
+        if (FUSED) { /* every fetching wavefront waits for all the tile's tables itself (lanes 0 ... rows - 1) */
+            bool ready = false;
+            for (uint32_t spin = 0; spin < DCP_SPINS; ++spin) {
+                const bool ok = (uint32_t)lane >= rows || dcp_ld(&ever[(uint32_t)ch * nb + r0 + (uint32_t)(lane % TILE)]) > pass;
+                if (__ballot(ok) == ~0ull) {
+                    ready = true;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* polled with plain coherent loads: one acquire at the end */
+                    break;
+                }
+                if (dcp_ld(&ctl->gaveup))
+                    break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!ready) {
+                if (lane == 0)
+                    *sh_fail = 1u;
+                return;
+            }
+        }
         const float4 *src = E + ((uint64_t)ch * nb + r0) * 64u;
         float4 *dst = et[t & 1u];
         for (uint32_t k = (uint32_t)(tid - first); k < rows * 64u; k += (uint32_t)nthr)
@@ -248,12 +314,12 @@ __global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t
     __syncthreads();
     bool exact = true;
     uint32_t frontier = nb, zfront = 0, guessed = 0;
-    for (uint32_t t = 0; t < ntiles; ++t) {
+    for (uint32_t t = 0; t < ntiles && !*sh_fail; ++t) {
         if (wave > 0) {
             if (t + 1 < ntiles)
                 fetch(t + 1, 64, 192);
         } else {
-            const uint32_t r0 = i0 + t * DCP_TILE, rows = nb - r0 < (uint32_t)DCP_TILE ? nb - r0 : (uint32_t)DCP_TILE;
+            const uint32_t r0 = i0 + t * TILE, rows = nb - r0 < (uint32_t)TILE ? nb - r0 : (uint32_t)TILE;
             const float4 *eb = et[t & 1u];
             const uint32_t *sb = st[t & 1u];
             float4 nx = eb[lane];
@@ -264,10 +330,11 @@ __global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t
                 if (r + 1 < rows)
                     nx = eb[(r + 1) * 64u + (uint32_t)lane]; /* does not depend on this block's outcome */
                 const float zf = __uint_as_float(zb);
-                const bool above = p.x <= zf;                      /* the order of the floats is the order of the states (-0 = +0) */
-                const bool own = (above || lane == 0) && zf < p.y; /* (lane 0 also takes a Z below every candidate) */
+                const bool above = p.x <= zf;
+                const bool own = (above || lane == 0) && (lane == 63 || zf < p.y); /* (lanes 0 and 63 also take what lies beyond) */
                 const bool sure = above && (p.x == zf || __float_as_uint(p.w) == 0x80000000u);
-                const float guess = (zf - p.x) * p.w + p.z;        /* = the table's value itself where `sure` */
+                const float s_low = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.y), 63));
+                const float guess = (zf - p.x) * (above ? p.w : s_low) + p.z; /* = the table's value itself where `sure` */
                 const uint64_t m = __ballot(own);
                 const int owner = m ? __builtin_ctzll(m) : 0;
                 const uint32_t nz = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(guess), owner);
@@ -279,29 +346,114 @@ __global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t
                     zfront = zb;
                     exact = false;
                 }
-                if (lane == 0 && zb != sold) {
+                if (lane == 0 && zb != sold)
                     S[row] = zb;
-                    dirty[row] = 1u;
-                }
                 zb = nz;
+            }
+            if (FUSED && ((t & 3u) == 3u || t + 1 == ntiles)) { /* the start states up to here are written: the evaluation may go on with
+                                                                   these blocks (every fourth tile: a release is microseconds) */
+                __threadfence();
+                if (lane == 0)
+                    dcp_st_rel(&ctl->prog[ch], pass * (nb + 1u) + r0 + rows);
             }
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    const bool failed = *sh_fail != 0u;
+    if (tid == 0 && !failed) {
         ctl->passes_ch[ch] += 1u;
         atomicAdd(&ctl->guessed, guessed);
         if (exact) {
             ctl->zend[ch] = zb;
             ctl->frontier[ch] = nb;
-            ctl->done_ch[ch] = 1u;
             __threadfence();
+            dcp_st_rel(&ctl->done_ch[ch], 1u);
             if (atomicAdd(&ctl->ndone, 1u) == 1u)
-                ctl->done = 1u; /* the other channel got there before */
+                dcp_st_rel(&ctl->done, 1u); /* the other channel got there before */
         } else {
-            ctl->frontier[ch] = frontier;
             ctl->zfront[ch] = zfront;
+            __threadfence();
+            dcp_st_rel(&ctl->frontier[ch], frontier);
         }
+    }
+    __syncthreads();
+    return !failed;
+}
+
+__global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t *S, const float4 *__restrict__ E, uint32_t nb)
+{
+    __shared__ float4 et[2][64 * 64];
+    __shared__ uint32_t st[2][64];
+    __shared__ uint32_t sh_fail;
+    const int ch = blockIdx.x;
+    if (ctl->done || ctl->done_ch[ch])
+        return;
+    dcp_walk<64, false>(ctl, S, E, nullptr, nb, ch, 0u, et, st, &sh_fail);
+}
+
+/* All passes in one cooperative launch: workgroups 0 and 1 walk channels 0 and 1, every wavefront of the others owns one
+ * (block, channel).  See the head of the file. */
+constexpr int DCP_FTILE = 16;
+template <int FMT>
+__global__ void __launch_bounds__(256) msd_dcp_fused_kernel(const uint8_t *__restrict__ iq, uint64_t nsamples, uint32_t L, float dc_a, float dc_b,
+                                                            DcpCtl *ctl, uint32_t *S, uint32_t *cen, float4 *E, uint32_t *fine, uint32_t *ever,
+                                                            uint32_t nb, uint64_t nfine, uint32_t max_passes)
+{
+    __shared__ float4 et[2][DCP_FTILE * 64]; /* the walk's two tiles; an evaluating workgroup's terms (8 KB) lie in the same bytes */
+    __shared__ uint32_t st[2][DCP_FTILE];
+    __shared__ uint32_t sh_fail;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x < 2u) {
+        const int ch = (int)blockIdx.x;
+        bool ok = true;
+        uint32_t w = 0;
+        for (; w < max_passes && ok; ++w) {
+            ok = dcp_walk<DCP_FTILE, true>(ctl, S, E, ever, nb, ch, w, et, st, &sh_fail);
+            if (dcp_ld_acq(&ctl->done_ch[ch]) || dcp_ld(&ctl->gaveup))
+                break;
+        }
+        if (threadIdx.x == 0 && !dcp_ld(&ctl->done_ch[ch]))
+            dcp_st_rel(&ctl->gaveup, 1u); /* the passes (or a wait) ran out: the in-order kernel takes the batch */
+        return;
+    }
+    float(*tbuf)[DCP_GROUP] = reinterpret_cast<float(*)[DCP_GROUP]>(reinterpret_cast<float *>(&et[0][0]) + (size_t)wv * 2 * DCP_GROUP);
+    const uint32_t w = (blockIdx.x - 2u) * 4u + (uint32_t)wv;
+    const uint32_t i = w >> 1;
+    const int ch = (int)(w & 1u);
+    if (i >= nb)
+        return;
+    const uint32_t row = (uint32_t)ch * nb + i;
+    for (uint32_t p = 0; p <= max_passes; ++p) {
+        bool stop = false;
+        if (p > 0) { /* walk p - 1 has gone past this block (or never will: it lies in front of the frontier) */
+            const uint32_t want = (p - 1u) * (nb + 1u) + i + 1u;
+            bool there = false;
+            for (uint32_t spin = 0; spin < DCP_SPINS; ++spin) {
+                there = dcp_ld(&ctl->prog[ch]) >= want;
+                stop = dcp_ld(&ctl->done_ch[ch]) || dcp_ld(&ctl->gaveup);
+                if (there || stop) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* polled with plain coherent loads: one acquire at the end */
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(127); /* 3 us: a thousand wavefronts ask the same word */
+            }
+            if (!there && !stop) {
+                if (lane == 0)
+                    dcp_st_rel(&ctl->gaveup, 1u);
+                return;
+            }
+        }
+        const uint32_t sbits = dcp_ld(&S[row]);
+        if (dcp_ld(&cen[row]) != sbits) {
+            dcp_eval_block<FMT>(iq, nsamples, L, dc_a, dc_b, sbits, row, i, ch, E, fine, nfine, tbuf, lane);
+            if (lane == 0)
+                cen[row] = sbits;
+        }
+        __threadfence(); /* every lane's part of the table, then the counter */
+        if (lane == 0)
+            dcp_st_rel(&ever[row], p + 1u);
+        if (stop || dcp_ld_acq(&ctl->frontier[ch]) > i)
+            return; /* the channel is done, or this block's start is final: nobody will ask for its table again */
     }
 }
 
@@ -394,46 +546,79 @@ uint32_t dcp_blocks(uint64_t nsamples, uint32_t L) { return (uint32_t)((nsamples
 
 /* The workspace of one batch of at most max_samples in blocks of block_len samples (0: of msd_dcp_block_len(n) for any n
  * up to max_samples: at most 1025 blocks below 32 Mi samples, blocks of 32768 beyond). */
+static size_t dcp_e_offset(uint64_t nb) { return 256 + (((size_t)nb * 2 * 4 * 3 + 255) & ~(size_t)255); } /* ctl; S, cen, ever */
 extern "C" size_t msd_dcp_work_bytes(uint64_t max_samples, uint32_t block_len)
 {
     uint64_t nb = block_len ? dcp_blocks(max_samples, block_len) + 1 : max_samples / 32768u + 2;
     if (!block_len && nb < 1032)
         nb = 1032;
     const uint64_t nfine = (max_samples + DCP_FINE - 1) / DCP_FINE + 1;
-    return 256 + (size_t)nb * 2 * 4 * 2 + (size_t)nb * 2 * 64 * 16 + (size_t)nfine * 2 * 4 + 512;
+    return dcp_e_offset(nb) + (size_t)nb * 2 * 64 * 16 + (size_t)nfine * 2 * 4 + 512;
 }
 
 /* Block length for a batch: a power of two between 1024 and 32768 samples that leaves about a thousand blocks -- the
  * evaluation is one wavefront per block and channel, latency-bound at 8 ns per sample of a block with one or two wavefronts
  * per SIMD and issue-bound at 3 ns per sample and SIMD beyond four (scripts/micro/dcp_chain_occupancy.hip); the walk costs
- * some tens of nanoseconds per block. */
+ * 0.2 us per block.  One buffer of 131072 samples is best served by 64 blocks of 2048 (16 + 13 us per pass). */
 extern "C" uint32_t msd_dcp_block_len(uint64_t nsamples)
 {
-    uint32_t L = 1024;
+    uint32_t L = nsamples >= 65536u ? 2048 : 1024;
     while (L < 32768u && nsamples / L > 1024u)
         L *= 2;
     return L;
 }
 
+/* How many workgroups of the fused kernel can be resident at once on the current device (0: no cooperative launch). */
+template <int FMT>
+static int dcp_fused_capacity()
+{
+    static int cap[16] = {0}; /* per device, filled in once: -1 none */
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+        return 0;
+    if (cap[dev] == 0) {
+        int coop = 0, per_cu = 0, cus = 0;
+        cap[dev] = -1;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(msd_dcp_fused_kernel<FMT>), 256, 0) == hipSuccess &&
+            per_cu > 0 && cus > 0)
+            cap[dev] = per_cu * cus;
+    }
+    return cap[dev] > 0 ? cap[dev] : 0;
+}
+
 template <int FMT>
 static void dcp_launch(const uint8_t *iq, uint64_t n, uint32_t L, float dc_a, float dc_b, float *d_state, uint16_t *d_mag,
-                       float *d_magsq, uint8_t *work, int max_passes, hipStream_t stream)
+                       float *d_magsq, uint8_t *work, int max_passes, int fused, hipStream_t stream)
 {
-    const uint32_t nb = dcp_blocks(n, L);
-    const uint64_t nfine = (n + DCP_FINE - 1) / DCP_FINE;
+    uint32_t nb = dcp_blocks(n, L);
+    uint64_t nfine = (n + DCP_FINE - 1) / DCP_FINE;
     DcpCtl *ctl = reinterpret_cast<DcpCtl *>(work);
     uint32_t *S = reinterpret_cast<uint32_t *>(work + 256);
-    uint32_t *dirty = S + 2 * (size_t)nb;
-    float4 *E = reinterpret_cast<float4 *>(work + 256 + (((size_t)nb * 16 + 255) & ~(size_t)255)); /* S and dirty in front, 16-byte aligned */
+    uint32_t *cen = S + 2 * (size_t)nb;
+    uint32_t *ever = cen + 2 * (size_t)nb;
+    float4 *E = reinterpret_cast<float4 *>(work + dcp_e_offset(nb));
     uint32_t *fine = reinterpret_cast<uint32_t *>(E + (size_t)nb * 2 * 64);
-    hipLaunchKernelGGL(msd_dcp_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, ctl, S, dirty, nb, d_state);
+    hipLaunchKernelGGL(msd_dcp_init_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, ctl, S, cen, ever, nb, d_state);
     const uint32_t eval_grid = (2 * nb + 3) / 4;
-    for (int p = 0; p < max_passes; ++p) {
-        hipLaunchKernelGGL(msd_dcp_eval_kernel<FMT>, dim3(eval_grid), dim3(256), 0, stream, iq, n, L, dc_a, dc_b, S, dirty, E, fine, nb, nfine);
-        hipLaunchKernelGGL(msd_dcp_walk_kernel, dim3(2), dim3(256), 0, stream, ctl, S, dirty, E, nb);
+    bool done_fused = false;
+    if (fused && (int)(eval_grid + 2u) <= dcp_fused_capacity<FMT>()) {
+        uint32_t mp = (uint32_t)max_passes;
+        void *args[] = {&iq, &n, &L, &dc_a, &dc_b, &ctl, &S, &cen, &E, &fine, &ever, &nb, &nfine, &mp};
+        done_fused = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(msd_dcp_fused_kernel<FMT>), dim3(eval_grid + 2u), dim3(256), args, 0,
+                                                stream) == hipSuccess;
+        if (!done_fused)
+            (void)hipGetLastError();
     }
-    /* the blocks whose exact start the last walk moved: their fine states */
-    hipLaunchKernelGGL(msd_dcp_eval_kernel<FMT>, dim3(eval_grid), dim3(256), 0, stream, iq, n, L, dc_a, dc_b, S, dirty, E, fine, nb, nfine);
+    if (!done_fused) {
+        for (int p = 0; p < max_passes; ++p) {
+            hipLaunchKernelGGL(msd_dcp_eval_kernel<FMT>, dim3(eval_grid), dim3(256), 0, stream, iq, n, L, dc_a, dc_b, S, cen, E, fine, nb, nfine);
+            hipLaunchKernelGGL(msd_dcp_walk_kernel, dim3(2), dim3(256), 0, stream, ctl, S, E, nb);
+        }
+    }
+    /* the blocks whose table is not centred on their final start state: the states at every 64th sample */
+    hipLaunchKernelGGL(msd_dcp_eval_kernel<FMT>, dim3(eval_grid), dim3(256), 0, stream, iq, n, L, dc_a, dc_b, S, cen, E, fine, nb, nfine);
     hipLaunchKernelGGL(msd_dcp_out_kernel<FMT>, dim3((unsigned)((nfine + 255) / 256)), dim3(256), 0, stream, iq, n, dc_a, dc_b, fine, nfine, ctl,
                        d_state, d_mag, d_magsq);
 }
@@ -441,7 +626,7 @@ static void dcp_launch(const uint8_t *iq, uint64_t n, uint32_t L, float dc_a, fl
 /* d_work: msd_dcp_work_bytes(>= nsamples, block_len) of device memory; behind this call the caller queues
  * msd_launch_dcfilter(..., skip_if = d_work), which does the batch in order if the passes did not get there. */
 extern "C" int msd_launch_dcfilter_parallel(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
-                                            uint16_t *d_mag, float *d_magsq, void *d_work, uint32_t block_len, int max_passes,
+                                            uint16_t *d_mag, float *d_magsq, void *d_work, uint32_t block_len, int max_passes, int fused,
                                             hipStream_t stream)
 {
     const uint8_t *iq = static_cast<const uint8_t *>(d_iq);
@@ -452,13 +637,13 @@ extern "C" int msd_launch_dcfilter_parallel(int format, const void *d_iq, uint64
         return -22;
     switch (format) {
     case MSD_FMT_UC8:
-        dcp_launch<MSD_FMT_UC8>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, stream);
+        dcp_launch<MSD_FMT_UC8>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, fused, stream);
         break;
     case MSD_FMT_SC16:
-        dcp_launch<MSD_FMT_SC16>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, stream);
+        dcp_launch<MSD_FMT_SC16>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, fused, stream);
         break;
     case MSD_FMT_SC16Q11:
-        dcp_launch<MSD_FMT_SC16Q11>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, stream);
+        dcp_launch<MSD_FMT_SC16Q11>(iq, nsamples, block_len, dc_a, dc_b, d_state, d_mag, d_magsq, work, max_passes, fused, stream);
         break;
     default:
         return -22;

@@ -41,7 +41,7 @@ for case in range(first, first + ncases):
     iq = pkg.siggen.generate(cfg, n)
     d = torch.from_numpy(iq).to("cuda:0")
     with_fields = int(rng.integers(0, 2))
-    dc = bool(rng.integers(0, 8) == 0) and n <= 12 * 131072  # the DC block runs at ~0.13 GS/s: short captures only
+    dc = bool(rng.integers(0, 8) < 2)  # --dcfilter: a quarter of the cases since round 6 (the DC block is parallel in time now; it ran at 0.13 GS/s)
     q11 = int(rng.choice([0, 0, 7, 8, 11])) if fmt_name == "sc16q11" and not dc else 0  # a -DSC16Q11_TABLE_BITS build (convert.c:264-328)
     # round 5: candidate arenas far too small for the traffic now and then (their region slices overflow: grown and
     # rescanned on the GPU, or -- growth switched off -- in pieces through the host resolver)

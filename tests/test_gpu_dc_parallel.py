@@ -85,6 +85,45 @@ def test_the_in_order_kernel_behind_the_passes(pkg, oracle, torch_cuda, fmt, way
         off += m
 
 
+@pytest.mark.parametrize("fmt", ["uc8", "sc16"])
+@pytest.mark.parametrize("kind", ["noise", "offset", "constant"])
+def test_the_passes_in_one_cooperative_launch(pkg, oracle, torch_cuda, fmt, kind):
+    """MSD_CFG_DC_FUSED_LAUNCH: all passes in one cooperative launch, the evaluation following the walk block by block through
+    bounded waits (msd_dcp_fused_kernel; measured slower than two launches per pass, kept as a switch) -- the same magnitudes,
+    the same means, exact as well."""
+    f, of = fmt_ids(pkg, oracle, fmt)
+    bps = 2 if fmt == "uc8" else 4
+    sizes = (CHUNK, 4097, 8 * CHUNK + 777, 3 * CHUNK)
+    iq = content(kind, fmt, sum(sizes), seed=zlib.crc32((kind + fmt).encode()) & 0xffff)
+    dem = pkg.Demodulator(fmt=f, nfix_crc=1, max_batch_samples=16 * CHUNK, dc_filter=True, flags=pkg.capi.CFG_DC_FUSED_LAUNCH)
+    orc = oracle.Oracle(of, 58, 1, 0, dc_filter=True)
+    off = 0
+    for m in sizes:
+        blk = iq[off * bps:(off + m) * bps]
+        gm, gl, gp = dem.convert(blk, m)
+        wm, wl, wp = orc.convert(blk, m)
+        assert dem.dc_filter_status()[0] == 1, (fmt, kind, off, m, dem.dc_filter_status())
+        assert np.array_equal(gm[:m], wm) and gl == wl and gp == wp, (fmt, kind, off, m)
+        off += m
+
+
+def test_two_receivers_with_the_dc_block_on_one_gpu(pkg, oracle, torch_cuda):
+    """Two contexts converting alternately, one of them with the cooperative launch: whatever way a batch goes
+    (msd_dc_filter_status may say 0 when a bounded wait ran out), the magnitudes are the oracle's."""
+    n = 4 * CHUNK
+    a = content("offset", "uc8", 3 * n, seed=11)
+    b = content("noise", "uc8", 3 * n, seed=12)
+    da = pkg.Demodulator(max_batch_samples=4 * CHUNK, dc_filter=True, flags=0)
+    db = pkg.Demodulator(max_batch_samples=4 * CHUNK, dc_filter=True, flags=pkg.capi.CFG_DC_FUSED_LAUNCH)
+    oa = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0, dc_filter=True)
+    ob = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0, dc_filter=True)
+    for k in range(3):
+        for dem, orc, iq in ((da, oa, a), (db, ob, b)):
+            blk = iq[2 * k * n:2 * (k + 1) * n]
+            gm = dem.convert(blk, n)[0]
+            assert np.array_equal(gm[:n], orc.convert(blk, n)[0]), k
+
+
 def test_parallel_dc_block_in_the_stream_interface(pkg, oracle, torch_cuda):
     """The same kernels in front of the scan (msd_launch_device of a MSD_CFG_DC_FILTER context): three batches of a capture
     with a DC offset, pipelined; the message list and the per-buffer means are the oracle's, every batch came out exact."""
