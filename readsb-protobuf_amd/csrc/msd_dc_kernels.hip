@@ -271,7 +271,7 @@ __device__ __forceinline__ void dcp_st_rel(uint32_t *p, uint32_t v) { __hip_atom
  * Returns (to every thread) false when a wait ran out. */
 template <int TILE, bool FUSED>
 __device__ __forceinline__ bool dcp_walk(DcpCtl *ctl, uint32_t *S, const float4 *E, const uint32_t *ever, uint32_t nb, int ch, uint32_t pass,
-                                         float4 (*et)[TILE * 64], uint32_t (*st)[TILE], uint32_t *sh_fail)
+                                         float4 (*et)[TILE * 64], uint32_t *sh_fail)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i0 = ctl->frontier[ch];
@@ -307,8 +307,6 @@ __device__ __forceinline__ bool dcp_walk(DcpCtl *ctl, uint32_t *S, const float4 
         float4 *dst = et[t & 1u];
         for (uint32_t k = (uint32_t)(tid - first); k < rows * 64u; k += (uint32_t)nthr)
             dst[k] = src[k];
-        for (uint32_t k = (uint32_t)(tid - first); k < rows; k += (uint32_t)nthr)
-            st[t & 1u][k] = S[ch * nb + r0 + k];
     };
     fetch(0, 0, 256);
     __syncthreads();
@@ -321,24 +319,34 @@ __device__ __forceinline__ bool dcp_walk(DcpCtl *ctl, uint32_t *S, const float4 
         } else {
             const uint32_t r0 = i0 + t * TILE, rows = nb - r0 < (uint32_t)TILE ? nb - r0 : (uint32_t)TILE;
             const float4 *eb = et[t & 1u];
-            const uint32_t *sb = st[t & 1u];
             float4 nx = eb[lane];
             for (uint32_t r = 0; r < rows; ++r) {
                 const uint32_t row = (uint32_t)ch * nb + r0 + r;
                 const float4 p = nx; /* x: the bracket's lower end, y: its upper end, z: the table at the lower end, w: the secant */
-                const uint32_t sold = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb[r]);
+                /* the table's centre is the start state it was evaluated around (S[row], but for the sign of a zero) */
+                const uint32_t sold = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.x), 31);
                 if (r + 1 < rows)
                     nx = eb[(r + 1) * 64u + (uint32_t)lane]; /* does not depend on this block's outcome */
                 const float zf = __uint_as_float(zb);
-                const bool above = p.x <= zf;
-                const bool own = (above || lane == 0) && (lane == 63 || zf < p.y); /* (lanes 0 and 63 also take what lies beyond) */
-                const bool sure = above && (p.x == zf || __float_as_uint(p.w) == 0x80000000u);
-                const float s_low = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.y), 63));
-                const float guess = (zf - p.x) * (above ? p.w : s_low) + p.z; /* = the table's value itself where `sure` */
-                const uint64_t m = __ballot(own);
-                const int owner = m ? __builtin_ctzll(m) : 0;
-                const uint32_t nz = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(guess), owner);
-                const bool ex = (__ballot(own && sure) != 0);
+                /* The candidates ascend with the lanes, so the lanes whose bracket starts at or below Z are a prefix: its last
+                 * lane owns Z (lane 63 also what lies beyond c_63; below c_0 nobody does: lane 0 extrapolates with the slope
+                 * that travels in lane 63's upper-end field). */
+                const uint64_t m_above = __ballot(p.x <= zf);
+                const uint64_t m_sure = __ballot(p.x == zf) | __ballot(__float_as_uint(p.w) == 0x80000000u); /* Z is the candidate, or the bracket is flat */
+                const float guess = (zf - p.x) * p.w + p.z; /* = the table's value itself where the lane is sure */
+                uint32_t nz;
+                bool ex;
+                if (m_above) {
+                    const int owner = __popcll(m_above) - 1;
+                    nz = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(guess), owner);
+                    ex = ((m_sure >> owner) & 1ull) != 0;
+                } else {
+                    const float s_low = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.y), 63));
+                    const float x_lo = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.x), 0));
+                    const float y_lo = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.z), 0));
+                    nz = __float_as_uint((zf - x_lo) * s_low + y_lo);
+                    ex = false;
+                }
                 if (!ex)
                     ++guessed;
                 if (exact && !ex) { /* this block's start is exact, its end is not: the next pass starts here */
@@ -383,12 +391,11 @@ __device__ __forceinline__ bool dcp_walk(DcpCtl *ctl, uint32_t *S, const float4 
 __global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t *S, const float4 *__restrict__ E, uint32_t nb)
 {
     __shared__ float4 et[2][64 * 64];
-    __shared__ uint32_t st[2][64];
     __shared__ uint32_t sh_fail;
     const int ch = blockIdx.x;
     if (ctl->done || ctl->done_ch[ch])
         return;
-    dcp_walk<64, false>(ctl, S, E, nullptr, nb, ch, 0u, et, st, &sh_fail);
+    dcp_walk<64, false>(ctl, S, E, nullptr, nb, ch, 0u, et, &sh_fail);
 }
 
 /* All passes in one cooperative launch: workgroups 0 and 1 walk channels 0 and 1, every wavefront of the others owns one
@@ -400,7 +407,6 @@ __global__ void __launch_bounds__(256) msd_dcp_fused_kernel(const uint8_t *__res
                                                             uint32_t nb, uint64_t nfine, uint32_t max_passes)
 {
     __shared__ float4 et[2][DCP_FTILE * 64]; /* the walk's two tiles; an evaluating workgroup's terms (8 KB) lie in the same bytes */
-    __shared__ uint32_t st[2][DCP_FTILE];
     __shared__ uint32_t sh_fail;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (blockIdx.x < 2u) {
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(256) msd_dcp_fused_kernel(const uint8_t *__res
         bool ok = true;
         uint32_t w = 0;
         for (; w < max_passes && ok; ++w) {
-            ok = dcp_walk<DCP_FTILE, true>(ctl, S, E, ever, nb, ch, w, et, st, &sh_fail);
+            ok = dcp_walk<DCP_FTILE, true>(ctl, S, E, ever, nb, ch, w, et, &sh_fail);
             if (dcp_ld_acq(&ctl->done_ch[ch]) || dcp_ld(&ctl->gaveup))
                 break;
         }
