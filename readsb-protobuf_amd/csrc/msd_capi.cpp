@@ -1926,8 +1926,12 @@ int launch_dc_block(msd_ctx *c, const void *d_iq, uint64_t nsamples, uint16_t *d
     c->dc_last_parallel = false;
     if (c->d_dc_work && nsamples && (reinterpret_cast<uintptr_t>(d_iq) & 15u) == 0) {
         const uint32_t L = msd_dcp_block_len(nsamples);
+        /* a pass that is not needed is two launches that return at once, 12 us: a batch of a buffer or two (at most 128 blocks,
+         * 5-10 passes measured, profiles/r06_dc_passes.txt) gets 12 queued, not 24 -- what the in-order kernel behind them
+         * would cost such a batch if they ever ran out is a millisecond */
+        const int passes = (nsamples + L - 1) / L <= 128u && c->dc_passes > 12 ? 12 : c->dc_passes;
         const int rc = msd_launch_dcfilter_parallel(c->cfg.format, d_iq, nsamples, c->dc_a, c->dc_b, c->d_dcstate, d_mag, d_magsq,
-                                                    c->d_dc_work, L, c->dc_passes, c->dc_fused ? 1 : 0, stream);
+                                                    c->d_dc_work, L, passes, c->dc_fused ? 1 : 0, stream);
         if (rc)
             return rc;
         skip_if = c->d_dc_work;

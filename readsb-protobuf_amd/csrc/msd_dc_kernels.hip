@@ -562,14 +562,17 @@ extern "C" size_t msd_dcp_work_bytes(uint64_t max_samples, uint32_t block_len)
     return dcp_e_offset(nb) + (size_t)nb * 2 * 64 * 16 + (size_t)nfine * 2 * 4 + 512;
 }
 
-/* Block length for a batch: a power of two between 1024 and 32768 samples that leaves about a thousand blocks -- the
+/* Block length for a batch: a power of two between 1024 and 65536 samples that leaves about a thousand blocks -- the
  * evaluation is one wavefront per block and channel, latency-bound at 8 ns per sample of a block with one or two wavefronts
  * per SIMD and issue-bound at 3 ns per sample and SIMD beyond four (scripts/micro/dcp_chain_occupancy.hip); the walk costs
- * 0.2 us per block.  One buffer of 131072 samples is best served by 64 blocks of 2048 (16 + 13 us per pass). */
+ * 0.17 us per block.  One buffer of 131072 samples is best served by 64 blocks of 2048 (16 + 11 us per pass); beyond 64 Mi
+ * samples the evaluation is issue-bound whatever the block length and the walk is what a longer block saves: 65536. */
 extern "C" uint32_t msd_dcp_block_len(uint64_t nsamples)
 {
     uint32_t L = nsamples >= 65536u ? 2048 : 1024;
     while (L < 32768u && nsamples / L > 1024u)
+        L *= 2;
+    if (nsamples / L > 2048u)
         L *= 2;
     return L;
 }
