@@ -3,8 +3,8 @@
  * The "generic" converters (convert.c:113-163 UC8, :165-213 SC16, :374-423 SC16Q11) run
  *     z = fl(fl(f * dc_a) + fl(z * dc_b))                     (convert.c:137-138)
  * per channel through the WHOLE stream.  The recurrence cannot be re-associated bit-exactly, and one dependent
- * multiply-add pair costs a lone wavefront 8.4 cycles: 130 Msamples/s for msd_dcfilter_kernel (msd_kernels.hip), a fifth
- * of one host core.  What the recurrence does have:
+ * multiply-add pair costs a lone wavefront 5.8 ns (scripts/micro/dcp_chain_occupancy.hip): 130 Msamples/s for
+ * msd_dcfilter_kernel (msd_kernels.hip) with its LDS traffic, a fifth of one host core.  What the recurrence does have:
  *   (1) every step z -> fl(t + fl(z * b)) is monotone non-decreasing in z (a product with b > 0, a sum and two roundings
  *       to nearest are all monotone), hence so is the map F_i of a whole block of L samples;
  *   (2) F_i is nearly a translation with a slope just below one, so a handful of its values pin it down well.
@@ -12,7 +12,8 @@
  *   msd_dcp_eval_kernel   one WAVEFRONT per (block, channel): its 64 lanes run the block's chain from 64 candidate start
  *                         states c_0 <= ... <= c_63 around the current guess S_i (S_i itself, its neighbours up to 8 units in
  *                         the last place either side, then geometrically out to whole binades: dcp_side); the samples
- *                         are wave-uniform: one coalesced load and conversion per 64 steps, v_readlane per step;
+ *                         are wave-uniform: one coalesced load and conversion per 256 steps, the terms f * dc_a broadcast
+ *                         from LDS sixteen steps ahead of the chain; it leaves the block's table prepared for the walk;
  *   msd_dcp_walk_kernel   one wavefront per channel walks the blocks in order from the last start state known EXACTLY:
  *                         Z_i = c_k for some k           -> Z_(i+1) = E_k            exactly (a table look-up)
  *                         c_k < Z_i < c_(k+1), E_k = E_(k+1) -> Z_(i+1) = E_k        exactly (monotonicity, (1))
@@ -21,14 +22,15 @@
  *                                                           walk goes on with guesses, which become the next pass's S_i.
  * The first block that had to guess is evaluated around its exact start in the next pass, so every pass extends the exact
  * prefix by at least one block; in practice the guesses are within a few units after two passes and the whole batch is exact
- * after 4-7 (up to 13 for constant and alternating inputs in the prototype; scripts/experiments/dc_parallel_proto.py has the numpy prototype and its pass counts).
+ * after 5-8 (12-14 for constant and alternating inputs: profiles/r06_dc_passes.txt; scripts/experiments/dc_parallel_proto.py
+ * and dc_parallel_table_walk.py are the numpy prototypes).
  * Nothing is verified by comparison with a tolerance: a start state is either derived exactly or it is a guess.  A batch that
  * is not exact after the passes queued falls through to msd_dcfilter_kernel (sequential, always right).
  * Afterwards msd_dcp_eval_kernel's centre lane leaves the exact state at every 64th sample and msd_dcp_out_kernel -- one LANE
  * per 64 samples -- repeats the chain from there and writes what msd_dcfilter_kernel writes: u16 magnitudes, f32 squares.
  *
- * Two ways of running the passes.  The default: msd_dcp_eval_kernel + msd_dcp_walk_kernel per pass, 24 passes queued (those
- * behind the one that finished return at once).  MSD_CFG_DC_FUSED_LAUNCH: msd_dcp_fused_kernel, ONE cooperative launch with the
+ * Two ways of running the passes.  The default: msd_dcp_eval_kernel + msd_dcp_walk_kernel per pass, 24 passes queued (12 for
+ * a batch of at most 128 blocks; those behind the one that finished return at once).  MSD_CFG_DC_FUSED_LAUNCH: msd_dcp_fused_kernel, ONE cooperative launch with the
  * two walking workgroups and all evaluating wavefronts resident together; an evaluating wavefront starts on pass p + 1 of its
  * block as soon as walk p has gone past it (a progress word per channel), the walk of pass p + 1 waits block by block for the
  * tables (a counter per block), so a pass costs the longer of the two instead of their sum and nothing runs once the batch is
