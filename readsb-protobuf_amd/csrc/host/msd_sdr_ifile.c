@@ -25,6 +25,12 @@ static struct {
     int fd;
     bool regular;  /* a regular file: large turns are read by several threads with pread (read_fully) */
     off_t pos;     /* ... from here */
+    /* fused mode: the page-locked turns the reader fills while the batches before them are in flight.  Like the reference's
+     * read buffer (sdr_ifile.c:141-148, 240-252) they are the handler's from Open to Close -- page-locking 16 MiB takes 3 ms
+     * and releasing it 2: in the run itself five of them were 24 of the 29 ms a 10 s capture took -- and a regular file gets
+     * no more of them than it has turns. */
+    char *ring[MSD_PIPELINE_DEPTH + 1];
+    unsigned nring;
     unsigned bytes_per_sample;
     char *readbuf;
     size_t readbuf_bytes;
@@ -253,10 +259,13 @@ bool msd_ifileOpen(void)
         snprintf(F.err, sizeof F.err, "ifile: could not open %s: %s", F.filename, strerror(errno));
         return false;
     }
+    off_t file_bytes = -1;
     {
         struct stat sb;
         F.regular = F.fd != STDIN_FILENO && fstat(F.fd, &sb) == 0 && S_ISREG(sb.st_mode);
         F.pos = 0;
+        if (F.regular)
+            file_bytes = sb.st_size;
     }
     F.bytes_per_sample = (F.format == MSD_FMT_UC8) ? 2 : 4;
     const unsigned nbuf = (F.mode == MSD_IFILE_FUSED) ? F.rx.batch_buffers : 1;
@@ -302,6 +311,18 @@ bool msd_ifileOpen(void)
         msd_ifileClose();
         return false;
     }
+    if (F.mode == MSD_IFILE_FUSED) {
+        const size_t turn = F.throttle ? (size_t)MSD_CHUNK_SAMPLES * F.bytes_per_sample : F.readbuf_bytes;
+        unsigned want = MSD_PIPELINE_DEPTH + 1;
+        if (file_bytes >= 0 && (uint64_t)file_bytes / turn + 1 < want)
+            want = (unsigned)((uint64_t)file_bytes / turn + 1); /* (the last turn is the short read that ends the capture) */
+        for (F.nring = 0; F.nring < want; ++F.nring)
+            if (msd_host_alloc(F.ctx, turn, (void **)&F.ring[F.nring])) {
+                snprintf(F.err, sizeof F.err, "ifile: %s", msd_last_error(F.ctx));
+                msd_ifileClose();
+                return false;
+            }
+    }
     warm_up();
     return true;
 }
@@ -342,7 +363,7 @@ static void warm_up(void)
  * whole replay's bound (2.7 Gsamples/s for a capture in /dev/shm against 27 from memory over PCIe).  A regular file's large turns
  * are therefore read by READ_THREADS threads with pread, each its slice of the turn; pipes, stdin and single buffers are read in
  * order as before.  A short slice ends the capture exactly as a short read does (sdr_ifile.c:197-209). */
-enum { READ_THREADS = 4, READ_PARALLEL_MIN = 4 << 20 };
+enum { READ_THREADS = 8, READ_PARALLEL_MIN = 4 << 20 };
 struct read_slice {
     char *dst;
     size_t want, got;
@@ -589,14 +610,10 @@ static void run_magbuf(void)
  * the next block, the upload of the previous one and the kernels of the one before overlap. */
 static void run_fused(void)
 {
-    enum { RING = MSD_PIPELINE_DEPTH + 1 };
-    char *ring[RING];
-    memset(ring, 0, sizeof ring);
-    for (int i = 0; i < RING; ++i)
-        if (msd_host_alloc(F.ctx, F.readbuf_bytes, (void **)&ring[i])) {
-            snprintf(F.err, sizeof F.err, "ifile: %s", msd_last_error(F.ctx));
-            goto out;
-        }
+    const unsigned RING = F.nring; /* a ring of fewer turns than the pipeline is deep holds the whole file: one turn each */
+    char **ring = F.ring;
+    if (!RING)
+        return;
     {
         bool eof = false;
         int in_flight = 0;
@@ -631,7 +648,7 @@ static void run_fused(void)
                 }
                 continue;
             }
-            if (in_flight == MSD_PIPELINE_DEPTH) {
+            if (in_flight > 0 && (in_flight == MSD_PIPELINE_DEPTH || (unsigned)in_flight + 1 >= RING)) { /* the next turn's buffer must be free by then */
                 rc = msd_collect(F.ctx, F.rx.sink, F.rx.sink_user);
                 in_flight--;
             }
@@ -651,8 +668,7 @@ static void run_fused(void)
             }
     }
 out:
-    for (int i = 0; i < RING; ++i)
-        msd_host_free(F.ctx, ring[i]);
+    return;
 }
 
 void msd_ifileRun(void)
@@ -690,6 +706,9 @@ void msd_ifileClose(void)
         F.converter_state = NULL;
     }
     if (F.ctx) {
+        for (unsigned i = 0; i < F.nring; ++i)
+            msd_host_free(F.ctx, F.ring[i]);
+        F.nring = 0;
         msd_destroy(F.ctx);
         F.ctx = NULL;
     }
