@@ -1,3 +1,7 @@
+"""Round 6, prototype 1 of the parallel-in-time DC block (LABLOG R6.3): Newton on the block boundaries -- every block run exactly
+(numpy float32, two roundings per step like convert.c:137-138) from a guessed start state, the guesses corrected by the scan of the
+mismatches with slope c = dc_b^L or 1.  Converges to the in-order chain (dc_parallel_chain.c), slowly: 18-62 passes, none within 100
+for a state that keeps crossing zero.  python dc_parallel_proto.py [samples]"""
 import numpy as np, ctypes, sys, time
 sys.path.insert(0,'/root/repo')
 import os, subprocess

@@ -1,3 +1,7 @@
+"""Round 6, prototype 2 (the one msd_dc_kernels.hip implements; LABLOG R6.3): per block a table of the block's map at 64 candidate
+start states around the guess, an in-order walk that is exact where the arriving state is a candidate or lies between two candidates
+with equal table values (every step is monotone), a secant guess otherwise; the guesses are the next pass's centres.  4-7 passes in
+every regime of the filter state.  python dc_parallel_table_walk.py [log2 samples]"""
 from dc_parallel_proto import *
 import sys
 def offsets(kind):
