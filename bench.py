@@ -480,6 +480,12 @@ def main():
                           else "host threads (%s)" % os.environ["MSD_RESOLVE_THREADS"]),
     }
 
+    if args.dcfilter:
+        # how the DC block of the last batch was computed (msd_dc_filter_status): by the exact parallel-in-time kernels, in how many passes
+        ex, passes, guessed, blocks = dems[0].dc_filter_status()
+        out["dc_block"] = {"exact_parallel": bool(ex), "passes": passes, "blocks": blocks, "blocks_guessed_all_passes": guessed,
+                           "what": "the last batch's DC block (convert.c:137-138): blocks evaluated from 64 candidate start states per pass, "
+                                   "an in-order walk that is exact by table hit or by monotonicity; false = the in-order kernel behind the passes took the batch"}
     # ---- N > 1: the evidence an N = 1 line carries, for every rank, after the clock stopped ----
     if world > 1 and not args.no_check:
         # every rank: its GPU's ordered message list and counters over the first 256 buffers of ITS capture (seed 10901 + rank)
