@@ -304,7 +304,7 @@ bool msd_ifileOpen(void)
     if (F.rx.dc_filter && F.mode == MSD_IFILE_FUSED)
         cfg.flags |= MSD_CFG_DC_FILTER; /* init_converter(..., Modes.dc_filter, ...), sdr_ifile.c:150-153 (the literal drop-in's
                                            converter above has it; its demodulator gets magnitudes) */
-    cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * (F.mode == MSD_IFILE_MAGBUF ? 8u /* MAGBUF_BATCH */ : nbuf);
+    cfg.max_batch_samples = (uint64_t)MSD_CHUNK_SAMPLES * (F.mode == MSD_IFILE_MAGBUF ? 12u /* MAGBUF_BATCH */ : nbuf);
     int rc = msd_create(&cfg, &F.ctx);
     if (rc) {
         snprintf(F.err, sizeof F.err, "ifile: msd_create failed: %s", strerror(-rc));
@@ -430,7 +430,7 @@ static size_t read_fully(char *dst, size_t want)
  * when this consumer finds several queued (a file replay: the reader is ahead) it hands up to MAGBUF_BATCH consecutive ones
  * to the GPU in one call -- the same messages in the same order, the round trips paid once (msd_demodulate_magbufs).  A
  * paced feed (--throttle, a live receiver) never has more than one waiting, and gets the one-buffer latency. */
-enum { MAGBUF_BATCH = 8 };
+enum { MAGBUF_BATCH = 12 };
 
 static void *magbuf_consumer(void *arg)
 {
