@@ -1839,6 +1839,17 @@ int finish(msd_ctx *c, Slot &s, int format, msd_message_fn sink, void *user,
                 const int64_t first = (int64_t)(rq >> 16) - (int64_t)MSD_OVERLAP + 19; /* index into the batch's new samples */
                 const uint64_t len = rq & 0xffffu;
                 uint64_t acc = 0;
+                if (first >= 0 && len) { /* nearly always the message lies inside one buffer's new samples: a plain sum of squares over
+                                            consecutive u16 (the general walk below cost 0.9 ns a sample, a quarter of a twelve-buffer call) */
+                    const uint64_t b = (uint64_t)first / MSD_CHUNK_SAMPLES, o = (uint64_t)first % MSD_CHUNK_SAMPLES;
+                    if (b < c->magbuf_nviews && o + len <= MSD_CHUNK_SAMPLES && o + len + MSD_OVERLAP <= c->magbuf_views[b].validLength) {
+                        const uint16_t *m = c->magbuf_views[b].data + MSD_OVERLAP + o;
+                        for (uint64_t k = 0; k < len; ++k)
+                            acc += (uint64_t)((uint32_t)m[k] * (uint32_t)m[k]);
+                        s.h_pow[i] = acc;
+                        continue;
+                    }
+                }
                 for (uint64_t k = 0; k < len; ++k) {
                     const int64_t idx = first + (int64_t)k;
                     uint64_t x = 0;
