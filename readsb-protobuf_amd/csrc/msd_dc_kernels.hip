@@ -25,7 +25,8 @@
  * after 5-8 (12-14 for constant and alternating inputs: profiles/r06_dc_passes.txt; scripts/experiments/dc_parallel_proto.py
  * and dc_parallel_table_walk.py are the numpy prototypes).
  * Nothing is verified by comparison with a tolerance: a start state is either derived exactly or it is a guess.  A batch that
- * is not exact after the passes queued falls through to msd_dcfilter_kernel (sequential, always right).
+ * is not exact after the passes queued falls through to msd_dcfilter_kernel (sequential, always right) -- from the first block
+ * whose end is not exact in both channels on: what the passes did derive is kept (msd_dcp_handover_kernel).
  * Afterwards msd_dcp_eval_kernel's centre lane leaves the exact state at every 64th sample and msd_dcp_out_kernel -- one LANE
  * per 64 samples -- repeats the chain from there and writes what msd_dcfilter_kernel writes: u16 magnitudes, f32 squares.
  *
@@ -60,7 +61,12 @@ struct DcpCtl {
     uint32_t ndone;
     uint32_t prog[2];      /* fused kernel: walk w has gone past block i of channel c when prog[c] >= w (nb + 1) + i + 1 */
     uint32_t gaveup;       /* fused kernel: a bounded wait ran out, or the passes did */
+    /* words 16-19, for a batch the passes did not finish (msd_dcp_handover_kernel): what they did get exact is kept -- the output
+     * kernel writes the samples in front of `resume`, msd_dcfilter_kernel goes on in order from there with these states */
+    uint32_t resume_lo, resume_hi; /* first sample of the first block whose end is not exact in both channels */
+    uint32_t resume_z[2];          /* the two channels' states in front of it (bits) */
 };
+static_assert(sizeof(DcpCtl) == 20 * 4, "msd_dcfilter_kernel reads words 0 and 16-19");
 
 /* floats in their order as integers: ord(-x) = -ord(x), ord(+-0) = 0, consecutive floats are consecutive integers */
 __device__ __forceinline__ int64_t dcp_ord(uint32_t bits)
@@ -400,6 +406,22 @@ __global__ void __launch_bounds__(256) msd_dcp_walk_kernel(DcpCtl *ctl, uint32_t
     dcp_walk<64, false>(ctl, S, E, nullptr, nb, ch, 0u, et, &sh_fail);
 }
 
+/* Behind the passes: where the in-order kernel has to take over, if at all. */
+__global__ void msd_dcp_handover_kernel(DcpCtl *ctl, const uint32_t *S, uint32_t nb, uint32_t L, uint64_t nsamples)
+{
+    if (threadIdx.x || blockIdx.x)
+        return;
+    const uint32_t f0 = ctl->done_ch[0] ? nb : ctl->frontier[0], f1 = ctl->done_ch[1] ? nb : ctl->frontier[1];
+    const uint32_t f = f0 < f1 ? f0 : f1; /* the starts of blocks 0 ... f are exact in both channels */
+    uint64_t resume = (uint64_t)f * L;
+    if (resume > nsamples || ctl->done)
+        resume = nsamples;
+    ctl->resume_lo = (uint32_t)resume;
+    ctl->resume_hi = (uint32_t)(resume >> 32);
+    ctl->resume_z[0] = f < nb ? S[f] : ctl->zend[0];
+    ctl->resume_z[1] = f < nb ? S[nb + f] : ctl->zend[1];
+}
+
 /* All passes in one cooperative launch: workgroups 0 and 1 walk channels 0 and 1, every wavefront of the others owns one
  * (block, channel).  See the head of the file. */
 constexpr int DCP_FTILE = 16;
@@ -471,16 +493,15 @@ __global__ void __launch_bounds__(256) msd_dcp_out_kernel(const uint8_t *__restr
                                                           const uint32_t *__restrict__ fine, uint64_t nfine, const DcpCtl *ctl,
                                                           float *state, uint16_t *__restrict__ mag, float *__restrict__ magsq_out)
 {
-    if (!ctl->done)
-        return; /* the sequential kernel behind this one does the batch */
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
+    if (g == 0 && ctl->done) { /* (a batch the passes did not finish: the in-order kernel behind this one leaves the state) */
         state[0] = __uint_as_float(ctl->zend[0]);
         state[1] = __uint_as_float(ctl->zend[1]);
     }
     const uint64_t base = g * DCP_FINE;
-    if (base >= nsamples)
-        return;
+    const uint64_t limit = (uint64_t)ctl->resume_lo | ((uint64_t)ctl->resume_hi << 32); /* nsamples when the batch is exact */
+    if (base >= nsamples || base >= limit)
+        return; /* (the blocks from `limit` on are the in-order kernel's) */
     float zi = __uint_as_float(fine[g]), zq = __uint_as_float(fine[nfine + g]);
     const uint32_t cnt = nsamples - base < (uint64_t)DCP_FINE ? (uint32_t)(nsamples - base) : (uint32_t)DCP_FINE;
     for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
@@ -630,6 +651,7 @@ static void dcp_launch(const uint8_t *iq, uint64_t n, uint32_t L, float dc_a, fl
     }
     /* the blocks whose table is not centred on their final start state: the states at every 64th sample */
     hipLaunchKernelGGL(msd_dcp_eval_kernel<FMT>, dim3(eval_grid), dim3(256), 0, stream, iq, n, L, dc_a, dc_b, S, cen, E, fine, nb, nfine);
+    hipLaunchKernelGGL(msd_dcp_handover_kernel, dim3(1), dim3(64), 0, stream, ctl, S, nb, L, n);
     hipLaunchKernelGGL(msd_dcp_out_kernel<FMT>, dim3((unsigned)((nfine + 255) / 256)), dim3(256), 0, stream, iq, n, dc_a, dc_b, fine, nfine, ctl,
                        d_state, d_mag, d_magsq);
 }

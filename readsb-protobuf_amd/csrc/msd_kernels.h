@@ -197,7 +197,8 @@ int msd_launch_dcfilter(int format, const void *d_iq, uint64_t nsamples, float d
 /* ... the same, exact and parallel in time (msd_dc_kernels.hip): blocks of block_len samples evaluated from 64 candidate start
  * states each, an in-order walk that is exact wherever a candidate or the monotonicity of the block's map decides, at most
  * max_passes passes.  d_work: msd_dcp_work_bytes(nsamples, block_len); its first word is 1 when the batch came out exact,
- * and msd_launch_dcfilter(..., d_skip_if = d_work, ...) queued behind does the batch in order when it did not.  d_iq 16-byte aligned.
+ * and msd_launch_dcfilter(..., d_skip_if = d_work, ...) queued behind finishes the batch in order when it did not -- from the first
+ * block the passes did not get exact (words 16-19 of d_work: that sample and the two states in front of it).  d_iq 16-byte aligned.
  * fused: all passes in one cooperative launch where the batch's blocks can be resident together (else, and with 0, two launches per pass). */
 int msd_launch_dcfilter_parallel(int format, const void *d_iq, uint64_t nsamples, float dc_a, float dc_b, float *d_state,
                                  uint16_t *d_mag, float *d_magsq, void *d_work, uint32_t block_len, int max_passes, int fused, hipStream_t stream);

@@ -2453,13 +2453,31 @@ __global__ void __launch_bounds__(DC_THREADS) msd_dcfilter_kernel(const uint8_t 
                                                                   float dc_b, float *state /* z1_I, z1_Q */,
                                                                   uint16_t *mag, float *magsq_out, const uint32_t *skip_if)
 {
-    if (skip_if && *skip_if)
-        return; /* the parallel-in-time kernels in front (msd_dc_kernels.hip) did the batch */
+    float z_in[2] = {0.0f, 0.0f};
+    bool resumed = false;
+    if (skip_if) { /* the parallel-in-time kernels in front (msd_dc_kernels.hip): word 0 = they did the batch; else words 16-19 =
+                      the sample from which this kernel has to go on, and the two states in front of it (DcpCtl) */
+        if (skip_if[0])
+            return;
+        const uint64_t s0 = (uint64_t)skip_if[16] | ((uint64_t)skip_if[17] << 32);
+        if (s0 >= nsamples) { /* (cannot be: an unfinished batch has an unfinished block) */
+            if (threadIdx.x < 2)
+                state[threadIdx.x] = __uint_as_float(skip_if[18 + threadIdx.x]);
+            return;
+        }
+        z_in[0] = __uint_as_float(skip_if[18]);
+        z_in[1] = __uint_as_float(skip_if[19]);
+        resumed = true;
+        iq += s0 * (FMT == MSD_FMT_UC8 ? 2u : 4u);
+        mag += s0;
+        magsq_out += s0;
+        nsamples -= s0;
+    }
     __shared__ __attribute__((aligned(16))) float tv[2][2][DC_BLK + 16]; /* [block parity][channel] f * dc_a (+ 16: the chain loop's last, unused prefetch) */
     __shared__ __attribute__((aligned(16))) float zv[2][2][DC_BLK]; /* [block parity][channel] z */
     const int tid = threadIdx.x;
     const uint64_t nblk = (nsamples + DC_BLK - 1) / DC_BLK;
-    float z = tid < 2 ? state[tid] : 0.0f;
+    float z = tid < 2 ? (resumed ? z_in[tid] : state[tid]) : 0.0f;
     for (uint64_t k = 0; k < nblk + 2; ++k) {
         if (tid >= 64) {
             const int p = tid - 64;
