@@ -417,9 +417,9 @@ int msd_arena_permille(const msd_ctx *ctx);
 int msd_get_timing(const msd_ctx *ctx, msd_timing *t);
 /* MSD_CFG_DC_FILTER: how the DC block of the most recent batch (or msd_convert call) was computed.  Waits for the
  * context's stream.  out[0] = 1: by the exact parallel-in-time kernels; 0: they had not arrived at an exact state for every
- * block within the passes queued (or the context is MSD_CFG_DC_SEQUENTIAL / the batch's IQ was not 16-byte aligned) and the
- * in-order kernel did the batch; out[1] = passes that did work, out[2] = blocks that had to guess (all passes),
- * out[3] = blocks.  -EINVAL for a context without the DC filter. */
+ * block within the passes queued and the in-order kernel finished the batch from the first such block on (or did all of
+ * it: the context is MSD_CFG_DC_SEQUENTIAL, or the batch's IQ was not 16-byte aligned); out[1] = passes that did work,
+ * out[2] = blocks that had to guess (all passes), out[3] = blocks.  -EINVAL for a context without the DC filter. */
 int msd_dc_filter_status(msd_ctx *ctx, uint32_t out[4]);
 /* mean_level / mean_power of the buffers of the most recent batch (mag_buf.mean_level/.mean_power,
  * fifo.h:70-71): 2 doubles per buffer, up to cap buffers; returns the number of buffers. */
