@@ -118,8 +118,9 @@ __global__ void msd_dcp_init_kernel(DcpCtl *ctl, uint32_t *S, uint32_t *cen, uin
     }
     if (i < nb) {
         for (int ch = 0; ch < 2; ++ch) {
-            S[ch * nb + i] = i == 0 ? __float_as_uint(state[ch]) : 0u; /* first guess: nothing; the first pass is then the */
-            cen[ch * nb + i] = DCP_NEVER;                              /* linear prediction F_i(0) + slope * Z              */
+            S[ch * nb + i] = __float_as_uint(state[ch]); /* first guess: the DC estimate stays where the last batch left it (it moves by
+                                                            its own noise only); the first pass is then the linear prediction from there */
+            cen[ch * nb + i] = DCP_NEVER;
             ever[ch * nb + i] = 0u;
         }
     }
