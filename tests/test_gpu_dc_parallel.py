@@ -143,3 +143,45 @@ def test_parallel_dc_block_in_the_stream_interface(pkg, oracle, torch_cuda):
     want, wstats = oracle.Oracle(oracle.FMT_UC8, 58, 1, 0, dc_filter=True).replay(iq, cap=1 << 17)
     assert len(want) > 1000
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16"])
+@pytest.mark.parametrize("kind", ["noise", "offset", "random"])
+def test_every_block_table_is_monotone(pkg, torch_cuda, fmt, kind):
+    """What the walk's second exactness rule rests on, checked on the hardware: the map of a block is monotone non-decreasing
+    (every step z -> fl(t + fl(z b)) is), so the table values ascend with the candidates -- every block's table after two passes,
+    read back from the workspace of msd_launch_dcfilter_parallel (white box: the layout of msd_dc_kernels.hip's dcp_launch).  Also
+    the brackets tile the line (a lane's upper end is the next lane's candidate) and a flat mark sits on equal table values only."""
+    import ctypes as C
+    L = C.CDLL(pkg.capi.LIB_PATH)
+    L.msd_dcp_work_bytes.restype = C.c_size_t
+    L.msd_dcp_work_bytes.argtypes = [C.c_uint64, C.c_uint32]
+    L.msd_launch_dcfilter_parallel.restype = C.c_int
+    L.msd_launch_dcfilter_parallel.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    f = pkg.FMT_UC8 if fmt == "uc8" else pkg.FMT_SC16
+    bps = 2 if fmt == "uc8" else 4
+    n, blk = 1 << 19, 1024
+    nb = n // blk
+    iq = content(kind, fmt, n, seed=21)
+    d_iq = torch_cuda.from_numpy(iq.copy()).cuda()
+    work = torch_cuda.zeros(L.msd_dcp_work_bytes(n, blk), dtype=torch_cuda.uint8, device="cuda")
+    mag = torch_cuda.zeros(n, dtype=torch_cuda.int16, device="cuda")
+    sq = torch_cuda.zeros(n, dtype=torch_cuda.float32, device="cuda")
+    state = torch_cuda.tensor([0.003, -0.0007], dtype=torch_cuda.float32, device="cuda")
+    b = np.float32(np.exp(-2 * np.pi / 2.4e6))
+    a = np.float32(1.0 - float(b))
+    assert len(iq) == n * bps
+    assert L.msd_launch_dcfilter_parallel(f, d_iq.data_ptr(), n, float(a), float(b), state.data_ptr(), mag.data_ptr(), sq.data_ptr(),
+                                          work.data_ptr(), blk, 2, 0, None) == 0
+    torch_cuda.cuda.synchronize()
+    e0 = 256 + ((nb * 24 + 255) & ~255)
+    T = work[e0:e0 + 2 * nb * 64 * 16].cpu().numpy().view(np.float32).reshape(2 * nb, 64, 4)
+    x0, x_up, y0, w = T[:, :, 0], T[:, :, 1], T[:, :, 2], T[:, :, 3]
+    assert not np.isnan(T[:, :63, :]).any()
+    assert (np.diff(x0, axis=1) >= 0).all()                       # the candidates ascend with the lanes
+    assert (np.diff(y0, axis=1) >= 0).all()                       # ... and so do the block's values at them: F is monotone
+    assert np.array_equal(x_up[:, :62], x0[:, 1:63])              # lane j's bracket ends where lane j + 1's begins
+    flat = w[:, :63].view(np.uint32) == 0x80000000
+    assert flat.any() and (y0[:, :63][flat] == y0[:, 1:][flat]).all()
+    assert (w[:, :63][~flat] >= 0).all()                          # a secant of a monotone map is not negative
