@@ -844,8 +844,9 @@ __global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const 
                         { /* the message the probation table is waiting for: every later try of its address was staged as
                            * known already (and the ones under the message are hidden), nothing is left to look for */
                             const int e = spec_find(spec_key, uni((uint32_t)(seg_res[i] >> 40)));
-                            if (e >= 0 && uni(spec_val[e] >> 1) == uni(ok_pos[kk]))
-                                continue;
+                            if (e >= 0 && uni(spec_val[e] >> 1) == uni(ok_pos[kk]) && uni((uint32_t)spec_conf[e]) != 2u)
+                                continue; /* (an entry that failed its probation has had its tries put back to unknown: the message
+                                             is a new aircraft like any other, should it be accepted after all) */
                         }
                         if (nf == FCAP) { /* more new aircraft than the check handles at once: stop in front of this one */
                             next = i;
@@ -948,6 +949,26 @@ __global__ void __launch_bounds__(RT, MSD_RESOLVE_OCC) msd_resolve_kernel(const 
                     }
                 }
                 const uint32_t cut = uni(sh_next);
+                if (nuse) {
+                    /* A confirmation by a message that the cut has dropped since is void (round 6: the fuzzer's case 702780 -- the
+                     * probation check above moved the cut in front of a message that had confirmed its entry a few lines earlier;
+                     * re-evaluated, another message hid it, it was never accepted, and every later try of its address stayed
+                     * "known" on the strength of a round that did not happen).  The message is looked at again behind the cut. */
+                    const uint32_t na1 = uni(sh_na);
+                    for (uint32_t j = tid; j < na1; j += RT) {
+                        const uint32_t k = acc_k[j], i = ok_idx[k];
+                        if (i < cut)
+                            continue;
+                        const uint64_t r = seg_res[i];
+                        const uint32_t df = (uint32_t)(r >> 20) & 31u, nerr = (uint32_t)(r >> 28) & 3u;
+                        if (nerr == 0 && (df == 17 || (df == 11 && ((r >> 36) & 1u)))) {
+                            const int e = spec_find(spec_key, (uint32_t)(r >> 40));
+                            if (e >= 0 && (spec_val[e] >> 1) == ok_pos[k] && spec_conf[e] == 1)
+                                spec_conf[e] = 0;
+                        }
+                    }
+                    __syncthreads();
+                }
                 /* the new addresses whose messages stay accepted are known from here on */
                 if (nf) {
                     for (uint32_t t = tid; t < ntries; t += RT) {

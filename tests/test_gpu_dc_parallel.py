@@ -185,3 +185,4 @@ def test_every_block_table_is_monotone(pkg, torch_cuda, fmt, kind):
     flat = w[:, :63].view(np.uint32) == 0x80000000
     assert flat.any() and (y0[:, :63][flat] == y0[:, 1:][flat]).all()
     assert (w[:, :63][~flat] >= 0).all()                          # a secant of a monotone map is not negative
+

@@ -628,3 +628,18 @@ def test_float_sums_of_a_full_batch_that_ends_on_a_buffer_boundary(pkg, oracle, 
     gm = dem.buffer_means()
     assert len(gm) == 513 and np.array_equal(gm, wmeans[:513], equal_nan=True)
     assert np.isfinite(gm[:512]).all() and gm[:512, 0].min() > 0
+
+
+@pytest.mark.gpu
+def test_a_probation_confirmed_by_a_message_the_round_then_dropped(pkg, oracle, torch_cuda):
+    """The fuzzer's case 702780 (round 6), the first four buffers of it: a new aircraft's clean squitter confirms its entry
+    of the resolve kernel's probation table (later tries of its address are staged as known while the message that will add
+    it is still to be accepted), the same round's probation check then moves the cut in front of that message, and in the
+    re-evaluation another message hides it: it is never accepted, the address never added (mode_s.c:717-726) -- and a
+    corrected DF17 of that address 0.1 s later must score 700, not 900 (mode_s.c:376-381).  The confirmation of a message
+    behind the final cut is void (msd_resolve_kernels.hip)."""
+    n = 4 * 131072
+    kw = dict(msgs_per_sec=12000, n_aircraft=800, overlap_permille=0, flip_permille=20, noise_fs=0.005, ac_per_sec=500)
+    got, dem = run_case(pkg, oracle, torch_cuda, pkg.FMT_UC8, n, 702780, 1, batch=4 * 131072, **kw)   # compares with the oracle
+    i = int(np.flatnonzero(got["addr"] == 0xF0F741)[0])
+    assert len(got) > 600 and got["score"][i] == 700 and got["correctedbits"][i] == 1 and got["msgtype"][i] == 17
