@@ -31,12 +31,17 @@ for case in range(first, first + ncases):
     batch = int(rng.choice([64, 256, 1024])) * 131072
     thr = int(rng.choice([58, 58, 75]))
     dc = bool(rng.integers(0, 4) == 0)
-    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=case, **kw), n)
+    fmt_name = str(rng.choice(["uc8", "uc8", "sc16", "sc16q11"]))  # (drawn last: the seeds of the first campaigns keep their traffic)
+    fmt, ofmt = {"uc8": (pkg.FMT_UC8, orc.FMT_UC8), "sc16": (pkg.FMT_SC16, orc.FMT_SC16), "sc16q11": (pkg.FMT_SC16Q11, orc.FMT_SC16Q11)}[fmt_name]
+    if fmt_name != "uc8":
+        nbuf = min(nbuf, 1400)  # 4 bytes a sample
+        n = min(n, nbuf * 131072)
+    iq = pkg.siggen.generate(pkg.siggen.make_cfg(seed=case, fmt=fmt, **kw), n)
     d = torch.from_numpy(iq).to("cuda:0")
-    dem = pkg.Demodulator(preamble_threshold=thr, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 22, dc_filter=dc)
+    dem = pkg.Demodulator(fmt=fmt, preamble_threshold=thr, nfix_crc=nfix, mode_ac=mode_ac, max_batch_samples=batch, message_capacity=1 << 22, dc_filter=dc)
     got = pkg.replay_device(dem, d.data_ptr(), n, batch)
-    want, wstats = orc.Oracle(orc.FMT_UC8, thr, nfix, mode_ac, dc_filter=dc).replay(iq, cap=1 << 22)
-    desc = f"case {case}: buffers={nbuf} batch={batch // 131072} nfix={nfix} ac={mode_ac} dc={int(dc)} thr={thr} {kw}"
+    want, wstats = orc.Oracle(ofmt, thr, nfix, mode_ac, dc_filter=dc).replay(iq, cap=1 << 22)
+    desc = f"case {case}: {fmt_name} buffers={nbuf} batch={batch // 131072} nfix={nfix} ac={mode_ac} dc={int(dc)} thr={thr} {kw}"
     try:
         assert_same(got, dem.stats(), want, wstats)
         print("ok  ", desc, "msgs", len(want), "passes", dem.timing()["resolve_passes"], "fallback", dem.timing()["resolve_fallback"], flush=True)
